@@ -1,0 +1,6 @@
+"""attend_infer_repeat_amd -- MI355X-native AIR (Attend, Infer, Repeat) hot path.
+
+Same API surface as akosiorek/attend_infer_repeat's `AIRCell` / `AIRModel` / `AIRonMNIST`, backed by hand-written
+gfx950 HIP kernels behind a C ABI (include/air_hip.h -> attend_infer_repeat_amd/lib/libair_hip.so).
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,94 @@
+"""ctypes binding of libair_hip.so -- every symbol declared in include/air_hip.h, nothing else.
+
+The library is the product: if it is missing or fails to load, importing any compute path raises (there is no
+CPU / PyTorch fallback).  Signatures mirror include/air_hip.h one to one.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
+
+c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
+                                                 ctypes.c_uint64)
+P = c_void_p   # device pointers travel as void*
+
+# name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
+SIGNATURES = {
+    "air_abi_version": (c_int, []),
+    "air_status_string": (ctypes.c_char_p, [c_int]),
+    "air_st_read_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_st_read_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_st_write_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_st_write_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_canvas_unroll_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_float, P]),
+    "air_canvas_unroll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_float, c_float, P]),
+    "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
+                         c_float, P, P, c_size_t, P]),
+    "air_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
+    "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "air_gauss_sample_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
+                                     c_int, c_int, P]),
+    "air_gauss_sample_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
+                                     P, c_int, c_int, c_int, P]),
+    "air_presence_fwd": (c_int, [P, P, P, c_float, c_float, c_int, P, P, c_int, c_int, P]),
+    "air_presence_bwd": (c_int, [P, c_float, c_float, c_int, P, P, P, c_int, c_int, P]),
+    "air_rec_loglik_fwd": (c_int, [P, P, c_float, c_float, P, c_int, c_int, P]),
+    "air_rec_loglik_bwd": (c_int, [P, P, c_float, c_float, P, c_float, P, c_int, c_int, P]),
+    "air_numsteps_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "air_numsteps_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
+    "air_nvil": (c_int, [P, P, P, P, P, P, c_int, P]),
+    "air_baseline_pack": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_rmsprop_centered": (c_int, [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, P]),
+    "air_rng_fill": (c_int, [P, c_size_t, P, c_size_t, P, P]),
+    "air_rng_advance": (c_int, [P, c_uint64, P]),
+    "air_fill": (c_int, [P, c_size_t, c_float, P]),
+    "air_axpby": (c_int, [P, c_float, P, c_float, P, c_size_t, P]),
+    "air_tile_rows": (c_int, [P, P, c_int, c_int, P]),
+    "air_colsum": (c_int, [P, c_int, P, c_int, c_int, P]),
+    "air_graph_begin_capture": (c_int, [P]),
+    "air_graph_end_capture": (c_int, [P, ctypes.POINTER(c_void_p)]),
+    "air_graph_launch": (c_int, [P, P]),
+    "air_graph_destroy": (c_int, [P]),
+    "air_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "air_event_record": (c_int, [P, P]),
+    "air_event_elapsed_ms": (c_int, [P, P, ctypes.POINTER(c_float)]),
+    "air_event_destroy": (c_int, [P]),
+}
+
+_lib = None
+
+
+class AirHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises loudly if the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AirHipError(
+            f"{LIB_PATH} not found: the HIP extension is the product and there is no fallback. "
+            "Build it with `python -m attend_infer_repeat_amd.build` (or __graft_entry__.build()).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.air_abi_version() != 1:
+        raise AirHipError("libair_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().air_status_string(int(status))
+        raise AirHipError(f"{what or 'air_hip call'} failed with status {status}: {msg.decode() if msg else '?'}")

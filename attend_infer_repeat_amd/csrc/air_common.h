@@ -1,0 +1,69 @@
+// Shared device/host helpers for the gfx950 kernels of libair_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/air_hip.h"
+
+#define AIR_WAVE 64
+
+#define AIR_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
+#define AIR_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+static inline hipStream_t air_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline bool air_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int air_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave / block reductions (64-wide wavefronts) -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;  // valid in every lane
+}
+
+// Sum NV values per thread across a block of up to 1024 threads; result valid in thread 0.
+// `scratch` must hold NV * (blockDim.x/64) floats; caller syncs before reusing scratch.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float *scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) scratch[wid * NV + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            float s = 0.f;
+            for (int i = 0; i < nw; ++i) s += scratch[i * NV + k];
+            v[k] = s;
+        }
+    }
+}
+
+// ---- scalar math with the exact op order of the oracle (no fp contraction) -----------------------------------
+__device__ __forceinline__ float lin_m11(int k, int n, double step) {
+    // np.linspace(-1, 1, n)[k] evaluated in fp64 (arange*step + start, last element = stop) then rounded to fp32
+    if (n <= 1) return -1.0f;
+    if (k == n - 1) return 1.0f;
+    return (float)__dadd_rn(__dmul_rn((double)k, step), -1.0);
+}
+// coord = ((s*X + t) + 1) * half_extent, each op rounded separately (matches numpy / torch-CPU eager)
+__device__ __forceinline__ float grid_coord(float s, float X, float t, float half_extent) {
+    return __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(s, X), t), 1.0f), half_extent);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplus_acc(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float elu_acc(float x) { return x > 0.0f ? x : expm1f(x); }

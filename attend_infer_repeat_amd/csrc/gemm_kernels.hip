@@ -1,0 +1,310 @@
+// fp32 MFMA GEMM for the small, weight-resident layers of AIR (snt.Linear / snt.LSTM matmuls: neural.py:42-60,
+// mnist_model.py:35; backward of the same).  C[M,N] = epi(op(A)[M,K].op(B)[K,N] + beta*C).
+//
+// Regime: M = B or T*B rows (64..3072), K,N in {1..3177}; all weights (10.5 MB) live in L2 / Infinity Cache, so at
+// the headline batch the problem is latency/occupancy bound, not HBM bound.  Design for that:
+//   * v_mfma_f32_16x16x4_f32 (exact fp32 fma chain; 157 TF peak = the fp32 vector rate, no TF32 on gfx950).
+//   * operands go global -> VGPR directly in MFMA fragment order, no LDS staging: lane (i = l&15, g = l>>4)
+//     supplies k = kc + 4g + j in MFMA step j for BOTH A and B, so a k-contiguous operand is one 16-byte load per
+//     lane per 16-deep chunk and a k-strided operand is four dword loads covering 64-byte row segments.
+//   * occupancy from split-K: the 4 waves of a workgroup interleave 16-deep K chunks of one output tile and reduce
+//     through LDS (deterministic); a second, cross-workgroup split writes fp32 slabs that a small epilogue kernel
+//     sums in a fixed order (no atomics => bitwise reproducible run to run).
+//   * epilogues fuse bias, ELU, ELU' (backward), residual add; the dW form fuses the bias gradient (column sums).
+// Arbitrary M/N/K and leading dimensions are handled with masked edge loads (test/cell_test.py uses 3x3 images and
+// hidden sizes 5/7/11/13/17).
+#include "air_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    const float *A, *B, *bias, *aux;
+    float *C, *colsum, *ws;
+    int M, N, K, lda, ldb, ldc, ldaux;
+    int ta, tb, epi, S, chunks_per_split, vecA, vecB;
+    float beta;
+};
+
+// element k..k+3 of a k-contiguous operand row (row-major [rows, K]); zero outside
+__device__ __forceinline__ f32x4 ld_kcontig(const float *p, int ld, int row, bool row_ok, int k, int K, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row_ok && k < K) {
+        const float *q = p + (size_t)row * ld + k;
+        if (vec && k + 3 < K) {
+            v = *reinterpret_cast<const f32x4 *>(q);
+        } else {
+            v.x = q[0];
+            if (k + 1 < K) v.y = q[1];
+            if (k + 2 < K) v.z = q[2];
+            if (k + 3 < K) v.w = q[3];
+        }
+    }
+    return v;
+}
+// rows k..k+3, fixed column, of a k-strided operand (row-major [K, cols]); zero outside
+__device__ __forceinline__ f32x4 ld_kstrided(const float *p, int ld, int col, bool col_ok, int k, int K) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok && k < K) {
+        const float *q = p + (size_t)k * ld + col;
+        v.x = q[0];
+        if (k + 1 < K) v.y = q[ld];
+        if (k + 2 < K) v.z = q[2 * (size_t)ld];
+        if (k + 3 < K) v.w = q[3 * (size_t)ld];
+    }
+    return v;
+}
+
+__device__ __forceinline__ float apply_epilogue(float v, int m, int n, const GemmArgs &g) {
+    if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
+    switch (g.epi) {
+        case AIR_EPI_BIAS: v += g.bias[n]; break;
+        case AIR_EPI_BIAS_ELU: v = elu_acc(v + g.bias[n]); break;
+        case AIR_EPI_MUL_DELU: {
+            const float y = g.aux[(size_t)m * g.ldaux + n];
+            v *= (y > 0.f ? 1.f : y + 1.f);
+        } break;
+        case AIR_EPI_ADD_AUX:
+            v += g.aux[(size_t)m * g.ldaux + n];
+            if (g.bias) v += g.bias[n];
+            break;
+        default: break;
+    }
+    return v;
+}
+
+// MT x NT 16x16 MFMA tiles per wave.  KW = 4: the workgroup's 4 waves split K for ONE tile (LDS reduce);
+// KW = 1: the 4 waves own 4 neighbouring N-tiles.
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+    constexpr int TM = 16 * MT, TN = 16 * NT;
+    constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
+    constexpr int LDT = TN + 4;                           // padded LDS tile row
+    __shared__ float s_tile[4][TM * LDT];
+    __shared__ float s_col[4][TN];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tiles_n = (g.N + TN * NWN - 1) / (TN * NWN);
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * TM;
+    const int n0 = (tn * NWN + (KW == 1 ? wave : 0)) * TN;
+    const int split = blockIdx.y;
+
+    const int total_chunks = (g.K + 15) >> 4;
+    const int c_begin = split * g.chunks_per_split;
+    int c_end = c_begin + g.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) csum[b] = 0.f;
+    const bool want_colsum = (g.colsum != nullptr) && (tm == 0);
+
+    int rowA[MT], colB[NT];
+    bool okA[MT], okB[NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) { rowA[a] = m0 + 16 * a + li; okA[a] = rowA[a] < g.M; }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) { colB[b] = n0 + 16 * b + li; okB[b] = colB[b] < g.N; }
+
+    const int c_step = (KW == 4) ? 4 : 1;
+    for (int c = c_begin + ((KW == 4) ? wave : 0); c < c_end; c += c_step) {
+        const int k = (c << 4) + 4 * lg;
+        f32x4 fa[MT], fb[NT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+            fa[a] = g.ta ? ld_kstrided(g.A, g.lda, rowA[a], okA[a], k, g.K)
+                         : ld_kcontig(g.A, g.lda, rowA[a], okA[a], k, g.K, g.vecA != 0);
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+            fb[b] = g.tb ? ld_kcontig(g.B, g.ldb, colB[b], okB[b], k, g.K, g.vecB != 0)
+                         : ld_kstrided(g.B, g.ldb, colB[b], okB[b], k, g.K);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        if (want_colsum) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) csum[b] += (fb[b].x + fb[b].y) + (fb[b].z + fb[b].w);
+        }
+    }
+
+    // accumulators -> LDS tile (C/D map: col = lane&15, row = (lane>>4)*4 + r)
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_tile[wave][(16 * a + 4 * lg + r) * LDT + 16 * b + li] = acc[a][b][r];
+    if (want_colsum) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            float v = csum[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) s_col[wave][16 * b + li] = v;
+        }
+    }
+    __syncthreads();
+
+    if (KW == 4) {
+        // all 256 threads reduce the 4 per-wave partial tiles and finish one TM x TN tile
+        for (int e = threadIdx.x; e < TM * TN; e += 256) {
+            const int r = e / TN, cidx = e - r * TN;
+            const int m = m0 + r, n = n0 + cidx;
+            if (m >= g.M || n >= g.N) continue;
+            const int off = r * LDT + cidx;
+            float v = (s_tile[0][off] + s_tile[1][off]) + (s_tile[2][off] + s_tile[3][off]);
+            if (g.S > 1) g.ws[((size_t)split * g.M + m) * g.N + n] = v;
+            else g.C[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
+        }
+        if (want_colsum && threadIdx.x < TN) {
+            const int n = n0 + threadIdx.x;
+            if (n < g.N)
+                g.colsum[n] = (s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + (s_col[2][threadIdx.x] + s_col[3][threadIdx.x]);
+        }
+    } else {
+        // each wave finishes its own tile
+        for (int e = lane; e < TM * TN; e += 64) {
+            const int r = e / TN, cidx = e - r * TN;
+            const int m = m0 + r, n = n0 + cidx;
+            if (m >= g.M || n >= g.N) continue;
+            const float v = s_tile[wave][r * LDT + cidx];
+            if (g.S > 1) g.ws[((size_t)split * g.M + m) * g.N + n] = v;
+            else g.C[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
+        }
+        if (want_colsum && lane < TN) {
+            const int n = n0 + lane;
+            if (n < g.N) g.colsum[n] = s_col[wave][lane];
+        }
+    }
+}
+
+// sums the S split-K slabs in fixed order and applies the epilogue
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
+    const size_t total = (size_t)g.M * g.N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int m = (int)(e / g.N), n = (int)(e - (size_t)m * g.N);
+        float v = 0.f;
+        for (int s = 0; s < g.S; ++s) v += g.ws[(size_t)s * total + e];
+        g.C[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
+    }
+}
+
+template <int MT, int NT, int KW>
+static int launch_gemm(const GemmArgs &g, hipStream_t st) {
+    constexpr int TM = 16 * MT, TN = 16 * NT * ((KW == 1) ? 4 : 1);
+    const int tiles = air_cdiv(g.M, TM) * air_cdiv(g.N, TN);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT, NT, KW>), dim3(tiles, g.S), dim3(256), 0, st, g);
+    AIR_LAUNCH_CHECK();
+    if (g.S > 1) {
+        const size_t total = (size_t)g.M * g.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, g);
+        AIR_LAUNCH_CHECK();
+    }
+    return AIR_OK;
+}
+
+extern "C" size_t air_gemm_workspace_bytes(int M, int N, int K) {
+    (void)K;
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)16 * (size_t)M * (size_t)N * sizeof(float);     // up to 16 split-K slabs
+}
+
+extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                        float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
+                        float *colsum, void *ws, size_t ws_bytes, void *stream) {
+    AIR_REQUIRE(A && B && C, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && N > 0 && K > 0, AIR_E_SHAPE);
+    AIR_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, AIR_E_SHAPE);
+    AIR_REQUIRE(epilogue >= AIR_EPI_NONE && epilogue <= AIR_EPI_ADD_AUX, AIR_E_UNSUPPORTED);
+    if (epilogue == AIR_EPI_BIAS || epilogue == AIR_EPI_BIAS_ELU) AIR_REQUIRE(bias, AIR_E_NULL);
+    if (epilogue == AIR_EPI_MUL_DELU || epilogue == AIR_EPI_ADD_AUX) AIR_REQUIRE(aux && ldaux >= N, AIR_E_NULL);
+    AIR_REQUIRE(!colsum || ta, AIR_E_UNSUPPORTED);
+
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.colsum = colsum; g.ws = (float *)ws;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+    g.ta = ta ? 1 : 0; g.tb = tb ? 1 : 0; g.epi = epilogue; g.beta = beta;
+    g.vecA = (!ta && (lda % 4 == 0) && air_aligned16(A)) ? 1 : 0;
+    g.vecB = (tb && (ldb % 4 == 0) && air_aligned16(B)) ? 1 : 0;
+
+    const int chunks = (K + 15) / 16;
+    // tile shape: few rows -> narrow tiles + intra-workgroup split-K; many tiles -> one tile per wave
+    const long tiles22 = (long)air_cdiv(M, 32) * air_cdiv(N, 32);
+    int S = 1;
+    hipStream_t st = air_stream(stream);
+    if (tiles22 >= 1024) {
+        g.S = 1; g.chunks_per_split = chunks;
+        return launch_gemm<2, 2, 1>(g, st);
+    }
+    const bool narrow = (M <= 64);
+    const long tiles = narrow ? (long)air_cdiv(M, 16) * air_cdiv(N, 32) : tiles22;
+    if (!colsum && ws && chunks >= 16) {
+        long want = 512 / (tiles > 0 ? tiles : 1);                       // aim for ~2 workgroups per CU
+        long max_by_k = chunks / 8;                                      // >= 2 chunks per wave per split
+        long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
+        long s = want;
+        if (s > max_by_k) s = max_by_k;
+        if (s > max_by_ws) s = max_by_ws;
+        if (s > 16) s = 16;
+        if (s >= 2) S = (int)s;
+    }
+    g.S = S;
+    g.chunks_per_split = (chunks + S - 1) / S;
+    g.S = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;       // drop empty tail splits
+    if (narrow) return launch_gemm<1, 2, 4>(g, st);
+    return launch_gemm<2, 2, 4>(g, st);
+}
+
+// ---- linear layer wrappers (neural.py:56-60) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mul_delu_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                       float *__restrict__ g, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float yy = y[i];
+        g[i] = dy[i] * (yy > 0.f ? 1.f : yy + 1.f);
+    }
+}
+
+extern "C" int air_linear_fwd(const float *x, const float *w, const float *b, float *y, int M, int K, int N, int act,
+                              void *ws, size_t ws_bytes, void *stream) {
+    AIR_REQUIRE(act == AIR_ACT_NONE || act == AIR_ACT_ELU, AIR_E_UNSUPPORTED);
+    AIR_REQUIRE(act == AIR_ACT_NONE || b, AIR_E_NULL);
+    const int epi = (act == AIR_ACT_ELU) ? AIR_EPI_BIAS_ELU : (b ? AIR_EPI_BIAS : AIR_EPI_NONE);
+    return air_gemm(0, 0, M, N, K, x, K, w, N, y, N, b, epi, nullptr, 0, 0.f, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int air_linear_bwd(const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw,
+                              float *db, float *gbuf, int M, int K, int N, int act, void *ws, size_t ws_bytes,
+                              void *stream) {
+    AIR_REQUIRE(x && w && dy && dw, AIR_E_NULL);
+    AIR_REQUIRE(act == AIR_ACT_NONE || act == AIR_ACT_ELU, AIR_E_UNSUPPORTED);
+    const float *g = dy;
+    if (act == AIR_ACT_ELU) {
+        AIR_REQUIRE(y && gbuf, AIR_E_NULL);
+        const size_t n = (size_t)M * N;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(mul_delu_kernel, dim3(blocks), dim3(256), 0, air_stream(stream), dy, y, gbuf, n);
+        AIR_LAUNCH_CHECK();
+        g = gbuf;
+    }
+    int st;
+    if (dx) {   // dx[M,K] = g[M,N] . w[K,N]^T
+        st = air_gemm(0, 1, M, K, N, g, N, w, N, dx, K, nullptr, AIR_EPI_NONE, nullptr, 0, 0.f, nullptr, ws, ws_bytes, stream);
+        if (st) return st;
+    }
+    // dw[K,N] = x[M,K]^T . g[M,N]; db = colsum(g)
+    st = air_gemm(1, 0, K, N, M, x, K, g, N, dw, N, nullptr, AIR_EPI_NONE, nullptr, 0, 0.f, db, ws, ws_bytes, stream);
+    return st;
+}

@@ -1,0 +1,242 @@
+// Objective-side kernels of AIR for gfx950: number-of-steps posterior / KL (float64 like the reference's prior.py),
+// the NVIL / REINFORCE scalars with the reference's [B]-[B,1] broadcast, plus hipGraph / event plumbing.
+#include <math.h>
+#include "air_common.h"
+
+#define NS_MAXT 32
+
+// ---- q(n), KL(q || geometric prior), step weights, log q(n_sampled)   (prior.py:62-151, model.py:139-163) --------
+struct NumSteps {
+    double p[NS_MAXT], u[NS_MAXT + 1], q[NS_MAXT + 1], S;
+    float q32[NS_MAXT + 1];
+};
+__device__ __forceinline__ void numsteps_posterior(const float *__restrict__ prob, int T, int B, int b, NumSteps &s) {
+    for (int t = 0; t < T; ++t) s.p[t] = (double)prob[(size_t)t * B + b];
+    double cum = 1.0;
+    s.u[0] = 1.0 - s.p[0];
+    for (int n = 1; n < T; ++n) { cum *= s.p[n - 1]; s.u[n] = (1.0 - s.p[n]) * cum; }
+    cum *= s.p[T - 1];
+    s.u[T] = cum;
+    s.S = 0.0;
+    for (int n = 0; n <= T; ++n) s.S += s.u[n];
+    for (int n = 0; n <= T; ++n) { s.q[n] = s.u[n] / s.S; s.q32[n] = (float)s.q[n]; }
+}
+__device__ __forceinline__ int sampled_steps(const float *__restrict__ presence, int T, int B, int b) {
+    float n = 0.f;
+    for (int t = 0; t < T; ++t) n += presence[(size_t)t * B + b];
+    int k = (int)n;
+    return k < 0 ? 0 : (k > T ? T : k);
+}
+
+__global__ __launch_bounds__(256) void numsteps_fwd_kernel(const float *__restrict__ prob,
+                                                           const float *__restrict__ presence,
+                                                           const double *__restrict__ prior, float *__restrict__ q,
+                                                           float *__restrict__ kl_ps, float *__restrict__ logp,
+                                                           float *__restrict__ step_w, int T, int B) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        NumSteps s;
+        numsteps_posterior(prob, T, B, b, s);
+        float kl = 0.f;
+        for (int n = 0; n <= T; ++n) {
+            if (q) q[(size_t)b * (T + 1) + n] = s.q32[n];
+            const double pn = (double)s.q32[n];                       // tabular_kl re-casts the f32 posterior to f64
+            kl += (pn > 0.0) ? (float)(pn * log(pn / prior[n])) : 0.f;
+        }
+        if (kl_ps) kl_ps[b] = kl;
+        if (step_w) {
+            float w = 0.f;
+            for (int t = T - 1; t >= 0; --t) { w += s.q32[t + 1]; step_w[(size_t)t * B + b] = w; }
+        }
+        if (logp) {
+            const float pr = s.q32[sampled_steps(presence, T, B, b)];
+            logp[b] = logf(fmaxf(pr, 1e-32f));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void numsteps_bwd_kernel(const float *__restrict__ prob,
+                                                           const float *__restrict__ presence,
+                                                           const double *__restrict__ prior, float kl_scale,
+                                                           const float *__restrict__ dstep_w,
+                                                           const float *__restrict__ dlogp,
+                                                           float *__restrict__ dprob, int T, int B) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        NumSteps s;
+        numsteps_posterior(prob, T, B, b, s);
+        double gq[NS_MAXT + 1];
+        double wsum = 0.0;
+        const int nstar = (dlogp && presence) ? sampled_steps(presence, T, B, b) : -1;
+        for (int n = 0; n <= T; ++n) {
+            const double pn = (double)s.q32[n];
+            double g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
+            if (n >= 1 && dstep_w) wsum += (double)dstep_w[(size_t)(n - 1) * B + b];   // w_t includes q(n) for all n > t
+            g += wsum;
+            if (n == nstar) g += (double)dlogp[b] / (double)fmaxf(s.q32[n], 1e-32f);
+            gq[n] = g;
+        }
+        // q = u / S
+        double dot = 0.0;
+        for (int n = 0; n <= T; ++n) dot += gq[n] * s.q[n];
+        double gu[NS_MAXT + 1];
+        for (int n = 0; n <= T; ++n) gu[n] = (gq[n] - dot) / s.S;
+        // u -> p, products taken without division (safe at p = 0, like the reference's scan-based cumprod)
+        for (int k = 0; k < T; ++k) {
+            double g = 0.0;
+            for (int n = 0; n <= T; ++n) {
+                double d;
+                if (n < T) {
+                    if (k > n) continue;
+                    if (k == n) {                                       // d/dp_n of (1-p_n) * prod_{j<n} p_j
+                        d = -1.0;
+                        for (int j = 0; j < n; ++j) d *= s.p[j];
+                    } else {                                            // k < n
+                        d = 1.0 - s.p[n];
+                        for (int j = 0; j < n; ++j) if (j != k) d *= s.p[j];
+                    }
+                } else {                                                // u_T = prod_j p_j
+                    d = 1.0;
+                    for (int j = 0; j < T; ++j) if (j != k) d *= s.p[j];
+                }
+                g += gu[n] * d;
+            }
+            dprob[(size_t)k * B + b] = (float)g;
+        }
+    }
+}
+
+extern "C" int air_numsteps_fwd(const float *presence_prob, const float *presence, const double *prior_f64, float *q,
+                                float *kl_per_sample, float *logp, float *step_weight, int T, int B, void *stream) {
+    AIR_REQUIRE(presence_prob && prior_f64, AIR_E_NULL);
+    AIR_REQUIRE(!logp || presence, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= NS_MAXT && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(numsteps_fwd_kernel, dim3(air_cdiv(B, 256)), dim3(256), 0, air_stream(stream), presence_prob,
+                       presence, prior_f64, q, kl_per_sample, logp, step_weight, T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_numsteps_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
+                                float kl_scale, const float *dstep_weight, const float *dlogp, float *dpresence_prob,
+                                int T, int B, void *stream) {
+    AIR_REQUIRE(presence_prob && prior_f64 && dpresence_prob, AIR_E_NULL);
+    AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= NS_MAXT && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(numsteps_bwd_kernel, dim3(air_cdiv(B, 256)), dim3(256), 0, air_stream(stream), presence_prob,
+                       presence, prior_f64, kl_scale, dstep_weight, dlogp, dpresence_prob, T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- NVIL / REINFORCE (model.py:218-259) --------------------------------------------------------------------------
+// importance_weight[i,j] = imp[j] - baseline[i]  ([B]-[B,1] broadcast), so
+//   reinforce_loss = mean_j (imp_j - mean_i b_i) * logp_j ;  baseline_loss = 0.5 * mean_ij (imp_j - b_i)^2.
+__global__ __launch_bounds__(256) void nvil_kernel(const float *__restrict__ imp, const float *__restrict__ base,
+                                                   const float *__restrict__ logp, float *__restrict__ out,
+                                                   float *__restrict__ dlogp, float *__restrict__ dbase, int B) {
+    __shared__ double red[4][5];
+    __shared__ double tot[5];
+    double a[5] = {0, 0, 0, 0, 0};                  // sum imp, sum imp^2, sum b, sum b^2, sum imp*logp
+    double sl = 0.0;                                // sum logp
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const double x = imp[i], b = base[i], l = logp[i];
+        a[0] += x; a[1] += x * x; a[2] += b; a[3] += b * b; a[4] += x * l; sl += l;
+    }
+    __shared__ double red_sl[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a[k] = wave_sum(a[k]);
+    sl = wave_sum(sl);
+    if (lane == 0) {
+        for (int k = 0; k < 5; ++k) red[wid][k] = a[k];
+        red_sl[wid] = sl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5], tsl = 0.0;
+        for (int k = 0; k < 5; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        tsl = red_sl[0] + red_sl[1] + red_sl[2] + red_sl[3];
+        const double n = (double)B;
+        const double mi = t[0] / n, mb = t[2] / n;
+        const double vi = t[1] / n - mi * mi, vb = t[3] / n - mb * mb;
+        out[0] = (float)((t[4] - mb * tsl) / n);                                  // reinforce_loss
+        out[1] = (float)(0.5 * (vi + vb + (mi - mb) * (mi - mb)));               // baseline_loss
+        out[2] = (float)(mi - mb);                                                // imp_weight_mean over [B,B]
+        out[3] = (float)(vi + vb);                                                // imp_weight_var  over [B,B]
+        tot[0] = mi; tot[1] = mb;
+    }
+    __syncthreads();
+    const double mi = tot[0], mb = tot[1];
+    for (int i = threadIdx.x; i < B; i += 256) {
+        if (dlogp) dlogp[i] = (float)(((double)imp[i] - mb) / (double)B);
+        if (dbase) dbase[i] = (float)(-(mi - (double)base[i]) / (double)B);
+    }
+}
+extern "C" int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
+                        float *dbaseline, int B, void *stream) {
+    AIR_REQUIRE(imp && baseline && logp && out, AIR_E_NULL);
+    AIR_REQUIRE(B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), imp, baseline, logp, out, dlogp,
+                       dbaseline, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- hipGraph + event plumbing -----------------------------------------------------------------------------------
+extern "C" int air_graph_begin_capture(void *stream) {
+    hipError_t e = hipStreamBeginCapture(air_stream(stream), hipStreamCaptureModeRelaxed);
+    return (int)e;
+}
+extern "C" int air_graph_end_capture(void *stream, void **graph_exec_out) {
+    AIR_REQUIRE(graph_exec_out, AIR_E_NULL);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(air_stream(stream), &graph);
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec_out = (void *)exec;
+    return AIR_OK;
+}
+extern "C" int air_graph_launch(void *graph_exec, void *stream) {
+    AIR_REQUIRE(graph_exec, AIR_E_NULL);
+    return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, air_stream(stream));
+}
+extern "C" int air_graph_destroy(void *graph_exec) {
+    if (!graph_exec) return AIR_OK;
+    return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+extern "C" int air_event_create(void **event_out) {
+    AIR_REQUIRE(event_out, AIR_E_NULL);
+    hipEvent_t ev;
+    hipError_t e = hipEventCreate(&ev);
+    if (e != hipSuccess) return (int)e;
+    *event_out = (void *)ev;
+    return AIR_OK;
+}
+extern "C" int air_event_record(void *event, void *stream) {
+    AIR_REQUIRE(event, AIR_E_NULL);
+    return (int)hipEventRecord((hipEvent_t)event, air_stream(stream));
+}
+extern "C" int air_event_elapsed_ms(void *start, void *stop, float *ms_host_out) {
+    AIR_REQUIRE(start && stop && ms_host_out, AIR_E_NULL);
+    hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipEventElapsedTime(ms_host_out, (hipEvent_t)start, (hipEvent_t)stop);
+}
+extern "C" int air_event_destroy(void *event) {
+    if (!event) return AIR_OK;
+    return (int)hipEventDestroy((hipEvent_t)event);
+}
+
+extern "C" int air_abi_version(void) { return AIR_ABI_VERSION; }
+extern "C" const char *air_status_string(int status) {
+    switch (status) {
+        case AIR_OK: return "ok";
+        case AIR_E_NULL: return "AIR_E_NULL: required pointer is NULL";
+        case AIR_E_SHAPE: return "AIR_E_SHAPE: bad dimension";
+        case AIR_E_ALIGN: return "AIR_E_ALIGN: alignment requirement violated";
+        case AIR_E_WORKSPACE: return "AIR_E_WORKSPACE: workspace too small";
+        case AIR_E_UNSUPPORTED: return "AIR_E_UNSUPPORTED: unsupported argument combination";
+        default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown AIR status";
+    }
+}

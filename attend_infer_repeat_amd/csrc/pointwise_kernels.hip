@@ -1,0 +1,452 @@
+// Pointwise / row-wise kernels of the AIR step for gfx950: LSTM gates, reparameterised Gaussians (+KL), presence,
+// reconstruction log-likelihood, baseline-input packing, centred RMSProp, Philox noise.  All are HBM/latency bound
+// elementwise passes: one coalesced read of every input, one coalesced write of every output, fp32 math.
+#include <math.h>
+#include "air_common.h"
+
+#define PW_THREADS 256
+static inline int pw_blocks(size_t n) {
+    size_t b = (n + PW_THREADS - 1) / PW_THREADS;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define PW_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * PW_THREADS + threadIdx.x; i < (n); i += (size_t)gridDim.x * PW_THREADS)
+
+// ---- LSTM pointwise (Sonnet v1 LSTM, gate order i,j,f,o; cell.py:126-127) ---------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void lstm_pw_fwd_kernel(const float *__restrict__ gates,
+                                                                 const float *__restrict__ c_prev,
+                                                                 float *__restrict__ h, float *__restrict__ c,
+                                                                 float *__restrict__ gate_act, int M, int Hd, float fb) {
+    const size_t n = (size_t)M * Hd;
+    PW_LOOP(e, n) {
+        const size_t m = e / Hd, u = e - m * Hd;
+        const float *gr = gates + m * 4 * (size_t)Hd;
+        const float gi = sigmoid_acc(gr[u]);
+        const float gj = tanhf(gr[Hd + u]);
+        const float gf = sigmoid_acc(gr[2 * (size_t)Hd + u] + fb);
+        const float go = sigmoid_acc(gr[3 * (size_t)Hd + u]);
+        const float cn = gf * c_prev[e] + gi * gj;
+        c[e] = cn;
+        h[e] = tanhf(cn) * go;
+        if (gate_act) {
+            float *ar = gate_act + m * 4 * (size_t)Hd;
+            ar[u] = gi; ar[Hd + u] = gj; ar[2 * (size_t)Hd + u] = gf; ar[3 * (size_t)Hd + u] = go;
+        }
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__restrict__ gate_act,
+                                                                 const float *__restrict__ c_prev,
+                                                                 const float *__restrict__ c,
+                                                                 const float *__restrict__ dh,
+                                                                 const float *__restrict__ dc_in,
+                                                                 float *__restrict__ dgates,
+                                                                 float *__restrict__ dc_prev, int M, int Hd) {
+    const size_t n = (size_t)M * Hd;
+    PW_LOOP(e, n) {
+        const size_t m = e / Hd, u = e - m * Hd;
+        const float *ar = gate_act + m * 4 * (size_t)Hd;
+        const float gi = ar[u], gj = ar[Hd + u], gf = ar[2 * (size_t)Hd + u], go = ar[3 * (size_t)Hd + u];
+        const float tc = tanhf(c[e]);
+        const float dhe = dh ? dh[e] : 0.f;
+        const float dct = (dc_in ? dc_in[e] : 0.f) + dhe * go * (1.f - tc * tc);
+        float *dr = dgates + m * 4 * (size_t)Hd;
+        dr[u] = dct * gj * gi * (1.f - gi);
+        dr[Hd + u] = dct * gi * (1.f - gj * gj);
+        dr[2 * (size_t)Hd + u] = dct * c_prev[e] * gf * (1.f - gf);
+        dr[3 * (size_t)Hd + u] = dhe * tc * go * (1.f - go);
+        dc_prev[e] = dct * gf;
+    }
+}
+extern "C" int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, float *c, float *gate_act,
+                                      int M, int Hd, float forget_bias, void *stream) {
+    AIR_REQUIRE(gates && c_prev && h && c, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(pw_blocks((size_t)M * Hd)), dim3(PW_THREADS), 0, air_stream(stream),
+                       gates, c_prev, h, c, gate_act, M, Hd, forget_bias);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
+                                      const float *dc, float *dgates, float *dc_prev, int M, int Hd, void *stream) {
+    AIR_REQUIRE(gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
+    AIR_REQUIRE(dh || dc, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(pw_blocks((size_t)M * Hd)), dim3(PW_THREADS), 0, air_stream(stream),
+                       gate_act, c_prev, c, dh, dc, dgates, dc_prev, M, Hd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- reparameterised Gaussian + KL (cell.py:130-133,154-156; modules.py:17-24,41-46,58-63; model.py:174-209) ----
+__device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps) {
+    const float ratio = (s * s) / (ps * ps);
+    const float d = mu - pm;
+    return d * d / (2.f * ps * ps) + 0.5f * (ratio - 1.f - logf(ratio));
+}
+// one 64-lane wave per row: D elements strided over lanes, KL reduced with a wave reduction
+__global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__restrict__ pre, int ld_pre,
+                                                               const float *__restrict__ eps, float raw_offset,
+                                                               int loc_mode, float pl0, float ps0, float pl1, float ps1,
+                                                               float *__restrict__ loc, float *__restrict__ scale,
+                                                               float *__restrict__ sample, float *__restrict__ kl_row,
+                                                               int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (int)((blockIdx.x * (size_t)PW_THREADS + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    for (int m = wave_global; m < M; m += nwaves) {
+        const float *pr = pre + (size_t)m * ld_pre;
+        float kl = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            float mu = pr[d];
+            if (loc_mode == 1) mu = (d & 1) ? tanhf(mu) : sigmoid_acc(mu);
+            const float s = softplus_acc(pr[D + d] + raw_offset);
+            const size_t o = (size_t)m * D + d;
+            loc[o] = mu; scale[o] = s;
+            if (sample) sample[o] = mu + s * eps[o];
+            kl += (d & 1) ? normal_kl(mu, s, pl1, ps1) : normal_kl(mu, s, pl0, ps0);
+        }
+        kl = wave_sum(kl);
+        if (kl_row && lane == 0) kl_row[m] = kl;
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__restrict__ pre, int ld_pre,
+                                                               const float *__restrict__ eps, float raw_offset,
+                                                               int loc_mode, float pl0, float ps0, float pl1, float ps1,
+                                                               const float *__restrict__ loc,
+                                                               const float *__restrict__ scale,
+                                                               const float *__restrict__ dsample,
+                                                               const float *__restrict__ dkl_row,
+                                                               float *__restrict__ dpre, int ld_dpre, int M, int D) {
+    const size_t n = (size_t)M * D;
+    PW_LOOP(e, n) {
+        const size_t m = e / D;
+        const int d = (int)(e - m * D);
+        const float mu = loc[e], s = scale[e];
+        const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
+        const float ds = dsample ? dsample[e] : 0.f;
+        const float dk = dkl_row ? dkl_row[m] : 0.f;
+        float dmu = ds + dk * (mu - pm) / (ps * ps);
+        const float dsc = (dsample ? ds * eps[e] : 0.f) + dk * (s / (ps * ps) - 1.f / s);
+        if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
+        const float raw = pre[m * ld_pre + D + d] + raw_offset;
+        const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus
+        dpre[m * ld_dpre + d] = dmu;
+        dpre[m * ld_dpre + D + d] = dsc * dsp;
+    }
+}
+extern "C" int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                                    float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
+                                    float *loc, float *scale, float *sample, float *kl_row, int M, int D,
+                                    void *stream) {
+    AIR_REQUIRE(pre && loc && scale, AIR_E_NULL);
+    AIR_REQUIRE(!sample || eps, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D, AIR_E_SHAPE);
+    AIR_REQUIRE(loc_mode == 0 || loc_mode == 1, AIR_E_UNSUPPORTED);
+    hipLaunchKernelGGL(gauss_fwd_kernel, dim3(pw_blocks((size_t)M * 64)), dim3(PW_THREADS), 0, air_stream(stream), pre,
+                       ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
+                       sample, kl_row, M, D);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                                    float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
+                                    const float *loc, const float *scale, const float *dsample, const float *dkl_row,
+                                    float *dpre, int ld_dpre, int M, int D, void *stream) {
+    AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
+    AIR_REQUIRE(!dsample || eps, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
+    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(pw_blocks((size_t)M * D)), dim3(PW_THREADS), 0, air_stream(stream), pre,
+                       ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
+                       dsample, dkl_row, dpre, ld_dpre, M, D);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- presence (cell.py:137-151) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void presence_fwd_kernel(const float *__restrict__ logit,
+                                                                  const float *__restrict__ u,
+                                                                  const float *__restrict__ presence_in,
+                                                                  float step_bias, float eps, int discrete,
+                                                                  float *__restrict__ prob, float *__restrict__ pres,
+                                                                  int T, int B) {
+    PW_LOOP(b, (size_t)B) {
+        float run = presence_in ? presence_in[b] : 1.0f;
+        for (int t = 0; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            float p = sigmoid_acc(logit[k] + step_bias);
+            if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
+            prob[k] = p;
+            if (discrete) {
+                run *= (u[k] < p) ? 1.0f : 0.0f;
+                pres[k] = run;
+            } else {
+                pres[k] = p;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void presence_bwd_kernel(const float *__restrict__ logit, float step_bias,
+                                                                  float eps, int discrete,
+                                                                  const float *__restrict__ dprob,
+                                                                  const float *__restrict__ dpres,
+                                                                  float *__restrict__ dlogit, size_t n) {
+    PW_LOOP(k, n) {
+        const float s = sigmoid_acc(logit[k] + step_bias);
+        float g = dprob ? dprob[k] : 0.f;
+        if (!discrete && dpres) g += dpres[k];
+        if (eps >= 0.f) g *= (1 - eps);
+        dlogit[k] = g * s * (1.f - s);
+    }
+}
+extern "C" int air_presence_fwd(const float *logit, const float *u, const float *presence_in, float step_bias,
+                                float explore_eps, int discrete, float *presence_prob, float *presence, int T, int B,
+                                void *stream) {
+    AIR_REQUIRE(logit && presence_prob && presence, AIR_E_NULL);
+    AIR_REQUIRE(!discrete || u, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(presence_fwd_kernel, dim3(pw_blocks(B)), dim3(PW_THREADS), 0, air_stream(stream), logit, u,
+                       presence_in, step_bias, explore_eps, discrete, presence_prob, presence, T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_presence_bwd(const float *logit, float step_bias, float explore_eps, int discrete,
+                                const float *dpresence_prob, const float *dpresence, float *dlogit, int T, int B,
+                                void *stream) {
+    AIR_REQUIRE(logit && dlogit, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(presence_bwd_kernel, dim3(pw_blocks((size_t)T * B)), dim3(PW_THREADS), 0, air_stream(stream),
+                       logit, step_bias, explore_eps, discrete, dpresence_prob, dpresence, dlogit, (size_t)T * B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- reconstruction term (model.py:319-324) ---------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void rec_fwd_kernel(const float *__restrict__ obs,
+                                                             const float *__restrict__ canvas, float mult, float std,
+                                                             float *__restrict__ per_sample, int B, int P) {
+    __shared__ float scratch[8];
+    const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float *x = obs + (size_t)b * P, *c = canvas + (size_t)b * P;
+        float s[1] = {0.f};
+        for (int p = threadIdx.x; p < P; p += PW_THREADS) {
+            const float z = (x[p] - mult * c[p]) / std;
+            s[0] += 0.5f * z * z + cst;
+        }
+        __syncthreads();
+        block_sum<1>(s, scratch);
+        if (threadIdx.x == 0) per_sample[b] = s[0];
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void rec_bwd_kernel(const float *__restrict__ obs,
+                                                             const float *__restrict__ canvas, float mult, float std,
+                                                             const float *__restrict__ dps, float scale,
+                                                             float *__restrict__ dcanvas, int B, int P) {
+    const size_t n = (size_t)B * P;
+    const float k = mult / (std * std);
+    PW_LOOP(e, n) {
+        const float g = dps ? dps[e / P] : scale;
+        dcanvas[e] = g * k * (mult * canvas[e] - obs[e]);
+    }
+}
+extern "C" int air_rec_loglik_fwd(const float *obs, const float *canvas, float mult, float std, float *per_sample,
+                                  int B, int P, void *stream) {
+    AIR_REQUIRE(obs && canvas && per_sample, AIR_E_NULL);
+    AIR_REQUIRE(B > 0 && P > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(rec_fwd_kernel, dim3(B < 2048 ? B : 2048), dim3(PW_THREADS), 0, air_stream(stream), obs, canvas,
+                       mult, std, per_sample, B, P);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_rec_loglik_bwd(const float *obs, const float *canvas, float mult, float std,
+                                  const float *dper_sample, float scale, float *dcanvas, int B, int P, void *stream) {
+    AIR_REQUIRE(obs && canvas && dcanvas, AIR_E_NULL);
+    AIR_REQUIRE(B > 0 && P > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(rec_bwd_kernel, dim3(pw_blocks((size_t)B * P)), dim3(PW_THREADS), 0, air_stream(stream), obs,
+                       canvas, mult, std, dper_sample, scale, dcanvas, B, P);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- baseline input packing (modules.py:131-139) ----------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void baseline_pack_kernel(const float *__restrict__ img,
+                                                                   const float *__restrict__ what,
+                                                                   const float *__restrict__ where,
+                                                                   const float *__restrict__ presence,
+                                                                   const float *__restrict__ s0,
+                                                                   const float *__restrict__ s1,
+                                                                   float *__restrict__ out, int T, int B, int P, int A,
+                                                                   int S0, int S1) {
+    const int width = P + T * A + T * 4 + T + S0 + S1;
+    const size_t n = (size_t)B * width;
+    PW_LOOP(e, n) {
+        const size_t b = e / width;
+        int c = (int)(e - b * width);
+        float v;
+        if (c < P) v = img[b * P + c];
+        else if ((c -= P) < T * A) { const int t = c / A, a = c - t * A; v = what[((size_t)t * B + b) * A + a]; }
+        else if ((c -= T * A) < T * 4) { const int t = c / 4, a = c - t * 4; v = where[((size_t)t * B + b) * 4 + a]; }
+        else if ((c -= T * 4) < T) v = presence[(size_t)c * B + b];
+        else if ((c -= T) < S0) v = s0[b * S0 + c];
+        else v = s1[b * S1 + (c - S0)];
+        out[e] = v;
+    }
+}
+extern "C" int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
+                                 const float *state0, const float *state1, float *out, int T, int B, int P, int A,
+                                 int S0, int S1, void *stream) {
+    AIR_REQUIRE(img && what && where && presence && out, AIR_E_NULL);
+    AIR_REQUIRE((S0 == 0 || state0) && (S1 == 0 || state1), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && P > 0 && A > 0 && S0 >= 0 && S1 >= 0, AIR_E_SHAPE);
+    const size_t n = (size_t)B * (P + T * A + T * 4 + T + S0 + S1);
+    hipLaunchKernelGGL(baseline_pack_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), img, what,
+                       where, presence, state0, state1, out, T, B, P, A, S0, S1);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- centred RMSProp with momentum (TF semantics; model.py:265,355-367) ----------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void rmsprop_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                             float *__restrict__ ms, float *__restrict__ mg,
+                                                             float *__restrict__ mom, size_t n,
+                                                             const float *__restrict__ lr_dev, float lr_mult,
+                                                             float decay, float momentum, float eps, float gscale) {
+    const float lr = lr_dev[0] * lr_mult;
+    PW_LOOP(i, n) {
+        const float gi = g[i] * gscale;
+        const float msi = decay * ms[i] + (1.f - decay) * gi * gi;
+        const float mgi = decay * mg[i] + (1.f - decay) * gi;
+        const float mo = momentum * mom[i] + lr * gi / sqrtf(msi - mgi * mgi + eps);
+        ms[i] = msi; mg[i] = mgi; mom[i] = mo;
+        p[i] -= mo;
+    }
+}
+extern "C" int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n,
+                                    const float *lr_dev, float lr_mult, float decay, float momentum, float eps,
+                                    float grad_scale, void *stream) {
+    AIR_REQUIRE(p && g && ms && mg && mom && lr_dev, AIR_E_NULL);
+    AIR_REQUIRE(n > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), p, g, ms, mg, mom,
+                       n, lr_dev, lr_mult, decay, momentum, eps, grad_scale);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- Philox4x32-10 noise ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32(uint64_t ctr, uint64_t stream_id, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }          // [0,1)
+__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+__global__ __launch_bounds__(PW_THREADS) void rng_fill_kernel(float *__restrict__ normal, size_t n_normal,
+                                                              float *__restrict__ uniform, size_t n_uniform,
+                                                              const uint64_t *__restrict__ state) {
+    const uint64_t seed = state[0], offset = state[1];
+    const size_t q_normal = (n_normal + 3) / 4, q_uniform = (n_uniform + 3) / 4;
+    PW_LOOP(q, q_normal + q_uniform) {
+        uint32_t r[4];
+        philox4x32(offset + q, 0, seed, r);
+        if (q < q_normal) {
+            // Box-Muller: two pairs -> four normals
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * k])));
+                float sn, cs;
+                sincosf(6.283185307179586f * u01(r[2 * k + 1]), &sn, &cs);
+                z[2 * k] = rad * cs; z[2 * k + 1] = rad * sn;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (4 * q + k < n_normal) normal[4 * q + k] = z[k];
+        } else {
+            const size_t qq = q - q_normal;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (4 * qq + k < n_uniform) uniform[4 * qq + k] = u01(r[k]);
+        }
+    }
+}
+__global__ void rng_advance_kernel(uint64_t *state, uint64_t inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += inc;
+}
+extern "C" int air_rng_fill(float *normal, size_t n_normal, float *uniform, size_t n_uniform,
+                            const uint64_t *state_dev, void *stream) {
+    AIR_REQUIRE(state_dev, AIR_E_NULL);
+    AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
+    const size_t q = (n_normal + 3) / 4 + (n_uniform + 3) / 4;
+    if (q == 0) return AIR_OK;
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(pw_blocks(q)), dim3(PW_THREADS), 0, air_stream(stream), normal, n_normal,
+                       uniform, n_uniform, state_dev);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_rng_advance(uint64_t *state_dev, uint64_t increment, void *stream) {
+    AIR_REQUIRE(state_dev, AIR_E_NULL);
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, air_stream(stream), state_dev, increment);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- utilities ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void fill_kernel(float *p, size_t n, float v) { PW_LOOP(i, n) p[i] = v; }
+__global__ __launch_bounds__(PW_THREADS) void axpby_kernel(const float *__restrict__ a, float alpha,
+                                                           const float *__restrict__ b, float beta,
+                                                           float *__restrict__ out, size_t n) {
+    PW_LOOP(i, n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+__global__ __launch_bounds__(PW_THREADS) void tile_rows_kernel(const float *__restrict__ src, float *__restrict__ out,
+                                                               int rows, int cols) {
+    PW_LOOP(i, (size_t)rows * cols) out[i] = src[i % cols];
+}
+__global__ __launch_bounds__(PW_THREADS) void colsum_kernel(const float *__restrict__ x, int ld, float *__restrict__ out,
+                                                            int M, int N) {
+    // one thread per column, rows in order (deterministic); coalesced across columns
+    PW_LOOP(n, (size_t)N) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += x[(size_t)m * ld + n];
+        out[n] = s;
+    }
+}
+extern "C" int air_fill(float *p, size_t n, float v, void *stream) {
+    AIR_REQUIRE(p, AIR_E_NULL);
+    if (n == 0) return AIR_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), p, n, v);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_axpby(const float *a, float alpha, const float *b, float beta, float *out, size_t n, void *stream) {
+    AIR_REQUIRE(a && out, AIR_E_NULL);
+    if (n == 0) return AIR_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), a, alpha, b, beta, out, n);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_tile_rows(const float *src, float *out, int rows, int cols, void *stream) {
+    AIR_REQUIRE(src && out, AIR_E_NULL);
+    AIR_REQUIRE(rows > 0 && cols > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(pw_blocks((size_t)rows * cols)), dim3(PW_THREADS), 0, air_stream(stream),
+                       src, out, rows, cols);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_colsum(const float *x, int ld, float *out, int M, int N, void *stream) {
+    AIR_REQUIRE(x && out, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && N > 0 && ld >= N, AIR_E_SHAPE);
+    hipLaunchKernelGGL(colsum_kernel, dim3(pw_blocks(N)), dim3(PW_THREADS), 0, air_stream(stream), x, ld, out, M, N);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}

@@ -1,0 +1,444 @@
+// Spatial-transformer kernels for gfx950: fused affine-grid + bilinear glimpse read, and the inverse canvas write.
+//
+// Replaces snt.AffineGridWarper + snt.resampler (+ gradient) behind attend_infer_repeat/modules.py:94-109
+// (called at cell.py:135 and cell.py:159-165).  Semantics: SURVEY.md Appendix A.4 / A.7; oracle: oracle/air_oracle.py
+// st_read / st_write and oracle/st_loops.c.
+//
+// Design (HBM-bound op, ~6 flop/byte): one 256-thread workgroup per source image.  The source (50x50 image for the
+// read, 20x20 glimpse for the write) is staged ONCE into LDS with coalesced 16-byte loads; the affine grid is never
+// materialised -- because the warp has no shear, x depends only on the output column and y only on the output row,
+// so per-axis tables (floor index, fractional weight) are built in LDS by h+w threads and every output pixel costs
+// four LDS gathers.  When T glimpses are read from one image (batched unroll) the image is staged once for all T.
+// Forward arithmetic uses explicitly-rounded ops in the oracle's order, so forward results are bit-identical to it.
+#include <limits.h>
+#include <math.h>
+#include "air_common.h"
+
+#define ST_THREADS 256
+#define ST_INVALID INT_MIN
+
+struct Taps { float ff, fc, cf, cc; };
+
+// bilinear taps around (fy, fx) of an LDS-resident Hs x Ws source; out-of-range taps are zero
+__device__ __forceinline__ Taps load_taps(const float *s, int Hs, int Ws, int fy, int fx) {
+    const bool x0 = fx >= 0, x1 = fx + 1 <= Ws - 1, y0 = fy >= 0, y1 = fy + 1 <= Hs - 1;
+    Taps t;
+    const int base = fy * Ws + fx;
+    t.ff = (x0 && y0) ? s[base] : 0.f;
+    t.fc = (x1 && y0) ? s[base + 1] : 0.f;
+    t.cf = (x0 && y1) ? s[base + Ws] : 0.f;
+    t.cc = (x1 && y1) ? s[base + Ws + 1] : 0.f;
+    return t;
+}
+// dx*dy*ff + (1-dx)*(1-dy)*cc + dx*(1-dy)*cf + (1-dx)*dy*fc, left-to-right, no contraction (== oracle)
+__device__ __forceinline__ float bilerp(const Taps &t, float dx, float dy) {
+    const float mx = __fsub_rn(1.f, dx), my = __fsub_rn(1.f, dy);
+    float r = __fmul_rn(__fmul_rn(dx, dy), t.ff);
+    r = __fadd_rn(r, __fmul_rn(__fmul_rn(mx, my), t.cc));
+    r = __fadd_rn(r, __fmul_rn(__fmul_rn(dx, my), t.cf));
+    r = __fadd_rn(r, __fmul_rn(__fmul_rn(mx, dy), t.fc));
+    return r;
+}
+// one axis entry: coordinate -> (floor index or ST_INVALID, d = (floor+1) - coord)
+__device__ __forceinline__ void axis_entry(float coord, int extent, int *f_out, float *d_out) {
+    const bool valid = (coord > -1.0f) && (coord < (float)extent);   // NaN -> invalid
+    const float fl = floorf(coord);
+    *f_out = valid ? (int)fl : ST_INVALID;
+    *d_out = __fsub_rn(__fadd_rn(fl, 1.0f), coord);
+}
+
+__device__ __forceinline__ void stage_to_lds(float *dst, const float *src, int count, bool vec4) {
+    if (vec4) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int q = threadIdx.x; q < (count >> 2); q += ST_THREADS) d4[q] = s4[q];
+    } else {
+        for (int p = threadIdx.x; p < count; p += ST_THREADS) dst[p] = src[p];
+    }
+}
+
+// LDS carve: [src: cnt_src padded to 4][aux: cnt_aux padded to 4][fx:W_][dx:W_][X:W_][fy:H_][dy:H_][Y:H_][scratch 32]
+struct Carve {
+    float *src, *aux, *dx, *X, *dy, *Y, *scratch;
+    int *fx, *fy;
+};
+__device__ __forceinline__ Carve carve_lds(float *smem, int cnt_src, int cnt_aux, int nx, int ny) {
+    Carve c;
+    float *p = smem;
+    c.src = p; p += (cnt_src + 3) & ~3;
+    c.aux = p; p += (cnt_aux + 3) & ~3;
+    c.fx = reinterpret_cast<int *>(p); p += nx;
+    c.dx = p; p += nx;
+    c.X = p; p += nx;
+    c.fy = reinterpret_cast<int *>(p); p += ny;
+    c.dy = p; p += ny;
+    c.Y = p; p += ny;
+    c.scratch = p;
+    return c;
+}
+static inline size_t carve_bytes(int cnt_src, int cnt_aux, int nx, int ny) {
+    return sizeof(float) * (size_t)(((cnt_src + 3) & ~3) + ((cnt_aux + 3) & ~3) + 3 * nx + 3 * ny + 32);
+}
+
+// ============================================================================================================
+// read: glimpse[k] = bilinear(img[k % n_img]; x = (W-1)/2*(sx*X_j+tx+1), y = (H-1)/2*(sy*Y_i+ty+1))
+// ============================================================================================================
+__global__ __launch_bounds__(ST_THREADS) void st_read_fwd_kernel(
+    const float *__restrict__ img, const float *__restrict__ where, float *__restrict__ out,
+    int n, int n_img, int H, int W, int h, int w, double stepx, double stepy, int vec4) {
+    extern __shared__ __align__(16) float smem[];
+    const int HW = H * W, hw = h * w, tid = threadIdx.x;
+    Carve c = carve_lds(smem, HW, 0, w, h);
+    const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    for (int b = blockIdx.x; b < n_img; b += gridDim.x) {
+        __syncthreads();
+        stage_to_lds(c.src, img + (size_t)b * HW, HW, vec4 != 0);
+        for (int k = b; k < n; k += n_img) {
+            __syncthreads();
+            const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
+            const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
+            for (int a = tid; a < w + h; a += ST_THREADS) {
+                if (a < w) axis_entry(grid_coord(sx, lin_m11(a, w, stepx), tx, cxs), W, &c.fx[a], &c.dx[a]);
+                else axis_entry(grid_coord(sy, lin_m11(a - w, h, stepy), ty, cys), H, &c.fy[a - w], &c.dy[a - w]);
+            }
+            __syncthreads();
+            float *o = out + (size_t)k * hw;
+            for (int p = tid; p < hw; p += ST_THREADS) {
+                const int i = p / w, j = p - i * w;
+                const int fx = c.fx[j], fy = c.fy[i];
+                float v = 0.f;
+                if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, H, W, fy, fx), c.dx[j], c.dy[i]);
+                o[p] = v;
+            }
+        }
+    }
+}
+
+// dwhere[k,4] = sum_ij dglimpse * d out / d(x,y) * d(x,y)/d where ; optional dimg (n_img == n)
+__global__ __launch_bounds__(ST_THREADS) void st_read_bwd_kernel(
+    const float *__restrict__ img, const float *__restrict__ where, const float *__restrict__ dout,
+    float *__restrict__ dwhere, float *__restrict__ dimg,
+    int n, int n_img, int H, int W, int h, int w, double stepx, double stepy, int vec4) {
+    extern __shared__ __align__(16) float smem[];
+    const int HW = H * W, hw = h * w, tid = threadIdx.x;
+    Carve c = carve_lds(smem, HW, dimg ? HW : 0, w, h);
+    const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    for (int b = blockIdx.x; b < n_img; b += gridDim.x) {
+        __syncthreads();
+        stage_to_lds(c.src, img + (size_t)b * HW, HW, vec4 != 0);
+        if (dimg) for (int p = tid; p < HW; p += ST_THREADS) c.aux[p] = 0.f;
+        for (int k = b; k < n; k += n_img) {
+            __syncthreads();
+            const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
+            const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
+            for (int a = tid; a < w + h; a += ST_THREADS) {
+                if (a < w) {
+                    const float X = lin_m11(a, w, stepx);
+                    c.X[a] = X;
+                    axis_entry(grid_coord(sx, X, tx, cxs), W, &c.fx[a], &c.dx[a]);
+                } else {
+                    const float Y = lin_m11(a - w, h, stepy);
+                    c.Y[a - w] = Y;
+                    axis_entry(grid_coord(sy, Y, ty, cys), H, &c.fy[a - w], &c.dy[a - w]);
+                }
+            }
+            __syncthreads();
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const float *g = dout + (size_t)k * hw;
+            for (int p = tid; p < hw; p += ST_THREADS) {
+                const int i = p / w, j = p - i * w;
+                const int fx = c.fx[j], fy = c.fy[i];
+                if (fx == ST_INVALID || fy == ST_INVALID) continue;
+                const float dx = c.dx[j], dy = c.dy[i], go = g[p];
+                const Taps t = load_taps(c.src, H, W, fy, fx);
+                const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
+                const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
+                const float ax = go * gx * cxs, ay = go * gy * cys;
+                acc[0] += ax * c.X[j]; acc[1] += ax;
+                acc[2] += ay * c.Y[i]; acc[3] += ay;
+                if (dimg) {
+                    const bool x0 = fx >= 0, x1 = fx + 1 <= W - 1, y0 = fy >= 0, y1 = fy + 1 <= H - 1;
+                    const int base = fy * W + fx;
+                    if (x0 && y0) atomicAdd(&c.aux[base], dx * dy * go);
+                    if (x1 && y0) atomicAdd(&c.aux[base + 1], (1.f - dx) * dy * go);
+                    if (x0 && y1) atomicAdd(&c.aux[base + W], dx * (1.f - dy) * go);
+                    if (x1 && y1) atomicAdd(&c.aux[base + W + 1], (1.f - dx) * (1.f - dy) * go);
+                }
+            }
+            block_sum<4>(acc, c.scratch);
+            if (tid == 0) {
+                float *d = dwhere + 4 * (size_t)k;
+                d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
+            }
+        }
+        if (dimg) {
+            __syncthreads();
+            for (int p = tid; p < HW; p += ST_THREADS) dimg[(size_t)b * HW + p] = c.aux[p];
+        }
+    }
+}
+
+// ============================================================================================================
+// write: canvas += presence * bilinear(glimpse; x_g = (w-1)/2*(X_J/sx - tx/sx + 1), y_g likewise)
+// One workgroup per image accumulates all T steps in LDS, optionally emitting every intermediate canvas and the
+// per-sample reconstruction term of the final canvas.
+// ============================================================================================================
+__global__ __launch_bounds__(ST_THREADS) void st_write_fwd_kernel(
+    const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
+    const float *__restrict__ canvas_in, const float *__restrict__ obs,
+    float *__restrict__ canvas_steps, float *__restrict__ final_canvas, float *__restrict__ rec,
+    int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, int vec4_canvas,
+    int vec4_glimpse) {
+    extern __shared__ __align__(16) float smem[];
+    const int HW = H * W, hw = h * w, tid = threadIdx.x;
+    Carve c = carve_lds(smem, hw, HW, W, H);           // src = glimpse tile, aux = running canvas
+    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        if (canvas_in) stage_to_lds(c.aux, canvas_in + (size_t)b * HW, HW, vec4_canvas != 0);
+        else for (int p = tid; p < HW; p += ST_THREADS) c.aux[p] = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            __syncthreads();                            // previous step finished with glimpse tile + tables
+            stage_to_lds(c.src, glimpse + k * hw, hw, vec4_glimpse != 0);
+            const float sx = where[4 * k + 0], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
+            const float ax = __fdiv_rn(1.0f, sx), bx = __fdiv_rn(-tx, sx);
+            const float ay = __fdiv_rn(1.0f, sy), by = __fdiv_rn(-ty, sy);
+            for (int a = tid; a < W + H; a += ST_THREADS) {
+                if (a < W) axis_entry(grid_coord(ax, lin_m11(a, W, stepX), bx, cxs), w, &c.fx[a], &c.dx[a]);
+                else axis_entry(grid_coord(ay, lin_m11(a - W, H, stepY), by, cys), h, &c.fy[a - W], &c.dy[a - W]);
+            }
+            __syncthreads();
+            const float pres = presence ? presence[k] : 1.0f;
+            float *steps_out = canvas_steps ? canvas_steps + k * HW : nullptr;
+            for (int p = tid; p < HW; p += ST_THREADS) {
+                const int I = p / W, J = p - I * W;
+                const int fx = c.fx[J], fy = c.fy[I];
+                float v = 0.f;
+                if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, h, w, fy, fx), c.dx[J], c.dy[I]);
+                const float cv = __fadd_rn(c.aux[p], __fmul_rn(pres, v));
+                c.aux[p] = cv;
+                if (steps_out) steps_out[p] = cv;
+            }
+        }
+        __syncthreads();
+        if (final_canvas) {
+            float *o = final_canvas + (size_t)b * HW;
+            if (vec4_canvas) {
+                float4 *o4 = reinterpret_cast<float4 *>(o);
+                const float4 *s4 = reinterpret_cast<const float4 *>(c.aux);
+                for (int q = tid; q < (HW >> 2); q += ST_THREADS) o4[q] = s4[q];
+            } else {
+                for (int p = tid; p < HW; p += ST_THREADS) o[p] = c.aux[p];
+            }
+        }
+        if (rec) {
+            const float *x = obs + (size_t)b * HW;
+            const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
+            float s[1] = {0.f};
+            for (int p = tid; p < HW; p += ST_THREADS) {
+                const float z = (x[p] - mult * c.aux[p]) / std;
+                s[0] += 0.5f * z * z + cst;
+            }
+            block_sum<1>(s, c.scratch);
+            if (tid == 0) rec[b] = s[0];
+        }
+    }
+}
+
+// Backward of the write for every (t, b): dglimpse, dwhere, optional dpresence.
+// dcanvas either given per step ([T*B,H,W]) or formed on the fly from the reconstruction term:
+//   dcanvas[b,p] = loss_scale * mult * (mult*final[b,p] - obs[b,p]) / std^2   (shared by all t)
+__global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
+    const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
+    const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
+    float *__restrict__ dglimpse, float *__restrict__ dwhere, float *__restrict__ dpresence,
+    int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, float loss_scale,
+    int vec4_glimpse) {
+    extern __shared__ __align__(16) float smem[];
+    const int HW = H * W, hw = h * w, tid = threadIdx.x;
+    Carve c = carve_lds(smem, hw, hw, W, H);           // src = glimpse tile, aux = dglimpse accumulator
+    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    const float coef = loss_scale * mult / (std * std);
+    const int n = T * B;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int b = k % B;
+        __syncthreads();
+        stage_to_lds(c.src, glimpse + (size_t)k * hw, hw, vec4_glimpse != 0);
+        for (int p = tid; p < hw; p += ST_THREADS) c.aux[p] = 0.f;
+        const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
+        const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
+        const float ax = __fdiv_rn(1.0f, sx), bx = __fdiv_rn(-tx, sx);
+        const float ay = __fdiv_rn(1.0f, sy), by = __fdiv_rn(-ty, sy);
+        for (int a = tid; a < W + H; a += ST_THREADS) {
+            if (a < W) {
+                const float X = lin_m11(a, W, stepX);
+                c.X[a] = X;
+                axis_entry(grid_coord(ax, X, bx, cxs), w, &c.fx[a], &c.dx[a]);
+            } else {
+                const float Y = lin_m11(a - W, H, stepY);
+                c.Y[a - W] = Y;
+                axis_entry(grid_coord(ay, Y, by, cys), h, &c.fy[a - W], &c.dy[a - W]);
+            }
+        }
+        __syncthreads();
+        const float pres = presence ? presence[k] : 1.0f;
+        const float *dc_ptr = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
+        const float *fc_ptr = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
+        const float *ob_ptr = obs ? obs + (size_t)b * HW : nullptr;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence
+        for (int p = tid; p < HW; p += ST_THREADS) {
+            const int I = p / W, J = p - I * W;
+            const int fx = c.fx[J], fy = c.fy[I];
+            if (fx == ST_INVALID || fy == ST_INVALID) continue;
+            const float dc = dc_ptr ? dc_ptr[p] : coef * (mult * fc_ptr[p] - ob_ptr[p]);
+            const float dx = c.dx[J], dy = c.dy[I];
+            const Taps t = load_taps(c.src, h, w, fy, fx);
+            const float v = bilerp(t, dx, dy);
+            const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
+            const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
+            const float go = pres * dc;
+            const float gax = go * gx * cxs, gay = go * gy * cys;
+            acc[0] += gax * c.X[J]; acc[1] += gax;
+            acc[2] += gay * c.Y[I]; acc[3] += gay;
+            acc[4] += dc * v;
+            const bool x0 = fx >= 0, x1 = fx + 1 <= w - 1, y0 = fy >= 0, y1 = fy + 1 <= h - 1;
+            const int base = fy * w + fx;
+            if (x0 && y0) atomicAdd(&c.aux[base], dx * dy * go);
+            if (x1 && y0) atomicAdd(&c.aux[base + 1], (1.f - dx) * dy * go);
+            if (x0 && y1) atomicAdd(&c.aux[base + w], dx * (1.f - dy) * go);
+            if (x1 && y1) atomicAdd(&c.aux[base + w + 1], (1.f - dx) * (1.f - dy) * go);
+        }
+        block_sum<5>(acc, c.scratch);                   // contains a __syncthreads: LDS atomics are complete after it
+        if (tid == 0) {
+            // chain through a = 1/s, b = -t/s
+            float *d = dwhere + 4 * (size_t)k;
+            d[0] = acc[0] * (-1.0f / (sx * sx)) + acc[1] * (tx / (sx * sx));
+            d[1] = acc[1] * (-1.0f / sx);
+            d[2] = acc[2] * (-1.0f / (sy * sy)) + acc[3] * (ty / (sy * sy));
+            d[3] = acc[3] * (-1.0f / sy);
+            if (dpresence) dpresence[k] = acc[4];
+        }
+        float *dg = dglimpse + (size_t)k * hw;
+        for (int p = tid; p < hw; p += ST_THREADS) dg[p] = c.aux[p];
+    }
+}
+
+// ============================================================================================================
+// host side
+// ============================================================================================================
+static inline double lin_step(int n) { return n > 1 ? 2.0 / (double)(n - 1) : 0.0; }
+static inline int st_grid(int items) {
+    const int cap = 256 * 8;   // 256 CUs x up to 8 resident 256-thread workgroups; grid-stride beyond that
+    return items < cap ? items : cap;
+}
+static inline int st_check_dims(int n, int H, int W, int h, int w) {
+    if (n <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return AIR_E_SHAPE;
+    return AIR_OK;
+}
+#define ST_MAX_LDS (160 * 1024)
+
+extern "C" int air_st_read_fwd(const float *img, const float *where, float *glimpse, int n, int n_img, int H, int W,
+                               int h, int w, void *stream) {
+    AIR_REQUIRE(img && where && glimpse, AIR_E_NULL);
+    int st = st_check_dims(n, H, W, h, w);
+    if (st) return st;
+    AIR_REQUIRE(n_img > 0 && n % n_img == 0, AIR_E_SHAPE);
+    const size_t lds = carve_bytes(H * W, 0, w, h);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
+    hipLaunchKernelGGL(st_read_fwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
+                       glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+extern "C" int air_st_read_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere,
+                               float *dimg, int n, int n_img, int H, int W, int h, int w, void *stream) {
+    AIR_REQUIRE(img && where && dglimpse && dwhere, AIR_E_NULL);
+    int st = st_check_dims(n, H, W, h, w);
+    if (st) return st;
+    AIR_REQUIRE(n_img > 0 && n % n_img == 0, AIR_E_SHAPE);
+    AIR_REQUIRE(!dimg || n_img == n, AIR_E_UNSUPPORTED);
+    const size_t lds = carve_bytes(H * W, dimg ? H * W : 0, w, h);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
+    hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
+                       dglimpse, dwhere, dimg, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+static int launch_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
+                            const float *obs, float *canvas_steps, float *final_canvas, float *rec, int T, int B,
+                            int H, int W, int h, int w, float mult, float std, void *stream) {
+    const size_t lds = carve_bytes(h * w, H * W, W, H);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    const int vec4c = ((H * W) % 4 == 0) && (!canvas_in || air_aligned16(canvas_in)) &&
+                      (!final_canvas || air_aligned16(final_canvas));
+    const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid(B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse, where,
+                       presence, canvas_in, obs, canvas_steps, final_canvas, rec, T, B, H, W, h, w, lin_step(W),
+                       lin_step(H), mult, std, vec4c, vec4g);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+extern "C" int air_st_write_fwd(const float *glimpse, const float *where, const float *presence,
+                                const float *canvas_in, float *canvas_out, int n, int H, int W, int h, int w,
+                                void *stream) {
+    AIR_REQUIRE(glimpse && where && canvas_out, AIR_E_NULL);
+    int st = st_check_dims(n, H, W, h, w);
+    if (st) return st;
+    return launch_write_fwd(glimpse, where, presence, canvas_in, nullptr, nullptr, canvas_out, nullptr, 1, n, H, W, h,
+                            w, 1.0f, 1.0f, stream);
+}
+
+extern "C" int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence,
+                                     const float *obs, float *canvas_steps, float *final_canvas,
+                                     float *rec_per_sample, int T, int B, int H, int W, int h, int w, float mult,
+                                     float std, void *stream) {
+    AIR_REQUIRE(glimpse && where && (final_canvas || canvas_steps), AIR_E_NULL);
+    AIR_REQUIRE(!rec_per_sample || obs, AIR_E_NULL);
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_per_sample, T, B,
+                            H, W, h, w, mult, std, stream);
+}
+
+static int launch_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
+                            const float *final_canvas, const float *obs, float *dglimpse, float *dwhere,
+                            float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
+                            float loss_scale, void *stream) {
+    const size_t lds = carve_bytes(h * w, h * w, W, H);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse,
+                       where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
+                       lin_step(W), lin_step(H), mult, std, loss_scale, vec4g);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+extern "C" int air_st_write_bwd(const float *glimpse, const float *where, const float *presence,
+                                const float *dcanvas, float *dglimpse, float *dwhere, float *dpresence, int n, int H,
+                                int W, int h, int w, void *stream) {
+    AIR_REQUIRE(glimpse && where && dcanvas && dglimpse && dwhere, AIR_E_NULL);
+    int st = st_check_dims(n, H, W, h, w);
+    if (st) return st;
+    return launch_write_bwd(glimpse, where, presence, dcanvas, nullptr, nullptr, dglimpse, dwhere, dpresence, 1, n, H,
+                            W, h, w, 1.0f, 1.0f, 1.0f, stream);
+}
+
+extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence,
+                                     const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
+                                     int T, int B, int H, int W, int h, int w, float mult, float std,
+                                     float loss_scale, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && final_canvas && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
+                            h, w, mult, std, loss_scale, stream);
+}

@@ -1,0 +1,213 @@
+/* air_hip.h -- C ABI of libair_hip.so: the MI355X (gfx950) kernels of the AIR hot path.
+ *
+ * The reference (akosiorek/attend_infer_repeat) has no FFI of its own: its only native operator boundary is the TF
+ * custom-op pair behind `snt.resampler(data, warp)` (attend_infer_repeat/modules.py:109) and the TF/Eigen kernels
+ * behind snt.Linear / snt.LSTM / tf.contrib.distributions.  Each entry point below replaces one of those op groups;
+ * the comment on each cites the reference call site it stands in for.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C"; returns int: 0 = ok, <0 = AIR_E_* argument error, >0 = hipError_t of the failed launch.
+ *   - every pointer is a DEVICE pointer to contiguous row-major float32 unless stated (`*_f64`: double, `host`).
+ *   - the caller owns every buffer, including workspaces; nothing is allocated, no host sync, no global state
+ *     => re-entrant and hipGraph-capturable.  `stream` is a hipStream_t passed as void*.
+ *   - `where` rows are [sx, tx, sy, ty] (modules.py:41-46, evaluation.py:23-28).
+ */
+#ifndef AIR_HIP_H
+#define AIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIR_ABI_VERSION 1
+
+enum {
+    AIR_OK = 0,
+    AIR_E_NULL = -1,      /* required pointer is NULL */
+    AIR_E_SHAPE = -2,     /* non-positive / inconsistent dimension */
+    AIR_E_ALIGN = -3,     /* pointer or leading dimension violates an alignment requirement */
+    AIR_E_WORKSPACE = -4, /* workspace too small */
+    AIR_E_UNSUPPORTED = -5
+};
+
+enum { AIR_ACT_NONE = 0, AIR_ACT_ELU = 1 };
+
+/* GEMM epilogues (air_gemm): applied to acc = op(A).op(B) (+ beta*C) */
+enum {
+    AIR_EPI_NONE = 0,
+    AIR_EPI_BIAS = 1,        /* + bias[n]                                    snt.Linear, neural.py:56-60          */
+    AIR_EPI_BIAS_ELU = 2,    /* elu(acc + bias[n])                           Affine(transfer=elu), neural.py:58-59 */
+    AIR_EPI_MUL_DELU = 3,    /* acc * elu'(aux[m,n]) with aux = saved elu OUTPUT (y>0 ? 1 : y+1): backward of ELU  */
+    AIR_EPI_ADD_AUX = 4      /* acc + aux[m,n] (+ bias[n] if given)          LSTM: x.Wx hoisted, h.Wh added        */
+};
+
+int air_abi_version(void);
+const char *air_status_string(int status);
+
+/* ---- spatial transformer ------------------------------------------------------------------------------------
+ * Replaces snt.AffineGridWarper + snt.resampler (+ registered gradient) at modules.py:100-109.                     */
+
+/* Glimpse read, cell.py:135.  glimpse[k] = bilinear(img[k % n_img], grid(where[k])), k < n.
+ * n_img == n for one image per glimpse; n = T*n_img when T glimpses are read from each image (batched unroll).   */
+int air_st_read_fwd(const float *img, const float *where, float *glimpse,
+                    int n, int n_img, int H, int W, int h, int w, void *stream);
+/* dwhere[n,4] always; dimg[n_img,H,W] optional (NULL to skip; requires n_img == n).                               */
+int air_st_read_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere, float *dimg,
+                    int n, int n_img, int H, int W, int h, int w, void *stream);
+
+/* Canvas write, cell.py:159-165: canvas_out[k] = canvas_in[k] + presence[k] * inverse_warp(glimpse[k], where[k]).
+ * canvas_in may be NULL (zeros) or alias canvas_out; presence may be NULL (ones).                                  */
+int air_st_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
+                     float *canvas_out, int n, int H, int W, int h, int w, void *stream);
+/* Gradients of the above wrt glimpse, where and (optionally, NULL to skip) presence given dcanvas[n,H,W].         */
+int air_st_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
+                     float *dglimpse, float *dwhere, float *dpresence,
+                     int n, int H, int W, int h, int w, void *stream);
+
+/* Fused T-step canvas accumulation + reconstruction term (cell.py:159-165 over dynamic_rnn model.py:83-84, then
+ * model.py:92-97, 319-324).  glimpse[T,B,h,w], where[T,B,4], presence[T,B] time-major.
+ *   canvas_steps[T,B,H,W] (optional): running canvas after each step, UNscaled.
+ *   final_canvas[B,H,W]: canvas after T steps, UNscaled.
+ *   rec_per_sample[B] (optional, needs obs): sum_pix -log N(obs | mult*canvas, std).                              */
+int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+                          float *canvas_steps, float *final_canvas, float *rec_per_sample,
+                          int T, int B, int H, int W, int h, int w, float mult, float std, void *stream);
+/* Backward of mean_b(rec_per_sample) * loss_scale through the fused op: dcanvas is formed on the fly from
+ * (final_canvas, obs).  Outputs dglimpse[T,B,h,w], dwhere[T,B,4].                                                  */
+int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+                          const float *final_canvas, float *dglimpse, float *dwhere,
+                          int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
+                          void *stream);
+
+/* ---- dense layers -------------------------------------------------------------------------------------------
+ * Replaces the TF MatMul/BiasAdd/Elu nodes under snt.Linear (neural.py:42-60) and snt.LSTM (mnist_model.py:35).   */
+
+/* C[M,N] = epi( op(A)[M,K] . op(B)[K,N] + beta*C ).  ta==0: A is [M,K] (lda); ta!=0: A is stored [K,M].
+ * tb==0: B is [K,N] (ldb); tb!=0: B is stored [N,K].  fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32 accumulate.
+ * bias[N] / aux[M,N](ldaux) as required by `epilogue`.  If colsum != NULL (only with ta!=0): colsum[n] = sum_k
+ * op(B)[k,n] (bias gradient fused into the dW GEMM).  ws / ws_bytes: optional split-K workspace (may be NULL).    */
+int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+             float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
+             float *colsum, void *ws, size_t ws_bytes, void *stream);
+size_t air_gemm_workspace_bytes(int M, int N, int K);
+
+/* y = act(x.w + b), neural.py:56-60.  x[M,K], w[K,N] (Sonnet layout), b[N] (may be NULL), y[M,N].                 */
+int air_linear_fwd(const float *x, const float *w, const float *b, float *y, int M, int K, int N, int act,
+                   void *ws, size_t ws_bytes, void *stream);
+/* Backward: g = dy * act'(y); dx = g.w^T (NULL to skip); dw = x^T.g; db = colsum(g) (NULL to skip).
+ * gbuf[M,N] is required when act != AIR_ACT_NONE (holds g).                                                        */
+int air_linear_bwd(const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db,
+                   float *gbuf, int M, int K, int N, int act, void *ws, size_t ws_bytes, void *stream);
+
+/* LSTM pointwise, Sonnet v1 gate order i,j,f,o (cell.py:126-127): c' = sig(f+fb)*c + sig(i)*tanh(j);
+ * h' = tanh(c')*sig(o).  gates[M,4H] pre-activation; gate_act[M,4H] receives the activated gates (saved for bwd). */
+int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, float *c, float *gate_act,
+                           int M, int Hd, float forget_bias, void *stream);
+/* dgates[M,4H], dc_prev[M,H] from dh[M,H] and (optional) dc[M,H] flowing in from step t+1.                        */
+int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
+                           const float *dc, float *dgates, float *dc_prev, int M, int Hd, void *stream);
+
+/* ---- stochastic nodes ---------------------------------------------------------------------------------------*/
+
+/* Reparameterised Gaussian + KL to a fixed Normal prior.  Replaces NormalWithSoftplusScale(...).sample() at
+ * cell.py:130-133 / 154-156 (modules.py:17-24, 41-46, 58-63) and _kl(Normal, Normal) at model.py:174-209.
+ *   pre[M,ld_pre]: columns [0,D) = loc pre-activation, [D,2D) = raw scale.
+ *   loc_mode 0: loc = pre;  1: loc = [sigmoid,tanh,sigmoid,tanh,...] (TransformParam._transform).
+ *   scale = softplus(raw + raw_offset); sample = loc + scale*eps.
+ *   kl_row[M] (optional) = sum_d KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])); prior4 = {loc_even, scale_even,
+ *   loc_odd, scale_odd} passed by value (where: even dims = scale prior, odd = shift prior; what: both equal).     */
+int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                         float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
+                         float *loc, float *scale, float *sample, float *kl_row, int M, int D, void *stream);
+/* dpre[M,ld_dpre] (both halves) from dsample[M,D] (may be NULL) and dkl_row[M] (may be NULL).                     */
+int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                         float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
+                         const float *loc, const float *scale, const float *dsample, const float *dkl_row,
+                         float *dpre, int ld_dpre, int M, int D, void *stream);
+
+/* Presence, cell.py:137-151: p = sigmoid(logit + step_bias); if explore_eps >= 0: p = eps/2 + (1-eps)*p;
+ * discrete: z = (u < p), presence[t] = presence[t-1]*z (presence[-1] = presence_in or 1); else presence = p.
+ * logit/u/presence_prob/presence are [T,B] time-major (T = 1 for a single cell step).                              */
+int air_presence_fwd(const float *logit, const float *u, const float *presence_in, float step_bias,
+                     float explore_eps, int discrete, float *presence_prob, float *presence, int T, int B,
+                     void *stream);
+/* dlogit[T,B] from dpresence_prob[T,B] (and dpresence[T,B] when !discrete; NULL otherwise).                        */
+int air_presence_bwd(const float *logit, float step_bias, float explore_eps, int discrete,
+                     const float *dpresence_prob, const float *dpresence, float *dlogit, int T, int B, void *stream);
+
+/* ---- objective ----------------------------------------------------------------------------------------------*/
+
+/* Reconstruction term, model.py:319-324: per_sample[b] = sum_p 0.5*((obs-mult*canvas)/std)^2 + 0.5*log(2pi)+log(std) */
+int air_rec_loglik_fwd(const float *obs, const float *canvas, float mult, float std, float *per_sample,
+                       int B, int P, void *stream);
+/* dcanvas[b,p] = dper_sample[b] * mult*(mult*canvas-obs)/std^2  (dper_sample NULL => uniform `scale`)             */
+int air_rec_loglik_bwd(const float *obs, const float *canvas, float mult, float std, const float *dper_sample,
+                       float scale, float *dcanvas, int B, int P, void *stream);
+
+/* Number-of-steps posterior and its KL (prior.py:62-151, model.py:139-163), evaluated in float64 like the reference.
+ *   presence_prob[T,B], presence[T,B] (sampled, cumulative); prior_f64[T+1] DEVICE doubles = geometric_prior(...).
+ *   q[B,T+1]; kl_per_sample[B] = sum_n tabular_kl; logp[B] = log max(q[b, sum_t presence], 1e-32);
+ *   step_weight[T,B] = sum_{n>t} q(n).                                                                             */
+int air_numsteps_fwd(const float *presence_prob, const float *presence, const double *prior_f64, float *q,
+                     float *kl_per_sample, float *logp, float *step_weight, int T, int B, void *stream);
+/* dpresence_prob[T,B] of  kl_scale*sum_b kl_per_sample[b] + sum_{t,b} dstep_weight[t,b]*step_weight[t,b]
+ *                         + sum_b dlogp[b]*logp[b]   (dstep_weight / dlogp may be NULL).                           */
+int air_numsteps_bwd(const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
+                     const float *dstep_weight, const float *dlogp, float *dpresence_prob, int T, int B,
+                     void *stream);
+
+/* NVIL / REINFORCE with the reference's [B]-[B,1]->[B,B] broadcast (model.py:218-259).
+ *   imp[B] (= rec_loss_per_sample), baseline[B], logp[B].
+ *   out[4] = {reinforce_loss, baseline_loss, imp_weight_mean, imp_weight_var};
+ *   dlogp[B] = d reinforce_loss / d logp; dbaseline[B] = d baseline_loss / d baseline.                              */
+int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
+             float *dbaseline, int B, void *stream);
+
+/* Baseline input assembly, modules.py:131-139: out[B, HW + T*A + T*4 + T + S] =
+ * [img | what (batch-major) | where | presence | state] from time-major what[T,B,A], where[T,B,4], presence[T,B],
+ * state[B,S] = concat of up to two state parts (h, c).                                                              */
+int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
+                      const float *state0, const float *state1, float *out, int T, int B, int P, int A, int S0,
+                      int S1, void *stream);
+
+/* ---- optimiser ----------------------------------------------------------------------------------------------
+ * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;
+ * mom<-m*mom + lr*g/sqrt(ms-mg^2+eps); p<-p-mom.  lr = *lr_dev * lr_mult (lr_dev: device float, graph-safe).
+ * grad_scale multiplies g first (1/world_size after an all-reduce sum).                                            */
+int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev,
+                         float lr_mult, float decay, float momentum, float eps, float grad_scale, void *stream);
+
+/* ---- noise --------------------------------------------------------------------------------------------------
+ * Philox4x32-10 counter RNG (replaces TF's sampler ops behind .sample(), cell.py:133,147,156).
+ * normal[n_normal] ~ N(0,1), uniform[n_uniform] ~ U[0,1).  state_dev[2] = {seed, offset} DEVICE uint64; the
+ * offset is advanced by air_rng_advance (separate launch, so a captured graph draws fresh noise per replay).      */
+int air_rng_fill(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *state_dev,
+                 void *stream);
+int air_rng_advance(uint64_t *state_dev, uint64_t increment, void *stream);
+
+/* ---- small utilities ---------------------------------------------------------------------------------------*/
+int air_fill(float *p, size_t n, float v, void *stream);
+/* out[m, n] = a[m, n] * row_scale[m]  (+ b[m,n] if b) : used for weighting per-row KL gradients etc.              */
+int air_axpby(const float *a, float alpha, const float *b, float beta, float *out, size_t n, void *stream);
+/* broadcast rows: out[r, :] = src[0, :] for r < rows (tiling the trainable LSTM initial state, cell.py:103)       */
+int air_tile_rows(const float *src, float *out, int rows, int cols, void *stream);
+int air_colsum(const float *x, int ld, float *out, int M, int N, void *stream);   /* out[n] = sum_m x[m,n] */
+
+/* ---- hipGraph capture + timing helpers (plumbing for bench / the fused train step) --------------------------*/
+int air_graph_begin_capture(void *stream);
+int air_graph_end_capture(void *stream, void **graph_exec_out);
+int air_graph_launch(void *graph_exec, void *stream);
+int air_graph_destroy(void *graph_exec);
+int air_event_create(void **event_out);
+int air_event_record(void *event, void *stream);
+int air_event_elapsed_ms(void *start, void *stop, float *ms_host_out);   /* synchronises on `stop` */
+int air_event_destroy(void *event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIR_HIP_H */

@@ -1,0 +1,443 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle on seeded inputs (run with -m gpu on an MI355X).
+
+Tolerances (fp32): forward ST is bit-exact (same op order, explicitly rounded); everything that reduces in a different
+order is checked to rtol 2e-5..1e-4 against an fp64 evaluation of the oracle, scaled by the magnitude of the terms."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import air_oracle as O
+from oracle import st_loops as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(gpu_device):
+    from attend_infer_repeat_amd import hip as H
+    H.lib()
+    return H
+
+
+def g(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def rand_where(B, rng, wide=False):
+    sx = rng.uniform(0.2, 1.4, B) * (rng.choice([-1, 1], B) if wide else 1)
+    sy = rng.uniform(0.2, 1.4, B)
+    return np.stack([sx, rng.uniform(-0.8, 0.8, B), sy, rng.uniform(-0.8, 0.8, B)], 1).astype(np.float32)
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{what}: max err {err.max():.3e} (tol {tol.flat[err.argmax()]:.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# spatial transformer
+# ---------------------------------------------------------------------------------------------------------------
+ST_SHAPES = [(50, 50, 20, 20), (100, 100, 28, 28), (7, 5, 3, 4), (3, 3, 2, 2), (9, 11, 9, 11)]
+
+
+@pytest.mark.parametrize("H,W,h,w", ST_SHAPES)
+def test_st_read_fwd_bit_exact(hip, H, W, h, w):
+    rng = np.random.default_rng(0)
+    B = 9
+    img = rng.random((B, H, W)).astype(np.float32)
+    where = rand_where(B, rng, wide=True)
+    ref = C.st_read_fwd(img, where, (h, w))
+    out = hip.st_read_fwd(g(img), g(where), (h, w)).cpu().numpy()
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_st_read_fwd_batched_over_steps(hip):
+    """T glimpses per image (row k reads image k % n_img): the engine's batched unroll."""
+    rng = np.random.default_rng(1)
+    B, T, H, W, h, w = 5, 3, 50, 50, 20, 20
+    img = rng.random((B, H, W)).astype(np.float32)
+    where = rand_where(T * B, rng)
+    ref = C.st_read_fwd(np.tile(img, (T, 1, 1)), where, (h, w))
+    out = hip.st_read_fwd(g(img), g(where), (h, w)).cpu().numpy()
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_st_read_identity_and_outside(hip):
+    img = torch.rand(3, 9, 11)
+    ident = torch.tensor([[1., 0., 1., 0.]] * 3)
+    out = hip.st_read_fwd(img.cuda(), ident.cuda(), (9, 11)).cpu()
+    assert torch.allclose(out, img, atol=1e-6)
+    far = torch.tensor([[0.1, 5.0, 0.1, 0.0]] * 3)
+    assert hip.st_read_fwd(img.cuda(), far.cuda(), (4, 4)).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4])
+def test_st_read_bwd(hip, H, W, h, w):
+    rng = np.random.default_rng(2)
+    B = 7
+    img = rng.random((B, H, W)).astype(np.float32)
+    where = rand_where(B, rng)
+    dout = rng.standard_normal((B, h, w)).astype(np.float32)
+    dwhere64, dimg64 = C.st_read_bwd(img.astype(np.float64), where.astype(np.float64), dout.astype(np.float64))
+    dwhere, dimg = hip.st_read_bwd(g(img), g(where), g(dout), want_dimg=True)
+    scale = np.abs(dout).sum((1, 2))[:, None] * max(H, W) / 2 * 0.05 + 1.0
+    assert_close(dwhere.cpu().numpy() / scale, dwhere64 / scale, 1e-4, 2e-5, "dwhere")
+    assert_close(dimg, dimg64, 1e-4, 1e-5, "dimg")
+    dwhere2, none = hip.st_read_bwd(g(img), g(where), g(dout), want_dimg=False)
+    assert none is None
+    assert_close(dwhere2, dwhere, 1e-6, 1e-6, "dwhere w/o dimg")
+
+
+@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4])
+def test_st_write_fwd_bit_exact(hip, H, W, h, w):
+    rng = np.random.default_rng(3)
+    B = 8
+    glm = rng.standard_normal((B, h, w)).astype(np.float32)
+    where = rand_where(B, rng, wide=True)
+    pres = rng.integers(0, 2, B).astype(np.float32)
+    canvas = rng.standard_normal((B, H, W)).astype(np.float32)
+    inv = C.st_write_fwd(glm, where, (H, W))
+    ref = canvas + pres[:, None, None] * inv
+    out = hip.st_write_fwd(g(glm), g(where), (H, W), presence=g(pres), canvas_in=g(canvas)).cpu().numpy()
+    np.testing.assert_array_equal(out, ref.astype(np.float32))
+    out0 = hip.st_write_fwd(g(glm), g(where), (H, W)).cpu().numpy()          # no presence, zero canvas
+    np.testing.assert_array_equal(out0, inv)
+
+
+def test_st_write_degenerate_scales(hip):
+    glm = torch.rand(3, 4, 4)
+    where = torch.tensor([[-0.5, 0.1, 0.7, 0.0], [0.0, 0.0, 1.0, 0.0], [1e-30, 0.3, 1.0, 0.0]])
+    ref = C.st_write_fwd(glm.numpy(), where.numpy(), (8, 8))
+    out = hip.st_write_fwd(glm.cuda(), where.cuda(), (8, 8)).cpu().numpy()
+    np.testing.assert_array_equal(np.nan_to_num(out, nan=12345.0), np.nan_to_num(ref, nan=12345.0))
+
+
+@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4])
+def test_st_write_bwd(hip, H, W, h, w):
+    rng = np.random.default_rng(4)
+    B = 6
+    glm = rng.standard_normal((B, h, w)).astype(np.float32)
+    where = rand_where(B, rng, wide=True)
+    pres = rng.uniform(0.2, 1.0, B).astype(np.float32)
+    dout = rng.standard_normal((B, H, W)).astype(np.float32)
+    tg = torch.tensor(glm, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(where, dtype=torch.float64, requires_grad=True)
+    tp = torch.tensor(pres, dtype=torch.float64, requires_grad=True)
+    out = tp[:, None, None] * O.st_write(tg, tw, (H, W))
+    gg, gw, gp = torch.autograd.grad((out * torch.tensor(dout, dtype=torch.float64)).sum(), [tg, tw, tp])
+    dg, dwhere, dpres = hip.st_write_bwd(g(glm), g(where), g(dout), presence=g(pres), want_dpresence=True)
+    assert_close(dg, gg, 1e-4, 1e-4, "dglimpse")
+    scale = gw.abs().max(1, keepdim=True)[0].numpy() + 1.0
+    assert_close(dwhere.cpu().numpy() / scale, gw.numpy() / scale, 2e-4, 2e-5, "dwhere")
+    assert_close(dpres, gp, 1e-4, 1e-3, "dpresence")
+
+
+def test_canvas_unroll_fwd_bwd(hip):
+    rng = np.random.default_rng(5)
+    T, B, H, W, h, w = 3, 6, 50, 50, 20, 20
+    glm = rng.standard_normal((T, B, h, w)).astype(np.float32)
+    where = rand_where(T * B, rng).reshape(T, B, 4)
+    pres = np.cumprod(rng.integers(0, 2, (T, B)), 0).astype(np.float32)
+    pres[:, 0] = 1.0
+    obs = rng.random((B, H, W)).astype(np.float32)
+    mult, std = 0.5, 0.3
+    # oracle: sequential accumulation
+    canvas = np.zeros((B, H, W), np.float32)
+    steps = []
+    for t in range(T):
+        canvas = canvas + pres[t][:, None, None] * C.st_write_fwd(glm[t], where[t], (H, W))
+        steps.append(canvas.copy())
+    st, final, rec = hip.canvas_unroll_fwd(g(glm), g(where), g(pres), (H, W), obs=g(obs), mult=mult, std=std)
+    np.testing.assert_array_equal(st.cpu().numpy(), np.stack(steps))
+    np.testing.assert_array_equal(final.cpu().numpy(), steps[-1])
+    tg = torch.tensor(glm, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(where, dtype=torch.float64, requires_grad=True)
+    cv = sum(torch.tensor(pres[t], dtype=torch.float64)[:, None, None] * O.st_write(tg[t], tw[t], (H, W)) for t in range(T))
+    nll = 0.5 * ((torch.tensor(obs, dtype=torch.float64) - mult * cv) / std) ** 2 + 0.5 * np.log(2 * np.pi) + np.log(std)
+    rec64 = nll.sum((1, 2))
+    assert_close(rec, rec64, 1e-5, 1e-3, "rec_per_sample")
+    gg, gw = torch.autograd.grad(rec64.mean(), [tg, tw])
+    dg, dwhere = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, mult, std, 1.0 / B)
+    assert_close(dg, gg, 2e-4, 1e-4 * gg.abs().max().item(), "dglimpse")
+    scale = gw.abs().amax(-1, keepdim=True).numpy() + 1.0
+    assert_close(dwhere.cpu().numpy() / scale, gw.numpy() / scale, 5e-4, 5e-5, "dwhere")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GEMM / linear / LSTM
+# ---------------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(64, 256, 2500), (192, 256, 400), (10, 5, 9), (64, 8, 256), (192, 1, 64), (64, 100, 256),
+               (64, 400, 256), (3, 17, 3), (64, 256, 3177), (192, 256, 50), (33, 47, 129), (2048, 256, 400)]
+
+
+def _gemm_ref(A, B, ta, tb):
+    a = A.double().cpu(); b = B.double().cpu()
+    return (a.t() if ta else a) @ (b.t() if tb else b)
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_all_layouts(hip, M, N, K, ta, tb):
+    gen = torch.Generator().manual_seed(M * 131 + N * 17 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=gen).cuda()
+    B = torch.randn((N, K) if tb else (K, N), generator=gen).cuda()
+    ref = _gemm_ref(A, B, ta, tb)
+    out = hip.gemm(A, B, ta=bool(ta), tb=bool(tb))
+    assert_close(out, ref, 1e-5, 2e-6 * K ** 0.5 * 4, f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
+    out2 = hip.gemm(A, B, ta=bool(ta), tb=bool(tb), use_workspace=False)       # no split-K path
+    assert_close(out2, ref, 1e-5, 2e-6 * K ** 0.5 * 4, "gemm no-workspace")
+
+
+def test_gemm_transpose_detecting_identity(hip):
+    """A = I with an asymmetric B catches row/col swaps in the C write."""
+    B = torch.arange(48 * 40, dtype=torch.float32).reshape(48, 40).cuda()
+    out = hip.gemm(torch.eye(48).cuda(), B)
+    assert torch.equal(out, B)
+
+
+def test_gemm_epilogues_views_beta_colsum(hip):
+    gen = torch.Generator().manual_seed(7)
+    M, N, K = 70, 45, 133
+    big = torch.randn(M, K + 11, generator=gen).cuda()
+    A = big[:, 3:3 + K]                                   # row view with a leading dimension, unaligned start
+    Bm = torch.randn(K, N, generator=gen).cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    aux = torch.randn(M, N, generator=gen).cuda()
+    ref = A.double().cpu() @ Bm.double().cpu()
+    assert_close(hip.gemm(A, Bm, bias=bias, epilogue=hip.EPI_BIAS), ref + bias.double().cpu(), 1e-5, 1e-4, "bias")
+    elu = torch.nn.functional.elu(ref + bias.double().cpu())
+    assert_close(hip.gemm(A, Bm, bias=bias, epilogue=hip.EPI_BIAS_ELU), elu, 1e-5, 1e-4, "bias+elu")
+    y = aux
+    d = torch.where(y > 0, torch.ones_like(y), y + 1).double().cpu()
+    assert_close(hip.gemm(A, Bm, aux=aux, epilogue=hip.EPI_MUL_DELU), ref * d, 1e-5, 1e-4, "mul delu")
+    assert_close(hip.gemm(A, Bm, aux=aux, bias=bias, epilogue=hip.EPI_ADD_AUX), ref + aux.double().cpu() + bias.double().cpu(),
+                 1e-5, 1e-4, "add aux")
+    C0 = torch.randn(M, N, generator=gen).cuda()
+    out = hip.gemm(A, Bm, beta=1.0, out=C0.clone())
+    assert_close(out, ref + C0.double().cpu(), 1e-5, 1e-4, "beta")
+    X = torch.randn(64, 300, generator=gen).cuda(); G = torch.randn(64, 40, generator=gen).cuda()
+    dw, cs = hip.gemm(X, G, ta=True, colsum=True)
+    assert_close(dw, X.double().cpu().t() @ G.double().cpu(), 1e-5, 1e-4, "dW")
+    assert_close(cs, G.double().cpu().sum(0), 1e-5, 1e-5, "colsum")
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 2500, 256), (192, 400, 256), (10, 9, 5), (192, 64, 1), (64, 50, 256)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_fwd_bwd(hip, M, K, N, act):
+    gen = torch.Generator().manual_seed(M + K + N + act)
+    x = torch.randn(M, K, generator=gen); w = torch.randn(K, N, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen); dy = torch.randn(M, N, generator=gen)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y64 = O.affine(x64, w64, b64, elu=bool(act))
+    gx, gw, gb = torch.autograd.grad((y64 * dy.double()).sum(), [x64, w64, b64])
+    y = hip.linear_fwd(x.cuda(), w.cuda(), b.cuda(), act)
+    assert_close(y, y64, 2e-5, 2e-5, "linear fwd")
+    dx, dw, db = hip.linear_bwd(x.cuda(), w.cuda(), y, dy.cuda(), act)
+    assert_close(dx, gx, 1e-4, 1e-4, "dx"); assert_close(dw, gw, 1e-4, 2e-4, "dw"); assert_close(db, gb, 1e-4, 1e-4, "db")
+
+
+def test_lstm_pointwise(hip):
+    gen = torch.Generator().manual_seed(11)
+    M, Hd = 37, 50
+    gates = torch.randn(M, 4 * Hd, generator=gen); c0 = torch.randn(M, Hd, generator=gen)
+    dh = torch.randn(M, Hd, generator=gen); dc = torch.randn(M, Hd, generator=gen)
+    g64 = gates.double().requires_grad_(True); c64 = c0.double().requires_grad_(True)
+    i, j, f, o = torch.chunk(g64, 4, -1)
+    c2 = torch.sigmoid(f + 1.0) * c64 + torch.sigmoid(i) * torch.tanh(j)
+    h2 = torch.tanh(c2) * torch.sigmoid(o)
+    gg, gc = torch.autograd.grad((h2 * dh.double()).sum() + (c2 * dc.double()).sum(), [g64, c64])
+    h, c, act = hip.lstm_pointwise_fwd(gates.cuda(), c0.cuda(), 1.0)
+    assert_close(h, h2, 1e-5, 1e-6, "h"); assert_close(c, c2, 1e-5, 1e-6, "c")
+    dgates, dc_prev = hip.lstm_pointwise_bwd(act, c0.cuda(), c, dh.cuda(), dc.cuda())
+    assert_close(dgates, gg, 1e-4, 1e-5, "dgates"); assert_close(dc_prev, gc, 1e-4, 1e-5, "dc_prev")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stochastic nodes + objective
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,loc_mode,off,prior4", [(50, 0, 0.5, (0., 1., 0., 1.)), (4, 1, 0.5, (0.3, 1.5, -0.2, 0.7)),
+                                                    (10, 0, -2.0, (0., 1., 0., 1.))])
+def test_gauss_sample_fwd_bwd(hip, D, loc_mode, off, prior4):
+    gen = torch.Generator().manual_seed(D)
+    M = 41
+    wide = torch.randn(M, 2 * D + 3, generator=gen)
+    pre = wide[:, :2 * D]
+    eps = torch.randn(M, D, generator=gen); dsample = torch.randn(M, D, generator=gen); dkl = torch.randn(M, generator=gen)
+    p64 = pre.double().requires_grad_(True)
+    loc = p64[:, :D]
+    if loc_mode == 1:
+        idx = torch.arange(D)
+        loc = torch.where(idx % 2 == 1, torch.tanh(loc), torch.sigmoid(loc))
+    scale = torch.nn.functional.softplus(p64[:, D:] + off)
+    sample = loc + scale * eps.double()
+    pl = torch.tensor([prior4[0] if d % 2 == 0 else prior4[2] for d in range(D)], dtype=torch.float64)
+    ps = torch.tensor([prior4[1] if d % 2 == 0 else prior4[3] for d in range(D)], dtype=torch.float64)
+    kl = O.normal_kl(loc, scale, pl, ps).sum(-1)
+    gp, = torch.autograd.grad((sample * dsample.double()).sum() + (kl * dkl.double()).sum(), [p64])
+    pre_gpu = wide.cuda()[:, :2 * D]
+    l, s, smp, k = hip.gauss_sample_fwd(pre_gpu, eps.cuda(), off, loc_mode, prior4)
+    assert_close(l, loc, 1e-5, 1e-6, "loc"); assert_close(s, scale, 1e-5, 1e-6, "scale")
+    assert_close(smp, sample, 1e-5, 1e-5, "sample"); assert_close(k, kl, 1e-5, 1e-4, "kl")
+    dpre = hip.gauss_sample_bwd(pre_gpu, eps.cuda(), off, loc_mode, prior4, l, s, dsample.cuda(), dkl.cuda())
+    assert_close(dpre, gp, 1e-4, 1e-5, "dpre")
+
+
+def test_presence(hip):
+    gen = torch.Generator().manual_seed(3)
+    T, B = 3, 300
+    logit = torch.randn(T, B, generator=gen); u = torch.rand(T, B, generator=gen)
+    p = 1e-3 / 2 + (1 - 1e-3) * torch.sigmoid(logit.double() + 0.75)
+    z = (u.double() < p).double()
+    pres = torch.cumprod(z, 0)
+    prob, pr = hip.presence_fwd(logit.cuda(), u.cuda(), 0.75, 1e-3, True)
+    assert_close(prob, p, 1e-6, 1e-7, "prob")
+    agree = (pr.cpu().double() == pres).float().mean().item()
+    assert agree > 0.995                                                     # u within 1 ulp of p may flip
+    dprob = torch.randn(T, B, generator=gen)
+    l64 = logit.double().requires_grad_(True)
+    p64 = 1e-3 / 2 + (1 - 1e-3) * torch.sigmoid(l64 + 0.75)
+    gl, = torch.autograd.grad((p64 * dprob.double()).sum(), [l64])
+    assert_close(hip.presence_bwd(logit.cuda(), 0.75, 1e-3, True, dprob.cuda()), gl, 1e-4, 1e-6, "dlogit")
+    prob2, pr2 = hip.presence_fwd(logit.cuda(), None, 0.0, None, False)      # non-discrete: presence = prob
+    assert torch.equal(prob2, pr2)
+    assert_close(prob2, torch.sigmoid(logit.double()), 1e-6, 1e-7, "prob (no eps)")
+
+
+def test_rec_loglik(hip):
+    gen = torch.Generator().manual_seed(5)
+    B, P = 9, 2500
+    obs = torch.rand(B, 50, 50, generator=gen); canvas = torch.randn(B, 50, 50, generator=gen)
+    c64 = canvas.double().requires_grad_(True)
+    nll = (0.5 * ((obs.double() - 0.5 * c64) / 0.3) ** 2 + 0.5 * np.log(2 * np.pi) + np.log(0.3)).sum((1, 2))
+    assert_close(hip.rec_loglik_fwd(obs.cuda(), canvas.cuda(), 0.5, 0.3), nll, 1e-5, 1e-3, "rec")
+    gc, = torch.autograd.grad(nll.mean(), [c64])
+    assert_close(hip.rec_loglik_bwd(obs.cuda(), canvas.cuda(), 0.5, 0.3, None, 1.0 / B), gc, 1e-5, 1e-6, "dcanvas")
+
+
+@pytest.mark.parametrize("T", [3, 5, 1])
+def test_numsteps_fwd_bwd(hip, T):
+    gen = torch.Generator().manual_seed(T)
+    B = 130
+    prob = torch.rand(T, B, generator=gen) * 0.98 + 0.01
+    prob[:, 0] = 1.0 - 1e-4; prob[:, 1] = 1e-4
+    pres = torch.cumprod((torch.rand(T, B, generator=gen) < prob).float(), 0)
+    prior = O.geometric_prior(0.3, T)
+    p64 = prob.double().requires_grad_(True)
+    # oracle path (f32 posterior re-cast to f64 inside tabular_kl, like the reference)
+    pf = prob.clone().requires_grad_(True)
+    q = O.bernoulli_to_modified_geometric(pf.t())
+    kl = O.tabular_kl(q, prior[None]).sum(1)
+    w = torch.flip(torch.cumsum(torch.flip(q[:, 1:].t(), [0]), 0), [0])
+    logp = O.num_steps_log_prob(q, pres.sum(0))
+    qg, klg, logpg, wg = hip.numsteps_fwd(prob.cuda(), pres.cuda(), prior.cuda())
+    assert_close(qg, q, 1e-6, 1e-8, "q"); assert_close(klg, kl, 1e-5, 1e-6, "kl")
+    assert_close(wg, w, 1e-6, 1e-7, "w"); assert_close(logpg, logp, 1e-5, 1e-6, "logp")
+    dw = torch.randn(T, B, generator=gen); dl = torch.randn(B, generator=gen)
+    # fp64 reference gradient
+    q64 = O.bernoulli_to_modified_geometric(p64.t())
+    L = 0.37 * O.tabular_kl(q64, prior[None]).sum() \
+        + (torch.flip(torch.cumsum(torch.flip(q64[:, 1:].t(), [0]), 0), [0]) * dw.double()).sum() \
+        + (O.num_steps_log_prob(q64, pres.sum(0)) * dl.double()).sum()
+    gp, = torch.autograd.grad(L, [p64])
+    dprob = hip.numsteps_bwd(prob.cuda(), pres.cuda(), prior.cuda(), 0.37, dw.cuda(), dl.cuda())
+    assert_close(dprob, gp, 2e-4, 2e-4, "dprob")
+
+
+def test_nvil(hip):
+    gen = torch.Generator().manual_seed(9)
+    B = 64
+    imp = torch.rand(B, generator=gen) * 3000 + 500; base = torch.randn(B, generator=gen) * 10
+    logp = -torch.rand(B, generator=gen) * 3
+    b64 = base.double().requires_grad_(True); l64 = logp.double().requires_grad_(True)
+    iw = imp.double()[None, :] - b64[:, None]                                   # [B,B]: (i,j) = imp_j - b_i
+    rl = (iw.detach() * l64).mean(); bl = 0.5 * (iw ** 2).mean()
+    gl, = torch.autograd.grad(rl, [l64]); gb, = torch.autograd.grad(bl, [b64])
+    out, dlogp, dbase = hip.nvil(imp.cuda(), base.cuda(), logp.cuda())
+    ref = torch.stack([rl.detach(), bl.detach(), iw.mean().detach(), iw.var(unbiased=False).detach()])
+    assert_close(out, ref, 1e-5, 1e-3, "nvil scalars")
+    assert_close(dlogp, gl, 1e-5, 1e-5, "dlogp"); assert_close(dbase, gb, 1e-5, 1e-5, "dbaseline")
+
+
+def test_baseline_pack(hip):
+    cfg = O.AIRConfig()
+    T, B = 3, 5
+    gen = torch.Generator().manual_seed(2)
+    obs = torch.rand(B, 50, 50, generator=gen); what = torch.randn(T, B, 50, generator=gen)
+    where = torch.randn(T, B, 4, generator=gen); pres = torch.rand(T, B, 1, generator=gen)
+    h = torch.randn(B, 256, generator=gen); c = torch.randn(B, 256, generator=gen)
+    parts = [t.permute(1, 0, 2).reshape(B, -1) for t in (what, where, pres)] + [h, c]
+    ref = torch.cat([obs.reshape(B, -1)] + parts, -1)
+    out = hip.baseline_pack(obs.cuda(), what.cuda(), where.cuda(), pres.cuda(), [h.cuda(), c.cuda()])
+    assert out.shape == (B, cfg.baseline_in)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_rmsprop_centered(hip):
+    cfg = O.AIRConfig()
+    gen = torch.Generator().manual_seed(4)
+    n = 10_007
+    p = {"a/w": torch.randn(n, generator=gen)}; gr = {"a/w": torch.randn(n, generator=gen)}
+    slots = O.rmsprop_init(p)
+    pg, gg = p["a/w"].clone().cuda(), gr["a/w"].cuda()
+    ms, mg, mom = torch.ones(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    lr = torch.tensor([cfg.learning_rate]).cuda()
+    for _ in range(3):
+        O.rmsprop_centered_step(p, gr, slots, cfg)
+        hip.rmsprop_centered_(pg, gg, ms, mg, mom, lr)
+    assert_close(pg, p["a/w"], 1e-6, 1e-7, "params"); assert_close(mom, slots["a/w"]["mom"], 1e-5, 1e-9, "mom")
+
+
+def test_rng_statistics_and_advance(hip):
+    state = torch.tensor([1234, 0], dtype=torch.int64).cuda()
+    n = 1 << 20
+    z = torch.empty(n).cuda(); u = torch.empty(n).cuda()
+    hip.rng_fill(state, z, u)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    assert abs(u.mean().item() - 0.5) < 2e-3 and 0 <= u.min().item() and u.max().item() < 1
+    assert abs((z ** 4).mean().item() - 3.0) < 0.05
+    assert state.cpu()[1].item() == 2 * (n // 4)
+    z2 = torch.empty(n).cuda()
+    hip.rng_fill(state, z2, None)
+    assert not torch.equal(z, z2)
+    state2 = torch.tensor([1234, 0], dtype=torch.int64).cuda()
+    z3 = torch.empty(n).cuda(); u3 = torch.empty(n).cuda()
+    hip.rng_fill(state2, z3, u3)
+    assert torch.equal(z, z3) and torch.equal(u, u3)                          # counter-based: reproducible
+
+
+def test_small_utils(hip):
+    x = torch.randn(7, 13).cuda()
+    assert torch.equal(hip.tile_rows(x[0], 5), x[0][None].expand(5, -1))
+    assert_close(hip.colsum(x), x.double().cpu().sum(0), 1e-6, 1e-6, "colsum")
+    assert torch.equal(hip.fill_(torch.empty(100).cuda(), 2.5).cpu(), torch.full((100,), 2.5))
+    assert_close(hip.axpby(x, 2.0, x, -0.5), 1.5 * x.double().cpu(), 1e-6, 1e-6, "axpby")
+
+
+def test_hipgraph_capture_replay(hip):
+    """A captured sequence of C-ABI launches replays with fresh inputs (static buffers)."""
+    import ctypes
+    from attend_infer_repeat_amd import _lib
+    lib = hip.lib()
+    s = torch.cuda.Stream()
+    x = torch.randn(64, 400).cuda(); w = torch.randn(400, 256).cuda(); b = torch.randn(256).cuda()
+    hip.workspace()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        y = hip.linear_fwd(x, w, b, 1)            # warm-up (allocates y)
+        s.synchronize()
+        sp = ctypes.c_void_p(s.cuda_stream)
+        _lib.check(lib.air_graph_begin_capture(sp))
+        wsb = ctypes.c_size_t(hip.workspace().numel() * 4)
+        _lib.check(lib.air_linear_fwd(hip._p(x), hip._p(w), hip._p(b), hip._p(y), 64, 400, 256, 1,
+                                      hip._p(hip.workspace()), wsb, sp))
+        exe = ctypes.c_void_p()
+        _lib.check(lib.air_graph_end_capture(sp, ctypes.byref(exe)))
+        x.copy_(torch.randn(64, 400).cuda())
+        _lib.check(lib.air_graph_launch(exe, sp))
+        s.synchronize()
+    ref = torch.nn.functional.elu(x.double().cpu() @ w.double().cpu() + b.double().cpu())
+    assert_close(y, ref, 2e-5, 2e-4, "graph replay")
+    _lib.check(lib.air_graph_destroy(exe))
