@@ -54,14 +54,20 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float *scratch) {
 
 // ---- scalar math with the exact op order of the oracle (no fp contraction) -----------------------------------
 __device__ __forceinline__ float lin_m11(int k, int n, double step) {
+#pragma clang fp contract(off)
     // np.linspace(-1, 1, n)[k] evaluated in fp64 (arange*step + start, last element = stop) then rounded to fp32
     if (n <= 1) return -1.0f;
     if (k == n - 1) return 1.0f;
-    return (float)__dadd_rn(__dmul_rn((double)k, step), -1.0);
+    const double prod = (double)k * step;
+    return (float)(prod + -1.0);
 }
 // coord = ((s*X + t) + 1) * half_extent, each op rounded separately (matches numpy / torch-CPU eager)
 __device__ __forceinline__ float grid_coord(float s, float X, float t, float half_extent) {
-    return __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(s, X), t), 1.0f), half_extent);
+#pragma clang fp contract(off)
+    const float a = s * X;
+    const float b = a + t;
+    const float c = b + 1.0f;
+    return c * half_extent;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }

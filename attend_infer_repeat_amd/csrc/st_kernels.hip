@@ -10,6 +10,9 @@
 // so per-axis tables (floor index, fractional weight) are built in LDS by h+w threads and every output pixel costs
 // four LDS gathers.  When T glimpses are read from one image (batched unroll) the image is staged once for all T.
 // Forward arithmetic uses explicitly-rounded ops in the oracle's order, so forward results are bit-identical to it.
+// Forward arithmetic must round every op separately to be bit-identical to the oracle: HIP's __fmul_rn/__fadd_rn are
+// plain operators, so contraction into FMA is disabled for this whole translation unit.
+#pragma clang fp contract(off)
 #include <limits.h>
 #include <math.h>
 #include "air_common.h"
@@ -32,11 +35,13 @@ __device__ __forceinline__ Taps load_taps(const float *s, int Hs, int Ws, int fy
 }
 // dx*dy*ff + (1-dx)*(1-dy)*cc + dx*(1-dy)*cf + (1-dx)*dy*fc, left-to-right, no contraction (== oracle)
 __device__ __forceinline__ float bilerp(const Taps &t, float dx, float dy) {
-    const float mx = __fsub_rn(1.f, dx), my = __fsub_rn(1.f, dy);
-    float r = __fmul_rn(__fmul_rn(dx, dy), t.ff);
-    r = __fadd_rn(r, __fmul_rn(__fmul_rn(mx, my), t.cc));
-    r = __fadd_rn(r, __fmul_rn(__fmul_rn(dx, my), t.cf));
-    r = __fadd_rn(r, __fmul_rn(__fmul_rn(mx, dy), t.fc));
+    // plain operators: the file-level `fp contract(off)` keeps every op separately rounded (HIP's __fmul_rn etc. are
+    // header functions whose instructions carry the default contract flag and WOULD be fused after inlining)
+    const float mx = 1.f - dx, my = 1.f - dy;
+    float r = (dx * dy) * t.ff;
+    r = r + (mx * my) * t.cc;
+    r = r + (dx * my) * t.cf;
+    r = r + (mx * dy) * t.fc;
     return r;
 }
 // one axis entry: coordinate -> (floor index or ST_INVALID, d = (floor+1) - coord)
@@ -44,7 +49,7 @@ __device__ __forceinline__ void axis_entry(float coord, int extent, int *f_out, 
     const bool valid = (coord > -1.0f) && (coord < (float)extent);   // NaN -> invalid
     const float fl = floorf(coord);
     *f_out = valid ? (int)fl : ST_INVALID;
-    *d_out = __fsub_rn(__fadd_rn(fl, 1.0f), coord);
+    *d_out = (fl + 1.0f) - coord;
 }
 
 __device__ __forceinline__ void stage_to_lds(float *dst, const float *src, int count, bool vec4) {
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_fwd_kernel(
             __syncthreads();                            // previous step finished with glimpse tile + tables
             stage_to_lds(c.src, glimpse + k * hw, hw, vec4_glimpse != 0);
             const float sx = where[4 * k + 0], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
-            const float ax = __fdiv_rn(1.0f, sx), bx = __fdiv_rn(-tx, sx);
-            const float ay = __fdiv_rn(1.0f, sy), by = __fdiv_rn(-ty, sy);
+            const float ax = 1.0f / sx, bx = -tx / sx;
+            const float ay = 1.0f / sy, by = -ty / sy;
             for (int a = tid; a < W + H; a += ST_THREADS) {
                 if (a < W) axis_entry(grid_coord(ax, lin_m11(a, W, stepX), bx, cxs), w, &c.fx[a], &c.dx[a]);
                 else axis_entry(grid_coord(ay, lin_m11(a - W, H, stepY), by, cys), h, &c.fy[a - W], &c.dy[a - W]);
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_fwd_kernel(
                 const int fx = c.fx[J], fy = c.fy[I];
                 float v = 0.f;
                 if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, h, w, fy, fx), c.dx[J], c.dy[I]);
-                const float cv = __fadd_rn(c.aux[p], __fmul_rn(pres, v));
+                const float cv = c.aux[p] + pres * v;
                 c.aux[p] = cv;
                 if (steps_out) steps_out[p] = cv;
             }
@@ -268,8 +273,8 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
         for (int p = tid; p < hw; p += ST_THREADS) c.aux[p] = 0.f;
         const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
         const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
-        const float ax = __fdiv_rn(1.0f, sx), bx = __fdiv_rn(-tx, sx);
-        const float ay = __fdiv_rn(1.0f, sy), by = __fdiv_rn(-ty, sy);
+        const float ax = 1.0f / sx, bx = -tx / sx;
+        const float ay = 1.0f / sy, by = -ty / sy;
         for (int a = tid; a < W + H; a += ST_THREADS) {
             if (a < W) {
                 const float X = lin_m11(a, W, stepX);
