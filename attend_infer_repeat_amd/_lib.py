@@ -42,6 +42,9 @@ SIGNATURES = {
     "air_rec_loglik_bwd": (c_int, [P, P, c_float, c_float, P, c_float, P, c_int, c_int, P]),
     "air_numsteps_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_numsteps_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
+    "air_steps_prior": (c_int, [P, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                ctypes.c_double, P, c_int, P]),
+    "air_counter_add": (c_int, [P, ctypes.c_int64, P]),
     "air_nvil": (c_int, [P, P, P, P, P, P, c_int, P]),
     "air_baseline_pack": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "air_rmsprop_centered": (c_int, [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, P]),
@@ -51,6 +54,7 @@ SIGNATURES = {
     "air_axpby": (c_int, [P, c_float, P, c_float, P, c_size_t, P]),
     "air_tile_rows": (c_int, [P, P, c_int, c_int, P]),
     "air_colsum": (c_int, [P, c_int, P, c_int, c_int, P]),
+    "air_sum_leading": (c_int, [P, P, c_int, c_size_t, P]),
     "air_graph_begin_capture": (c_int, [P]),
     "air_graph_end_capture": (c_int, [P, ctypes.POINTER(c_void_p)]),
     "air_graph_launch": (c_int, [P, P]),

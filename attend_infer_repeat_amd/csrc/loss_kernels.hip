@@ -126,6 +126,48 @@ extern "C" int air_numsteps_bwd(const float *presence_prob, const float *presenc
     return AIR_OK;
 }
 
+// ---- annealed geometric prior on device (model.py:106-124, prior.py:26-32) -------------------------------------------
+__global__ void steps_prior_kernel(const int64_t *__restrict__ gstep, int anneal_type, double init, double fin,
+                                   double anneal_steps, double hold_for, double steps_div,
+                                   double *__restrict__ prior, int T) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double s = init;
+    if (anneal_type != 0) {
+        double step = (double)gstep[0] - hold_for;
+        if (step < 0.0) step = 0.0;
+        double val = init;
+        if (anneal_type == 1) {
+            const double decay_rate = pow(fin / init, steps_div / anneal_steps);
+            val = init * pow(decay_rate, step / steps_div);
+        } else {
+            val = fin + (init - fin) * (1.0 - step / anneal_steps);
+        }
+        s = val > fin ? val : fin;
+    }
+    s = s < 1e-7 ? 1e-7 : (s > 1.0 - 1e-15 ? 1.0 - 1e-15 : s);
+    const double probs = 1.0 - s;
+    for (int n = 0; n <= T; ++n) prior[n] = exp((double)n * log1p(-probs) + log(probs));
+}
+__global__ void counter_add_kernel(int64_t *c, int64_t inc) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) c[0] += inc;
+}
+extern "C" int air_steps_prior(const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+                               double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
+                               void *stream) {
+    AIR_REQUIRE(global_step_dev && prior_out_f64, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && anneal_type >= 0 && anneal_type <= 2, AIR_E_SHAPE);
+    hipLaunchKernelGGL(steps_prior_kernel, dim3(1), dim3(64), 0, air_stream(stream), global_step_dev, anneal_type,
+                       init, final_value, anneal_steps, hold_for, steps_div, prior_out_f64, T);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream) {
+    AIR_REQUIRE(counter_dev, AIR_E_NULL);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, air_stream(stream), counter_dev, increment);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
 // ---- NVIL / REINFORCE (model.py:218-259) --------------------------------------------------------------------------
 // importance_weight[i,j] = imp[j] - baseline[i]  ([B]-[B,1] broadcast), so
 //   reinforce_loss = mean_j (imp_j - mean_i b_i) * logp_j ;  baseline_loss = 0.5 * mean_ij (imp_j - b_i)^2.

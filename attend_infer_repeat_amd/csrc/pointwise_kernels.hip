@@ -450,3 +450,19 @@ extern "C" int air_colsum(const float *x, int ld, float *out, int M, int N, void
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
+
+__global__ __launch_bounds__(PW_THREADS) void sum_leading_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                                 int T, size_t n) {
+    PW_LOOP(i, n) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += x[(size_t)t * n + i];
+        out[i] = s;
+    }
+}
+extern "C" int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream) {
+    AIR_REQUIRE(x && out, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(sum_leading_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), x, out, T, n);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}

@@ -254,6 +254,38 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_fwd_kernel(
 // Backward of the write for every (t, b): dglimpse, dwhere, optional dpresence.
 // dcanvas either given per step ([T*B,H,W]) or formed on the fly from the reconstruction term:
 //   dcanvas[b,p] = loss_scale * mult * (mult*final[b,p] - obs[b,p]) / std^2   (shared by all t)
+// dglimpse is the transpose of a separable bilinear map, dG = Wy^T . g . Wx with two non-zeros per row of Wy / Wx,
+// evaluated as two small LDS passes in a fixed order (no float atomics => bitwise reproducible):
+//   T1[I,j] = sum_J g[I,J] * wx[J,j]   over the contiguous J-range that touches glimpse column j
+//   dG[i,j] = sum_I wy[I,i] * T1[I,j]  over the contiguous I-range that touches glimpse row i
+struct CarveBwd {
+    float *src, *g, *t1, *dx, *X, *dy, *Y, *scratch;
+    int *fx, *fy, *jlo, *jhi, *ilo, *ihi;
+};
+__device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, int w) {
+    CarveBwd c;
+    float *p = smem;
+    c.src = p; p += (h * w + 3) & ~3;
+    c.g = p; p += (H * W + 3) & ~3;
+    c.t1 = p; p += (H * w + 3) & ~3;
+    c.fx = reinterpret_cast<int *>(p); p += W;
+    c.dx = p; p += W;
+    c.X = p; p += W;
+    c.fy = reinterpret_cast<int *>(p); p += H;
+    c.dy = p; p += H;
+    c.Y = p; p += H;
+    c.jlo = reinterpret_cast<int *>(p); p += w;
+    c.jhi = reinterpret_cast<int *>(p); p += w;
+    c.ilo = reinterpret_cast<int *>(p); p += h;
+    c.ihi = reinterpret_cast<int *>(p); p += h;
+    c.scratch = p;
+    return c;
+}
+static inline size_t carve_bwd_bytes(int H, int W, int h, int w) {
+    return sizeof(float) * (size_t)(((h * w + 3) & ~3) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 3 * W + 3 * H +
+                                    2 * w + 2 * h + 32);
+}
+
 __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
     const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
@@ -262,7 +294,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
     int vec4_glimpse) {
     extern __shared__ __align__(16) float smem[];
     const int HW = H * W, hw = h * w, tid = threadIdx.x;
-    Carve c = carve_lds(smem, hw, hw, W, H);           // src = glimpse tile, aux = dglimpse accumulator
+    CarveBwd c = carve_bwd(smem, H, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
     const float coef = loss_scale * mult / (std * std);
     const int n = T * B;
@@ -270,7 +302,6 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
         const int b = k % B;
         __syncthreads();
         stage_to_lds(c.src, glimpse + (size_t)k * hw, hw, vec4_glimpse != 0);
-        for (int p = tid; p < hw; p += ST_THREADS) c.aux[p] = 0.f;
         const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
         const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
         const float ax = 1.0f / sx, bx = -tx / sx;
@@ -287,6 +318,18 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
             }
         }
         __syncthreads();
+        // contiguous source ranges per glimpse column / row (min & max index that touches it)
+        for (int a = tid; a < w + h; a += ST_THREADS) {
+            const bool col = a < w;
+            const int idx = col ? a : a - w, cnt = col ? W : H;
+            const int *f = col ? c.fx : c.fy;
+            int lo = cnt, hi = -1;
+            for (int q = 0; q < cnt; ++q) {
+                const int fq = f[q];
+                if (fq != ST_INVALID && (fq == idx || fq + 1 == idx)) { lo = q < lo ? q : lo; hi = q; }
+            }
+            if (col) { c.jlo[idx] = lo; c.jhi[idx] = hi; } else { c.ilo[idx] = lo; c.ihi[idx] = hi; }
+        }
         const float pres = presence ? presence[k] : 1.0f;
         const float *dc_ptr = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
         const float *fc_ptr = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
@@ -295,26 +338,53 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
         for (int p = tid; p < HW; p += ST_THREADS) {
             const int I = p / W, J = p - I * W;
             const int fx = c.fx[J], fy = c.fy[I];
-            if (fx == ST_INVALID || fy == ST_INVALID) continue;
-            const float dc = dc_ptr ? dc_ptr[p] : coef * (mult * fc_ptr[p] - ob_ptr[p]);
-            const float dx = c.dx[J], dy = c.dy[I];
-            const Taps t = load_taps(c.src, h, w, fy, fx);
-            const float v = bilerp(t, dx, dy);
-            const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
-            const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
-            const float go = pres * dc;
-            const float gax = go * gx * cxs, gay = go * gy * cys;
-            acc[0] += gax * c.X[J]; acc[1] += gax;
-            acc[2] += gay * c.Y[I]; acc[3] += gay;
-            acc[4] += dc * v;
-            const bool x0 = fx >= 0, x1 = fx + 1 <= w - 1, y0 = fy >= 0, y1 = fy + 1 <= h - 1;
-            const int base = fy * w + fx;
-            if (x0 && y0) atomicAdd(&c.aux[base], dx * dy * go);
-            if (x1 && y0) atomicAdd(&c.aux[base + 1], (1.f - dx) * dy * go);
-            if (x0 && y1) atomicAdd(&c.aux[base + w], dx * (1.f - dy) * go);
-            if (x1 && y1) atomicAdd(&c.aux[base + w + 1], (1.f - dx) * (1.f - dy) * go);
+            float go = 0.f;
+            if (fx != ST_INVALID && fy != ST_INVALID) {
+                const float dc = dc_ptr ? dc_ptr[p] : coef * (mult * fc_ptr[p] - ob_ptr[p]);
+                const float dx = c.dx[J], dy = c.dy[I];
+                const Taps t = load_taps(c.src, h, w, fy, fx);
+                const float v = bilerp(t, dx, dy);
+                const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
+                const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
+                go = pres * dc;
+                const float gax = go * gx * cxs, gay = go * gy * cys;
+                acc[0] += gax * c.X[J]; acc[1] += gax;
+                acc[2] += gay * c.Y[I]; acc[3] += gay;
+                acc[4] += dc * v;
+            }
+            c.g[p] = go;
         }
-        block_sum<5>(acc, c.scratch);                   // contains a __syncthreads: LDS atomics are complete after it
+        __syncthreads();
+        for (int e = tid; e < H * w; e += ST_THREADS) {            // pass 1: contract canvas columns
+            const int I = e / w, j = e - I * w;
+            float s = 0.f;
+            if (c.fy[I] != ST_INVALID) {
+                const float *grow = c.g + I * W;
+                for (int J = c.jlo[j]; J <= c.jhi[j]; ++J) {
+                    const int fx = c.fx[J];
+                    if (fx == ST_INVALID) continue;
+                    const float dx = c.dx[J];
+                    const float wgt = (fx == j ? dx : 0.f) + (fx + 1 == j ? 1.f - dx : 0.f);
+                    s += grow[J] * wgt;
+                }
+            }
+            c.t1[e] = s;
+        }
+        __syncthreads();
+        float *dg = dglimpse + (size_t)k * hw;
+        for (int e = tid; e < hw; e += ST_THREADS) {               // pass 2: contract canvas rows
+            const int i = e / w, j = e - i * w;
+            float s = 0.f;
+            for (int I = c.ilo[i]; I <= c.ihi[i]; ++I) {
+                const int fy = c.fy[I];
+                if (fy == ST_INVALID) continue;
+                const float dy = c.dy[I];
+                const float wgt = (fy == i ? dy : 0.f) + (fy + 1 == i ? 1.f - dy : 0.f);
+                s += c.t1[I * w + j] * wgt;
+            }
+            dg[e] = s;
+        }
+        block_sum<5>(acc, c.scratch);
         if (tid == 0) {
             // chain through a = 1/s, b = -t/s
             float *d = dwhere + 4 * (size_t)k;
@@ -324,8 +394,6 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
             d[3] = acc[3] * (-1.0f / sy);
             if (dpresence) dpresence[k] = acc[4];
         }
-        float *dg = dglimpse + (size_t)k * hw;
-        for (int p = tid; p < hw; p += ST_THREADS) dg[p] = c.aux[p];
     }
 }
 
@@ -341,7 +409,7 @@ static inline int st_check_dims(int n, int H, int W, int h, int w) {
     if (n <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return AIR_E_SHAPE;
     return AIR_OK;
 }
-#define ST_MAX_LDS (160 * 1024)
+#define ST_MAX_LDS (64 * 1024)   // dynamic LDS above 64 KiB would need hipFuncSetAttribute
 
 extern "C" int air_st_read_fwd(const float *img, const float *where, float *glimpse, int n, int n_img, int H, int W,
                                int h, int w, void *stream) {
@@ -416,7 +484,7 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
                             const float *final_canvas, const float *obs, float *dglimpse, float *dwhere,
                             float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
                             float loss_scale, void *stream) {
-    const size_t lds = carve_bytes(h * w, h * w, W, H);
+    const size_t lds = carve_bwd_bytes(H, W, h, w);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse,

@@ -1,0 +1,625 @@
+"""AIREngine -- the fused MI355X train step of AIR on multi-MNIST-shaped inputs.
+
+One object owns every byte the step touches: a flat fp32 parameter buffer (Sonnet layouts), a flat gradient buffer
+(=> a single RCCL all-reduce in data-parallel runs), flat centred-RMSProp slots and a static activation arena.  The
+forward unroll, the hand-derived backward and the optimiser are a fixed list of C-ABI launches (include/air_hip.h)
+over those buffers, so the whole step is hipGraph-capturable and replays with zero Python in the loop.
+
+What is restated from the reference (file:line under attend_infer_repeat/):
+  forward   cell.py:116-171 unrolled by model.py:83-84, re-scheduled: the input encoder and x.W_x of the LSTM are
+            computed once (the image never changes, cell.py:121-125), the T tiny recurrences run, and everything
+            downstream of h_t is batched over T*B rows.  Same numbers up to fp32 summation order.
+  objective model.py:126-259,319-343 (ELBO with analytic step weights, NVIL with the [B,B] broadcast quirk).
+  update    model.py:355-367 (centred RMSProp, baseline at 10x lr).
+torch supplies device memory, streams and (optionally) torch.distributed; all arithmetic is in libair_hip.so.
+"""
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from . import hip as H
+
+
+@dataclass
+class EngineConfig:
+    """Hyper-parameters of the standard AIR-on-MNIST architecture (mnist_model.py:13-44, scripts/multi_mnist.py:24-94)."""
+    img_size: Tuple[int, int] = (50, 50)
+    crop_size: Tuple[int, int] = (20, 20)
+    n_appearance: int = 50
+    n_hidden: int = 256
+    inpt_encoder_hidden: Sequence[int] = (256, 256)
+    glimpse_encoder_hidden: Sequence[int] = (256, 256)
+    glimpse_decoder_hidden: Sequence[int] = (256, 256)
+    transform_estimator_hidden: Sequence[int] = (256, 256)
+    steps_pred_hidden: Sequence[int] = (128, 64)
+    baseline_hidden: Sequence[int] = (256, 128)
+    max_steps: int = 3
+    transform_var_bias: float = 0.5
+    step_bias: float = 0.75
+    output_multiplier: float = 0.5
+    output_std: float = 0.3
+    explore_eps: Optional[float] = 1e-3
+    what_scale_offset: float = 0.5
+    what_prior: Tuple[float, float] = (0.0, 1.0)
+    where_scale_prior: Tuple[float, float] = (0.0, 1.0)
+    where_shift_prior: Tuple[float, float] = (0.0, 1.0)
+    nsp_anneal: Optional[str] = "exp"
+    nsp_init: float = 1.0 - 1e-15
+    nsp_final: float = 1e-7
+    nsp_steps_div: float = 1e4
+    nsp_steps: float = 1e5
+    nsp_hold_init: float = 1e3
+    use_prior: bool = True
+    use_reinforce: bool = True
+    learning_rate: float = 1e-4
+    baseline_lr_mult: float = 10.0
+    rms_decay: float = 0.9
+    rms_momentum: float = 0.9
+    rms_eps: float = 1e-10
+
+    @property
+    def n_pix(self):
+        return int(self.img_size[0] * self.img_size[1])
+
+    @property
+    def n_crop(self):
+        return int(self.crop_size[0] * self.crop_size[1])
+
+    @property
+    def baseline_in(self):
+        T = self.max_steps
+        return self.n_pix + T * self.n_appearance + T * 4 + T + 2 * self.n_hidden
+
+
+def _mlp_shapes(n_in, hiddens, n_out):
+    sizes = list(hiddens) + ([n_out] if n_out is not None else [])
+    out, prev = [], n_in
+    for s in sizes:
+        out.append((prev, int(s)))
+        prev = int(s)
+    return out
+
+
+def param_shapes(cfg: EngineConfig) -> "Dict[str, Tuple[int, ...]]":
+    """Ordered name -> shape of every trainable tensor; model variables first, baseline variables last (the two
+    optimisers of model.py:355-367 each own one contiguous segment of the flat buffer)."""
+    Hd, A = cfg.n_hidden, cfg.n_appearance
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def add(prefix, n_in, hiddens, n_out):
+        for i, (a, b) in enumerate(_mlp_shapes(n_in, hiddens, n_out)):
+            out[f"{prefix}/{i}/w"] = (a, b)
+            out[f"{prefix}/{i}/b"] = (b,)
+
+    add("input_encoder", cfg.n_pix, cfg.inpt_encoder_hidden, None)
+    enc_out = int(cfg.inpt_encoder_hidden[-1])
+    out["lstm/w_gates"] = (enc_out + Hd, 4 * Hd)
+    out["lstm/b_gates"] = (4 * Hd,)
+    out["lstm/h0"] = (1, Hd)
+    out["lstm/c0"] = (1, Hd)
+    add("transform", Hd, cfg.transform_estimator_hidden, 8)
+    add("steps", Hd, cfg.steps_pred_hidden, 1)
+    add("glimpse_encoder", cfg.n_crop, cfg.glimpse_encoder_hidden, None)
+    out["what/w"] = (int(cfg.glimpse_encoder_hidden[-1]), 2 * A)
+    out["what/b"] = (2 * A,)
+    add("glimpse_decoder", A, cfg.glimpse_decoder_hidden, cfg.n_crop)
+    add("baseline", cfg.baseline_in, cfg.baseline_hidden, 1)
+    return out
+
+
+def anneal_weight(init_val, final_val, anneal_type, global_step, anneal_steps, hold_for=0.0, steps_div=1.0):
+    """model.py:106-124 (float64 == python float)."""
+    val, final = float(init_val), float(final_val)
+    step = max(float(global_step) - float(hold_for), 0.0)
+    if anneal_type == "exp":
+        decay_rate = (final / val) ** (float(steps_div) / float(anneal_steps))
+        val = val * decay_rate ** (step / float(steps_div))
+    elif anneal_type == "linear":
+        val = final + (val - final) * (1.0 - step / float(anneal_steps))
+    else:
+        raise NotImplementedError(anneal_type)
+    return max(final, val)
+
+
+def geometric_prior_f64(success_prob: float, n_steps: int) -> List[float]:
+    """prior.py:26-32: clip, Geometric(probs=1-s).prob(k) = exp(k*log1p(-probs) + log(probs)); not renormalised."""
+    s = min(max(float(success_prob), 1e-7), 1.0 - 1e-15)
+    probs = 1.0 - s
+    return [math.exp(k * math.log1p(-probs) + math.log(probs)) for k in range(n_steps + 1)]
+
+
+class _Mlp:
+    """bookkeeping for one MLP: weights/bias/grad views, activation buffers"""
+
+    def __init__(self, eng, prefix, n_rows, n_in, hiddens, n_out):
+        self.prefix = prefix
+        self.shapes = _mlp_shapes(n_in, hiddens, n_out)
+        self.n = len(self.shapes)
+        self.last_linear = n_out is not None
+        self.w = [eng.params[f"{prefix}/{i}/w"] for i in range(self.n)]
+        self.b = [eng.params[f"{prefix}/{i}/b"] for i in range(self.n)]
+        self.dw = [eng.grads[f"{prefix}/{i}/w"] for i in range(self.n)]
+        self.db = [eng.grads[f"{prefix}/{i}/b"] for i in range(self.n)]
+        self.out = [eng._buf(f"{prefix}/act{i}", (n_rows, s[1])) for i, s in enumerate(self.shapes)]
+        self.g = [eng._buf(f"{prefix}/g{i}", (n_rows, s[1])) for i, s in enumerate(self.shapes)]
+        self.rows = n_rows
+
+
+class AIREngine:
+    def __init__(self, cfg: EngineConfig, batch_size: int, device=None, seed: int = 0, keep_canvas_steps: bool = True):
+        H.lib()
+        self.cfg = cfg
+        self.B = int(batch_size)
+        self.T = int(cfg.max_steps)
+        self.M = self.T * self.B
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise _lib.AirHipError("AIREngine needs a HIP device; there is no CPU fallback")
+        self.keep_canvas_steps = keep_canvas_steps
+        self.global_step = 0
+        self.world_size = 1
+        self._graph = None
+        self._graph_opt = None
+        self._bufs: Dict[str, torch.Tensor] = {}
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(device=self.device)
+            self._alloc_params(seed)
+            self._alloc_activations()
+            # private split-K workspace: engines on different streams must not share slabs
+            self.ws = torch.empty((32 << 20) // 4, dtype=torch.float32, device=self.device)
+            self._build_plans()
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # memory
+    # ------------------------------------------------------------------------------------------------------------
+    def _alloc_params(self, seed):
+        cfg = self.cfg
+        shapes = param_shapes(cfg)
+        sizes = {k: int(math.prod(s)) for k, s in shapes.items()}
+        # every tensor starts on a 16-byte boundary so vectorised operand loads apply
+        offs, off = {}, 0
+        self.n_model = None
+        for k, n in sizes.items():
+            if k.startswith("baseline/") and self.n_model is None:
+                off = (off + 63) // 64 * 64
+                self.n_model = off
+            offs[k] = off
+            off += (n + 3) // 4 * 4
+        if self.n_model is None:
+            self.n_model = off
+        self.n_total = off
+        dev = self.device
+        self.flat_params = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_ms = torch.ones(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_mg = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.params = {k: self.flat_params[offs[k]:offs[k] + sizes[k]].view(shapes[k]) for k in shapes}
+        self.grads = {k: self.flat_grads[offs[k]:offs[k] + sizes[k]].view(shapes[k]) for k in shapes}
+        self.param_offsets, self.param_sizes, self.param_shapes = offs, sizes, shapes
+        self.lr_dev = torch.tensor([cfg.learning_rate], dtype=torch.float32, device=dev)
+        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+        self.init_parameters(seed)
+
+    def init_parameters(self, seed: int = 0):
+        """Sonnet defaults: w ~ TruncNormal(0, 1/sqrt(fan_in)) (+-2 sigma), b = 0, LSTM initial state = 0."""
+        gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        for k, shape in self.param_shapes.items():
+            if len(shape) == 2 and not k.endswith(("/h0", "/c0")):
+                w = torch.empty(shape, dtype=torch.float32)
+                torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+                self.params[k].copy_(w * (1.0 / math.sqrt(shape[0])))
+            else:
+                self.params[k].zero_()
+
+    def load_parameters(self, named: Dict[str, torch.Tensor]):
+        for k, v in named.items():
+            self.params[k].copy_(torch.as_tensor(v, dtype=torch.float32).reshape(self.param_shapes[k]))
+
+    def reset_optimizer(self):
+        self.flat_ms.fill_(1.0); self.flat_mg.zero_(); self.flat_mom.zero_()
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        if name not in self._bufs:
+            self._bufs[name] = torch.zeros(shape, dtype=dtype, device=self.device)
+        return self._bufs[name]
+
+    def _alloc_activations(self):
+        cfg, B, T, M = self.cfg, self.B, self.T, self.M
+        Hd, A, P, hw = cfg.n_hidden, cfg.n_appearance, cfg.n_pix, cfg.n_crop
+        b = self._buf
+        self.obs = b("obs", (B, P))
+        # noise: one flat normal buffer [eps_where | eps_what], one uniform buffer
+        self.noise_normal = b("noise_normal", (M * 4 + M * A,))
+        self.eps_where = self.noise_normal[:M * 4].view(T, B, 4)
+        self.eps_what = self.noise_normal[M * 4:].view(T, B, A)
+        self.u_pres = b("u_pres", (T, B))
+        self.prior_dev = b("prior", (T + 1,), torch.float64)
+        self.step_dev = b("global_step", (1,), torch.int64)
+        self.enc = _Mlp(self, "input_encoder", B, P, cfg.inpt_encoder_hidden, None)
+        self.gx = b("gx", (B, 4 * Hd))
+        self.gates = b("gates", (T, B, 4 * Hd)); self.gate_act = b("gate_act", (T, B, 4 * Hd))
+        self.h_seq = b("h_seq", (T + 1, B, Hd)); self.c_seq = b("c_seq", (T + 1, B, Hd))
+        self.tr = _Mlp(self, "transform", M, Hd, cfg.transform_estimator_hidden, 8)
+        self.st = _Mlp(self, "steps", M, Hd, cfg.steps_pred_hidden, 1)
+        self.where_loc = b("where_loc", (T, B, 4)); self.where_scale = b("where_scale", (T, B, 4))
+        self.where = b("where", (T, B, 4)); self.kl_where_row = b("kl_where_row", (T, B))
+        self.presence_prob = b("presence_prob", (T, B)); self.presence = b("presence", (T, B))
+        self.glimpse_in = b("glimpse_in", (T, B, hw))
+        self.ge = _Mlp(self, "glimpse_encoder", M, hw, cfg.glimpse_encoder_hidden, None)
+        self.q = b("what_pre", (M, 2 * A)); self.dq = b("dwhat_pre", (M, 2 * A))
+        self.what_loc = b("what_loc", (T, B, A)); self.what_scale = b("what_scale", (T, B, A))
+        self.what = b("what", (T, B, A)); self.kl_what_row = b("kl_what_row", (T, B))
+        self.gd = _Mlp(self, "glimpse_decoder", M, A, cfg.glimpse_decoder_hidden, hw)
+        self.canvas_steps = b("canvas_steps", (T, B, P)) if self.keep_canvas_steps else None
+        self.final_canvas = b("final_canvas", (B, P)); self.rec = b("rec", (B,))
+        self.q_n = b("q_n", (B, T + 1)); self.kl_n = b("kl_n", (B,)); self.logp = b("logp", (B,))
+        self.step_w = b("step_w", (T, B))
+        self.base_in = b("base_in", (B, cfg.baseline_in))
+        self.bl = _Mlp(self, "baseline", B, cfg.baseline_in, cfg.baseline_hidden, 1)
+        self.nvil_out = b("nvil_out", (4,)); self.dlogp = b("dlogp", (B,)); self.dbase = b("dbase", (B,))
+        # backward scratch
+        self.d_what = b("d_what", (M, A)); self.d_glimpse_in = b("d_glimpse_in", (M, hw))
+        self.dwhere_w = b("dwhere_w", (M, 4)); self.dwhere_r = b("dwhere_r", (M, 4)); self.dwhere = b("dwhere", (M, 4))
+        self.dkl_row = b("dkl_row", (M,)); self.dstep_w = b("dstep_w", (T, B)); self.dprob = b("dprob", (T, B))
+        self.dH = b("dH", (T, B, Hd)); self.dh_init = b("dh_init", (B, Hd))
+        self.dgates = b("dgates", (T, B, 4 * Hd)); self.dc_a = b("dc_a", (B, Hd)); self.dc_b = b("dc_b", (B, Hd))
+        self.dgx = b("dgx", (B, 4 * Hd))
+
+    # ------------------------------------------------------------------------------------------------------------
+    # launch plans
+    # ------------------------------------------------------------------------------------------------------------
+    def _build_plans(self):
+        L = H.lib()
+        cfg, B, T, M = self.cfg, self.B, self.T, self.M
+        Hd, A, P, hw = cfg.n_hidden, cfg.n_appearance, cfg.n_pix, cfg.n_crop
+        (Hi, Wi), (hc, wc) = cfg.img_size, cfg.crop_size
+        p = H._p
+        wsp, wsb = p(self.ws), ctypes.c_size_t(self.ws.numel() * 4)
+        fwd, bwd, opt, rng = [], [], [], []
+        NONE, BIAS, BELU, MDELU, ADDAUX = H.EPI_NONE, H.EPI_BIAS, H.EPI_BIAS_ELU, H.EPI_MUL_DELU, H.EPI_ADD_AUX
+
+        def gemm(plan, ta, tb, Mm, Nn, Kk, Aa, lda, Bb, ldb, Cc, ldc, bias=None, epi=NONE, aux=None, ldaux=0,
+                 beta=0.0, colsum=None):
+            plan.append((L.air_gemm, (int(ta), int(tb), Mm, Nn, Kk, p(Aa), lda, p(Bb), ldb, p(Cc), ldc, p(bias),
+                                      epi, p(aux), ldaux, float(beta), p(colsum), wsp, wsb), "air_gemm"))
+
+        def mlp_fwd(plan, m: _Mlp, x, ldx):
+            for i, (k, n) in enumerate(m.shapes):
+                last = i == m.n - 1
+                epi = BIAS if (last and m.last_linear) else BELU
+                gemm(plan, 0, 0, m.rows, n, k, x, ldx, m.w[i], n, m.out[i], n, bias=m.b[i], epi=epi)
+                x, ldx = m.out[i], n
+
+        def mlp_bwd(plan, m: _Mlp, x_in, ldx, g_last, dx_out=None, dx_aux=None, dx_beta=0.0):
+            """g_last = gradient wrt the LAST layer's pre-activation [rows, n_last].  Writes dW/db of every layer.
+            dx_out: where to put the gradient wrt the MLP input (None to skip); dx_aux: if given, the input was itself
+            an ELU output and the result is multiplied by elu'(dx_aux) (so it is again a pre-activation gradient)."""
+            g = g_last
+            for i in reversed(range(m.n)):
+                k, n = m.shapes[i]
+                xin, ld_in = (m.out[i - 1], m.shapes[i - 1][1]) if i > 0 else (x_in, ldx)
+                gemm(plan, 1, 0, k, n, m.rows, xin, ld_in, g, n, m.dw[i], n, colsum=m.db[i])      # dW, db
+                if i > 0:
+                    gemm(plan, 0, 1, m.rows, k, n, g, n, m.w[i], n, m.g[i - 1], k, epi=MDELU, aux=m.out[i - 1],
+                         ldaux=k)                                                                  # G_{i-1}
+                    g = m.g[i - 1]
+                elif dx_out is not None:
+                    if dx_aux is not None:
+                        gemm(plan, 0, 1, m.rows, k, n, g, n, m.w[0], n, dx_out, k, epi=MDELU, aux=dx_aux, ldaux=k,
+                             beta=dx_beta)
+                    else:
+                        gemm(plan, 0, 1, m.rows, k, n, g, n, m.w[0], n, dx_out, k, beta=dx_beta)
+
+        # ---- noise ------------------------------------------------------------------------------------------------
+        n_norm, n_uni = self.noise_normal.numel(), self.u_pres.numel()
+        rng.append((L.air_rng_fill, (p(self.noise_normal), ctypes.c_size_t(n_norm), p(self.u_pres),
+                                     ctypes.c_size_t(n_uni), p(self.rng_state)), "air_rng_fill"))
+        rng.append((L.air_rng_advance, (p(self.rng_state), ctypes.c_uint64((n_norm + 3) // 4 + (n_uni + 3) // 4)),
+                    "air_rng_advance"))
+
+        # ---- forward ----------------------------------------------------------------------------------------------
+        anneal = {None: 0, "exp": 1, "linear": 2}[cfg.nsp_anneal]
+        fwd.append((L.air_steps_prior, (p(self.step_dev), anneal, float(cfg.nsp_init), float(cfg.nsp_final),
+                                        float(cfg.nsp_steps), float(cfg.nsp_hold_init), float(cfg.nsp_steps_div),
+                                        p(self.prior_dev), T), "air_steps_prior"))        # model.py:139-146
+        mlp_fwd(fwd, self.enc, self.obs, P)                                                 # cell.py:125 (hoisted)
+        enc_out, E = self.enc.out[-1], self.enc.shapes[-1][1]
+        wg, bg = self.params["lstm/w_gates"], self.params["lstm/b_gates"]
+        w_x, w_h = wg[:E], wg[E:]
+        gemm(fwd, 0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)
+        fwd.append((L.air_tile_rows, (p(self.params["lstm/h0"]), p(self.h_seq[0]), B, Hd), "air_tile_rows"))
+        fwd.append((L.air_tile_rows, (p(self.params["lstm/c0"]), p(self.c_seq[0]), B, Hd), "air_tile_rows"))
+        for t in range(T):                                                                  # cell.py:126-127
+            gemm(fwd, 0, 0, B, 4 * Hd, Hd, self.h_seq[t], Hd, w_h, 4 * Hd, self.gates[t], 4 * Hd, epi=ADDAUX,
+                 aux=self.gx, ldaux=4 * Hd)
+            fwd.append((L.air_lstm_pointwise_fwd, (p(self.gates[t]), p(self.c_seq[t]), p(self.h_seq[t + 1]),
+                                                   p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd, 1.0),
+                        "air_lstm_pointwise_fwd"))
+        h_all = self.h_seq[1:]                                                              # [T,B,Hd] contiguous
+        mlp_fwd(fwd, self.tr, h_all, Hd)                                                    # cell.py:129
+        mlp_fwd(fwd, self.st, h_all, Hd)                                                    # cell.py:138
+        sp, shp = cfg.where_scale_prior, cfg.where_shift_prior
+        fwd.append((L.air_gauss_sample_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
+                                             sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
+                                             p(self.where), p(self.kl_where_row), M, 4), "air_gauss_sample_fwd"))
+        eps = -1.0 if cfg.explore_eps is None else float(cfg.explore_eps)
+        fwd.append((L.air_presence_fwd, (p(self.st.out[-1]), p(self.u_pres), None, cfg.step_bias, eps, 1,
+                                         p(self.presence_prob), p(self.presence), T, B), "air_presence_fwd"))
+        fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
+                    "air_st_read_fwd"))                                                     # cell.py:135
+        mlp_fwd(fwd, self.ge, self.glimpse_in, hw)                                          # cell.py:153
+        ge_out, G = self.ge.out[-1], self.ge.shapes[-1][1]
+        gemm(fwd, 0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
+             bias=self.params["what/b"], epi=BIAS)                                          # modules.py:20-21
+        wp = cfg.what_prior
+        fwd.append((L.air_gauss_sample_fwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
+                                             wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale), p(self.what),
+                                             p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
+        mlp_fwd(fwd, self.gd, self.what, A)                                                 # cell.py:158
+        decoded = self.gd.out[-1]
+        fwd.append((L.air_canvas_unroll_fwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
+                                              p(self.canvas_steps), p(self.final_canvas), p(self.rec), T, B, Hi, Wi,
+                                              hc, wc, cfg.output_multiplier, cfg.output_std),
+                    "air_canvas_unroll_fwd"))                                               # cell.py:159-165, model.py:319-324
+        fwd.append((L.air_numsteps_fwd, (p(self.presence_prob), p(self.presence), p(self.prior_dev), p(self.q_n),
+                                         p(self.kl_n), p(self.logp), p(self.step_w), T, B), "air_numsteps_fwd"))
+        if cfg.use_reinforce:                                                               # model.py:218-259
+            fwd.append((L.air_baseline_pack, (p(self.obs), p(self.what), p(self.where), p(self.presence),
+                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_in), T, B, P, A, Hd,
+                                              Hd), "air_baseline_pack"))
+            mlp_fwd(fwd, self.bl, self.base_in, cfg.baseline_in)
+            fwd.append((L.air_nvil, (p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out), p(self.dlogp),
+                                     p(self.dbase), B), "air_nvil"))
+
+        # ---- backward of opt_loss = mean(rec) + pw*(mean kl_n + mean sum_t w*(kl_what+kl_where)) + reinforce -------
+        pw = 1.0 if cfg.use_prior else 0.0
+        inv_b = 1.0 / B
+        bwd.append((L.air_canvas_unroll_bwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
+                                              p(self.final_canvas), p(self.gd.g[-1]), p(self.dwhere_w), T, B, Hi, Wi,
+                                              hc, wc, cfg.output_multiplier, cfg.output_std, inv_b),
+                    "air_canvas_unroll_bwd"))
+        mlp_bwd(bwd, self.gd, self.what, A, self.gd.g[-1], dx_out=self.d_what)
+        bwd.append((L.air_axpby, (p(self.step_w), pw * inv_b, None, 0.0, p(self.dkl_row), ctypes.c_size_t(M)),
+                    "air_axpby"))
+        bwd.append((L.air_gauss_sample_bwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
+                                             wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale),
+                                             p(self.d_what), p(self.dkl_row), p(self.dq), 2 * A, M, A),
+                    "air_gauss_sample_bwd"))
+        gemm(bwd, 1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
+             colsum=self.grads["what/b"])
+        gemm(bwd, 0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
+             aux=ge_out, ldaux=G)
+        mlp_bwd(bwd, self.ge, self.glimpse_in, hw, self.ge.g[-1], dx_out=self.d_glimpse_in)
+        bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
+                                        B, Hi, Wi, hc, wc), "air_st_read_bwd"))
+        bwd.append((L.air_axpby, (p(self.dwhere_w), 1.0, p(self.dwhere_r), 1.0, p(self.dwhere),
+                                  ctypes.c_size_t(M * 4)), "air_axpby"))
+        bwd.append((L.air_gauss_sample_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
+                                             sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
+                                             p(self.dwhere), p(self.dkl_row), p(self.tr.g[-1]), 8, M, 4),
+                    "air_gauss_sample_bwd"))
+        bwd.append((L.air_axpby, (p(self.kl_what_row), pw * inv_b, p(self.kl_where_row), pw * inv_b, p(self.dstep_w),
+                                  ctypes.c_size_t(M)), "air_axpby"))
+        bwd.append((L.air_numsteps_bwd, (p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                         p(self.dstep_w), p(self.dlogp) if cfg.use_reinforce else None,
+                                         p(self.dprob), T, B), "air_numsteps_bwd"))
+        bwd.append((L.air_presence_bwd, (p(self.st.out[-1]), cfg.step_bias, eps, 1, p(self.dprob), None,
+                                         p(self.st.g[-1]), T, B), "air_presence_bwd"))
+        mlp_bwd(bwd, self.tr, h_all, Hd, self.tr.g[-1], dx_out=self.dH)
+        mlp_bwd(bwd, self.st, h_all, Hd, self.st.g[-1], dx_out=self.dH, dx_beta=1.0)
+        # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)
+        dc_in, dc_out = None, self.dc_a
+        for t in reversed(range(T)):
+            bwd.append((L.air_lstm_pointwise_bwd, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
+                                                   p(self.dH[t]), p(dc_in) if dc_in is not None else None,
+                                                   p(self.dgates[t]), p(dc_out), B, Hd), "air_lstm_pointwise_bwd"))
+            tgt = self.dH[t - 1] if t > 0 else self.dh_init
+            gemm(bwd, 0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, tgt, Hd, beta=1.0 if t > 0 else 0.0)
+            dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
+        gw = self.grads["lstm/w_gates"]
+        gemm(bwd, 1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
+             colsum=self.grads["lstm/b_gates"])                                              # dW_h, db_gates
+        bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
+                    "air_sum_leading"))
+        gemm(bwd, 1, 0, E, 4 * Hd, B, enc_out, E, self.dgx, 4 * Hd, gw[:E], 4 * Hd)        # dW_x
+        bwd.append((L.air_colsum, (p(self.dh_init), Hd, p(self.grads["lstm/h0"]), B, Hd), "air_colsum"))
+        bwd.append((L.air_colsum, (p(dc_in), Hd, p(self.grads["lstm/c0"]), B, Hd), "air_colsum"))
+        gemm(bwd, 0, 1, B, E, 4 * Hd, self.dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
+             ldaux=E)
+        mlp_bwd(bwd, self.enc, self.obs, P, self.enc.g[-1])
+        if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
+            mlp_bwd(bwd, self.bl, self.base_in, cfg.baseline_in, self.dbase)
+
+        # ---- optimiser (two contiguous segments: model vars / baseline vars) ----------------------------------------
+        self._opt_calls_factory = lambda gscale: [
+            (L.air_rmsprop_centered, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
+                                      p(self.flat_mom), ctypes.c_size_t(self.n_model), p(self.lr_dev), 1.0,
+                                      cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale), "air_rmsprop_centered"),
+        ] + ([(L.air_rmsprop_centered, (p(self.flat_params[self.n_model:]), p(self.flat_grads[self.n_model:]),
+                                        p(self.flat_ms[self.n_model:]), p(self.flat_mg[self.n_model:]),
+                                        p(self.flat_mom[self.n_model:]), ctypes.c_size_t(self.n_total - self.n_model),
+                                        p(self.lr_dev), cfg.baseline_lr_mult, cfg.rms_decay, cfg.rms_momentum,
+                                        cfg.rms_eps, gscale), "air_rmsprop_centered")]
+             if (cfg.use_reinforce and self.n_total > self.n_model) else [])
+        step_inc = [(L.air_counter_add, (p(self.step_dev), ctypes.c_int64(1)), "air_counter_add")]
+        base_factory = self._opt_calls_factory
+        self._opt_calls_factory = lambda gscale: base_factory(gscale) + step_inc
+        self._plan_rng, self._plan_fwd, self._plan_bwd = rng, fwd, bwd
+        self._plan_opt = self._opt_calls_factory(1.0)
+
+    def _run(self, plan, stream_ptr):
+        for fn, args, name in plan:
+            st = fn(*args, stream_ptr)
+            if st != 0:
+                _lib.check(st, name)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # public API
+    # ------------------------------------------------------------------------------------------------------------
+    def _sp(self):
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    def set_learning_rate(self, lr: float):
+        self.lr_dev.fill_(float(lr))
+
+    def set_obs(self, obs: torch.Tensor):
+        with torch.cuda.stream(self.stream):
+            self.obs.copy_(obs.reshape(self.B, -1), non_blocking=True)
+
+    def set_noise(self, eps_where, eps_what, u_pres):
+        with torch.cuda.stream(self.stream):
+            self.eps_where.copy_(eps_where.reshape(self.T, self.B, 4))
+            self.eps_what.copy_(eps_what.reshape(self.T, self.B, -1))
+            self.u_pres.copy_(u_pres.reshape(self.T, self.B))
+
+    def steps_prior_success_prob(self, global_step=None) -> float:
+        cfg = self.cfg
+        gs = self.global_step if global_step is None else global_step
+        if cfg.nsp_anneal is None:
+            return float(cfg.nsp_init)
+        return anneal_weight(cfg.nsp_init, cfg.nsp_final, cfg.nsp_anneal, gs, cfg.nsp_steps, cfg.nsp_hold_init,
+                             cfg.nsp_steps_div)
+
+    def set_global_step(self, step: int):
+        """Host mirror + the device counter the captured graph reads (annealing schedule, model.py:106-124)."""
+        self.global_step = int(step)
+        with torch.cuda.stream(self.stream):
+            self.step_dev.fill_(int(step))
+
+    def sample_noise(self):
+        self._run(self._plan_rng, self._sp())
+
+    def forward(self, obs=None, sample_noise=True):
+        """T-step unroll + objective terms.  Results live in the engine's buffers (see `outputs()`)."""
+        if obs is not None:
+            self.set_obs(obs)
+        if sample_noise:
+            self.sample_noise()
+        self._run(self._plan_fwd, self._sp())
+
+    def backward(self):
+        """Fills flat_grads with d opt_loss / d model vars and d baseline_loss / d baseline vars (model.py:355-367)."""
+        self._run(self._plan_bwd, self._sp())
+
+    def optimizer_step(self, grad_scale: float = 1.0):
+        plan = self._plan_opt if grad_scale == 1.0 else self._opt_calls_factory(float(grad_scale))
+        self._run(plan, self._sp())
+        self.global_step += 1
+
+    def capture(self, split_optimizer: bool = False):
+        """Capture noise + forward + backward (+ optimiser) into hipGraphs.  With split_optimizer the update is a
+        second graph so that a gradient all-reduce can run between the two (data-parallel)."""
+        L = H.lib()
+        self.release_graphs()
+        self.stream.synchronize()
+        sp = self._sp()
+        _lib.check(L.air_graph_begin_capture(sp), "air_graph_begin_capture")
+        try:
+            self._run(self._plan_rng, sp)
+            self._run(self._plan_fwd, sp)
+            self._run(self._plan_bwd, sp)
+            if not split_optimizer:
+                self._run(self._plan_opt, sp)
+        finally:
+            exe = ctypes.c_void_p()
+            st = L.air_graph_end_capture(sp, ctypes.byref(exe))
+        _lib.check(st, "air_graph_end_capture")
+        self._graph = exe
+        self._graph_has_opt = not split_optimizer
+        if split_optimizer:
+            _lib.check(L.air_graph_begin_capture(sp), "air_graph_begin_capture")
+            try:
+                self._run(self._opt_calls_factory(1.0 / self.world_size), sp)
+            finally:
+                exe2 = ctypes.c_void_p()
+                st = L.air_graph_end_capture(sp, ctypes.byref(exe2))
+            _lib.check(st, "air_graph_end_capture")
+            self._graph_opt = exe2
+
+    def release_graphs(self):
+        L = H.lib()
+        for g in (self._graph, self._graph_opt):
+            if g is not None:
+                L.air_graph_destroy(g)
+        self._graph = self._graph_opt = None
+
+    def train_step(self, obs=None, allreduce=None):
+        """One full update: fresh noise, forward, backward, (all-reduce), centred RMSProp x2.
+        `allreduce(flat_grads)`: optional callable run on the engine stream between backward and the update."""
+        if obs is not None:
+            self.set_obs(obs)
+        sp = self._sp()
+        if self._graph is not None:
+            _lib.check(H.lib().air_graph_launch(self._graph, sp), "air_graph_launch")
+            if not self._graph_has_opt:
+                if allreduce is not None:
+                    with torch.cuda.stream(self.stream):
+                        allreduce(self.flat_grads)
+                _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
+        else:
+            self._run(self._plan_rng, sp)
+            self._run(self._plan_fwd, sp)
+            self._run(self._plan_bwd, sp)
+            if allreduce is not None:
+                with torch.cuda.stream(self.stream):
+                    allreduce(self.flat_grads)
+            self._run(self._plan_opt if self.world_size == 1 else self._opt_calls_factory(1.0 / self.world_size), sp)
+        self.global_step += 1
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    # ---- read-outs (plumbing; not part of the timed step) ---------------------------------------------------------
+    def outputs(self) -> Dict[str, torch.Tensor]:
+        """The reference's model attributes (model.py:86-104, 319-343) as tensors, time-major."""
+        cfg, T, B = self.cfg, self.T, self.B
+        self.synchronize()
+        o = {}
+        o["what"], o["what_loc"], o["what_scale"] = self.what, self.what_loc, self.what_scale
+        o["where"], o["where_loc"], o["where_scale"] = self.where, self.where_loc, self.where_scale
+        o["presence_prob"] = self.presence_prob.view(T, B, 1)
+        o["presence"] = self.presence.view(T, B, 1)
+        o["glimpse_raw"] = self.gd.out[-1].view(T, B, cfg.n_crop)
+        o["glimpse"] = (o["presence"] * torch.sigmoid(o["glimpse_raw"])).view(T, B, *cfg.crop_size)
+        if self.canvas_steps is not None:
+            o["canvas"] = self.canvas_steps.view(T, B, *cfg.img_size) * cfg.output_multiplier
+        o["final_canvas"] = self.final_canvas.view(B, *cfg.img_size) * cfg.output_multiplier
+        o["final_state"] = (self.h_seq[T], self.c_seq[T])
+        o["rec_loss_per_sample"] = self.rec
+        o["rec_loss"] = self.rec.mean()
+        o["num_steps_posterior"] = self.q_n
+        o["kl_num_steps_per_sample"] = self.kl_n
+        o["kl_num_steps"] = self.kl_n.mean()
+        o["prior_step_weight"] = self.step_w
+        o["kl_what_per_sample"] = (self.kl_what_row * self.step_w).sum(0)
+        o["kl_where_per_sample"] = (self.kl_where_row * self.step_w).sum(0)
+        o["kl_what"] = o["kl_what_per_sample"].mean()
+        o["kl_where"] = o["kl_where_per_sample"].mean()
+        pw = 1.0 if cfg.use_prior else 0.0
+        o["prior_loss"] = o["kl_num_steps"] + o["kl_what"] + o["kl_where"]
+        o["loss"] = o["rec_loss"] + pw * o["prior_loss"]
+        o["num_step_per_sample"] = self.presence.sum(0)
+        o["num_steps_log_prob"] = self.logp
+        o["opt_loss"] = o["loss"]
+        if cfg.use_reinforce:
+            o["baseline"] = self.bl.out[-1]
+            o["reinforce_loss"] = self.nvil_out[0]
+            o["baseline_loss"] = self.nvil_out[1]
+            o["imp_weight_mean"] = self.nvil_out[2]
+            o["imp_weight_var"] = self.nvil_out[3]
+            o["opt_loss"] = o["loss"] + o["reinforce_loss"]
+        return o
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        self.synchronize()
+        return dict(self.grads)
+
+    def kernel_launch_count(self) -> Dict[str, int]:
+        return {"rng": len(self._plan_rng), "forward": len(self._plan_fwd), "backward": len(self._plan_bwd),
+                "optimizer": len(self._plan_opt)}

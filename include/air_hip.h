@@ -160,6 +160,17 @@ int air_numsteps_bwd(const float *presence_prob, const float *presence, const do
                      const float *dstep_weight, const float *dlogp, float *dpresence_prob, int T, int B,
                      void *stream);
 
+/* Annealed geometric prior over the number of steps, entirely on device (model.py:106-124,139-146; prior.py:26-32):
+ *   step' = max(*global_step_dev - hold_for, 0);  anneal_type 0: s = init; 1 ("exp"): s = max(final, init *
+ *   ((final/init)^(steps_div/anneal_steps))^(step'/steps_div)); 2 ("linear"): s = max(final, final + (init-final) *
+ *   (1 - step'/anneal_steps)).  s is clipped to [1e-7, 1-1e-15]; prior_out_f64[n] = (1-s) s^n, n = 0..T (float64,
+ *   NOT renormalised, exactly like the reference).  Reading the step counter on device keeps a captured hipGraph
+ *   valid across replays; air_counter_add advances it.                                                             */
+int air_steps_prior(const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+                    double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
+                    void *stream);
+int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
+
 /* NVIL / REINFORCE with the reference's [B]-[B,1]->[B,B] broadcast (model.py:218-259).
  *   imp[B] (= rec_loss_per_sample), baseline[B], logp[B].
  *   out[4] = {reinforce_loss, baseline_loss, imp_weight_mean, imp_weight_var};
@@ -196,6 +207,8 @@ int air_axpby(const float *a, float alpha, const float *b, float beta, float *ou
 /* broadcast rows: out[r, :] = src[0, :] for r < rows (tiling the trainable LSTM initial state, cell.py:103)       */
 int air_tile_rows(const float *src, float *out, int rows, int cols, void *stream);
 int air_colsum(const float *x, int ld, float *out, int M, int N, void *stream);   /* out[n] = sum_m x[m,n] */
+/* out[i] = sum_t x[t*n + i], t < T: sums a time-major [T, n] stack over time (dGX = sum_t dgates_t in the LSTM BPTT) */
+int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream);
 
 /* ---- hipGraph capture + timing helpers (plumbing for bench / the fused train step) --------------------------*/
 int air_graph_begin_capture(void *stream);
