@@ -81,6 +81,9 @@ def load():
         raise AirHipError(
             f"{LIB_PATH} not found: the HIP extension is the product and there is no fallback. "
             "Build it with `python -m attend_infer_repeat_amd.build` (or __graft_entry__.build()).")
+    # torch bundles its own libamdhip64; import it FIRST so that this library binds to the same HIP runtime instance
+    # (loading /opt/rocm's copy first leaves the process with two runtimes and kernels fail with hipErrorNoDevice).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of one AIR train step (T-step unroll forward, ELBO/NVIL backward, both RMSProp updates).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run
+with one rank per GPU.  Rank 0 prints ONE JSON line.  A "step" is one pass of the hot path over one synthetic batch of
+64 images per GPU (BASELINE.json configs[1]: multi-MNIST 50x50, max_steps=3, batch=64, fp32); data-parallel runs keep
+64 images per GPU (weak scaling) and all-reduce the flat gradient bucket once per step over RCCL.
+
+Besides the headline value the line carries
+  roofline     : the fused ST glimpse-read kernel (north_star's target kernel): algorithmic bytes per launch
+                 (4*(HW+hw+4) B per image-step) / its average duration measured here with HIP events on the
+                 engine's stream, vs the 8 TB/s HBM3E peak; plus the same figure over a batch sweep (the working set
+                 only leaves the 256 MiB Infinity Cache at large batch) and for the other three ST kernels.
+  cpu_baseline : the CPU oracle (reference-equivalent restatement, torch-CPU fp32) timed on this host's cores on a
+                 bounded sample of the same workload (kind "port").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="eager C-ABI launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2: 50x50/20x20/T=3 (headline); c4: 100x100/28x28/T=5 (bandwidth study)")
+    return ap.parse_args()
+
+
+def event_time_ms(lib, stream_ptr, fn, reps):
+    """Average duration of `fn()` (which enqueues work on the stream) measured with HIP events on that stream."""
+    from attend_infer_repeat_amd import _lib
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.air_event_create(ctypes.byref(e0))); _lib.check(lib.air_event_create(ctypes.byref(e1)))
+    for _ in range(3):
+        fn()
+    _lib.check(lib.air_event_record(e0, stream_ptr))
+    for _ in range(reps):
+        fn()
+    _lib.check(lib.air_event_record(e1, stream_ptr))
+    ms = ctypes.c_float()
+    _lib.check(lib.air_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    lib.air_event_destroy(e0); lib.air_event_destroy(e1)
+    return ms.value / reps
+
+
+def st_rooflines(eng, reps=200):
+    """Per-launch algorithmic GB/s of the four ST kernels at the engine's own shapes and buffers."""
+    import torch
+    from attend_infer_repeat_amd import hip as H
+    lib = H.lib()
+    cfg, T, B, M = eng.cfg, eng.T, eng.B, eng.M
+    (Hh, Ww), (h, w) = cfg.img_size, cfg.crop_size
+    HW, hw = Hh * Ww, h * w
+    p, sp = H._p, eng._sp()
+    dec, dgl = eng.gd.out[-1], eng.gd.g[-1]
+    calls = {
+        "st_read_fwd": (lambda: lib.air_st_read_fwd(p(eng.obs), p(eng.where), p(eng.glimpse_in), M, B, Hh, Ww, h, w, sp),
+                        4 * (HW + hw + 4) * M),
+        "st_read_bwd": (lambda: lib.air_st_read_bwd(p(eng.obs), p(eng.where), p(eng.d_glimpse_in), p(eng.dwhere_r), None,
+                                                    M, B, Hh, Ww, h, w, sp), 4 * (HW + hw + 4 + 4) * M),
+        "canvas_unroll_fwd": (lambda: lib.air_canvas_unroll_fwd(p(dec), p(eng.where), p(eng.presence), p(eng.obs),
+                                                                 p(eng.canvas_steps), p(eng.final_canvas), p(eng.rec),
+                                                                 T, B, Hh, Ww, h, w, cfg.output_multiplier,
+                                                                 cfg.output_std, sp), 4 * (hw + 2 * HW + 4 + 1) * M),
+        "canvas_unroll_bwd": (lambda: lib.air_canvas_unroll_bwd(p(dec), p(eng.where), p(eng.presence), p(eng.obs),
+                                                                 p(eng.final_canvas), p(dgl), p(eng.dwhere_w), T, B, Hh,
+                                                                 Ww, h, w, cfg.output_multiplier, cfg.output_std,
+                                                                 1.0 / B, sp), 4 * (HW + 2 * hw + 4 + 4 + 1) * M),
+    }
+    out = {}
+    for name, (fn, nbytes) in calls.items():
+        ms = event_time_ms(lib, sp, fn, reps)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "us_per_launch": round(ms * 1e3, 3),
+                     "algorithmic_bytes_per_launch": nbytes}
+    return out
+
+
+def st_read_sweep(cfg, T, batches, device, share_image=True):
+    """ST glimpse read over a batch sweep: the >=70%-of-roofline target is only meaningful once the working set
+    (B*10 KB images + T*B*1.6 KB glimpses) exceeds the 256 MiB Infinity Cache."""
+    import torch
+    from attend_infer_repeat_amd import hip as H
+    lib = H.lib()
+    (Hh, Ww), (h, w) = cfg.img_size, cfg.crop_size
+    HW, hw = Hh * Ww, h * w
+    res = []
+    stream = torch.cuda.Stream(device=device)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    for B in batches:
+        n = T * B
+        n_img = B if share_image else n
+        img = torch.rand(n_img, Hh, Ww, device=device)
+        where = torch.empty(n, 4, device=device)
+        where[:, 0] = 0.45 + 0.2 * torch.rand(n, device=device); where[:, 2] = 0.45 + 0.2 * torch.rand(n, device=device)
+        where[:, 1] = 0.6 * torch.rand(n, device=device) - 0.3; where[:, 3] = 0.6 * torch.rand(n, device=device) - 0.3
+        out = torch.empty(n, h, w, device=device)
+        torch.cuda.synchronize()
+        fn = lambda: lib.air_st_read_fwd(H._p(img), H._p(where), H._p(out), n, n_img, Hh, Ww, h, w, sp)
+        ms = event_time_ms(lib, sp, fn, 20 if B >= 16384 else 100)
+        nbytes = 4 * (HW + hw + 4) * n
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        res.append({"batch": B, "glimpses": n, "us_per_launch": round(ms * 1e3, 2), "achieved": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "images": n_img, "working_set_MiB": round((n_img * HW + n * hw) * 4 / 2 ** 20, 1)})
+        del img, where, out
+    return res
+
+
+def cpu_baseline(cfg_kw, batch, seconds):
+    """The CPU oracle's full train step (reference-equivalent restatement) on this host's cores, bounded sample."""
+    import torch
+    from oracle import air_oracle as O
+    ocfg = O.AIRConfig(**cfg_kw)
+    params = O.init_params(ocfg, seed=1)
+    slots = O.rmsprop_init(params)
+    obs, _ = O.synthetic_batch(ocfg, batch, seed=0)
+    # pick the thread count that serves this small-op workload best on this host (more threads != faster here)
+    avail = os.cpu_count() or 1
+    best = (None, 1e9)
+    for th in sorted({4, 8, 16, 32}):
+        if th > avail:
+            continue
+        torch.set_num_threads(th)
+        O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=90), global_step=0)
+        t0 = time.perf_counter()
+        for i in range(2):
+            O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=91 + i), global_step=0)
+        dt = (time.perf_counter() - t0) / 2
+        if dt < best[1]:
+            best = (th, dt)
+    cores = best[0]
+    torch.set_num_threads(cores)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=200 + n), global_step=2 + n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 400:
+            break
+    return {"value": round(batch * n / el, 1), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} full train steps at batch {batch} ({el:.1f} s) of the torch-CPU fp32 oracle "
+                      f"(oracle/air_oracle.py); threads={cores} chosen as the fastest of a sweep on this {avail}-cpu host"}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from attend_infer_repeat_amd import build as air_build
+    air_build.build()
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+
+    cfg_kw = {} if args.config == "c2" else dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5)
+    cfg = EngineConfig(**cfg_kw)
+    B = args.batch
+    eng = AIREngine(cfg, B, device=device, seed=1 + rank, keep_canvas_steps=False)
+    eng.world_size = world
+    imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=2 if args.config == "c2" else 4, seed=rank)
+    eng.set_obs(torch.from_numpy(imgs).to(device))
+    allreduce = None
+    if world > 1:
+        allreduce = lambda g: dist.all_reduce(g)            # one RCCL all-reduce (sum) of the flat gradient bucket
+    if not args.no_graph:
+        eng.capture(split_optimizer=world > 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        eng.train_step(allreduce=allreduce)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(allreduce=allreduce)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    finite = bool(torch.isfinite(eng.flat_params).all().item())
+
+    line = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        roof = st_rooflines(eng)
+        line = {
+            "metric": "images/sec (train step, ELBO backward) multi-MNIST 50x50, 3-step AIR" if args.config == "c2"
+                      else "images/sec (train step, ELBO backward) 100x100 canvas, 5-step AIR, glimpse 28x28",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("multi-MNIST 50x50, max_steps=3, glimpse 20x20, batch=64 per GPU (BASELINE configs[1])"
+                                    if args.config == "c2" else
+                                    "canvas 100x100, 0-4 objects, max_steps=5, glimpse 28x28 (BASELINE configs[3])"),
+                       "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
+                       "hipgraph": not args.no_graph, "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
+                       "params_finite_after_run": finite},
+            "roofline": roof["st_read_fwd"],
+            "roofline_other_kernels": {k: v for k, v in roof.items() if k != "st_read_fwd"},
+        }
+        if not args.no_sweep and world == 1:
+            # T glimpses per staged image (as in the train step) and the 1:1 case (one image per glimpse)
+            line["roofline_sweep_st_read_fwd"] = st_read_sweep(cfg, eng.T, [64, 1024, 8192, 65536], device)
+            line["roofline_sweep_st_read_fwd_one_image_per_glimpse"] = st_read_sweep(cfg, 1, [192, 3072, 24576, 196608],
+                                                                                     device, share_image=False)
+        if not args.no_cpu_baseline and world == 1:
+            torch.cuda.synchronize(device)
+            line["cpu_baseline"] = cpu_baseline(cfg_kw, B, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
