@@ -54,6 +54,22 @@ __device__ __forceinline__ f32x4 ld_kstrided(const float *p, int ld, int col, bo
     return v;
 }
 
+// Unmasked variants for chunks that lie fully inside K.  Rows / columns beyond the matrix are CLAMPED to a valid
+// address instead of masked: they only feed accumulator rows / columns that are never stored.
+__device__ __forceinline__ f32x4 ld_kcontig_full(const float *p, int ld, int row, int k, bool vec) {
+    const float *q = p + (size_t)row * ld + k;
+    if (vec) return *reinterpret_cast<const f32x4 *>(q);
+    f32x4 v;
+    v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
+    return v;
+}
+__device__ __forceinline__ f32x4 ld_kstrided_full(const float *p, int ld, int col, int k) {
+    const float *q = p + (size_t)k * ld + col;
+    f32x4 v;
+    v.x = q[0]; v.y = q[ld]; v.z = q[2 * (size_t)ld]; v.w = q[3 * (size_t)ld];
+    return v;
+}
+
 __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const GemmArgs &g) {
     if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
     switch (g.epi) {
@@ -113,7 +129,50 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     for (int b = 0; b < NT; ++b) { colB[b] = n0 + 16 * b + li; okB[b] = colB[b] < g.N; }
 
     const int c_step = (KW == 4) ? 4 : 1;
-    for (int c = c_begin + ((KW == 4) ? wave : 0); c < c_end; c += c_step) {
+    int c = c_begin + ((KW == 4) ? wave : 0);
+    // ---- main loop: U chunks in flight per wave.  The problem is latency bound (operands sit in L2 / Infinity
+    // Cache, each wave owns only a handful of 16-deep chunks), so all loads of U chunks are issued before the first
+    // MFMA: one memory round trip per U chunks instead of one per chunk.
+    constexpr int U = 4;
+    int full_end = g.K >> 4;                               // chunks [0, full_end) need no k masking
+    if (full_end > c_end) full_end = c_end;
+    int rowAc[MT], colBc[NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) rowAc[a] = okA[a] ? rowA[a] : g.M - 1;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) colBc[b] = okB[b] ? colB[b] : g.N - 1;
+    for (; c + (U - 1) * c_step < full_end; c += U * c_step) {
+        f32x4 fa[U][MT], fb[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = ((c + u * c_step) << 4) + 4 * lg;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                fa[u][a] = g.ta ? ld_kstrided_full(g.A, g.lda, rowAc[a], k)
+                                : ld_kcontig_full(g.A, g.lda, rowAc[a], k, g.vecA != 0);
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                fb[u][b] = g.tb ? ld_kcontig_full(g.B, g.ldb, colBc[b], k, g.vecB != 0)
+                                : ld_kstrided_full(g.B, g.ldb, colBc[b], k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][a][j], fb[u][b][j], acc[a][b], 0, 0, 0);
+            if (want_colsum) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    csum[b] += okB[b] ? (fb[u][b].x + fb[u][b].y) + (fb[u][b].z + fb[u][b].w) : 0.f;
+            }
+        }
+    }
+    // ---- remainder: one chunk at a time, fully masked (also covers the partial last chunk of K)
+    for (; c < c_end; c += c_step) {
         const int k = (c << 4) + 4 * lg;
         f32x4 fa[MT], fb[NT];
 #pragma unroll
@@ -250,7 +309,8 @@ extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int
     }
     const bool narrow = (M <= 64);
     const long tiles = narrow ? (long)air_cdiv(M, 16) * air_cdiv(N, 32) : tiles22;
-    if (!colsum && ws && chunks >= 16) {
+    // cross-workgroup split-K costs a second (epilogue) launch, ~4.5 us on this part: only worth it for long K
+    if (!colsum && ws && chunks >= 64) {
         long want = 512 / (tiles > 0 ? tiles : 1);                       // aim for ~2 workgroups per CU
         long max_by_k = chunks / 8;                                      // >= 2 chunks per wave per split
         long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));

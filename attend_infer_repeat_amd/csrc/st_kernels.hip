@@ -409,7 +409,14 @@ static inline int st_check_dims(int n, int H, int W, int h, int w) {
     if (n <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return AIR_E_SHAPE;
     return AIR_OK;
 }
-#define ST_MAX_LDS (64 * 1024)   // dynamic LDS above 64 KiB would need hipFuncSetAttribute
+#define ST_MAX_LDS (160 * 1024)
+// dynamic LDS above 64 KiB must be opted into per kernel
+template <typename K>
+static inline int st_allow_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return AIR_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e == hipSuccess ? AIR_OK : (int)e;
+}
 
 extern "C" int air_st_read_fwd(const float *img, const float *where, float *glimpse, int n, int n_img, int H, int W,
                                int h, int w, void *stream) {
@@ -420,6 +427,7 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
     const size_t lds = carve_bytes(H * W, 0, w, h);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
+    { int st_ = st_allow_lds(st_read_fwd_kernel, lds); if (st_) return st_; }
     hipLaunchKernelGGL(st_read_fwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
                        glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
     AIR_LAUNCH_CHECK();
@@ -436,6 +444,7 @@ extern "C" int air_st_read_bwd(const float *img, const float *where, const float
     const size_t lds = carve_bytes(H * W, dimg ? H * W : 0, w, h);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
+    { int st_ = st_allow_lds(st_read_bwd_kernel, lds); if (st_) return st_; }
     hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
                        dglimpse, dwhere, dimg, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
     AIR_LAUNCH_CHECK();
@@ -450,6 +459,7 @@ static int launch_write_fwd(const float *glimpse, const float *where, const floa
     const int vec4c = ((H * W) % 4 == 0) && (!canvas_in || air_aligned16(canvas_in)) &&
                       (!final_canvas || air_aligned16(final_canvas));
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    { int st_ = st_allow_lds(st_write_fwd_kernel, lds); if (st_) return st_; }
     hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid(B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse, where,
                        presence, canvas_in, obs, canvas_steps, final_canvas, rec, T, B, H, W, h, w, lin_step(W),
                        lin_step(H), mult, std, vec4c, vec4g);
@@ -487,6 +497,7 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     const size_t lds = carve_bwd_bytes(H, W, h, w);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    { int st_ = st_allow_lds(st_write_bwd_kernel, lds); if (st_) return st_; }
     hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse,
                        where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
                        lin_step(W), lin_step(H), mult, std, loss_scale, vec4g);

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--breakdown", action="store_true",
+                    help="time every launch of the step plan in isolation (HIP events, back-to-back repeats) -> stderr")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2: 50x50/20x20/T=3 (headline); c4: 100x100/28x28/T=5 (bandwidth study)")
     return ap.parse_args()
@@ -92,6 +94,30 @@ def st_rooflines(eng, reps=200):
                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "us_per_launch": round(ms * 1e3, 3),
                      "algorithmic_bytes_per_launch": nbytes}
     return out
+
+
+def plan_breakdown(eng, reps=100):
+    """Per-launch steady-state cost (launch + execution) of each entry of the step plan, run back-to-back in isolation."""
+    from attend_infer_repeat_amd import hip as H
+    lib = H.lib()
+    sp = eng._sp()
+    rows = []
+    for phase, plan in (("rng", eng._plan_rng), ("fwd", eng._plan_fwd), ("bwd", eng._plan_bwd), ("opt", eng._plan_opt)):
+        for i, (fn, a, name) in enumerate(plan):
+            ms = event_time_ms(lib, sp, lambda: fn(*a, sp), reps)
+            desc = ""
+            if name == "air_gemm":
+                desc = f"ta={a[0]} tb={a[1]} M={a[2]} N={a[3]} K={a[4]} epi={a[12]}"
+            rows.append((phase, i, name, desc, ms * 1e3))
+    tot = sum(r[4] for r in rows)
+    print(f"# isolated per-launch cost, {len(rows)} launches, sum {tot:.1f} us", file=sys.stderr)
+    for r in rows:
+        print(f"{r[0]:4s} {r[1]:3d} {r[2]:28s} {r[3]:44s} {r[4]:8.2f} us", file=sys.stderr)
+    agg = {}
+    for r in rows:
+        agg.setdefault(r[2], [0, 0.0]); agg[r[2]][0] += 1; agg[r[2]][1] += r[4]
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"## {k:28s} x{n:3d} {t:8.1f} us ({100 * t / tot:4.1f}%)", file=sys.stderr)
 
 
 def st_read_sweep(cfg, T, batches, device, share_image=True):
@@ -219,6 +245,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
+        if args.breakdown:
+            plan_breakdown(eng)
         roof = st_rooflines(eng)
         line = {
             "metric": "images/sec (train step, ELBO backward) multi-MNIST 50x50, 3-step AIR" if args.config == "c2"
