@@ -163,6 +163,58 @@ extern "C" int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *e
     return AIR_OK;
 }
 
+__global__ __launch_bounds__(PW_THREADS) void normal_kl_fwd_kernel(const float *__restrict__ loc,
+                                                                   const float *__restrict__ scale, float pl0,
+                                                                   float ps0, float pl1, float ps1,
+                                                                   float *__restrict__ kl_row, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (int)((blockIdx.x * (size_t)PW_THREADS + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    for (int m = wave_global; m < M; m += nwaves) {
+        float kl = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const size_t o = (size_t)m * D + d;
+            kl += (d & 1) ? normal_kl(loc[o], scale[o], pl1, ps1) : normal_kl(loc[o], scale[o], pl0, ps0);
+        }
+        kl = wave_sum(kl);
+        if (lane == 0) kl_row[m] = kl;
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void normal_kl_bwd_kernel(const float *__restrict__ loc,
+                                                                   const float *__restrict__ scale, float pl0,
+                                                                   float ps0, float pl1, float ps1,
+                                                                   const float *__restrict__ dkl,
+                                                                   float *__restrict__ dloc,
+                                                                   float *__restrict__ dscale, int M, int D) {
+    PW_LOOP(e, (size_t)M * D) {
+        const size_t m = e / D;
+        const int d = (int)(e - m * D);
+        const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
+        const float g = dkl[m], s = scale[e];
+        dloc[e] = g * (loc[e] - pm) / (ps * ps);
+        dscale[e] = g * (s / (ps * ps) - 1.f / s);
+    }
+}
+extern "C" int air_normal_kl_fwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even,
+                                 float p_loc_odd, float p_scale_odd, float *kl_row, int M, int D, void *stream) {
+    AIR_REQUIRE(loc && scale && kl_row, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(normal_kl_fwd_kernel, dim3(pw_blocks((size_t)M * 64)), dim3(PW_THREADS), 0, air_stream(stream),
+                       loc, scale, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, kl_row, M, D);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_normal_kl_bwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even,
+                                 float p_loc_odd, float p_scale_odd, const float *dkl_row, float *dloc, float *dscale,
+                                 int M, int D, void *stream) {
+    AIR_REQUIRE(loc && scale && dkl_row && dloc && dscale, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(normal_kl_bwd_kernel, dim3(pw_blocks((size_t)M * D)), dim3(PW_THREADS), 0, air_stream(stream),
+                       loc, scale, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, dkl_row, dloc, dscale, M, D);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
 // ---- presence (cell.py:137-151) ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(PW_THREADS) void presence_fwd_kernel(const float *__restrict__ logit,
                                                                   const float *__restrict__ u,

@@ -240,6 +240,24 @@ def gauss_sample_bwd(pre, eps, raw_offset, loc_mode, prior4, loc, scale, dsample
     return dpre
 
 
+def normal_kl_fwd(loc, scale, prior4):
+    loc = _f32(loc, "loc", 2); scale = _f32(scale, "scale", 2)
+    M, D = loc.shape
+    kl = torch.empty((M,), dtype=torch.float32, device=loc.device)
+    a, b, c, d = (float(v) for v in prior4)
+    _lib.check(lib().air_normal_kl_fwd(_p(loc), _p(scale), a, b, c, d, _p(kl), M, D, _stream()), "air_normal_kl_fwd")
+    return kl
+
+
+def normal_kl_bwd(loc, scale, prior4, dkl_row):
+    M, D = loc.shape
+    dloc = torch.empty_like(loc); dscale = torch.empty_like(scale)
+    a, b, c, d = (float(v) for v in prior4)
+    _lib.check(lib().air_normal_kl_bwd(_p(loc), _p(scale), a, b, c, d, _p(_f32(dkl_row, "dkl_row", 1)), _p(dloc),
+                                       _p(dscale), M, D, _stream()), "air_normal_kl_bwd")
+    return dloc, dscale
+
+
 def presence_fwd(logit, u, step_bias, explore_eps, discrete, presence_in=None):
     """logit, u: [T,B] -> presence_prob[T,B], presence[T,B]"""
     logit = _f32(logit, "logit", 2); u = _f32(u, "u"); presence_in = _f32(presence_in, "presence_in")

@@ -1,0 +1,143 @@
+"""AIRonMNIST -- AIR for the multi-MNIST dataset with the constructor of the reference
+(attend_infer_repeat/mnist_model.py:10-44): n_appearance=50, LSTM(256) transition, output_std=.3, stock modules.
+
+Because this is the standard architecture, `train_step` runs through the fused hipGraph-captured engine
+(engine.AIREngine) instead of autograd; the module tree shares its parameters with the engine's flat buffer, so
+cell-by-cell calls and `forward()` always see the trained weights.
+"""
+from functools import partial
+
+import torch
+
+from .engine import AIREngine, EngineConfig
+from .model import AIRModel
+from .modules import BaselineMLP, Decoder, Encoder, StepsPredictor, StochasticTransformParam
+from .rnn import LSTM
+
+
+class AIRonMNIST(AIRModel):
+    """Implements AIR for the MNIST dataset"""
+
+    def __init__(self, obs, nums, glimpse_size=(20, 20),
+                 inpt_encoder_hidden=[256] * 2,
+                 glimpse_encoder_hidden=[256] * 2,
+                 glimpse_decoder_hidden=[252] * 2,
+                 transform_estimator_hidden=[256] * 2,
+                 steps_pred_hidden=[50] * 1,
+                 baseline_hidden=[256, 128] * 1,
+                 transform_var_bias=-2.,
+                 step_bias=0.,
+                 *args, **kwargs):
+        self.transform_var_bias = torch.tensor(float(transform_var_bias))     # non-trainable variables,
+        self.step_bias = torch.tensor(float(step_bias))                       # mnist_model.py:24-26
+        self.baseline = BaselineMLP(baseline_hidden)
+        self._hyper = dict(inpt_encoder_hidden=tuple(inpt_encoder_hidden),
+                           glimpse_encoder_hidden=tuple(glimpse_encoder_hidden),
+                           glimpse_decoder_hidden=tuple(glimpse_decoder_hidden),
+                           transform_estimator_hidden=tuple(transform_estimator_hidden),
+                           steps_pred_hidden=tuple(steps_pred_hidden), baseline_hidden=tuple(baseline_hidden))
+        super(AIRonMNIST, self).__init__(
+            *args,
+            obs=obs,
+            nums=nums,
+            glimpse_size=glimpse_size,
+            n_appearance=50,
+            transition=LSTM(256),
+            input_encoder=partial(Encoder, inpt_encoder_hidden),
+            glimpse_encoder=partial(Encoder, glimpse_encoder_hidden),
+            glimpse_decoder=partial(Decoder, glimpse_decoder_hidden),
+            transform_estimator=partial(StochasticTransformParam, transform_estimator_hidden,
+                                        scale_bias=self.transform_var_bias),
+            steps_predictor=partial(StepsPredictor, steps_pred_hidden, self.step_bias),
+            output_std=.3,
+            **kwargs
+        )
+
+    # ---- name map between the module tree and the engine's flat parameter buffer -------------------------------------
+    def _named_module_params(self):
+        c = self.cell
+        out = {}
+
+        def mlp(prefix, m):
+            for i, layer in enumerate(m.layers):
+                out[f"{prefix}/{i}/w"], out[f"{prefix}/{i}/b"] = layer.w, layer.b
+
+        mlp("input_encoder", c._input_encoder.mlp)
+        out["lstm/w_gates"], out["lstm/b_gates"] = c._transition.w_gates, c._transition.b_gates
+        out["lstm/h0"], out["lstm/c0"] = c._transition.h0, c._transition.c0
+        mlp("transform", c._transform_estimator.mlp)
+        mlp("steps", c._steps_predictor.mlp)
+        mlp("glimpse_encoder", c._glimpse_encoder.mlp)
+        out["what/w"], out["what/b"] = c._what_distrib.w, c._what_distrib.b
+        mlp("glimpse_decoder", c._glimpse_decoder.mlp)
+        mlp("baseline", self.baseline_module.mlp)
+        return out
+
+    def engine_config(self, learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior):
+        nsp = num_steps_prior
+        return EngineConfig(
+            img_size=tuple(self.img_size), crop_size=tuple(self.glimpse_size), n_appearance=self.n_appearance,
+            n_hidden=256, max_steps=self.max_steps,
+            transform_var_bias=float(self.transform_var_bias), step_bias=float(self.step_bias),
+            output_multiplier=float(self.output_multiplier), output_std=float(self.output_std),
+            explore_eps=None if self.explore_eps is None else float(self.explore_eps),
+            what_prior=(what_prior.loc, what_prior.scale),
+            where_scale_prior=(where_scale_prior.loc, where_scale_prior.scale),
+            where_shift_prior=(where_shift_prior.loc, where_shift_prior.scale),
+            nsp_anneal=getattr(nsp, 'anneal', None), nsp_init=nsp.init, nsp_final=getattr(nsp, 'final', nsp.init),
+            nsp_steps_div=getattr(nsp, 'steps_div', 1.), nsp_steps=getattr(nsp, 'steps', 1.),
+            nsp_hold_init=getattr(nsp, 'hold_init', 0.),
+            use_prior=self.use_prior, use_reinforce=self.use_reinforce, learning_rate=float(learning_rate),
+            **self._hyper)
+
+    def train_step(self, learning_rate, l2_weight=0., what_prior=None, where_scale_prior=None,
+                   where_shift_prior=None, num_steps_prior=None, use_prior=True, use_reinforce=True, baseline=None,
+                   decay_rate=None, optimizer=None, opt_kwargs=None, use_engine=True, capture_graph=True):
+        fn, gs = super(AIRonMNIST, self).train_step(learning_rate, l2_weight, what_prior, where_scale_prior,
+                                                    where_shift_prior, num_steps_prior, use_prior, use_reinforce,
+                                                    baseline, decay_rate, optimizer, opt_kwargs)
+        standard = (use_engine and self.discrete_steps and getattr(num_steps_prior, 'analytic', True)
+                    and decay_rate is None and not l2_weight)
+        if not standard:
+            return fn, gs
+        cfg = self.engine_config(learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior)
+        eng = AIREngine(cfg, self.batch_size, device=self.obs.device)
+        named = self._named_module_params()
+        eng.load_parameters({k: v.detach() for k, v in named.items()})
+        for k, p in named.items():                           # share storage: modules now view the engine's flat buffer
+            p.data = eng.params[k]
+        eng.set_obs(self.obs)
+        if capture_graph:
+            eng.capture()
+        self._engine = eng
+
+        def train_step_fn(obs=None, nums=None):
+            """One fused update (fresh noise, forward, backward, both RMSProp updates) as a hipGraph replay."""
+            if obs is not None:
+                self.obs = obs
+            if nums is not None:
+                self.nums = nums
+            eng.set_learning_rate(float(self.learning_rate))
+            eng.train_step(obs)
+            self.global_step += 1
+            self._refresh_from_engine()
+            return self.global_step
+
+        self._train_step = train_step_fn
+        return self._train_step, self.global_step
+
+    def _refresh_from_engine(self):
+        """Expose the engine's buffers under the reference's attribute names (model.py:86-104,319-343)."""
+        eng, T, B = self._engine, self.max_steps, self.batch_size
+        o = eng.outputs()
+        for k in ("what", "what_loc", "what_scale", "where", "where_loc", "where_scale", "presence_prob", "presence",
+                  "glimpse", "canvas", "final_canvas", "final_state", "rec_loss_per_sample", "rec_loss",
+                  "kl_num_steps_per_sample", "kl_num_steps", "kl_what", "kl_where", "prior_step_weight",
+                  "num_step_per_sample", "opt_loss", "reinforce_loss", "baseline_loss", "baseline"):
+            if k in o:
+                setattr(self, k, o[k])
+        self.num_step = self.num_step_per_sample.mean()
+        self.steps_prior_success_prob = eng.steps_prior_success_prob(max(eng.global_step - 1, 0))
+        if self.nums is not None:
+            self.gt_num_steps = self.nums.sum(0).reshape(-1)
+            self.num_step_accuracy = (self.gt_num_steps == self.num_step_per_sample).float().mean()

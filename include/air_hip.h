@@ -129,6 +129,14 @@ int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float r
                          const float *loc, const float *scale, const float *dsample, const float *dkl_row,
                          float *dpre, int ld_dpre, int M, int D, void *stream);
 
+/* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
+ * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
+int air_normal_kl_fwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even, float p_loc_odd,
+                      float p_scale_odd, float *kl_row, int M, int D, void *stream);
+int air_normal_kl_bwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even, float p_loc_odd,
+                      float p_scale_odd, const float *dkl_row, float *dloc, float *dscale, int M, int D,
+                      void *stream);
+
 /* Presence, cell.py:137-151: p = sigmoid(logit + step_bias); if explore_eps >= 0: p = eps/2 + (1-eps)*p;
  * discrete: z = (u < p), presence[t] = presence[t-1]*z (presence[-1] = presence_in or 1); else presence = p.
  * logit/u/presence_prob/presence are [T,B] time-major (T = 1 for a single cell step).                              */

@@ -469,8 +469,9 @@ def tabular_kl(p: Tensor, q: Tensor, zero_prob_value: float = 0.0) -> Tensor:
 
 def clip_preserve(expr: Tensor, lo, hi) -> Tensor:
     """ops.py:67-76."""
-    clipped = torch.maximum(expr, torch.as_tensor(lo, dtype=expr.dtype))
-    clipped = torch.minimum(clipped, torch.as_tensor(hi, dtype=expr.dtype) if not torch.is_tensor(hi) else hi)
+    # tf.clip_by_value = maximum(minimum(t, clip_max), clip_min): the lower bound wins
+    clipped = torch.minimum(expr, torch.as_tensor(hi, dtype=expr.dtype) if not torch.is_tensor(hi) else hi)
+    clipped = torch.maximum(clipped, torch.as_tensor(lo, dtype=expr.dtype))
     return (clipped - expr).detach() + expr
 
 

@@ -1,0 +1,192 @@
+"""GPU tests of the drop-in Python surface (AIRCell / AIRModel / AIRonMNIST) -- they read like the reference's own
+test/cell_test.py, plus parity against the CPU oracle with injected noise."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import air_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_modules(amd):                                        # test/cell_test.py:9-18
+    return dict(
+        transition=amd.rnn.GRU(3),
+        input_encoder=(lambda: amd.modules.Encoder(5)),
+        glimpse_encoder=(lambda: amd.modules.Encoder(7)),
+        glimpse_decoder=(lambda x: amd.modules.Decoder(11, x)),
+        transform_estimator=(lambda x: amd.modules.StochasticTransformParam(13, x)),
+        steps_predictor=(lambda: amd.modules.StepsPredictor(17)))
+
+
+@pytest.fixture(scope="module")
+def amd(gpu_device):
+    import attend_infer_repeat_amd as pkg
+    from attend_infer_repeat_amd import cell, mnist_model, model, modules, neural, rnn, utils  # noqa: F401
+    return pkg
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().reshape(-1); b = b.detach().cpu().double().reshape(-1)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def test_cell_instantiate_like_reference(amd):               # test/cell_test.py:21-63
+    batch_size, img_size, crop_size, n_latent, n_steps = 10, (3, 3), (2, 2), 10, 3
+    x = torch.rand((batch_size,) + img_size).cuda()
+    air = amd.cell.AIRCell(img_size, crop_size, n_latent, **make_modules(amd))
+    state = air.initial_state(x)
+    outs = []
+    for _ in range(n_steps):                                  # tf.nn.dynamic_rnn(air, dummy_sequence, time_major=True)
+        o, state = air(None, state)
+        outs.append(o)
+    outputs = [torch.stack([o[i] for o in outs]) for i in range(10)]
+    assert air.output_names == 'canvas glimpse what what_loc what_scale where where_loc where_scale presence_prob presence'.split()
+    widths = [9, 4, 10, 10, 10, 4, 4, 4, 1, 1]
+    assert [tuple(o.shape) for o in outputs] == [(n_steps, batch_size, wd) for wd in widths]
+    assert [int(s) if not isinstance(s, tuple) else s for s in air.output_size] == widths
+    canvas = outputs[0].reshape((n_steps, batch_size) + img_size)
+    loss = 0.5 * ((x - canvas[-1]) ** 2).sum()                # tf.nn.l2_loss
+    opt = torch.optim.Adam(air.parameters(), 1e-4)
+    loss.backward(); opt.step()
+    assert np.isfinite(loss.item())
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in air.parameters())
+
+
+def _load_oracle_params(amd, cell, baseline, params, transition):
+    """copy oracle-named tensors into the lazily-built modules"""
+    def mlp(prefix, m):
+        for i, layer in enumerate(m.layers):
+            layer.w.data.copy_(params[f"{prefix}/{i}/w"]); layer.b.data.copy_(params[f"{prefix}/{i}/b"])
+    mlp("input_encoder", cell._input_encoder.mlp); mlp("transform", cell._transform_estimator.mlp)
+    mlp("steps", cell._steps_predictor.mlp); mlp("glimpse_encoder", cell._glimpse_encoder.mlp)
+    mlp("glimpse_decoder", cell._glimpse_decoder.mlp)
+    cell._what_distrib.w.data.copy_(params["what/w"]); cell._what_distrib.b.data.copy_(params["what/b"])
+    tr = cell._transition
+    if transition == "lstm":
+        tr.w_gates.data.copy_(params["lstm/w_gates"]); tr.b_gates.data.copy_(params["lstm/b_gates"])
+        tr.h0.data.copy_(params["lstm/h0"]); tr.c0.data.copy_(params["lstm/c0"])
+    else:
+        for g in "zrh":
+            for k in "wub":
+                getattr(tr, f"{k}{g}").data.copy_(params[f"gru/{k}{g}"])
+        tr.h0.data.copy_(params["gru/h0"])
+    if baseline is not None:
+        mlp("baseline", baseline.mlp)
+
+
+def _build_model(amd, ocfg, obs, transition):
+    M = amd.modules
+    tr = amd.rnn.LSTM(ocfg.n_hidden) if transition == "lstm" else amd.rnn.GRU(ocfg.n_hidden)
+    model = amd.model.AIRModel(
+        obs, None, ocfg.max_steps, ocfg.crop_size, ocfg.n_appearance, tr,
+        input_encoder=partial(M.Encoder, list(ocfg.inpt_encoder_hidden)),
+        glimpse_encoder=partial(M.Encoder, list(ocfg.glimpse_encoder_hidden)),
+        glimpse_decoder=partial(M.Decoder, list(ocfg.glimpse_decoder_hidden)),
+        transform_estimator=partial(M.StochasticTransformParam, list(ocfg.transform_estimator_hidden),
+                                    scale_bias=ocfg.transform_var_bias),
+        steps_predictor=partial(M.StepsPredictor, list(ocfg.steps_pred_hidden), ocfg.step_bias),
+        output_std=ocfg.output_std, output_multiplier=ocfg.output_multiplier, explore_eps=ocfg.explore_eps)
+    return model
+
+
+@pytest.mark.parametrize("transition", ["lstm", "gru"])
+def test_model_unroll_matches_oracle(amd, transition):
+    ocfg = O.tiny_config(transition=transition, step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5,
+                         output_std=0.3, transform_var_bias=0.5, n_hidden=6)
+    B = 10
+    params = O.init_params(ocfg, seed=4, bias_std=0.2)
+    obs, _ = O.synthetic_batch(ocfg, B, seed=5); obs = torch.rand(B, *ocfg.img_size)
+    noise = O.make_noise(ocfg, B, seed=6)
+    model = _build_model(amd, ocfg, obs.cuda(), transition)
+    _load_oracle_params(amd, model.cell, None, params, transition)
+    model.forward(noise={k: v.cuda() for k, v in noise.items()})
+    ref = O.unroll({k: v.double() for k, v in params.items()}, ocfg, obs.double(), {k: v.double() for k, v in noise.items()})
+    assert torch.equal(model.presence.cpu().double(), ref["presence"])
+    for k in ["what", "what_loc", "what_scale", "where", "where_loc", "where_scale", "presence_prob", "canvas",
+              "final_canvas", "glimpse", "num_step_per_sample"]:
+        assert rel(getattr(model, k).reshape(ref[k].shape), ref[k]) < 1e-4, k
+    q = model.num_steps_distrib.prob()
+    assert rel(q, O.bernoulli_to_modified_geometric(ref["presence_prob"].reshape(ocfg.max_steps, B).t())) < 1e-5
+
+
+def test_generic_train_step_matches_oracle(amd):
+    """AIRModel (autograd over the HIP kernels) with an LSTM: losses, both gradient sets and one RMSProp update."""
+    ocfg = O.AIRConfig(img_size=(12, 10), crop_size=(5, 4), n_appearance=6, n_hidden=16, inpt_encoder_hidden=(24,),
+                       glimpse_encoder_hidden=(20,), glimpse_decoder_hidden=(18,), transform_estimator_hidden=(14,),
+                       steps_pred_hidden=(9,), baseline_hidden=(12, 7), max_steps=3)
+    B = 9
+    params = O.init_params(ocfg, seed=7, bias_std=0.2)
+    obs = torch.rand(B, *ocfg.img_size)
+    noise = O.make_noise(ocfg, B, seed=8)
+    AD = amd.utils.AttrDict
+    model = _build_model(amd, ocfg, obs.cuda(), "lstm")
+    baseline = amd.modules.BaselineMLP(list(ocfg.baseline_hidden))
+    nsp = AD(anneal='exp', init=ocfg.nsp_init, final=ocfg.nsp_final, steps_div=ocfg.nsp_steps_div,
+             steps=ocfg.nsp_steps, hold_init=ocfg.nsp_hold_init)
+    train_step, global_step = model.train_step(ocfg.learning_rate, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                                               AD(loc=0., scale=1.), nsp, baseline=baseline)
+    _load_oracle_params(amd, model.cell, model.baseline_module, params, "lstm")
+    gnoise = {k: v.cuda() for k, v in noise.items()}
+    train_step(noise=gnoise)
+    assert int(global_step) == 1
+    p64 = {k: v.double() for k, v in params.items()}
+    res, grads = O.forward_backward(p64, ocfg, obs.double(), {k: v.double() for k, v in noise.items()}, global_step=0)
+    for k in ["rec_loss", "kl_num_steps", "kl_what", "kl_where", "reinforce_loss", "baseline_loss", "opt_loss"]:
+        assert abs(getattr(model, k).item() - res[k].item()) < 2e-4 * (abs(res[k].item()) + 1), k
+    assert rel(model.loss.value, res["loss"]) < 2e-4 and rel(model.loss.per_sample, res["loss_per_sample"]) < 2e-4
+    assert tuple(model.importance_weight.shape) == (B, B)                     # the reference's broadcast quirk
+    named = {"what/w": model.cell._what_distrib.w, "lstm/w_gates": model.cell._transition.w_gates,
+             "lstm/h0": model.cell._transition.h0,
+             "input_encoder/0/w": model.cell._input_encoder.mlp.layers[0].w,
+             "transform/1/b": model.cell._transform_estimator.mlp.layers[1].b,
+             "steps/1/w": model.cell._steps_predictor.mlp.layers[1].w,
+             "glimpse_decoder/1/w": model.cell._glimpse_decoder.mlp.layers[1].w,
+             "baseline/0/w": model.baseline_module.mlp.layers[0].w, "baseline/2/b": model.baseline_module.mlp.layers[2].b}
+    for k, p in named.items():
+        assert rel(p.grad, grads[k]) < 2e-3, (k, rel(p.grad, grads[k]))
+    slots = O.rmsprop_init(p64)
+    O.rmsprop_centered_step(p64, grads, slots, ocfg)
+    for k, p in named.items():
+        assert rel(p.data.cpu().double() - params[k].double(), p64[k] - params[k].double()) < 5e-3, k
+
+
+def test_aironmnist_engine_backed_training(amd):
+    """The reference script's model (scripts/multi_mnist.py:82-100) with the fused engine behind train_step."""
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    AD = amd.utils.AttrDict
+    B = 16
+    imgs, nums = synthetic_multi_mnist(B, (50, 50), 2, seed=0)
+    x, y = torch.from_numpy(imgs).cuda(), torch.from_numpy(nums).cuda()
+    n_hiddens = [256, 256]
+    air = amd.mnist_model.AIRonMNIST(x, y, max_steps=3, explore_eps=1e-3, inpt_encoder_hidden=n_hiddens,
+                                     glimpse_encoder_hidden=n_hiddens, glimpse_decoder_hidden=n_hiddens,
+                                     transform_estimator_hidden=n_hiddens, steps_pred_hidden=[128, 64],
+                                     baseline_hidden=[256, 128], transform_var_bias=.5, step_bias=.75,
+                                     output_multiplier=.5)
+    nsp = AD(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3)
+    train_step, global_step = air.train_step(1e-4, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                                             AD(loc=0., scale=1.), nsp)
+    assert air._engine is not None
+    w_before = air.cell._input_encoder.mlp.layers[0].w.detach().clone()
+    for _ in range(3):
+        train_step()
+    assert int(global_step) == 3 and air._engine.step_dev.item() == 3
+    assert air.canvas.shape == (3, B, 50, 50) and air.glimpse.shape == (3, B, 20, 20)
+    assert air.what.shape == (3, B, 50) and air.where.shape == (3, B, 4) and air.presence.shape == (3, B, 1)
+    assert air.rec_loss_per_sample.shape == (B,) and np.isfinite(air.opt_loss.item())
+    assert 0.0 <= air.num_step_accuracy.item() <= 1.0
+    # module tree and engine share storage: the cell sees the trained weights
+    w_after = air.cell._input_encoder.mlp.layers[0].w
+    assert w_after.data_ptr() == air._engine.params["input_encoder/0/w"].data_ptr()
+    assert not torch.equal(w_before, w_after)
+    # stepping the cell by hand with the engine's noise reproduces the engine's forward
+    eng = air._engine
+    eng.forward(sample_noise=False)
+    eo = eng.outputs()
+    air.forward(noise=dict(eps_where=eng.eps_where.clone(), eps_what=eng.eps_what.clone(),
+                           u_pres=eng.u_pres.clone().unsqueeze(-1)))
+    assert torch.equal(air.presence.reshape(3, B), eo["presence"].reshape(3, B))
+    assert rel(air.where, eo["where"]) < 1e-4 and rel(air.final_canvas, eo["final_canvas"]) < 1e-4
