@@ -198,29 +198,25 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     from attend_infer_repeat_amd import build as air_build
     air_build.build()
+    import torch.distributed as dist
+    from attend_infer_repeat_amd import distributed as D
+    if world > 1:
+        D.init_from_env(backend="nccl")                       # RCCL over xGMI
     from attend_infer_repeat_amd.data import synthetic_multi_mnist
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
 
     cfg_kw = {} if args.config == "c2" else dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5)
     cfg = EngineConfig(**cfg_kw)
     B = args.batch
-    eng = AIREngine(cfg, B, device=device, seed=1 + rank, keep_canvas_steps=False)
-    eng.world_size = world
+    eng = AIREngine(cfg, B, device=device, seed=D.rank_seed(1, rank), keep_canvas_steps=False)
     imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=2 if args.config == "c2" else 4, seed=rank)
     eng.set_obs(torch.from_numpy(imgs).to(device))
-    allreduce = None
-    if world > 1:
-        allreduce = lambda g: dist.all_reduce(g)            # one RCCL all-reduce (sum) of the flat gradient bucket
-    if not args.no_graph:
-        eng.capture(split_optimizer=world > 1)
+    # replicated weights (broadcast from rank 0), one all-reduce (sum) of the flat gradient bucket per step,
+    # RMSProp applies grad_scale = 1/world
+    dp = D.DataParallelEngine(eng, capture_graph=not args.no_graph)
+    allreduce = dp._allreduce if world > 1 else None
 
     def barrier():
         if world > 1:

@@ -138,3 +138,37 @@ def test_loss_decreases_on_fixed_batch(gpu_device):
         eng.train_step()
     eng.forward(); last = eng.outputs()["loss"].item()
     assert np.isfinite(last) and last < first, (first, last)
+
+
+def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
+    """The multi-GPU step structure (graph A: fwd+bwd -> RCCL all-reduce of the flat bucket -> graph B: RMSProp) run
+    with a 1-rank nccl (RCCL) group: must equal the single-graph step bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from attend_infer_repeat_amd import distributed as D
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ocfg, B = CONFIGS["mnist_b8"]
+        eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+        eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+        eng_a.capture()
+        eng_b.world_size = 1
+        eng_b.capture(split_optimizer=True)
+        calls = []
+
+        def allreduce(g):
+            calls.append(g.numel())
+            D.allreduce_gradients(g)                  # world 1 -> returns immediately
+            dist.all_reduce(g)                        # force the real RCCL call on the engine stream
+
+        for _ in range(3):
+            eng_a.train_step()
+            eng_b.train_step(allreduce=allreduce)
+        eng_a.synchronize(); eng_b.synchronize()
+        assert calls == [eng_b.n_total] * 3           # exactly one collective per step over the whole flat bucket
+        assert torch.equal(eng_a.flat_params, eng_b.flat_params)
+    finally:
+        dist.destroy_process_group()
