@@ -13,6 +13,14 @@ c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ct
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
 
+class AirGemmDesc(ctypes.Structure):
+    """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
+    _fields_ = [("ta", c_int), ("tb", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
+                ("bias", c_void_p), ("epilogue", c_int), ("aux", c_void_p), ("ldaux", c_int), ("beta", c_float),
+                ("colsum", c_void_p)]
+
+
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
 SIGNATURES = {
     "air_abi_version": (c_int, []),
@@ -28,14 +36,15 @@ SIGNATURES = {
     "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
                          c_float, P, P, c_size_t, P]),
     "air_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "air_gemm_grouped": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, P]),
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
-    "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
+    "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_gauss_sample_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
                                      c_int, c_int, P]),
     "air_gauss_sample_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                     P, c_int, c_int, c_int, P]),
+                                     P, c_float, P, c_int, c_int, c_int, P]),
     "air_normal_kl_fwd": (c_int, [P, P, c_float, c_float, c_float, c_float, P, c_int, c_int, P]),
     "air_normal_kl_bwd": (c_int, [P, P, c_float, c_float, c_float, c_float, P, P, P, c_int, c_int, P]),
     "air_presence_fwd": (c_int, [P, P, P, c_float, c_float, c_int, P, P, c_int, c_int, P]),
@@ -44,6 +53,13 @@ SIGNATURES = {
     "air_rec_loglik_bwd": (c_int, [P, P, c_float, c_float, P, c_float, P, c_int, c_int, P]),
     "air_numsteps_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_numsteps_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
+    "air_presence_numsteps_fwd": (c_int, [P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "air_numsteps_presence_bwd": (c_int, [P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P, c_int, c_int, P]),
+    "air_step_prologue": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
+                                  c_int, P]),
+    "air_step_epilogue": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
+                                  P, P, c_uint64, P]),
     "air_steps_prior": (c_int, [P, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_double, P, c_int, P]),
     "air_counter_add": (c_int, [P, ctypes.c_int64, P]),

@@ -91,7 +91,7 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // MT x NT 16x16 MFMA tiles per wave.  KW = 4: the workgroup's 4 waves split K for ONE tile (LDS reduce);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
 template <int MT, int NT, int KW>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
     constexpr int LDT = TN + 4;                           // padded LDS tile row
@@ -101,10 +101,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int tiles_n = (g.N + TN * NWN - 1) / (TN * NWN);
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tm = block_tile / tiles_n, tn = block_tile - tm * tiles_n;
     const int m0 = tm * TM;
     const int n0 = (tn * NWN + (KW == 1 ? wave : 0)) * TN;
-    const int split = blockIdx.y;
 
     const int total_chunks = (g.K + 15) >> 4;
     const int c_begin = split * g.chunks_per_split;
@@ -247,6 +246,28 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     }
 }
 
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+    gemm_body<MT, NT, KW>(g, blockIdx.x, blockIdx.y);
+}
+
+// Several independent GEMMs in ONE launch (the step is launch/latency bound: a dW / dX pair, or the two heads that
+// read the same hidden state, cost one dispatch instead of two).  Problem p owns blocks [tile_start[p], tile_start[p+1]).
+#define AIR_GEMM_GROUP_MAX 8
+struct GroupArgs {
+    GemmArgs g[AIR_GEMM_GROUP_MAX];
+    int tile_start[AIR_GEMM_GROUP_MAX + 1];
+    int count;
+};
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs ga) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    gemm_body<MT, NT, KW>(ga.g[p], (int)blockIdx.x - ga.tile_start[p], 0);
+}
+
 // sums the S split-K slabs in fixed order and applies the epilogue
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
     const size_t total = (size_t)g.M * g.N;
@@ -325,6 +346,42 @@ extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int
     g.S = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;       // drop empty tail splits
     if (narrow) return launch_gemm<1, 2, 4>(g, st);
     return launch_gemm<2, 2, 4>(g, st);
+}
+
+static int fill_gemm_args(GemmArgs &g, const AirGemmDesc &d) {
+    AIR_REQUIRE(d.A && d.B && d.C, AIR_E_NULL);
+    AIR_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, AIR_E_SHAPE);
+    AIR_REQUIRE(d.lda >= (d.ta ? d.M : d.K) && d.ldb >= (d.tb ? d.K : d.N) && d.ldc >= d.N, AIR_E_SHAPE);
+    AIR_REQUIRE(d.epilogue >= AIR_EPI_NONE && d.epilogue <= AIR_EPI_ADD_AUX, AIR_E_UNSUPPORTED);
+    if (d.epilogue == AIR_EPI_BIAS || d.epilogue == AIR_EPI_BIAS_ELU) AIR_REQUIRE(d.bias, AIR_E_NULL);
+    if (d.epilogue == AIR_EPI_MUL_DELU || d.epilogue == AIR_EPI_ADD_AUX) AIR_REQUIRE(d.aux && d.ldaux >= d.N, AIR_E_NULL);
+    AIR_REQUIRE(!d.colsum || d.ta, AIR_E_UNSUPPORTED);
+    g.A = d.A; g.B = d.B; g.C = d.C; g.bias = d.bias; g.aux = d.aux; g.colsum = d.colsum; g.ws = nullptr;
+    g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldaux = d.ldaux;
+    g.ta = d.ta ? 1 : 0; g.tb = d.tb ? 1 : 0; g.epi = d.epilogue; g.beta = d.beta;
+    g.vecA = (!d.ta && (d.lda % 4 == 0) && air_aligned16(d.A)) ? 1 : 0;
+    g.vecB = (d.tb && (d.ldb % 4 == 0) && air_aligned16(d.B)) ? 1 : 0;
+    g.S = 1; g.chunks_per_split = (d.K + 15) / 16;
+    return AIR_OK;
+}
+
+extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream) {
+    AIR_REQUIRE(descs, AIR_E_NULL);
+    AIR_REQUIRE(count > 0 && count <= AIR_GEMM_GROUP_MAX, AIR_E_SHAPE);
+    GroupArgs ga;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        int st = fill_gemm_args(ga.g[i], descs[i]);
+        if (st) return st;
+        ga.tile_start[i] = tiles;
+        tiles += air_cdiv(descs[i].M, 32) * air_cdiv(descs[i].N, 32);
+    }
+    for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
+    for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
+    ga.count = count;
+    hipLaunchKernelGGL((gemm_grouped_kernel<2, 2, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 // ---- linear layer wrappers (neural.py:56-60) ------------------------------------------------------------------

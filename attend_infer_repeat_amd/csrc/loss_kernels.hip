@@ -126,6 +126,111 @@ extern "C" int air_numsteps_bwd(const float *presence_prob, const float *presenc
     return AIR_OK;
 }
 
+// ---- fused forms used by the engine (one thread per image; the step is launch bound) -----------------------------
+// presence (cell.py:137-151) + q(n) / KL / step weights / log q(n_sampled) in one launch
+__global__ __launch_bounds__(256) void presence_numsteps_fwd_kernel(
+    const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float eps,
+    const double *__restrict__ prior, float *__restrict__ prob, float *__restrict__ pres, float *__restrict__ q,
+    float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        float run = 1.0f;
+        for (int t = 0; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            float p = 1.0f / (1.0f + expf(-(logit[k] + step_bias)));
+            if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
+            prob[k] = p;
+            run *= (u[k] < p) ? 1.0f : 0.0f;
+            pres[k] = run;
+        }
+        NumSteps s;
+        numsteps_posterior(prob, T, B, b, s);
+        float kl = 0.f;
+        for (int n = 0; n <= T; ++n) {
+            q[(size_t)b * (T + 1) + n] = s.q32[n];
+            const double pn = (double)s.q32[n];
+            kl += (pn > 0.0) ? (float)(pn * log(pn / prior[n])) : 0.f;
+        }
+        kl_ps[b] = kl;
+        float w = 0.f;
+        for (int t = T - 1; t >= 0; --t) { w += s.q32[t + 1]; step_w[(size_t)t * B + b] = w; }
+        logp[b] = logf(fmaxf(s.q32[sampled_steps(pres, T, B, b)], 1e-32f));
+    }
+}
+extern "C" int air_presence_numsteps_fwd(const float *logit, const float *u, float step_bias, float explore_eps,
+                                         const double *prior_f64, float *presence_prob, float *presence, float *q,
+                                         float *kl_per_sample, float *logp, float *step_weight, int T, int B,
+                                         void *stream) {
+    AIR_REQUIRE(logit && u && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight,
+                AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= NS_MAXT && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(presence_numsteps_fwd_kernel, dim3(air_cdiv(B, 256)), dim3(256), 0, air_stream(stream), logit, u,
+                       step_bias, explore_eps, prior_f64, presence_prob, presence, q, kl_per_sample, logp, step_weight,
+                       T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// backward of the above wrt the steps-predictor logit: the step-weight gradient is formed in place from the two
+// per-row KL buffers (dstep_w[t,b] = w_scale * (kl_a[t,b] + kl_b[t,b])), then numsteps_bwd, then sigmoid'.
+__global__ __launch_bounds__(256) void numsteps_presence_bwd_kernel(
+    const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
+    float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
+    const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
+    float *__restrict__ dlogit, int T, int B) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        NumSteps s;
+        numsteps_posterior(prob, T, B, b, s);
+        double gq[NS_MAXT + 1];
+        double wsum = 0.0;
+        const int nstar = dlogp ? sampled_steps(presence, T, B, b) : -1;
+        for (int n = 0; n <= T; ++n) {
+            const double pn = (double)s.q32[n];
+            double g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
+            if (n >= 1) {
+                const size_t k = (size_t)(n - 1) * B + b;
+                wsum += (double)(w_scale * ((kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f)));
+            }
+            g += wsum;
+            if (n == nstar) g += (double)dlogp[b] / (double)fmaxf(s.q32[n], 1e-32f);
+            gq[n] = g;
+        }
+        double dot = 0.0;
+        for (int n = 0; n <= T; ++n) dot += gq[n] * s.q[n];
+        double gu[NS_MAXT + 1];
+        for (int n = 0; n <= T; ++n) gu[n] = (gq[n] - dot) / s.S;
+        for (int k = 0; k < T; ++k) {
+            double g = 0.0;
+            for (int n = 0; n <= T; ++n) {
+                double d;
+                if (n < T) {
+                    if (k > n) continue;
+                    if (k == n) { d = -1.0; for (int j = 0; j < n; ++j) d *= s.p[j]; }
+                    else { d = 1.0 - s.p[n]; for (int j = 0; j < n; ++j) if (j != k) d *= s.p[j]; }
+                } else { d = 1.0; for (int j = 0; j < T; ++j) if (j != k) d *= s.p[j]; }
+                g += gu[n] * d;
+            }
+            const size_t idx = (size_t)k * B + b;
+            const float sg = 1.0f / (1.0f + expf(-(logit[idx] + step_bias)));
+            float gg = (float)g;
+            if (eps >= 0.f) gg *= (1 - eps);
+            dlogit[idx] = gg * sg * (1.f - sg);
+        }
+    }
+}
+extern "C" int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
+                                         float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
+                                         const float *dlogp, const float *logit, float step_bias, float explore_eps,
+                                         float *dlogit, int T, int B, void *stream) {
+    AIR_REQUIRE(presence_prob && prior_f64 && logit && dlogit, AIR_E_NULL);
+    AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= NS_MAXT && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(numsteps_presence_bwd_kernel, dim3(air_cdiv(B, 256)), dim3(256), 0, air_stream(stream),
+                       presence_prob, presence, prior_f64, kl_scale, kl_row_a, kl_row_b, w_scale, dlogp, logit,
+                       step_bias, explore_eps, dlogit, T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
 // ---- annealed geometric prior on device (model.py:106-124, prior.py:26-32) -------------------------------------------
 __global__ void steps_prior_kernel(const int64_t *__restrict__ gstep, int anneal_type, double init, double fin,
                                    double anneal_steps, double hold_for, double steps_div,

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__
                                                                  const float *__restrict__ c_prev,
                                                                  const float *__restrict__ c,
                                                                  const float *__restrict__ dh,
+                                                                 const float *__restrict__ dh2,
                                                                  const float *__restrict__ dc_in,
                                                                  float *__restrict__ dgates,
                                                                  float *__restrict__ dc_prev, int M, int Hd) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__
         const float *ar = gate_act + m * 4 * (size_t)Hd;
         const float gi = ar[u], gj = ar[Hd + u], gf = ar[2 * (size_t)Hd + u], go = ar[3 * (size_t)Hd + u];
         const float tc = tanhf(c[e]);
-        const float dhe = dh ? dh[e] : 0.f;
+        const float dhe = (dh ? dh[e] : 0.f) + (dh2 ? dh2[e] : 0.f);
         const float dct = (dc_in ? dc_in[e] : 0.f) + dhe * go * (1.f - tc * tc);
         float *dr = dgates + m * 4 * (size_t)Hd;
         dr[u] = dct * gj * gi * (1.f - gi);
@@ -68,12 +69,13 @@ extern "C" int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, f
     return AIR_OK;
 }
 extern "C" int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
-                                      const float *dc, float *dgates, float *dc_prev, int M, int Hd, void *stream) {
+                                      const float *dh2, const float *dc, float *dgates, float *dc_prev, int M, int Hd,
+                                      void *stream) {
     AIR_REQUIRE(gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
     AIR_REQUIRE(dh || dc, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
     hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(pw_blocks((size_t)M * Hd)), dim3(PW_THREADS), 0, air_stream(stream),
-                       gate_act, c_prev, c, dh, dc, dgates, dc_prev, M, Hd);
+                       gate_act, c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__re
                                                                const float *__restrict__ loc,
                                                                const float *__restrict__ scale,
                                                                const float *__restrict__ dsample,
-                                                               const float *__restrict__ dkl_row,
+                                                               const float *__restrict__ dsample2,
+                                                               const float *__restrict__ dkl_row, float dkl_scale,
                                                                float *__restrict__ dpre, int ld_dpre, int M, int D) {
     const size_t n = (size_t)M * D;
     PW_LOOP(e, n) {
@@ -124,10 +127,10 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__re
         const int d = (int)(e - m * D);
         const float mu = loc[e], s = scale[e];
         const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
-        const float ds = dsample ? dsample[e] : 0.f;
-        const float dk = dkl_row ? dkl_row[m] : 0.f;
+        const float ds = (dsample ? dsample[e] : 0.f) + (dsample2 ? dsample2[e] : 0.f);
+        const float dk = dkl_row ? dkl_row[m] * dkl_scale : 0.f;
         float dmu = ds + dk * (mu - pm) / (ps * ps);
-        const float dsc = (dsample ? ds * eps[e] : 0.f) + dk * (s / (ps * ps) - 1.f / s);
+        const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + dk * (s / (ps * ps) - 1.f / s);
         if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
         const float raw = pre[m * ld_pre + D + d] + raw_offset;
         const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus
@@ -151,14 +154,15 @@ extern "C" int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *e
 }
 extern "C" int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                                     float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
-                                    const float *loc, const float *scale, const float *dsample, const float *dkl_row,
-                                    float *dpre, int ld_dpre, int M, int D, void *stream) {
+                                    const float *loc, const float *scale, const float *dsample,
+                                    const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
+                                    int ld_dpre, int M, int D, void *stream) {
     AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
-    AIR_REQUIRE(!dsample || eps, AIR_E_NULL);
+    AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
     hipLaunchKernelGGL(gauss_bwd_kernel, dim3(pw_blocks((size_t)M * D)), dim3(PW_THREADS), 0, air_stream(stream), pre,
                        ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
-                       dsample, dkl_row, dpre, ld_dpre, M, D);
+                       dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -449,6 +453,119 @@ extern "C" int air_rng_fill(float *normal, size_t n_normal, float *uniform, size
 extern "C" int air_rng_advance(uint64_t *state_dev, uint64_t increment, void *stream) {
     AIR_REQUIRE(state_dev, AIR_E_NULL);
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, air_stream(stream), state_dev, increment);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- fused step prologue / epilogue (the train step is launch bound: 6 tiny launches become 2) -------------------
+// prologue: Philox noise for the whole step + annealed geometric prior (float64) + tiling of the trainable LSTM
+//           initial state over the batch.  Roles are split by block index.
+__global__ __launch_bounds__(PW_THREADS) void step_prologue_kernel(
+    float *__restrict__ normal, size_t n_normal, float *__restrict__ uniform, size_t n_uniform,
+    const uint64_t *__restrict__ rng_state, int rng_blocks,
+    const int64_t *__restrict__ gstep, int anneal_type, double init, double fin, double anneal_steps, double hold_for,
+    double steps_div, double *__restrict__ prior, int T,
+    const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ h_out, float *__restrict__ c_out,
+    int B, int Hd) {
+    const int bid = blockIdx.x;
+    if (bid < rng_blocks) {
+        const uint64_t seed = rng_state[0], offset = rng_state[1];
+        const size_t q_normal = (n_normal + 3) / 4, q_uniform = (n_uniform + 3) / 4;
+        for (size_t q = (size_t)bid * PW_THREADS + threadIdx.x; q < q_normal + q_uniform; q += (size_t)rng_blocks * PW_THREADS) {
+            uint32_t r[4];
+            philox4x32(offset + q, 0, seed, r);
+            if (q < q_normal) {
+                float z[4];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * k])));
+                    float sn, cs;
+                    sincosf(6.283185307179586f * u01(r[2 * k + 1]), &sn, &cs);
+                    z[2 * k] = rad * cs; z[2 * k + 1] = rad * sn;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (4 * q + k < n_normal) normal[4 * q + k] = z[k];
+            } else {
+                const size_t qq = q - q_normal;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (4 * qq + k < n_uniform) uniform[4 * qq + k] = u01(r[k]);
+            }
+        }
+    } else if (bid == rng_blocks) {
+        if (threadIdx.x == 0) {
+            double s = init;
+            if (anneal_type != 0) {
+                double step = (double)gstep[0] - hold_for;
+                if (step < 0.0) step = 0.0;
+                double val = (anneal_type == 1) ? init * pow(pow(fin / init, steps_div / anneal_steps), step / steps_div)
+                                                : fin + (init - fin) * (1.0 - step / anneal_steps);
+                s = val > fin ? val : fin;
+            }
+            s = s < 1e-7 ? 1e-7 : (s > 1.0 - 1e-15 ? 1.0 - 1e-15 : s);
+            const double probs = 1.0 - s;
+            for (int n = 0; n <= T; ++n) prior[n] = exp((double)n * log1p(-probs) + log(probs));
+        }
+    } else {
+        const int tb = bid - rng_blocks - 1, ntb = gridDim.x - rng_blocks - 1;
+        const size_t n = (size_t)B * Hd;
+        for (size_t i = (size_t)tb * PW_THREADS + threadIdx.x; i < n; i += (size_t)ntb * PW_THREADS) {
+            h_out[i] = h0[i % Hd];
+            c_out[i] = c0[i % Hd];
+        }
+    }
+}
+extern "C" int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_uniform,
+                                 const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
+                                 double init, double final_value, double anneal_steps, double hold_for,
+                                 double steps_div, double *prior_out_f64, int T, const float *h0, const float *c0,
+                                 float *h_tiled, float *c_tiled, int B, int Hd, void *stream) {
+    AIR_REQUIRE(rng_state_dev && global_step_dev && prior_out_f64 && h0 && c0 && h_tiled && c_tiled, AIR_E_NULL);
+    AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && Hd > 0 && anneal_type >= 0 && anneal_type <= 2, AIR_E_SHAPE);
+    const size_t q = (n_normal + 3) / 4 + (n_uniform + 3) / 4;
+    const int rng_blocks = q ? pw_blocks(q) : 1;
+    const int tile_blocks = pw_blocks((size_t)B * Hd);
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(rng_blocks + 1 + tile_blocks), dim3(PW_THREADS), 0,
+                       air_stream(stream), normal, n_normal, uniform, n_uniform, rng_state_dev, rng_blocks,
+                       global_step_dev, anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
+                       prior_out_f64, T, h0, c0, h_tiled, c_tiled, B, Hd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// epilogue: both centred-RMSProp updates (model segment [0, n_model) at lr, baseline segment at lr * lr_mult_tail) in
+//           one pass over the flat buffers, then the device counters (global step, Philox offset) advance.
+__global__ __launch_bounds__(PW_THREADS) void step_epilogue_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                                   float *__restrict__ ms, float *__restrict__ mg,
+                                                                   float *__restrict__ mom, size_t n_model, size_t n_total,
+                                                                   const float *__restrict__ lr_dev, float lr_mult_tail,
+                                                                   float decay, float momentum, float eps, float gscale,
+                                                                   int64_t *__restrict__ gstep, uint64_t *__restrict__ rng_state,
+                                                                   uint64_t rng_inc) {
+    const float lr0 = lr_dev[0];
+    PW_LOOP(i, n_total) {
+        const float lr = i < n_model ? lr0 : lr0 * lr_mult_tail;
+        const float gi = g[i] * gscale;
+        const float msi = decay * ms[i] + (1.f - decay) * gi * gi;
+        const float mgi = decay * mg[i] + (1.f - decay) * gi;
+        const float mo = momentum * mom[i] + lr * gi / sqrtf(msi - mgi * mgi + eps);
+        ms[i] = msi; mg[i] = mgi; mom[i] = mo;
+        p[i] -= mo;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (gstep) gstep[0] += 1;
+        if (rng_state) rng_state[1] += rng_inc;
+    }
+}
+extern "C" int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model,
+                                 size_t n_total, const float *lr_dev, float lr_mult_tail, float decay, float momentum,
+                                 float eps, float grad_scale, int64_t *global_step_dev, uint64_t *rng_state_dev,
+                                 uint64_t rng_increment, void *stream) {
+    AIR_REQUIRE(p && g && ms && mg && mom && lr_dev, AIR_E_NULL);
+    AIR_REQUIRE(n_total > 0 && n_model <= n_total, AIR_E_SHAPE);
+    hipLaunchKernelGGL(step_epilogue_kernel, dim3(pw_blocks(n_total)), dim3(PW_THREADS), 0, air_stream(stream), p, g,
+                       ms, mg, mom, n_model, n_total, lr_dev, lr_mult_tail, decay, momentum, eps, grad_scale,
+                       global_step_dev, rng_state_dev, rng_increment);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -267,7 +267,8 @@ class AIREngine:
         self.d_what = b("d_what", (M, A)); self.d_glimpse_in = b("d_glimpse_in", (M, hw))
         self.dwhere_w = b("dwhere_w", (M, 4)); self.dwhere_r = b("dwhere_r", (M, 4)); self.dwhere = b("dwhere", (M, 4))
         self.dkl_row = b("dkl_row", (M,)); self.dstep_w = b("dstep_w", (T, B)); self.dprob = b("dprob", (T, B))
-        self.dH = b("dH", (T, B, Hd)); self.dh_init = b("dh_init", (B, Hd))
+        self.dH = b("dH", (T, B, Hd)); self.dH_b = b("dH_b", (T, B, Hd)); self.dh_init = b("dh_init", (B, Hd))
+        self.ones_b = b("ones_b", (B, 1)); self.ones_b.fill_(1.0)
         self.dgates = b("dgates", (T, B, 4 * Hd)); self.dc_a = b("dc_a", (B, Hd)); self.dc_b = b("dc_b", (B, Hd))
         self.dgx = b("dgx", (B, 4 * Hd))
 
@@ -275,105 +276,149 @@ class AIREngine:
     # launch plans
     # ------------------------------------------------------------------------------------------------------------
     def _build_plans(self):
+        """The step as a fixed list of C-ABI launches.  It is launch/latency bound at batch 64 (~6 us per dependent
+        launch), so independent GEMMs are dispatched together (air_gemm_grouped: the dW / dX pair of a layer, the
+        transform / steps heads, decoder + baseline levels) and the tiny ops are fused (step prologue / epilogue,
+        presence + num-steps)."""
         L = H.lib()
         cfg, B, T, M = self.cfg, self.B, self.T, self.M
         Hd, A, P, hw = cfg.n_hidden, cfg.n_appearance, cfg.n_pix, cfg.n_crop
         (Hi, Wi), (hc, wc) = cfg.img_size, cfg.crop_size
         p = H._p
         wsp, wsb = p(self.ws), ctypes.c_size_t(self.ws.numel() * 4)
-        fwd, bwd, opt, rng = [], [], [], []
+        fwd, bwd, rng = [], [], []
+        self._keep = []
         NONE, BIAS, BELU, MDELU, ADDAUX = H.EPI_NONE, H.EPI_BIAS, H.EPI_BIAS_ELU, H.EPI_MUL_DELU, H.EPI_ADD_AUX
+        dp = lambda t: (t.data_ptr() if t is not None else None)
 
-        def gemm(plan, ta, tb, Mm, Nn, Kk, Aa, lda, Bb, ldb, Cc, ldc, bias=None, epi=NONE, aux=None, ldaux=0,
-                 beta=0.0, colsum=None):
-            plan.append((L.air_gemm, (int(ta), int(tb), Mm, Nn, Kk, p(Aa), lda, p(Bb), ldb, p(Cc), ldc, p(bias),
-                                      epi, p(aux), ldaux, float(beta), p(colsum), wsp, wsb), "air_gemm"))
+        def desc(ta, tb, Mm, Nn, Kk, Aa, lda, Bb, ldb, Cc, ldc, bias=None, epi=NONE, aux=None, ldaux=0, beta=0.0,
+                 colsum=None):
+            return _lib.AirGemmDesc(int(ta), int(tb), Mm, Nn, Kk, dp(Aa), lda, dp(Bb), ldb, dp(Cc), ldc, dp(bias), epi,
+                                    dp(aux), ldaux, float(beta), dp(colsum))
 
-        def mlp_fwd(plan, m: _Mlp, x, ldx):
-            for i, (k, n) in enumerate(m.shapes):
-                last = i == m.n - 1
-                epi = BIAS if (last and m.last_linear) else BELU
-                gemm(plan, 0, 0, m.rows, n, k, x, ldx, m.w[i], n, m.out[i], n, bias=m.b[i], epi=epi)
-                x, ldx = m.out[i], n
+        def launch(plan, descs, allow_splitk=False):
+            """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
+            if len(descs) == 1 and allow_splitk and descs[0].K >= 1024:
+                d = descs[0]
+                plan.append((L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
+                                          d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, wsp, wsb), "air_gemm"))
+                return
+            for i in range(0, len(descs), 8):
+                chunk = descs[i:i + 8]
+                arr = (_lib.AirGemmDesc * len(chunk))(*chunk)
+                self._keep.append(arr)
+                plan.append((L.air_gemm_grouped, (arr, len(chunk)), "air_gemm_grouped"))
 
-        def mlp_bwd(plan, m: _Mlp, x_in, ldx, g_last, dx_out=None, dx_aux=None, dx_beta=0.0):
-            """g_last = gradient wrt the LAST layer's pre-activation [rows, n_last].  Writes dW/db of every layer.
-            dx_out: where to put the gradient wrt the MLP input (None to skip); dx_aux: if given, the input was itself
-            an ELU output and the result is multiplied by elu'(dx_aux) (so it is again a pre-activation gradient)."""
-            g = g_last
-            for i in reversed(range(m.n)):
-                k, n = m.shapes[i]
-                xin, ld_in = (m.out[i - 1], m.shapes[i - 1][1]) if i > 0 else (x_in, ldx)
-                gemm(plan, 1, 0, k, n, m.rows, xin, ld_in, g, n, m.dw[i], n, colsum=m.db[i])      # dW, db
-                if i > 0:
-                    gemm(plan, 0, 1, m.rows, k, n, g, n, m.w[i], n, m.g[i - 1], k, epi=MDELU, aux=m.out[i - 1],
-                         ldaux=k)                                                                  # G_{i-1}
-                    g = m.g[i - 1]
-                elif dx_out is not None:
-                    if dx_aux is not None:
-                        gemm(plan, 0, 1, m.rows, k, n, g, n, m.w[0], n, dx_out, k, epi=MDELU, aux=dx_aux, ldaux=k,
-                             beta=dx_beta)
-                    else:
-                        gemm(plan, 0, 1, m.rows, k, n, g, n, m.w[0], n, dx_out, k, beta=dx_beta)
+        def fwd_desc(m: _Mlp, i, x, ldx):
+            k, n = m.shapes[i]
+            last = i == m.n - 1
+            xin, ld_in = (m.out[i - 1], m.shapes[i - 1][1]) if i > 0 else (x, ldx)
+            return desc(0, 0, m.rows, n, k, xin, ld_in, m.w[i], n, m.out[i], n, bias=m.b[i],
+                        epi=BIAS if (last and m.last_linear) else BELU)
 
-        # ---- noise ------------------------------------------------------------------------------------------------
+        def mlp_fwd_multi(plan, chains, splitk_first=False):
+            """chains: [(mlp, x, ldx)] advanced level by level, one dispatch per level"""
+            depth = max(m.n for m, _, _ in chains)
+            for i in range(depth):
+                descs = [fwd_desc(m, i, x, ldx) for m, x, ldx in chains if i < m.n]
+                if i == 0 and splitk_first:
+                    for d in descs:
+                        launch(plan, [d], allow_splitk=True)
+                else:
+                    launch(plan, descs)
+
+        def mlp_bwd_multi(plan, chains):
+            """chains: dicts(m, x, ldx, g_last, dx_out=None, dx_aux=None).  g_last = gradient wrt the last layer's
+            pre-activation.  Per level one dispatch holding every chain's dW (+db) and dX."""
+            depth = max(c["m"].n for c in chains)
+            gcur = {id(c["m"]): c["g_last"] for c in chains}
+            for s_ in range(depth):
+                descs = []
+                for c in chains:
+                    m = c["m"]
+                    i = m.n - 1 - s_
+                    if i < 0:
+                        continue
+                    k, n = m.shapes[i]
+                    g = gcur[id(m)]
+                    xin, ld_in = (m.out[i - 1], m.shapes[i - 1][1]) if i > 0 else (c["x"], c["ldx"])
+                    descs.append(desc(1, 0, k, n, m.rows, xin, ld_in, g, n, m.dw[i], n, colsum=m.db[i]))
+                    if i > 0:
+                        descs.append(desc(0, 1, m.rows, k, n, g, n, m.w[i], n, m.g[i - 1], k, epi=MDELU,
+                                          aux=m.out[i - 1], ldaux=k))
+                        gcur[id(m)] = m.g[i - 1]
+                    elif c.get("dx_out") is not None:
+                        aux = c.get("dx_aux")
+                        descs.append(desc(0, 1, m.rows, k, n, g, n, m.w[0], n, c["dx_out"], k,
+                                          epi=MDELU if aux is not None else NONE, aux=aux, ldaux=k if aux is not None else 0))
+                launch(plan, descs)
+
+        # ---- noise only (used when forward() is asked to keep injected noise: the prologue then draws nothing) -------
         n_norm, n_uni = self.noise_normal.numel(), self.u_pres.numel()
+        self._rng_inc = (n_norm + 3) // 4 + (n_uni + 3) // 4
         rng.append((L.air_rng_fill, (p(self.noise_normal), ctypes.c_size_t(n_norm), p(self.u_pres),
                                      ctypes.c_size_t(n_uni), p(self.rng_state)), "air_rng_fill"))
-        rng.append((L.air_rng_advance, (p(self.rng_state), ctypes.c_uint64((n_norm + 3) // 4 + (n_uni + 3) // 4)),
-                    "air_rng_advance"))
 
-        # ---- forward ----------------------------------------------------------------------------------------------
+        # ---- forward ------------------------------------------------------------------------------------------------
         anneal = {None: 0, "exp": 1, "linear": 2}[cfg.nsp_anneal]
-        fwd.append((L.air_steps_prior, (p(self.step_dev), anneal, float(cfg.nsp_init), float(cfg.nsp_final),
-                                        float(cfg.nsp_steps), float(cfg.nsp_hold_init), float(cfg.nsp_steps_div),
-                                        p(self.prior_dev), T), "air_steps_prior"))        # model.py:139-146
-        mlp_fwd(fwd, self.enc, self.obs, P)                                                 # cell.py:125 (hoisted)
+
+        def prologue(with_noise):
+            return (L.air_step_prologue,
+                    (p(self.noise_normal), ctypes.c_size_t(n_norm if with_noise else 0), p(self.u_pres),
+                     ctypes.c_size_t(n_uni if with_noise else 0), p(self.rng_state), p(self.step_dev), anneal,
+                     float(cfg.nsp_init), float(cfg.nsp_final), float(cfg.nsp_steps), float(cfg.nsp_hold_init),
+                     float(cfg.nsp_steps_div), p(self.prior_dev), T, p(self.params["lstm/h0"]),
+                     p(self.params["lstm/c0"]), p(self.h_seq[0]), p(self.c_seq[0]), B, Hd), "air_step_prologue")
+
+        mlp_fwd_multi(fwd, [(self.enc, self.obs, P)], splitk_first=True)                    # cell.py:125 (hoisted)
         enc_out, E = self.enc.out[-1], self.enc.shapes[-1][1]
         wg, bg = self.params["lstm/w_gates"], self.params["lstm/b_gates"]
         w_x, w_h = wg[:E], wg[E:]
-        gemm(fwd, 0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)
-        fwd.append((L.air_tile_rows, (p(self.params["lstm/h0"]), p(self.h_seq[0]), B, Hd), "air_tile_rows"))
-        fwd.append((L.air_tile_rows, (p(self.params["lstm/c0"]), p(self.c_seq[0]), B, Hd), "air_tile_rows"))
+        launch(fwd, [desc(0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)])
         for t in range(T):                                                                  # cell.py:126-127
-            gemm(fwd, 0, 0, B, 4 * Hd, Hd, self.h_seq[t], Hd, w_h, 4 * Hd, self.gates[t], 4 * Hd, epi=ADDAUX,
-                 aux=self.gx, ldaux=4 * Hd)
+            launch(fwd, [desc(0, 0, B, 4 * Hd, Hd, self.h_seq[t], Hd, w_h, 4 * Hd, self.gates[t], 4 * Hd, epi=ADDAUX,
+                              aux=self.gx, ldaux=4 * Hd)])
             fwd.append((L.air_lstm_pointwise_fwd, (p(self.gates[t]), p(self.c_seq[t]), p(self.h_seq[t + 1]),
                                                    p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd, 1.0),
                         "air_lstm_pointwise_fwd"))
         h_all = self.h_seq[1:]                                                              # [T,B,Hd] contiguous
-        mlp_fwd(fwd, self.tr, h_all, Hd)                                                    # cell.py:129
-        mlp_fwd(fwd, self.st, h_all, Hd)                                                    # cell.py:138
+        mlp_fwd_multi(fwd, [(self.tr, h_all, Hd), (self.st, h_all, Hd)])                    # cell.py:129,138
         sp, shp = cfg.where_scale_prior, cfg.where_shift_prior
         fwd.append((L.air_gauss_sample_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
                                              sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
                                              p(self.where), p(self.kl_where_row), M, 4), "air_gauss_sample_fwd"))
         eps = -1.0 if cfg.explore_eps is None else float(cfg.explore_eps)
-        fwd.append((L.air_presence_fwd, (p(self.st.out[-1]), p(self.u_pres), None, cfg.step_bias, eps, 1,
-                                         p(self.presence_prob), p(self.presence), T, B), "air_presence_fwd"))
+        fwd.append((L.air_presence_numsteps_fwd, (p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps,
+                                                  p(self.prior_dev), p(self.presence_prob), p(self.presence),
+                                                  p(self.q_n), p(self.kl_n), p(self.logp), p(self.step_w), T, B),
+                    "air_presence_numsteps_fwd"))                                           # cell.py:137-151, prior.py
         fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
                     "air_st_read_fwd"))                                                     # cell.py:135
-        mlp_fwd(fwd, self.ge, self.glimpse_in, hw)                                          # cell.py:153
+        mlp_fwd_multi(fwd, [(self.ge, self.glimpse_in, hw)])                                # cell.py:153
         ge_out, G = self.ge.out[-1], self.ge.shapes[-1][1]
-        gemm(fwd, 0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
-             bias=self.params["what/b"], epi=BIAS)                                          # modules.py:20-21
+        launch(fwd, [desc(0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
+                          bias=self.params["what/b"], epi=BIAS)])                           # modules.py:20-21
         wp = cfg.what_prior
         fwd.append((L.air_gauss_sample_fwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
                                              wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale), p(self.what),
                                              p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
-        mlp_fwd(fwd, self.gd, self.what, A)                                                 # cell.py:158
+        if cfg.use_reinforce:                                                               # model.py:218-259
+            fwd.append((L.air_baseline_pack, (p(self.obs), p(self.what), p(self.where), p(self.presence),
+                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_in), T, B, P, A, Hd,
+                                              Hd), "air_baseline_pack"))
+            launch(fwd, [fwd_desc(self.bl, 0, self.base_in, cfg.baseline_in)], allow_splitk=True)
+            launch(fwd, [fwd_desc(self.gd, 0, self.what, A)])                               # cell.py:158
+            depth = max(self.gd.n, self.bl.n)
+            for i in range(1, depth):
+                launch(fwd, [fwd_desc(m, i, None, 0) for m in (self.gd, self.bl) if i < m.n])
+        else:
+            mlp_fwd_multi(fwd, [(self.gd, self.what, A)])
         decoded = self.gd.out[-1]
         fwd.append((L.air_canvas_unroll_fwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
                                               p(self.canvas_steps), p(self.final_canvas), p(self.rec), T, B, Hi, Wi,
                                               hc, wc, cfg.output_multiplier, cfg.output_std),
                     "air_canvas_unroll_fwd"))                                               # cell.py:159-165, model.py:319-324
-        fwd.append((L.air_numsteps_fwd, (p(self.presence_prob), p(self.presence), p(self.prior_dev), p(self.q_n),
-                                         p(self.kl_n), p(self.logp), p(self.step_w), T, B), "air_numsteps_fwd"))
-        if cfg.use_reinforce:                                                               # model.py:218-259
-            fwd.append((L.air_baseline_pack, (p(self.obs), p(self.what), p(self.where), p(self.presence),
-                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_in), T, B, P, A, Hd,
-                                              Hd), "air_baseline_pack"))
-            mlp_fwd(fwd, self.bl, self.base_in, cfg.baseline_in)
+        if cfg.use_reinforce:
             fwd.append((L.air_nvil, (p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out), p(self.dlogp),
                                      p(self.dbase), B), "air_nvil"))
 
@@ -384,73 +429,67 @@ class AIREngine:
                                               p(self.final_canvas), p(self.gd.g[-1]), p(self.dwhere_w), T, B, Hi, Wi,
                                               hc, wc, cfg.output_multiplier, cfg.output_std, inv_b),
                     "air_canvas_unroll_bwd"))
-        mlp_bwd(bwd, self.gd, self.what, A, self.gd.g[-1], dx_out=self.d_what)
-        bwd.append((L.air_axpby, (p(self.step_w), pw * inv_b, None, 0.0, p(self.dkl_row), ctypes.c_size_t(M)),
-                    "air_axpby"))
+        chains = [dict(m=self.gd, x=self.what, ldx=A, g_last=self.gd.g[-1], dx_out=self.d_what)]
+        if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
+            chains.append(dict(m=self.bl, x=self.base_in, ldx=cfg.baseline_in, g_last=self.dbase))
+        mlp_bwd_multi(bwd, chains)
         bwd.append((L.air_gauss_sample_bwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
                                              wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale),
-                                             p(self.d_what), p(self.dkl_row), p(self.dq), 2 * A, M, A),
-                    "air_gauss_sample_bwd"))
-        gemm(bwd, 1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
-             colsum=self.grads["what/b"])
-        gemm(bwd, 0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
-             aux=ge_out, ldaux=G)
-        mlp_bwd(bwd, self.ge, self.glimpse_in, hw, self.ge.g[-1], dx_out=self.d_glimpse_in)
+                                             p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M,
+                                             A), "air_gauss_sample_bwd"))
+        launch(bwd, [desc(1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
+                          colsum=self.grads["what/b"]),
+                     desc(0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
+                          aux=ge_out, ldaux=G)])
+        mlp_bwd_multi(bwd, [dict(m=self.ge, x=self.glimpse_in, ldx=hw, g_last=self.ge.g[-1], dx_out=self.d_glimpse_in)])
         bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
                                         B, Hi, Wi, hc, wc), "air_st_read_bwd"))
-        bwd.append((L.air_axpby, (p(self.dwhere_w), 1.0, p(self.dwhere_r), 1.0, p(self.dwhere),
-                                  ctypes.c_size_t(M * 4)), "air_axpby"))
         bwd.append((L.air_gauss_sample_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
                                              sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
-                                             p(self.dwhere), p(self.dkl_row), p(self.tr.g[-1]), 8, M, 4),
-                    "air_gauss_sample_bwd"))
-        bwd.append((L.air_axpby, (p(self.kl_what_row), pw * inv_b, p(self.kl_where_row), pw * inv_b, p(self.dstep_w),
-                                  ctypes.c_size_t(M)), "air_axpby"))
-        bwd.append((L.air_numsteps_bwd, (p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
-                                         p(self.dstep_w), p(self.dlogp) if cfg.use_reinforce else None,
-                                         p(self.dprob), T, B), "air_numsteps_bwd"))
-        bwd.append((L.air_presence_bwd, (p(self.st.out[-1]), cfg.step_bias, eps, 1, p(self.dprob), None,
-                                         p(self.st.g[-1]), T, B), "air_presence_bwd"))
-        mlp_bwd(bwd, self.tr, h_all, Hd, self.tr.g[-1], dx_out=self.dH)
-        mlp_bwd(bwd, self.st, h_all, Hd, self.st.g[-1], dx_out=self.dH, dx_beta=1.0)
+                                             p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
+                                             p(self.tr.g[-1]), 8, M, 4), "air_gauss_sample_bwd"))
+        bwd.append((L.air_numsteps_presence_bwd, (p(self.presence_prob), p(self.presence), p(self.prior_dev),
+                                                  pw * inv_b, p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
+                                                  p(self.dlogp) if cfg.use_reinforce else None, p(self.st.out[-1]),
+                                                  cfg.step_bias, eps, p(self.st.g[-1]), T, B),
+                    "air_numsteps_presence_bwd"))
+        mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
+                            dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)])
         # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)
         dc_in, dc_out = None, self.dc_a
         for t in reversed(range(T)):
             bwd.append((L.air_lstm_pointwise_bwd, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
-                                                   p(self.dH[t]), p(dc_in) if dc_in is not None else None,
+                                                   p(self.dH[t]), p(self.dH_b[t]),
+                                                   p(dc_in) if dc_in is not None else None,
                                                    p(self.dgates[t]), p(dc_out), B, Hd), "air_lstm_pointwise_bwd"))
             tgt = self.dH[t - 1] if t > 0 else self.dh_init
-            gemm(bwd, 0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, tgt, Hd, beta=1.0 if t > 0 else 0.0)
+            launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, tgt, Hd,
+                              beta=1.0 if t > 0 else 0.0)])
             dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
         gw = self.grads["lstm/w_gates"]
-        gemm(bwd, 1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
-             colsum=self.grads["lstm/b_gates"])                                              # dW_h, db_gates
         bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
                     "air_sum_leading"))
-        gemm(bwd, 1, 0, E, 4 * Hd, B, enc_out, E, self.dgx, 4 * Hd, gw[:E], 4 * Hd)        # dW_x
-        bwd.append((L.air_colsum, (p(self.dh_init), Hd, p(self.grads["lstm/h0"]), B, Hd), "air_colsum"))
-        bwd.append((L.air_colsum, (p(dc_in), Hd, p(self.grads["lstm/c0"]), B, Hd), "air_colsum"))
-        gemm(bwd, 0, 1, B, E, 4 * Hd, self.dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
-             ldaux=E)
-        mlp_bwd(bwd, self.enc, self.obs, P, self.enc.g[-1])
-        if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
-            mlp_bwd(bwd, self.bl, self.base_in, cfg.baseline_in, self.dbase)
+        launch(bwd, [desc(1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
+                          colsum=self.grads["lstm/b_gates"]),                                # dW_h, db_gates
+                     desc(1, 0, E, 4 * Hd, B, enc_out, E, self.dgx, 4 * Hd, gw[:E], 4 * Hd),  # dW_x
+                     desc(0, 1, B, E, 4 * Hd, self.dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
+                          ldaux=E),                                                          # d enc_out (pre-activation)
+                     desc(1, 0, 1, Hd, B, self.ones_b, 1, self.dh_init, Hd, self.grads["lstm/h0"], Hd),   # dh0 = 1^T.dh_-1
+                     desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)])         # dc0
+        mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])])
 
-        # ---- optimiser (two contiguous segments: model vars / baseline vars) ----------------------------------------
+        # ---- optimiser: both centred-RMSProp updates + device counters in one launch ---------------------------------
+        tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
         self._opt_calls_factory = lambda gscale: [
-            (L.air_rmsprop_centered, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
-                                      p(self.flat_mom), ctypes.c_size_t(self.n_model), p(self.lr_dev), 1.0,
-                                      cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale), "air_rmsprop_centered"),
-        ] + ([(L.air_rmsprop_centered, (p(self.flat_params[self.n_model:]), p(self.flat_grads[self.n_model:]),
-                                        p(self.flat_ms[self.n_model:]), p(self.flat_mg[self.n_model:]),
-                                        p(self.flat_mom[self.n_model:]), ctypes.c_size_t(self.n_total - self.n_model),
-                                        p(self.lr_dev), cfg.baseline_lr_mult, cfg.rms_decay, cfg.rms_momentum,
-                                        cfg.rms_eps, gscale), "air_rmsprop_centered")]
-             if (cfg.use_reinforce and self.n_total > self.n_model) else [])
-        step_inc = [(L.air_counter_add, (p(self.step_dev), ctypes.c_int64(1)), "air_counter_add")]
-        base_factory = self._opt_calls_factory
-        self._opt_calls_factory = lambda gscale: base_factory(gscale) + step_inc
-        self._plan_rng, self._plan_fwd, self._plan_bwd = rng, fwd, bwd
+            (L.air_step_epilogue, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
+                                   p(self.flat_mom), ctypes.c_size_t(self.n_model), ctypes.c_size_t(self.n_total),
+                                   p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale,
+                                   p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
+             "air_step_epilogue")]
+        self._plan_rng = rng
+        self._plan_fwd_noise = [prologue(True)] + fwd
+        self._plan_fwd = [prologue(False)] + fwd
+        self._plan_bwd = bwd
         self._plan_opt = self._opt_calls_factory(1.0)
 
     def _run(self, plan, stream_ptr):
@@ -499,9 +538,7 @@ class AIREngine:
         """T-step unroll + objective terms.  Results live in the engine's buffers (see `outputs()`)."""
         if obs is not None:
             self.set_obs(obs)
-        if sample_noise:
-            self.sample_noise()
-        self._run(self._plan_fwd, self._sp())
+        self._run(self._plan_fwd_noise if sample_noise else self._plan_fwd, self._sp())
 
     def backward(self):
         """Fills flat_grads with d opt_loss / d model vars and d baseline_loss / d baseline vars (model.py:355-367)."""
@@ -521,8 +558,7 @@ class AIREngine:
         sp = self._sp()
         _lib.check(L.air_graph_begin_capture(sp), "air_graph_begin_capture")
         try:
-            self._run(self._plan_rng, sp)
-            self._run(self._plan_fwd, sp)
+            self._run(self._plan_fwd_noise, sp)
             self._run(self._plan_bwd, sp)
             if not split_optimizer:
                 self._run(self._plan_opt, sp)
@@ -563,8 +599,7 @@ class AIREngine:
                         allreduce(self.flat_grads)
                 _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
         else:
-            self._run(self._plan_rng, sp)
-            self._run(self._plan_fwd, sp)
+            self._run(self._plan_fwd_noise, sp)
             self._run(self._plan_bwd, sp)
             if allreduce is not None:
                 with torch.cuda.stream(self.stream):
@@ -621,5 +656,4 @@ class AIREngine:
         return dict(self.grads)
 
     def kernel_launch_count(self) -> Dict[str, int]:
-        return {"rng": len(self._plan_rng), "forward": len(self._plan_fwd), "backward": len(self._plan_bwd),
-                "optimizer": len(self._plan_opt)}
+        return {"forward": len(self._plan_fwd_noise), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}

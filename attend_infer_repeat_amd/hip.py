@@ -205,8 +205,8 @@ def lstm_pointwise_bwd(gate_act, c_prev, c, dh, dc):
     dh = _f32(dh, "dh"); dc = _f32(dc, "dc")
     M, Hd = c_prev.shape
     dgates = torch.empty_like(gate_act); dc_prev = torch.empty_like(c_prev)
-    _lib.check(lib().air_lstm_pointwise_bwd(_p(gate_act), _p(c_prev), _p(c), _p(dh), _p(dc), _p(dgates), _p(dc_prev),
-                                            M, Hd, _stream()), "air_lstm_pointwise_bwd")
+    _lib.check(lib().air_lstm_pointwise_bwd(_p(gate_act), _p(c_prev), _p(c), _p(dh), None, _p(dc), _p(dgates),
+                                            _p(dc_prev), M, Hd, _stream()), "air_lstm_pointwise_bwd")
     return dgates, dc_prev
 
 
@@ -235,8 +235,8 @@ def gauss_sample_bwd(pre, eps, raw_offset, loc_mode, prior4, loc, scale, dsample
     dpre = torch.empty((M, 2 * D), dtype=torch.float32, device=pre.device)
     a, b, c, d = (float(v) for v in prior4)
     _lib.check(lib().air_gauss_sample_bwd(_p(pre), ld, _p(eps), float(raw_offset), int(loc_mode), a, b, c, d, _p(loc),
-                                          _p(scale), _p(_f32(dsample, "dsample")), _p(_f32(dkl_row, "dkl_row")),
-                                          _p(dpre), 2 * D, M, D, _stream()), "air_gauss_sample_bwd")
+                                          _p(scale), _p(_f32(dsample, "dsample")), None, _p(_f32(dkl_row, "dkl_row")),
+                                          1.0, _p(dpre), 2 * D, M, D, _stream()), "air_gauss_sample_bwd")
     return dpre
 
 

@@ -102,17 +102,19 @@ def plan_breakdown(eng, reps=100):
     lib = H.lib()
     sp = eng._sp()
     rows = []
-    for phase, plan in (("rng", eng._plan_rng), ("fwd", eng._plan_fwd), ("bwd", eng._plan_bwd), ("opt", eng._plan_opt)):
+    for phase, plan in (("fwd", eng._plan_fwd_noise), ("bwd", eng._plan_bwd), ("opt", eng._plan_opt)):
         for i, (fn, a, name) in enumerate(plan):
             ms = event_time_ms(lib, sp, lambda: fn(*a, sp), reps)
             desc = ""
             if name == "air_gemm":
                 desc = f"ta={a[0]} tb={a[1]} M={a[2]} N={a[3]} K={a[4]} epi={a[12]}"
+            elif name == "air_gemm_grouped":
+                desc = " | ".join(f"{'T' if d.ta else 'N'}{'T' if d.tb else 'N'} {d.M}x{d.N}x{d.K}" for d in a[0])
             rows.append((phase, i, name, desc, ms * 1e3))
     tot = sum(r[4] for r in rows)
     print(f"# isolated per-launch cost, {len(rows)} launches, sum {tot:.1f} us", file=sys.stderr)
     for r in rows:
-        print(f"{r[0]:4s} {r[1]:3d} {r[2]:28s} {r[3]:44s} {r[4]:8.2f} us", file=sys.stderr)
+        print(f"{r[0]:4s} {r[1]:3d} {r[2]:28s} {r[4]:8.2f} us  {r[3]}", file=sys.stderr)
     agg = {}
     for r in rows:
         agg.setdefault(r[2], [0, 0.0]); agg[r[2]][0] += 1; agg[r[2]][1] += r[4]

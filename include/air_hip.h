@@ -95,6 +95,21 @@ int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const
              float *colsum, void *ws, size_t ws_bytes, void *stream);
 size_t air_gemm_workspace_bytes(int M, int N, int K);
 
+/* Up to 8 INDEPENDENT GEMMs in one launch (same semantics as air_gemm, no split-K).  The step is launch/latency
+ * bound at batch 64, so e.g. the dW and dX products of one layer, or the transform / steps heads that share h_t,
+ * are dispatched together.  `descs` is a HOST array; outputs must not alias another problem's inputs.              */
+typedef struct AirGemmDesc {
+    int ta, tb, M, N, K;
+    const float *A; int lda;
+    const float *B; int ldb;
+    float *C; int ldc;
+    const float *bias; int epilogue;
+    const float *aux; int ldaux;
+    float beta;
+    float *colsum;
+} AirGemmDesc;
+int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
+
 /* y = act(x.w + b), neural.py:56-60.  x[M,K], w[K,N] (Sonnet layout), b[N] (may be NULL), y[M,N].                 */
 int air_linear_fwd(const float *x, const float *w, const float *b, float *y, int M, int K, int N, int act,
                    void *ws, size_t ws_bytes, void *stream);
@@ -107,9 +122,10 @@ int air_linear_bwd(const float *x, const float *w, const float *y, const float *
  * h' = tanh(c')*sig(o).  gates[M,4H] pre-activation; gate_act[M,4H] receives the activated gates (saved for bwd). */
 int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, float *c, float *gate_act,
                            int M, int Hd, float forget_bias, void *stream);
-/* dgates[M,4H], dc_prev[M,H] from dh[M,H] and (optional) dc[M,H] flowing in from step t+1.                        */
+/* dgates[M,4H], dc_prev[M,H] from dh[M,H] (+ dh2) and (optional) dc[M,H] flowing in from step t+1.              */
 int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
-                           const float *dc, float *dgates, float *dc_prev, int M, int Hd, void *stream);
+                           const float *dh2 /* optional second dh term, summed */, const float *dc, float *dgates,
+                           float *dc_prev, int M, int Hd, void *stream);
 
 /* ---- stochastic nodes ---------------------------------------------------------------------------------------*/
 
@@ -123,11 +139,12 @@ int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const flo
 int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          float *loc, float *scale, float *sample, float *kl_row, int M, int D, void *stream);
-/* dpre[M,ld_dpre] (both halves) from dsample[M,D] (may be NULL) and dkl_row[M] (may be NULL).                     */
+/* dpre[M,ld_dpre] (both halves) from dsample[M,D] (+ dsample2[M,D]; either may be NULL) and dkl_row[M]*dkl_scale
+ * (dkl_row may be NULL).                                                                                            */
 int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
-                         const float *loc, const float *scale, const float *dsample, const float *dkl_row,
-                         float *dpre, int ld_dpre, int M, int D, void *stream);
+                         const float *loc, const float *scale, const float *dsample, const float *dsample2,
+                         const float *dkl_row, float dkl_scale, float *dpre, int ld_dpre, int M, int D, void *stream);
 
 /* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
  * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
@@ -168,6 +185,18 @@ int air_numsteps_bwd(const float *presence_prob, const float *presence, const do
                      const float *dstep_weight, const float *dlogp, float *dpresence_prob, int T, int B,
                      void *stream);
 
+/* Engine fusions of the two above with presence (the step is launch bound at batch 64):
+ *   air_presence_numsteps_fwd  = air_presence_fwd (discrete) + air_numsteps_fwd;
+ *   air_numsteps_presence_bwd  = [dstep_weight = w_scale*(kl_row_a + kl_row_b)] + air_numsteps_bwd + air_presence_bwd,
+ *                                producing d loss / d logit directly.                                               */
+int air_presence_numsteps_fwd(const float *logit, const float *u, float step_bias, float explore_eps,
+                              const double *prior_f64, float *presence_prob, float *presence, float *q,
+                              float *kl_per_sample, float *logp, float *step_weight, int T, int B, void *stream);
+int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
+                              float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
+                              const float *dlogp, const float *logit, float step_bias, float explore_eps,
+                              float *dlogit, int T, int B, void *stream);
+
 /* Annealed geometric prior over the number of steps, entirely on device (model.py:106-124,139-146; prior.py:26-32):
  *   step' = max(*global_step_dev - hold_for, 0);  anneal_type 0: s = init; 1 ("exp"): s = max(final, init *
  *   ((final/init)^(steps_div/anneal_steps))^(step'/steps_div)); 2 ("linear"): s = max(final, final + (init-final) *
@@ -199,6 +228,18 @@ int air_baseline_pack(const float *img, const float *what, const float *where, c
  * grad_scale multiplies g first (1/world_size after an all-reduce sum).                                            */
 int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev,
                          float lr_mult, float decay, float momentum, float eps, float grad_scale, void *stream);
+
+/* Fused step prologue / epilogue for the launch-bound train step.
+ *   prologue: air_rng_fill + air_steps_prior + tiling of the trainable LSTM initial state (h0,c0 [1,Hd] -> [B,Hd]).
+ *   epilogue: centred RMSProp over the whole flat buffer (elements >= n_model use lr * lr_mult_tail: the baseline
+ *             optimiser, model.py:363), then *global_step_dev += 1 and rng_state_dev[1] += rng_increment.            */
+int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
+                      const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+                      double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
+                      const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, void *stream);
+int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+                      const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
+                      int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
 
 /* ---- noise --------------------------------------------------------------------------------------------------
  * Philox4x32-10 counter RNG (replaces TF's sampler ops behind .sample(), cell.py:133,147,156).
