@@ -132,7 +132,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     // ---- main loop: U chunks in flight per wave.  The problem is latency bound (operands sit in L2 / Infinity
     // Cache, each wave owns only a handful of 16-deep chunks), so all loads of U chunks are issued before the first
     // MFMA: one memory round trip per U chunks instead of one per chunk.
-    constexpr int U = 4;
+    constexpr int U = (MT * NT == 1) ? 8 : 4;             // chunks in flight: small tiles can afford more registers
     int full_end = g.K >> 4;                               // chunks [0, full_end) need no k masking
     if (full_end > c_end) full_end = c_end;
     int rowAc[MT], colBc[NT];
@@ -140,22 +140,31 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     for (int a = 0; a < MT; ++a) rowAc[a] = okA[a] ? rowA[a] : g.M - 1;
 #pragma unroll
     for (int b = 0; b < NT; ++b) colBc[b] = okB[b] ? colB[b] : g.N - 1;
-    for (; c + (U - 1) * c_step < full_end; c += U * c_step) {
+    for (; c < full_end; c += U * c_step) {
         f32x4 fa[U][MT], fb[U][NT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k = ((c + u * c_step) << 4) + 4 * lg;
+            const int cu = c + u * c_step;
+            if (cu < full_end) {                           // wave-uniform: a short tail group issues fewer loads
+                const int k = (cu << 4) + 4 * lg;
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
-                fa[u][a] = g.ta ? ld_kstrided_full(g.A, g.lda, rowAc[a], k)
-                                : ld_kcontig_full(g.A, g.lda, rowAc[a], k, g.vecA != 0);
+                for (int a = 0; a < MT; ++a)
+                    fa[u][a] = g.ta ? ld_kstrided_full(g.A, g.lda, rowAc[a], k)
+                                    : ld_kcontig_full(g.A, g.lda, rowAc[a], k, g.vecA != 0);
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
-                fb[u][b] = g.tb ? ld_kcontig_full(g.B, g.ldb, colBc[b], k, g.vecB != 0)
-                                : ld_kstrided_full(g.B, g.ldb, colBc[b], k);
+                for (int b = 0; b < NT; ++b)
+                    fb[u][b] = g.tb ? ld_kcontig_full(g.B, g.ldb, colBc[b], k, g.vecB != 0)
+                                    : ld_kstrided_full(g.B, g.ldb, colBc[b], k);
+            } else {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) fa[u][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < NT; ++b) fb[u][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (c + u * c_step >= full_end) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -170,9 +179,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
             }
         }
     }
-    // ---- remainder: one chunk at a time, fully masked (also covers the partial last chunk of K)
-    for (; c < c_end; c += c_step) {
-        const int k = (c << 4) + 4 * lg;
+    // ---- the partial last chunk of K (if any), fully masked, done by the wave that owns it
+    const int pc = g.K >> 4;
+    if ((g.K & 15) && pc >= c_begin && pc < c_end && (KW == 1 || ((pc - c_begin) & 3) == wave)) {
+        const int k = (pc << 4) + 4 * lg;
         f32x4 fa[MT], fb[NT];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -324,16 +334,18 @@ extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int
     const long tiles22 = (long)air_cdiv(M, 32) * air_cdiv(N, 32);
     int S = 1;
     hipStream_t st = air_stream(stream);
-    if (tiles22 >= 1024) {
+    if (tiles22 >= 2048) {
         g.S = 1; g.chunks_per_split = chunks;
         return launch_gemm<2, 2, 1>(g, st);
     }
-    const bool narrow = (M <= 64);
-    const long tiles = narrow ? (long)air_cdiv(M, 16) * air_cdiv(N, 32) : tiles22;
+    // latency regime (the whole problem fits a fraction of the chip): 16x16 tiles, one per workgroup, 4 waves split K,
+    // 8 chunks in flight -- every wave does one or two memory round trips whatever the shape
+    const bool narrow = true;
+    const long tiles = (long)air_cdiv(M, 16) * air_cdiv(N, 16);
     // cross-workgroup split-K costs a second (epilogue) launch, ~4.5 us on this part: only worth it for long K
     if (!colsum && ws && chunks >= 64) {
-        long want = 512 / (tiles > 0 ? tiles : 1);                       // aim for ~2 workgroups per CU
-        long max_by_k = chunks / 8;                                      // >= 2 chunks per wave per split
+        long want = 1024 / (tiles > 0 ? tiles : 1);                      // aim for ~4 workgroups per CU
+        long max_by_k = chunks / 16;                                     // >= 4 chunks per wave per split
         long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
         long s = want;
         if (s > max_by_k) s = max_by_k;
@@ -344,8 +356,8 @@ extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int
     g.S = S;
     g.chunks_per_split = (chunks + S - 1) / S;
     g.S = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;       // drop empty tail splits
-    if (narrow) return launch_gemm<1, 2, 4>(g, st);
-    return launch_gemm<2, 2, 4>(g, st);
+    (void)narrow;
+    return launch_gemm<1, 1, 4>(g, st);
 }
 
 static int fill_gemm_args(GemmArgs &g, const AirGemmDesc &d) {
@@ -374,12 +386,12 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         int st = fill_gemm_args(ga.g[i], descs[i]);
         if (st) return st;
         ga.tile_start[i] = tiles;
-        tiles += air_cdiv(descs[i].M, 32) * air_cdiv(descs[i].N, 32);
+        tiles += air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
     }
     for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
     for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
-    hipLaunchKernelGGL((gemm_grouped_kernel<2, 2, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
+    hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
