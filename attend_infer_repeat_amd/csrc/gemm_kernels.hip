@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs ga) {
 #pragma unroll
     for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
         if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);                 // provably wave-uniform: the descriptor stays in SGPRs
     gemm_body<MT, NT, KW>(ga.g[p], (int)blockIdx.x - ga.tile_start[p], 0);
 }
 
@@ -381,17 +382,23 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     AIR_REQUIRE(descs, AIR_E_NULL);
     AIR_REQUIRE(count > 0 && count <= AIR_GEMM_GROUP_MAX, AIR_E_SHAPE);
     GroupArgs ga;
+    // tile shape for the whole group: 16x16 tiles (more, shorter-lived workgroups) while the group is far from filling
+    // the chip, 32x32 tiles once it holds thousands of them (less operand re-read, fewer workgroup rounds)
+    long tiles16 = 0;
+    for (int i = 0; i < count; ++i) tiles16 += (long)air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+    const int T_ = tiles16 > 1536 ? 32 : 16;
     int tiles = 0;
     for (int i = 0; i < count; ++i) {
         int st = fill_gemm_args(ga.g[i], descs[i]);
         if (st) return st;
         ga.tile_start[i] = tiles;
-        tiles += air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+        tiles += air_cdiv(descs[i].M, T_) * air_cdiv(descs[i].N, T_);
     }
     for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
     for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
-    hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
+    if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
+    else hipLaunchKernelGGL((gemm_grouped_kernel<2, 2, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -327,7 +327,7 @@ class AIREngine:
                 else:
                     launch(plan, descs)
 
-        def mlp_bwd_multi(plan, chains):
+        def mlp_bwd_multi(plan, chains, extra_first=()):
             """chains: dicts(m, x, ldx, g_last, dx_out=None, dx_aux=None).  g_last = gradient wrt the last layer's
             pre-activation.  Per level one dispatch holding every chain's dW (+db) and dX."""
             depth = max(c["m"].n for c in chains)
@@ -351,6 +351,8 @@ class AIREngine:
                         aux = c.get("dx_aux")
                         descs.append(desc(0, 1, m.rows, k, n, g, n, m.w[0], n, c["dx_out"], k,
                                           epi=MDELU if aux is not None else NONE, aux=aux, ldaux=k if aux is not None else 0))
+                if s_ == 0:
+                    descs = list(extra_first) + descs
                 launch(plan, descs)
 
         # ---- noise only (used when forward() is asked to keep injected noise: the prologue then draws nothing) -------
@@ -456,27 +458,28 @@ class AIREngine:
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
                             dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)])
         # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)
+        gw = self.grads["lstm/w_gates"]
         dc_in, dc_out = None, self.dc_a
         for t in reversed(range(T)):
             bwd.append((L.air_lstm_pointwise_bwd, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
                                                    p(self.dH[t]), p(self.dH_b[t]),
                                                    p(dc_in) if dc_in is not None else None,
                                                    p(self.dgates[t]), p(dc_out), B, Hd), "air_lstm_pointwise_bwd"))
-            tgt = self.dH[t - 1] if t > 0 else self.dh_init
-            launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, tgt, Hd,
-                              beta=1.0 if t > 0 else 0.0)])
+            if t > 0:
+                launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, self.dH[t - 1], Hd,
+                                  beta=1.0)])
             dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
-        gw = self.grads["lstm/w_gates"]
         bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
                     "air_sum_leading"))
+        launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[0], 4 * Hd, w_h, 4 * Hd, self.dh_init, Hd),   # d h_{-1}
+                     desc(0, 1, B, E, 4 * Hd, self.dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
+                          ldaux=E)])                                                         # d enc_out (pre-activation)
         launch(bwd, [desc(1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
                           colsum=self.grads["lstm/b_gates"]),                                # dW_h, db_gates
-                     desc(1, 0, E, 4 * Hd, B, enc_out, E, self.dgx, 4 * Hd, gw[:E], 4 * Hd),  # dW_x
-                     desc(0, 1, B, E, 4 * Hd, self.dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
-                          ldaux=E),                                                          # d enc_out (pre-activation)
-                     desc(1, 0, 1, Hd, B, self.ones_b, 1, self.dh_init, Hd, self.grads["lstm/h0"], Hd),   # dh0 = 1^T.dh_-1
-                     desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)])         # dc0
-        mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])])
+                     desc(1, 0, E, 4 * Hd, B, enc_out, E, self.dgx, 4 * Hd, gw[:E], 4 * Hd)])  # dW_x
+        self._lstm_tail = [desc(1, 0, 1, Hd, B, self.ones_b, 1, self.dh_init, Hd, self.grads["lstm/h0"], Hd),   # dh0
+                           desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)]          # dc0
+        mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail)
 
         # ---- optimiser: both centred-RMSProp updates + device counters in one launch ---------------------------------
         tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
