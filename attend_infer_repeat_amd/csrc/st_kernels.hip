@@ -119,6 +119,72 @@ __global__ __launch_bounds__(ST_THREADS) void st_read_fwd_kernel(
     }
 }
 
+// Software-pipelined variant used when the image is 16-byte addressable: while a workgroup computes the glimpses of
+// image b out of LDS, the 16-byte loads of its NEXT image (and the `where` row of its next glimpse) are already in
+// flight in registers, so the HBM stream never stops between images (the un-pipelined kernel above alternates
+// load / compute and tops out near half of the achievable bandwidth when every glimpse has its own image).
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its outstanding global loads (a plain
+// __syncthreads() drains vmcnt too, which would serialise the register prefetch of the next image behind the barrier).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// (three NAMED float4 registers per thread: an indexed register array is demoted to scratch by hipcc here, which
+//  serialises every load behind a scratch store; blockDim.x = 256 covers images up to 768 float4, 1024 up to 3072)
+__global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
+    const float *__restrict__ img, const float *__restrict__ where, float *__restrict__ out,
+    int n, int n_img, int H, int W, int h, int w, double stepx, double stepy) {
+    extern __shared__ __align__(16) float smem[];
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, nq = HW >> 2;
+    Carve c = carve_lds(smem, HW, 0, w, h);
+    const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    const float4 *where4 = reinterpret_cast<const float4 *>(where);
+    const int q0 = tid < nq ? tid : nq - 1, q1 = tid + nt < nq ? tid + nt : nq - 1;
+    const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+    int b = blockIdx.x;
+    if (b < n_img) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(img + (size_t)b * HW);
+        p0 = s4[q0]; p1 = s4[q1]; p2 = s4[q2];
+    }
+    float4 wnext = (b < n_img) ? where4[b] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = tid; a < w + h; a += nt) {                   // the linspace tables do not depend on the image
+        if (a < w) c.X[a] = lin_m11(a, w, stepx); else c.Y[a - w] = lin_m11(a - w, h, stepy);
+    }
+    float4 *d4 = reinterpret_cast<float4 *>(c.src);
+    for (; b < n_img; b += gridDim.x) {
+        lds_barrier();                                        // readers of the previous image are done
+        if (tid < nq) d4[tid] = p0;
+        if (tid + nt < nq) d4[tid + nt] = p1;
+        if (tid + 2 * nt < nq) d4[tid + 2 * nt] = p2;
+        const int nb = b + gridDim.x;
+        if (nb < n_img) {                                     // next image: in flight during this image's compute
+            const float4 *s4 = reinterpret_cast<const float4 *>(img + (size_t)nb * HW);
+            p0 = s4[q0]; p1 = s4[q1]; p2 = s4[q2];
+        }
+        for (int k = b; k < n; k += n_img) {
+            const float4 wk = wnext;
+            const bool more = k + n_img < n;
+            if (more || nb < n_img) wnext = where4[more ? k + n_img : nb];
+            lds_barrier();
+            for (int a = tid; a < w + h; a += nt) {
+                if (a < w) axis_entry(grid_coord(wk.x, c.X[a], wk.y, cxs), W, &c.fx[a], &c.dx[a]);
+                else axis_entry(grid_coord(wk.z, c.Y[a - w], wk.w, cys), H, &c.fy[a - w], &c.dy[a - w]);
+            }
+            lds_barrier();
+            float *o = out + (size_t)k * hw;
+            for (int p = tid; p < hw; p += nt) {
+                const int i = p / w, j = p - i * w;
+                const int fx = c.fx[j], fy = c.fy[i];
+                float v = 0.f;
+                if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, H, W, fy, fx), c.dx[j], c.dy[i]);
+                o[p] = v;
+            }
+        }
+    }
+}
+
 // dwhere[k,4] = sum_ij dglimpse * d out / d(x,y) * d(x,y)/d where ; optional dimg (n_img == n)
 __global__ __launch_bounds__(ST_THREADS) void st_read_bwd_kernel(
     const float *__restrict__ img, const float *__restrict__ where, const float *__restrict__ dout,
@@ -427,6 +493,15 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
     const size_t lds = carve_bytes(H * W, 0, w, h);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
+    const int nq = (H * W) / 4;
+    if (vec4 && air_aligned16(where) && nq <= 3 * 1024) {
+        const int threads = nq <= 3 * 256 ? 256 : 1024;
+        { int st_ = st_allow_lds(st_read_fwd_pipe_kernel, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(st_read_fwd_pipe_kernel, dim3(st_grid(n_img)), dim3(threads), lds, air_stream(stream), img,
+                           where, glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h));
+        AIR_LAUNCH_CHECK();
+        return AIR_OK;
+    }
     { int st_ = st_allow_lds(st_read_fwd_kernel, lds); if (st_) return st_; }
     hipLaunchKernelGGL(st_read_fwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
                        glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
