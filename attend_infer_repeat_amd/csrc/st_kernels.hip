@@ -53,12 +53,13 @@ __device__ __forceinline__ void axis_entry(float coord, int extent, int *f_out, 
 }
 
 __device__ __forceinline__ void stage_to_lds(float *dst, const float *src, int count, bool vec4) {
+    const int nt = blockDim.x;
     if (vec4) {
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int q = threadIdx.x; q < (count >> 2); q += ST_THREADS) d4[q] = s4[q];
+        for (int q = threadIdx.x; q < (count >> 2); q += nt) d4[q] = s4[q];
     } else {
-        for (int p = threadIdx.x; p < count; p += ST_THREADS) dst[p] = src[p];
+        for (int p = threadIdx.x; p < count; p += nt) dst[p] = src[p];
     }
 }
 
@@ -254,63 +255,85 @@ __global__ __launch_bounds__(ST_THREADS) void st_read_bwd_kernel(
 // One workgroup per image accumulates all T steps in LDS, optionally emitting every intermediate canvas and the
 // per-sample reconstruction term of the final canvas.
 // ============================================================================================================
-__global__ __launch_bounds__(ST_THREADS) void st_write_fwd_kernel(
+// Single-phase form: ALL T glimpses of an image and their T axis tables are staged in LDS behind ONE barrier, then
+// each thread walks its canvas pixels with the running canvas in a register (t inner, in order, so the accumulation is
+// the oracle's ((0 + p0*v0) + p1*v1) + ...).  One memory round trip per image instead of one per step.
+struct CarveWr {
+    float *glm, *dx, *dy, *X, *Y, *pres, *scratch;
+    int *fx, *fy;
+    int hwp;
+};
+__device__ __forceinline__ CarveWr carve_wr(float *smem, int T, int H, int W, int h, int w) {
+    CarveWr c;
+    c.hwp = (h * w + 3) & ~3;
+    float *p = smem;
+    c.glm = p; p += (size_t)T * c.hwp;
+    c.fx = reinterpret_cast<int *>(p); p += T * W;
+    c.dx = p; p += T * W;
+    c.fy = reinterpret_cast<int *>(p); p += T * H;
+    c.dy = p; p += T * H;
+    c.X = p; p += W;
+    c.Y = p; p += H;
+    c.pres = p; p += (T + 3) & ~3;
+    c.scratch = p;
+    return c;
+}
+static inline size_t carve_wr_bytes(int T, int H, int W, int h, int w) {
+    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + 2 * (size_t)T * (W + H) + W + H + ((T + 3) & ~3) + 128);
+}
+
+__global__ __launch_bounds__(1024) void st_write_fwd_kernel(
     const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ canvas_in, const float *__restrict__ obs,
     float *__restrict__ canvas_steps, float *__restrict__ final_canvas, float *__restrict__ rec,
     int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, int vec4_canvas,
     int vec4_glimpse) {
     extern __shared__ __align__(16) float smem[];
-    const int HW = H * W, hw = h * w, tid = threadIdx.x;
-    Carve c = carve_lds(smem, hw, HW, W, H);           // src = glimpse tile, aux = running canvas
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
+    CarveWr c = carve_wr(smem, T, H, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
+    for (int a = tid; a < W + H; a += nt) {           // linspace tables: image independent
+        if (a < W) c.X[a] = lin_m11(a, W, stepX); else c.Y[a - W] = lin_m11(a - W, H, stepY);
+    }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        __syncthreads();
-        if (canvas_in) stage_to_lds(c.aux, canvas_in + (size_t)b * HW, HW, vec4_canvas != 0);
-        else for (int p = tid; p < HW; p += ST_THREADS) c.aux[p] = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const size_t k = (size_t)t * B + b;
-            __syncthreads();                            // previous step finished with glimpse tile + tables
-            stage_to_lds(c.src, glimpse + k * hw, hw, vec4_glimpse != 0);
-            const float sx = where[4 * k + 0], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
-            const float ax = 1.0f / sx, bx = -tx / sx;
-            const float ay = 1.0f / sy, by = -ty / sy;
-            for (int a = tid; a < W + H; a += ST_THREADS) {
-                if (a < W) axis_entry(grid_coord(ax, lin_m11(a, W, stepX), bx, cxs), w, &c.fx[a], &c.dx[a]);
-                else axis_entry(grid_coord(ay, lin_m11(a - W, H, stepY), by, cys), h, &c.fy[a - W], &c.dy[a - W]);
-            }
-            __syncthreads();
-            const float pres = presence ? presence[k] : 1.0f;
-            float *steps_out = canvas_steps ? canvas_steps + k * HW : nullptr;
-            for (int p = tid; p < HW; p += ST_THREADS) {
-                const int I = p / W, J = p - I * W;
-                const int fx = c.fx[J], fy = c.fy[I];
-                float v = 0.f;
-                if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, h, w, fy, fx), c.dx[J], c.dy[I]);
-                const float cv = c.aux[p] + pres * v;
-                c.aux[p] = cv;
-                if (steps_out) steps_out[p] = cv;
+        __syncthreads();                                      // previous image done (and X/Y visible)
+        for (int t = 0; t < T; ++t)
+            stage_to_lds(c.glm + (size_t)t * c.hwp, glimpse + ((size_t)t * B + b) * hw, hw, vec4_glimpse != 0);
+        for (int a = tid; a < T * (W + H); a += nt) {
+            const int t = a / (W + H), r = a - t * (W + H);
+            const float *wk = where + 4 * ((size_t)t * B + b);
+            if (r < W) {
+                const float sx = wk[0], tx = wk[1];
+                axis_entry(grid_coord(1.0f / sx, c.X[r], -tx / sx, cxs), w, &c.fx[t * W + r], &c.dx[t * W + r]);
+            } else {
+                const float sy = wk[2], ty = wk[3];
+                const int i = r - W;
+                axis_entry(grid_coord(1.0f / sy, c.Y[i], -ty / sy, cys), h, &c.fy[t * H + i], &c.dy[t * H + i]);
             }
         }
+        if (tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
         __syncthreads();
-        if (final_canvas) {
-            float *o = final_canvas + (size_t)b * HW;
-            if (vec4_canvas) {
-                float4 *o4 = reinterpret_cast<float4 *>(o);
-                const float4 *s4 = reinterpret_cast<const float4 *>(c.aux);
-                for (int q = tid; q < (HW >> 2); q += ST_THREADS) o4[q] = s4[q];
-            } else {
-                for (int p = tid; p < HW; p += ST_THREADS) o[p] = c.aux[p];
+        float s[1] = {0.f};
+        for (int p = tid; p < HW; p += nt) {
+            const int I = p / W, J = p - I * W;
+            const float xo = rec ? obs[(size_t)b * HW + p] : 0.f;
+            float acc = canvas_in ? canvas_in[(size_t)b * HW + p] : 0.f;
+            for (int t = 0; t < T; ++t) {
+                const int fx = c.fx[t * W + J], fy = c.fy[t * H + I];
+                float v = 0.f;
+                if (fx != ST_INVALID && fy != ST_INVALID)
+                    v = bilerp(load_taps(c.glm + (size_t)t * c.hwp, h, w, fy, fx), c.dx[t * W + J], c.dy[t * H + I]);
+                acc = acc + c.pres[t] * v;
+                if (canvas_steps) canvas_steps[((size_t)t * B + b) * HW + p] = acc;
+            }
+            if (final_canvas) final_canvas[(size_t)b * HW + p] = acc;
+            if (rec) {
+                const float z = (xo - mult * acc) / std;
+                s[0] += 0.5f * z * z + cst;
             }
         }
         if (rec) {
-            const float *x = obs + (size_t)b * HW;
-            const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
-            float s[1] = {0.f};
-            for (int p = tid; p < HW; p += ST_THREADS) {
-                const float z = (x[p] - mult * c.aux[p]) / std;
-                s[0] += 0.5f * z * z + cst;
-            }
             block_sum<1>(s, c.scratch);
             if (tid == 0) rec[b] = s[0];
         }
@@ -349,17 +372,17 @@ __device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, 
 }
 static inline size_t carve_bwd_bytes(int H, int W, int h, int w) {
     return sizeof(float) * (size_t)(((h * w + 3) & ~3) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 3 * W + 3 * H +
-                                    2 * w + 2 * h + 32);
+                                    2 * w + 2 * h + 128);
 }
 
-__global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
+__global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
     float *__restrict__ dglimpse, float *__restrict__ dwhere, float *__restrict__ dpresence,
     int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, float loss_scale,
     int vec4_glimpse) {
     extern __shared__ __align__(16) float smem[];
-    const int HW = H * W, hw = h * w, tid = threadIdx.x;
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
     CarveBwd c = carve_bwd(smem, H, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
     const float coef = loss_scale * mult / (std * std);
@@ -368,11 +391,18 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
         const int b = k % B;
         __syncthreads();
         stage_to_lds(c.src, glimpse + (size_t)k * hw, hw, vec4_glimpse != 0);
+        {   // incoming canvas gradient -> LDS up front: these global loads do not depend on the tables, so their
+            // latency overlaps the table construction instead of sitting inside the per-pixel dependency chain
+            const float *dcp = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
+            const float *fcp = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
+            const float *obp = obs ? obs + (size_t)b * HW : nullptr;
+            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : coef * (mult * fcp[p] - obp[p]);
+        }
         const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
         const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
         const float ax = 1.0f / sx, bx = -tx / sx;
         const float ay = 1.0f / sy, by = -ty / sy;
-        for (int a = tid; a < W + H; a += ST_THREADS) {
+        for (int a = tid; a < W + H; a += nt) {
             if (a < W) {
                 const float X = lin_m11(a, W, stepX);
                 c.X[a] = X;
@@ -385,7 +415,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
         }
         __syncthreads();
         // contiguous source ranges per glimpse column / row (min & max index that touches it)
-        for (int a = tid; a < w + h; a += ST_THREADS) {
+        for (int a = tid; a < w + h; a += nt) {
             const bool col = a < w;
             const int idx = col ? a : a - w, cnt = col ? W : H;
             const int *f = col ? c.fx : c.fy;
@@ -397,16 +427,13 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
             if (col) { c.jlo[idx] = lo; c.jhi[idx] = hi; } else { c.ilo[idx] = lo; c.ihi[idx] = hi; }
         }
         const float pres = presence ? presence[k] : 1.0f;
-        const float *dc_ptr = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
-        const float *fc_ptr = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
-        const float *ob_ptr = obs ? obs + (size_t)b * HW : nullptr;
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence
-        for (int p = tid; p < HW; p += ST_THREADS) {
+        for (int p = tid; p < HW; p += nt) {
             const int I = p / W, J = p - I * W;
             const int fx = c.fx[J], fy = c.fy[I];
             float go = 0.f;
             if (fx != ST_INVALID && fy != ST_INVALID) {
-                const float dc = dc_ptr ? dc_ptr[p] : coef * (mult * fc_ptr[p] - ob_ptr[p]);
+                const float dc = c.g[p];
                 const float dx = c.dx[J], dy = c.dy[I];
                 const Taps t = load_taps(c.src, h, w, fy, fx);
                 const float v = bilerp(t, dx, dy);
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
             c.g[p] = go;
         }
         __syncthreads();
-        for (int e = tid; e < H * w; e += ST_THREADS) {            // pass 1: contract canvas columns
+        for (int e = tid; e < H * w; e += nt) {            // pass 1: contract canvas columns
             const int I = e / w, j = e - I * w;
             float s = 0.f;
             if (c.fy[I] != ST_INVALID) {
@@ -438,7 +465,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_write_bwd_kernel(
         }
         __syncthreads();
         float *dg = dglimpse + (size_t)k * hw;
-        for (int e = tid; e < hw; e += ST_THREADS) {               // pass 2: contract canvas rows
+        for (int e = tid; e < hw; e += nt) {               // pass 2: contract canvas rows
             const int i = e / w, j = e - i * w;
             float s = 0.f;
             for (int I = c.ilo[i]; I <= c.ihi[i]; ++I) {
@@ -529,13 +556,15 @@ extern "C" int air_st_read_bwd(const float *img, const float *where, const float
 static int launch_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
                             const float *obs, float *canvas_steps, float *final_canvas, float *rec, int T, int B,
                             int H, int W, int h, int w, float mult, float std, void *stream) {
-    const size_t lds = carve_bytes(h * w, H * W, W, H);
+    const size_t lds = carve_wr_bytes(T, H, W, h, w);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4c = ((H * W) % 4 == 0) && (!canvas_in || air_aligned16(canvas_in)) &&
                       (!final_canvas || air_aligned16(final_canvas));
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     { int st_ = st_allow_lds(st_write_fwd_kernel, lds); if (st_) return st_; }
-    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid(B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse, where,
+    // few images: the chip is mostly idle, so give each image 16 waves (4 per SIMD) to hide LDS / global latency
+    const int wr_threads = (long)B * T <= 4096 ? 1024 : ST_THREADS;
+    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid(B)), dim3(wr_threads), lds, air_stream(stream), glimpse, where,
                        presence, canvas_in, obs, canvas_steps, final_canvas, rec, T, B, H, W, h, w, lin_step(W),
                        lin_step(H), mult, std, vec4c, vec4g);
     AIR_LAUNCH_CHECK();
@@ -573,7 +602,8 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     { int st_ = st_allow_lds(st_write_bwd_kernel, lds); if (st_) return st_; }
-    hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B)), dim3(ST_THREADS), lds, air_stream(stream), glimpse,
+    const int wr_threads = (long)B * T <= 4096 ? 1024 : ST_THREADS;
+    hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B)), dim3(wr_threads), lds, air_stream(stream), glimpse,
                        where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
                        lin_step(W), lin_step(H), mult, std, loss_scale, vec4g);
     AIR_LAUNCH_CHECK();

@@ -128,16 +128,18 @@ def test_noise_changes_every_step_and_prior_anneals(gpu_device):
 
 
 def test_loss_decreases_on_fixed_batch(gpu_device):
-    """Sanity of the whole loop: 60 updates on one batch reduce the ELBO loss."""
-    ocfg, B = O.AIRConfig(learning_rate=1e-3), 32
+    """Sanity of the whole loop at the reference script's learning rate (multi_mnist.py:24): 200 graph-replayed updates
+    on one batch reduce the ELBO loss and stay finite.  (At 10x that rate the raw where-scale runs to -50, softplus
+    underflows and KL(where) = +inf -- in the reference's arithmetic as well; AIR is known to be touchy, README.md:37.)"""
+    ocfg, B = O.AIRConfig(), 32
     eng, params, obs, noise = make_pair(ocfg, B, bias_std=0.0)
-    eng.set_learning_rate(1e-3)
     eng.forward(); first = eng.outputs()["loss"].item()
     eng.capture()
-    for _ in range(60):
+    for _ in range(200):
         eng.train_step()
     eng.forward(); last = eng.outputs()["loss"].item()
-    assert np.isfinite(last) and last < first, (first, last)
+    assert torch.isfinite(eng.flat_params).all() and torch.isfinite(eng.flat_grads).all()
+    assert np.isfinite(last) and last < first - 50.0, (first, last)
 
 
 def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
