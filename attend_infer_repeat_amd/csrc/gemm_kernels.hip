@@ -16,6 +16,11 @@
 #include "air_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// explicit global address space: descriptors that travel through memory (grouped launch) would otherwise make every
+// operand access a FLAT load with a 64-bit VGPR address (+100 VGPRs, half the occupancy)
+typedef const float __attribute__((address_space(1))) *gcf;
+typedef float __attribute__((address_space(1))) *gf;
+typedef const f32x4 __attribute__((address_space(1))) *gcf4;
 
 struct GemmArgs {
     const float *A, *B, *bias, *aux;
@@ -26,12 +31,12 @@ struct GemmArgs {
 };
 
 // element k..k+3 of a k-contiguous operand row (row-major [rows, K]); zero outside
-__device__ __forceinline__ f32x4 ld_kcontig(const float *p, int ld, int row, bool row_ok, int k, int K, bool vec) {
+__device__ __forceinline__ f32x4 ld_kcontig(gcf p, int ld, int row, bool row_ok, int k, int K, bool vec) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row_ok && k < K) {
-        const float *q = p + (size_t)row * ld + k;
+        gcf q = p + (size_t)row * ld + k;
         if (vec && k + 3 < K) {
-            v = *reinterpret_cast<const f32x4 *>(q);
+            v = *(gcf4)q;
         } else {
             v.x = q[0];
             if (k + 1 < K) v.y = q[1];
@@ -42,10 +47,10 @@ __device__ __forceinline__ f32x4 ld_kcontig(const float *p, int ld, int row, boo
     return v;
 }
 // rows k..k+3, fixed column, of a k-strided operand (row-major [K, cols]); zero outside
-__device__ __forceinline__ f32x4 ld_kstrided(const float *p, int ld, int col, bool col_ok, int k, int K) {
+__device__ __forceinline__ f32x4 ld_kstrided(gcf p, int ld, int col, bool col_ok, int k, int K) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (col_ok && k < K) {
-        const float *q = p + (size_t)k * ld + col;
+        gcf q = p + (size_t)k * ld + col;
         v.x = q[0];
         if (k + 1 < K) v.y = q[ld];
         if (k + 2 < K) v.z = q[2 * (size_t)ld];
@@ -56,15 +61,15 @@ __device__ __forceinline__ f32x4 ld_kstrided(const float *p, int ld, int col, bo
 
 // Unmasked variants for chunks that lie fully inside K.  Rows / columns beyond the matrix are CLAMPED to a valid
 // address instead of masked: they only feed accumulator rows / columns that are never stored.
-__device__ __forceinline__ f32x4 ld_kcontig_full(const float *p, int ld, int row, int k, bool vec) {
-    const float *q = p + (size_t)row * ld + k;
-    if (vec) return *reinterpret_cast<const f32x4 *>(q);
+__device__ __forceinline__ f32x4 ld_kcontig_full(gcf p, int ld, int row, int k, bool vec) {
+    gcf q = p + (size_t)row * ld + k;
+    if (vec) return *(gcf4)q;
     f32x4 v;
     v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
     return v;
 }
-__device__ __forceinline__ f32x4 ld_kstrided_full(const float *p, int ld, int col, int k) {
-    const float *q = p + (size_t)k * ld + col;
+__device__ __forceinline__ f32x4 ld_kstrided_full(gcf p, int ld, int col, int k) {
+    gcf q = p + (size_t)k * ld + col;
     f32x4 v;
     v.x = q[0]; v.y = q[ld]; v.z = q[2 * (size_t)ld]; v.w = q[3 * (size_t)ld];
     return v;
@@ -98,6 +103,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     __shared__ float s_tile[4][TM * LDT];
     __shared__ float s_col[4][TN];
 
+    const gcf gA = (gcf)g.A, gB = (gcf)g.B, gBias = (gcf)g.bias, gAux = (gcf)g.aux;
+    const gf gC = (gf)g.C, gWs = (gf)g.ws, gCol = (gf)g.colsum;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int tiles_n = (g.N + TN * NWN - 1) / (TN * NWN);
@@ -127,6 +134,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 #pragma unroll
     for (int b = 0; b < NT; ++b) { colB[b] = n0 + 16 * b + li; okB[b] = colB[b] < g.N; }
 
+    // Epilogue operands (bias / aux / beta*C) are fetched NOW, before the K loop, so their memory round trip overlaps
+    // the operand loads instead of following the LDS reduction (the kernel is a chain of round trips, not of flops).
+    constexpr int EPT = (KW == 4) ? (TM * TN + 255) / 256 : 1;
+    float e_bias[EPT], e_aux[EPT], e_c[EPT];
+    if (KW == 4 && g.S == 1) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            const int r = e / TN, cidx = e - r * TN;
+            const int m = m0 + r, n = n0 + cidx;
+            const bool ok = (e < TM * TN) && m < g.M && n < g.N;
+            e_bias[i] = (ok && g.bias != nullptr) ? gBias[n] : 0.f;
+            e_aux[i] = (ok && (g.epi == AIR_EPI_MUL_DELU || g.epi == AIR_EPI_ADD_AUX)) ? gAux[(size_t)m * g.ldaux + n] : 0.f;
+            e_c[i] = (ok && g.beta != 0.f) ? gC[(size_t)m * g.ldc + n] : 0.f;
+        }
+    }
+
     const int c_step = (KW == 4) ? 4 : 1;
     int c = c_begin + ((KW == 4) ? wave : 0);
     // ---- main loop: U chunks in flight per wave.  The problem is latency bound (operands sit in L2 / Infinity
@@ -140,7 +164,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     for (int a = 0; a < MT; ++a) rowAc[a] = okA[a] ? rowA[a] : g.M - 1;
 #pragma unroll
     for (int b = 0; b < NT; ++b) colBc[b] = okB[b] ? colB[b] : g.N - 1;
-    for (; c < full_end; c += U * c_step) {
+#pragma nounroll
+    for (; c < full_end; c += U * c_step) {   // (unrolling this loop doubles the live operand registers: 94 -> 194 VGPRs)
         f32x4 fa[U][MT], fb[U][NT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -149,12 +174,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                 const int k = (cu << 4) + 4 * lg;
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
-                    fa[u][a] = g.ta ? ld_kstrided_full(g.A, g.lda, rowAc[a], k)
-                                    : ld_kcontig_full(g.A, g.lda, rowAc[a], k, g.vecA != 0);
+                    fa[u][a] = g.ta ? ld_kstrided_full(gA, g.lda, rowAc[a], k)
+                                    : ld_kcontig_full(gA, g.lda, rowAc[a], k, g.vecA != 0);
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    fb[u][b] = g.tb ? ld_kcontig_full(g.B, g.ldb, colBc[b], k, g.vecB != 0)
-                                    : ld_kstrided_full(g.B, g.ldb, colBc[b], k);
+                    fb[u][b] = g.tb ? ld_kcontig_full(gB, g.ldb, colBc[b], k, g.vecB != 0)
+                                    : ld_kstrided_full(gB, g.ldb, colBc[b], k);
             } else {
 #pragma unroll
                 for (int a = 0; a < MT; ++a) fa[u][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -186,12 +211,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
         f32x4 fa[MT], fb[NT];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
-            fa[a] = g.ta ? ld_kstrided(g.A, g.lda, rowA[a], okA[a], k, g.K)
-                         : ld_kcontig(g.A, g.lda, rowA[a], okA[a], k, g.K, g.vecA != 0);
+            fa[a] = g.ta ? ld_kstrided(gA, g.lda, rowA[a], okA[a], k, g.K)
+                         : ld_kcontig(gA, g.lda, rowA[a], okA[a], k, g.K, g.vecA != 0);
 #pragma unroll
         for (int b = 0; b < NT; ++b)
-            fb[b] = g.tb ? ld_kcontig(g.B, g.ldb, colB[b], okB[b], k, g.K, g.vecB != 0)
-                         : ld_kstrided(g.B, g.ldb, colB[b], okB[b], k, g.K);
+            fb[b] = g.tb ? ld_kcontig(gB, g.ldb, colB[b], okB[b], k, g.K, g.vecB != 0)
+                         : ld_kstrided(gB, g.ldb, colB[b], okB[b], k, g.K);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -225,19 +250,33 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 
     if (KW == 4) {
         // all 256 threads reduce the 4 per-wave partial tiles and finish one TM x TN tile
-        for (int e = threadIdx.x; e < TM * TN; e += 256) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            if (e >= TM * TN) continue;
             const int r = e / TN, cidx = e - r * TN;
             const int m = m0 + r, n = n0 + cidx;
             if (m >= g.M || n >= g.N) continue;
             const int off = r * LDT + cidx;
             float v = (s_tile[0][off] + s_tile[1][off]) + (s_tile[2][off] + s_tile[3][off]);
-            if (g.S > 1) g.ws[((size_t)split * g.M + m) * g.N + n] = v;
-            else g.C[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
+            if (g.S > 1) {
+                gWs[((size_t)split * g.M + m) * g.N + n] = v;
+            } else {
+                if (g.beta != 0.f) v += g.beta * e_c[i];
+                switch (g.epi) {
+                    case AIR_EPI_BIAS: v += e_bias[i]; break;
+                    case AIR_EPI_BIAS_ELU: v = elu_acc(v + e_bias[i]); break;
+                    case AIR_EPI_MUL_DELU: v *= (e_aux[i] > 0.f ? 1.f : e_aux[i] + 1.f); break;
+                    case AIR_EPI_ADD_AUX: v += e_aux[i] + e_bias[i]; break;
+                    default: break;
+                }
+                gC[(size_t)m * g.ldc + n] = v;
+            }
         }
         if (want_colsum && threadIdx.x < TN) {
             const int n = n0 + threadIdx.x;
             if (n < g.N)
-                g.colsum[n] = (s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + (s_col[2][threadIdx.x] + s_col[3][threadIdx.x]);
+                gCol[n] = (s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + (s_col[2][threadIdx.x] + s_col[3][threadIdx.x]);
         }
     } else {
         // each wave finishes its own tile
@@ -246,12 +285,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
             const int m = m0 + r, n = n0 + cidx;
             if (m >= g.M || n >= g.N) continue;
             const float v = s_tile[wave][r * LDT + cidx];
-            if (g.S > 1) g.ws[((size_t)split * g.M + m) * g.N + n] = v;
-            else g.C[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
+            if (g.S > 1) gWs[((size_t)split * g.M + m) * g.N + n] = v;
+            else gC[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
         }
         if (want_colsum && lane < TN) {
             const int n = n0 + lane;
-            if (n < g.N) g.colsum[n] = s_col[wave][lane];
+            if (n < g.N) gCol[n] = s_col[wave][lane];
         }
     }
 }
@@ -275,8 +314,22 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs ga) {
 #pragma unroll
     for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
         if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
-    p = __builtin_amdgcn_readfirstlane(p);                 // provably wave-uniform: the descriptor stays in SGPRs
-    gemm_body<MT, NT, KW>(ga.g[p], (int)blockIdx.x - ga.tile_start[p], 0);
+    p = __builtin_amdgcn_readfirstlane(p);                 // provably wave-uniform
+    // One specialised copy of the body per descriptor slot: with a CONSTANT index the descriptor is read straight from
+    // the kernarg SGPRs like a single-GEMM launch (94 VGPRs).  A dynamic index (or a descriptor copied through
+    // memory) costs +100 VGPRs and halves the occupancy of exactly the launches that have the most workgroups.
+    // (blockIdx.y is always 0 here, but passing it instead of a literal 0 keeps hipcc from restructuring the K loop
+    //  around a known start, which doubles the live registers: 94 -> 194 VGPRs, measured)
+    switch (p) {
+        case 0: gemm_body<MT, NT, KW>(ga.g[0], (int)blockIdx.x - ga.tile_start[0], blockIdx.y); break;
+        case 1: gemm_body<MT, NT, KW>(ga.g[1], (int)blockIdx.x - ga.tile_start[1], blockIdx.y); break;
+        case 2: gemm_body<MT, NT, KW>(ga.g[2], (int)blockIdx.x - ga.tile_start[2], blockIdx.y); break;
+        case 3: gemm_body<MT, NT, KW>(ga.g[3], (int)blockIdx.x - ga.tile_start[3], blockIdx.y); break;
+        case 4: gemm_body<MT, NT, KW>(ga.g[4], (int)blockIdx.x - ga.tile_start[4], blockIdx.y); break;
+        case 5: gemm_body<MT, NT, KW>(ga.g[5], (int)blockIdx.x - ga.tile_start[5], blockIdx.y); break;
+        case 6: gemm_body<MT, NT, KW>(ga.g[6], (int)blockIdx.x - ga.tile_start[6], blockIdx.y); break;
+        default: gemm_body<MT, NT, KW>(ga.g[7], (int)blockIdx.x - ga.tile_start[7], blockIdx.y); break;
+    }
 }
 
 // sums the S split-K slabs in fixed order and applies the epilogue
