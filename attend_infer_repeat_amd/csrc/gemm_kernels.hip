@@ -93,15 +93,18 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
     return v;
 }
 
-// MT x NT 16x16 MFMA tiles per wave.  KW = 4: the workgroup's 4 waves split K for ONE tile (LDS reduce);
+// MT x NT 16x16 MFMA tiles per wave.  KW = 4 / 16: the workgroup's KW waves split K for ONE tile (LDS reduce; 16
+// waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
 template <int MT, int NT, int KW>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
+    constexpr int NWV = (KW == 1) ? 4 : KW;               // waves per workgroup
+    constexpr int NTH = 64 * NWV;                         // threads per workgroup
     constexpr int LDT = TN + 4;                           // padded LDS tile row
-    __shared__ float s_tile[4][TM * LDT];
-    __shared__ float s_col[4][TN];
+    __shared__ float s_tile[NWV][TM * LDT];
+    __shared__ float s_col[NWV][TN];
 
     const gcf gA = (gcf)g.A, gB = (gcf)g.B, gBias = (gcf)g.bias, gAux = (gcf)g.aux;
     const gf gC = (gf)g.C, gWs = (gf)g.ws, gCol = (gf)g.colsum;
@@ -136,12 +139,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 
     // Epilogue operands (bias / aux / beta*C) are fetched NOW, before the K loop, so their memory round trip overlaps
     // the operand loads instead of following the LDS reduction (the kernel is a chain of round trips, not of flops).
-    constexpr int EPT = (KW == 4) ? (TM * TN + 255) / 256 : 1;
+    constexpr int EPT = (KW > 1) ? (TM * TN + NTH - 1) / NTH : 1;
     float e_bias[EPT], e_aux[EPT], e_c[EPT];
-    if (KW == 4 && g.S == 1) {
+    if (KW > 1 && g.S == 1) {
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            const int e = threadIdx.x + 256 * i;
+            const int e = threadIdx.x + NTH * i;
             const int r = e / TN, cidx = e - r * TN;
             const int m = m0 + r, n = n0 + cidx;
             const bool ok = (e < TM * TN) && m < g.M && n < g.N;
@@ -151,8 +154,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
         }
     }
 
-    const int c_step = (KW == 4) ? 4 : 1;
-    int c = c_begin + ((KW == 4) ? wave : 0);
+    const int c_step = (KW > 1) ? KW : 1;
+    int c = c_begin + ((KW > 1) ? wave : 0);
     // ---- main loop: U chunks in flight per wave.  The problem is latency bound (operands sit in L2 / Infinity
     // Cache, each wave owns only a handful of 16-deep chunks), so all loads of U chunks are issued before the first
     // MFMA: one memory round trip per U chunks instead of one per chunk.
@@ -206,7 +209,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     }
     // ---- the partial last chunk of K (if any), fully masked, done by the wave that owns it
     const int pc = g.K >> 4;
-    if ((g.K & 15) && pc >= c_begin && pc < c_end && (KW == 1 || ((pc - c_begin) & 3) == wave)) {
+    if ((g.K & 15) && pc >= c_begin && pc < c_end && (KW == 1 || ((pc - c_begin) % KW) == wave)) {
         const int k = (pc << 4) + 4 * lg;
         f32x4 fa[MT], fb[NT];
 #pragma unroll
@@ -248,17 +251,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     }
     __syncthreads();
 
-    if (KW == 4) {
-        // all 256 threads reduce the 4 per-wave partial tiles and finish one TM x TN tile
+    if (KW > 1) {
+        // all threads reduce the KW per-wave partial tiles (fixed order) and finish one TM x TN tile
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            const int e = threadIdx.x + 256 * i;
+            const int e = threadIdx.x + NTH * i;
             if (e >= TM * TN) continue;
             const int r = e / TN, cidx = e - r * TN;
             const int m = m0 + r, n = n0 + cidx;
             if (m >= g.M || n >= g.N) continue;
             const int off = r * LDT + cidx;
-            float v = (s_tile[0][off] + s_tile[1][off]) + (s_tile[2][off] + s_tile[3][off]);
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < NWV; q += 4)
+                v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
             if (g.S > 1) {
                 gWs[((size_t)split * g.M + m) * g.N + n] = v;
             } else {
@@ -275,8 +281,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
         }
         if (want_colsum && threadIdx.x < TN) {
             const int n = n0 + threadIdx.x;
-            if (n < g.N)
-                gCol[n] = (s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + (s_col[2][threadIdx.x] + s_col[3][threadIdx.x]);
+            if (n < g.N) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < NWV; q += 4)
+                    v += (s_col[q][threadIdx.x] + s_col[q + 1][threadIdx.x]) + (s_col[q + 2][threadIdx.x] + s_col[q + 3][threadIdx.x]);
+                gCol[n] = v;
+            }
         }
     } else {
         // each wave finishes its own tile
@@ -296,7 +307,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 }
 
 template <int MT, int NT, int KW>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_f32_mfma_kernel(GemmArgs g) {
     gemm_body<MT, NT, KW>(g, blockIdx.x, blockIdx.y);
 }
 
@@ -309,7 +320,7 @@ struct GroupArgs {
     int count;
 };
 template <int MT, int NT, int KW>
-__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs ga) {
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(GroupArgs ga) {
     int p = 0;
 #pragma unroll
     for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
@@ -347,7 +358,7 @@ template <int MT, int NT, int KW>
 static int launch_gemm(const GemmArgs &g, hipStream_t st) {
     constexpr int TM = 16 * MT, TN = 16 * NT * ((KW == 1) ? 4 : 1);
     const int tiles = air_cdiv(g.M, TM) * air_cdiv(g.N, TN);
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT, NT, KW>), dim3(tiles, g.S), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT, NT, KW>), dim3(tiles, g.S), dim3(KW == 1 ? 256 : 64 * KW), 0, st, g);
     AIR_LAUNCH_CHECK();
     if (g.S > 1) {
         const size_t total = (size_t)g.M * g.N;
@@ -450,7 +461,12 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
     for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
-    if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
+    // long K on a handful of tiles (the BPTT products, 64x256x1024): 16 waves split K inside the workgroup, so every wave
+    // still needs only one or two memory round trips and no second (split-K epilogue) launch is paid
+    bool long_k = tiles16 <= 256;
+    for (int i = 0; i < count; ++i) long_k = long_k && descs[i].K >= 512;
+    if (long_k) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 16>), dim3(tiles), dim3(1024), 0, air_stream(stream), ga);
+    else if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
     else hipLaunchKernelGGL((gemm_grouped_kernel<2, 2, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

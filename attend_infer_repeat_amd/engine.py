@@ -298,7 +298,8 @@ class AIREngine:
 
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
-            if len(descs) == 1 and allow_splitk and descs[0].K >= 1024:
+            tiles16 = sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in descs)
+            if len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256:
                 d = descs[0]
                 plan.append((L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
                                           d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, wsp, wsb), "air_gemm"))
