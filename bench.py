@@ -146,7 +146,16 @@ def st_read_sweep(cfg, T, batches, device, share_image=True):
         ms = event_time_ms(lib, sp, fn, 20 if B >= 16384 else 100)
         nbytes = 4 * (HW + hw + 4) * n
         gbs = nbytes / (ms * 1e-3) / 1e9
+        traffic = None
+        try:                                   # HBM bytes per launch from the committed rocprofv3 PMC passes (same shapes)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_st_read_pmc.json")))["cases"]
+            for case in pmc.values():
+                if case["glimpses"] == n and case["images"] == n_img and (Hh, Ww, h, w) == (50, 50, 20, 20):
+                    traffic = case["traffic_bytes"]
+        except Exception:
+            traffic = None
         res.append({"batch": B, "glimpses": n, "us_per_launch": round(ms * 1e3, 2), "achieved": round(gbs, 1),
+                    "traffic": traffic,
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "images": n_img, "working_set_MiB": round((n_img * HW + n * hw) * 4 / 2 ** 20, 1)})
         del img, where, out
     return res
