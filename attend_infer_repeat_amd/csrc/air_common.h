@@ -42,12 +42,13 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float *scratch) {
         for (int k = 0; k < NV; ++k) scratch[wid * NV + k] = v[k];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (wid == 0) {
+        // second stage by the first wave (fixed tree order => deterministic); a serial loop in thread 0 costs
+        // nw dependent LDS reads per value, which is microseconds with 16 waves
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            float s = 0.f;
-            for (int i = 0; i < nw; ++i) s += scratch[i * NV + k];
-            v[k] = s;
+            float x = lane < nw ? scratch[lane * NV + k] : 0.f;
+            v[k] = wave_sum(x);
         }
     }
 }

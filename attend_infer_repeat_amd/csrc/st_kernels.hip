@@ -83,7 +83,7 @@ __device__ __forceinline__ Carve carve_lds(float *smem, int cnt_src, int cnt_aux
     return c;
 }
 static inline size_t carve_bytes(int cnt_src, int cnt_aux, int nx, int ny) {
-    return sizeof(float) * (size_t)(((cnt_src + 3) & ~3) + ((cnt_aux + 3) & ~3) + 3 * nx + 3 * ny + 32);
+    return sizeof(float) * (size_t)(((cnt_src + 3) & ~3) + ((cnt_aux + 3) & ~3) + 3 * nx + 3 * ny + 128);
 }
 
 // ============================================================================================================
@@ -187,23 +187,25 @@ __global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
 }
 
 // dwhere[k,4] = sum_ij dglimpse * d out / d(x,y) * d(x,y)/d where ; optional dimg (n_img == n)
-__global__ __launch_bounds__(ST_THREADS) void st_read_bwd_kernel(
+__global__ __launch_bounds__(1024) void st_read_bwd_kernel(
     const float *__restrict__ img, const float *__restrict__ where, const float *__restrict__ dout,
     float *__restrict__ dwhere, float *__restrict__ dimg,
-    int n, int n_img, int H, int W, int h, int w, double stepx, double stepy, int vec4) {
+    int n, int n_img, int H, int W, int h, int w, double stepx, double stepy, int vec4, int per_glimpse) {
     extern __shared__ __align__(16) float smem[];
-    const int HW = H * W, hw = h * w, tid = threadIdx.x;
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
     Carve c = carve_lds(smem, HW, dimg ? HW : 0, w, h);
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
-    for (int b = blockIdx.x; b < n_img; b += gridDim.x) {
+    // per_glimpse: one workgroup per glimpse (few glimpses, idle chip: parallelism beats re-using the staged image)
+    const int n_units = per_glimpse ? n : n_img;
+    for (int b = blockIdx.x; b < n_units; b += gridDim.x) {
         __syncthreads();
-        stage_to_lds(c.src, img + (size_t)b * HW, HW, vec4 != 0);
-        if (dimg) for (int p = tid; p < HW; p += ST_THREADS) c.aux[p] = 0.f;
-        for (int k = b; k < n; k += n_img) {
+        stage_to_lds(c.src, img + (size_t)(b % n_img) * HW, HW, vec4 != 0);
+        if (dimg) for (int p = tid; p < HW; p += nt) c.aux[p] = 0.f;
+        for (int k = b; k < (per_glimpse ? b + 1 : n); k += n_img) {
             __syncthreads();
             const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
             const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
-            for (int a = tid; a < w + h; a += ST_THREADS) {
+            for (int a = tid; a < w + h; a += nt) {
                 if (a < w) {
                     const float X = lin_m11(a, w, stepx);
                     c.X[a] = X;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_read_bwd_kernel(
             __syncthreads();
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             const float *g = dout + (size_t)k * hw;
-            for (int p = tid; p < hw; p += ST_THREADS) {
+            for (int p = tid; p < hw; p += nt) {
                 const int i = p / w, j = p - i * w;
                 const int fx = c.fx[j], fy = c.fy[i];
                 if (fx == ST_INVALID || fy == ST_INVALID) continue;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_read_bwd_kernel(
         }
         if (dimg) {
             __syncthreads();
-            for (int p = tid; p < HW; p += ST_THREADS) dimg[(size_t)b * HW + p] = c.aux[p];
+            for (int p = tid; p < HW; p += nt) dimg[(size_t)b * HW + p] = c.aux[p];
         }
     }
 }
@@ -398,34 +400,41 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
             const float *obp = obs ? obs + (size_t)b * HW : nullptr;
             for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : coef * (mult * fcp[p] - obp[p]);
         }
+        for (int a = tid; a < w + h; a += nt) {               // empty index ranges (lo > hi)
+            if (a < w) { c.jlo[a] = W; c.jhi[a] = -1; } else { c.ilo[a - w] = H; c.ihi[a - w] = -1; }
+        }
         const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
         const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
         const float ax = 1.0f / sx, bx = -tx / sx;
         const float ay = 1.0f / sy, by = -ty / sy;
+        __syncthreads();
+        // axis tables; each canvas column / row also registers itself in the contiguous source range of the (at most
+        // two) glimpse columns / rows it touches -- integer LDS min / max atomics: order independent, deterministic
         for (int a = tid; a < W + H; a += nt) {
             if (a < W) {
                 const float X = lin_m11(a, W, stepX);
                 c.X[a] = X;
-                axis_entry(grid_coord(ax, X, bx, cxs), w, &c.fx[a], &c.dx[a]);
+                int f; float d;
+                axis_entry(grid_coord(ax, X, bx, cxs), w, &f, &d);
+                c.fx[a] = f; c.dx[a] = d;
+                if (f != ST_INVALID) {
+                    if (f >= 0) { atomicMin(&c.jlo[f], a); atomicMax(&c.jhi[f], a); }
+                    if (f + 1 <= w - 1) { atomicMin(&c.jlo[f + 1], a); atomicMax(&c.jhi[f + 1], a); }
+                }
             } else {
-                const float Y = lin_m11(a - W, H, stepY);
-                c.Y[a - W] = Y;
-                axis_entry(grid_coord(ay, Y, by, cys), h, &c.fy[a - W], &c.dy[a - W]);
+                const int i = a - W;
+                const float Y = lin_m11(i, H, stepY);
+                c.Y[i] = Y;
+                int f; float d;
+                axis_entry(grid_coord(ay, Y, by, cys), h, &f, &d);
+                c.fy[i] = f; c.dy[i] = d;
+                if (f != ST_INVALID) {
+                    if (f >= 0) { atomicMin(&c.ilo[f], i); atomicMax(&c.ihi[f], i); }
+                    if (f + 1 <= h - 1) { atomicMin(&c.ilo[f + 1], i); atomicMax(&c.ihi[f + 1], i); }
+                }
             }
         }
         __syncthreads();
-        // contiguous source ranges per glimpse column / row (min & max index that touches it)
-        for (int a = tid; a < w + h; a += nt) {
-            const bool col = a < w;
-            const int idx = col ? a : a - w, cnt = col ? W : H;
-            const int *f = col ? c.fx : c.fy;
-            int lo = cnt, hi = -1;
-            for (int q = 0; q < cnt; ++q) {
-                const int fq = f[q];
-                if (fq != ST_INVALID && (fq == idx || fq + 1 == idx)) { lo = q < lo ? q : lo; hi = q; }
-            }
-            if (col) { c.jlo[idx] = lo; c.jhi[idx] = hi; } else { c.ilo[idx] = lo; c.ihi[idx] = hi; }
-        }
         const float pres = presence ? presence[k] : 1.0f;
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence
         for (int p = tid; p < HW; p += nt) {
@@ -547,8 +556,10 @@ extern "C" int air_st_read_bwd(const float *img, const float *where, const float
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
     { int st_ = st_allow_lds(st_read_bwd_kernel, lds); if (st_) return st_; }
-    hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
-                       dglimpse, dwhere, dimg, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
+    const int per_glimpse = (!dimg && n <= 2048 && n_img < n) ? 1 : 0;
+    hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(per_glimpse ? n : n_img)), dim3(ST_THREADS), lds,
+                       air_stream(stream), img, where, dglimpse, dwhere, dimg, n, n_img, H, W, h, w, lin_step(w),
+                       lin_step(h), vec4, per_glimpse);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
