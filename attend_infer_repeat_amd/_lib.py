@@ -55,6 +55,11 @@ SIGNATURES = {
     "air_numsteps_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
     "air_presence_numsteps_fwd": (c_int, [P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_numsteps_presence_bwd": (c_int, [P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P, c_int, c_int, P]),
+    "air_heads_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P, c_int, c_int,
+                              P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "air_heads_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P, P, c_float,
+                              P, c_int, c_int, c_int, P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
+                              c_int, c_int, P]),
     "air_step_prologue": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
                                   c_int, P]),

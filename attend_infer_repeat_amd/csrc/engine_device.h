@@ -1,0 +1,200 @@
+// Device-side bodies shared by the stand-alone kernels (pointwise_kernels.hip / loss_kernels.hip) and by the fused
+// "heads" launches of the engine (engine_kernels.hip): reparameterised Gaussian (+KL) rows and the register-resident
+// number-of-steps posterior.  Every body takes a VIRTUAL block index / grid size so that two independent bodies can
+// share one launch (the train step is launch bound at batch 64).
+#pragma once
+#include <math.h>
+#include "air_common.h"
+
+#ifndef PW_THREADS
+#define PW_THREADS 256
+#endif
+
+__device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps) {
+    const float ratio = (s * s) / (ps * ps);
+    const float d = mu - pm;
+    return d * d / (2.f * ps * ps) + 0.5f * (ratio - 1.f - logf(ratio));
+}
+// one 64-lane wave per row: D elements strided over lanes, KL reduced with a wave reduction
+__device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const float *__restrict__ pre, int ld_pre,
+                                                               const float *__restrict__ eps, float raw_offset,
+                                                               int loc_mode, float pl0, float ps0, float pl1, float ps1,
+                                                               float *__restrict__ loc, float *__restrict__ scale,
+                                                               float *__restrict__ sample, float *__restrict__ kl_row,
+                                                               int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (int)((vblock * (size_t)PW_THREADS + threadIdx.x) >> 6);
+    const int nwaves = (vgrid * PW_THREADS) >> 6;
+    for (int m = wave_global; m < M; m += nwaves) {
+        const float *pr = pre + (size_t)m * ld_pre;
+        float kl = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            float mu = pr[d];
+            if (loc_mode == 1) mu = (d & 1) ? tanhf(mu) : sigmoid_acc(mu);
+            const float s = softplus_acc(pr[D + d] + raw_offset);
+            const size_t o = (size_t)m * D + d;
+            loc[o] = mu; scale[o] = s;
+            if (sample) sample[o] = mu + s * eps[o];
+            kl += (d & 1) ? normal_kl(mu, s, pl1, ps1) : normal_kl(mu, s, pl0, ps0);
+        }
+        kl = wave_sum(kl);
+        if (kl_row && lane == 0) kl_row[m] = kl;
+    }
+}
+__device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const float *__restrict__ pre, int ld_pre,
+                                                               const float *__restrict__ eps, float raw_offset,
+                                                               int loc_mode, float pl0, float ps0, float pl1, float ps1,
+                                                               const float *__restrict__ loc,
+                                                               const float *__restrict__ scale,
+                                                               const float *__restrict__ dsample,
+                                                               const float *__restrict__ dsample2,
+                                                               const float *__restrict__ dkl_row, float dkl_scale,
+                                                               float *__restrict__ dpre, int ld_dpre, int M, int D) {
+    const size_t n = (size_t)M * D;
+    for (size_t e = (size_t)vblock * PW_THREADS + threadIdx.x; e < n; e += (size_t)vgrid * PW_THREADS) {
+        const size_t m = e / D;
+        const int d = (int)(e - m * D);
+        const float mu = loc[e], s = scale[e];
+        const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
+        const float ds = (dsample ? dsample[e] : 0.f) + (dsample2 ? dsample2[e] : 0.f);
+        const float dk = dkl_row ? dkl_row[m] * dkl_scale : 0.f;
+        float dmu = ds + dk * (mu - pm) / (ps * ps);
+        const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + dk * (s / (ps * ps) - 1.f / s);
+        if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
+        const float raw = pre[m * ld_pre + D + d] + raw_offset;
+        const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus
+        dpre[m * ld_dpre + d] = dmu;
+        dpre[m * ld_dpre + D + d] = dsc * dsp;
+    }
+}
+
+template <int MT>
+struct NumStepsR {
+    double p[MT], P[MT + 1], q[MT + 1], S;   // p_t, prefix products P[n] = prod_{j<n} p_j, posterior q(n), normaliser
+    float q32[MT + 1];
+};
+template <int MT>
+__device__ __forceinline__ void posterior_r(const float *__restrict__ prob, int T, int B, int b, NumStepsR<MT> &s) {
+    s.P[0] = 1.0;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        s.p[t] = t < T ? (double)prob[(size_t)t * B + b] : 1.0;
+        s.P[t + 1] = s.P[t] * s.p[t];
+    }
+    double u[MT + 1];
+    s.S = 0.0;
+#pragma unroll
+    for (int n = 0; n <= MT; ++n) {
+        u[n] = n < T ? (1.0 - s.p[n < MT ? n : 0]) * s.P[n] : (n == T ? s.P[n] : 0.0);
+        if (n <= T) s.S += u[n];
+    }
+#pragma unroll
+    for (int n = 0; n <= MT; ++n) { s.q[n] = n <= T ? u[n] / s.S : 0.0; s.q32[n] = (float)s.q[n]; }
+}
+
+// presence (cell.py:137-151) + q(n) / KL / step weights / log q(n_sampled) in one launch
+template <int MT>
+__device__ __forceinline__ void presence_numsteps_fwd_body(int vblock, int vgrid,
+    
+    const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float eps,
+    const double *__restrict__ prior, float *__restrict__ prob, float *__restrict__ pres, float *__restrict__ q,
+    float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
+    for (int b = vblock * 64 + (int)threadIdx.x; b < B; b += vgrid * 64) {
+        if (threadIdx.x >= 64) break;
+        float run = 1.0f, nsteps = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            if (t < T) {
+                const size_t k = (size_t)t * B + b;
+                float p = 1.0f / (1.0f + expf(-(logit[k] + step_bias)));
+                if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
+                prob[k] = p;
+                run *= (u[k] < p) ? 1.0f : 0.0f;
+                pres[k] = run;
+                nsteps += run;
+            }
+        }
+        NumStepsR<MT> s;
+        posterior_r<MT>(prob, T, B, b, s);
+        float kl = 0.f, w = 0.f, qstar = 0.f;
+        const int nstar = (int)nsteps;
+#pragma unroll
+        for (int n = 0; n <= MT; ++n) {
+            if (n <= T) {
+                q[(size_t)b * (T + 1) + n] = s.q32[n];
+                const double pn = (double)s.q32[n];
+                kl += (pn > 0.0) ? (float)(pn * log(pn / prior[n])) : 0.f;
+                if (n == nstar) qstar = s.q32[n];
+            }
+        }
+        kl_ps[b] = kl;
+#pragma unroll
+        for (int t = MT - 1; t >= 0; --t) {
+            if (t < T) { w += s.q32[t + 1]; step_w[(size_t)t * B + b] = w; }
+        }
+        logp[b] = logf(fmaxf(qstar, 1e-32f));
+    }
+}
+
+// backward of the above wrt the steps-predictor logit: the step-weight gradient is formed in place from the two
+// per-row KL buffers (dstep_w[t,b] = w_scale * (kl_a[t,b] + kl_b[t,b])), then d/dq -> d/du -> d/dp (products only, no
+// divisions: safe at p = 0 like the reference's scan-based cumprod), then sigmoid'.
+template <int MT>
+__device__ __forceinline__ void numsteps_presence_bwd_body(int vblock, int vgrid,
+    
+    const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
+    float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
+    const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
+    float *__restrict__ dlogit, int T, int B) {
+    for (int b = vblock * 64 + (int)threadIdx.x; b < B; b += vgrid * 64) {
+        if (threadIdx.x >= 64) break;
+        NumStepsR<MT> s;
+        posterior_r<MT>(prob, T, B, b, s);
+        int nstar = -1;
+        if (dlogp) {
+            float ns = 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) if (t < T) ns += presence[(size_t)t * B + b];
+            nstar = (int)ns;
+        }
+        double gq[MT + 1], wsum = 0.0, dot = 0.0;
+#pragma unroll
+        for (int n = 0; n <= MT; ++n) {
+            double g = 0.0;
+            if (n <= T) {
+                const double pn = (double)s.q32[n];
+                g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
+                if (n >= 1) {
+                    const size_t k = (size_t)(n - 1) * B + b;
+                    wsum += (double)(w_scale * ((kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f)));
+                }
+                g += wsum;
+                if (n == nstar) g += (double)dlogp[b] / (double)fmaxf(s.q32[n], 1e-32f);
+                dot += g * s.q[n];
+            }
+            gq[n] = g;
+        }
+        double gu[MT + 1];
+#pragma unroll
+        for (int n = 0; n <= MT; ++n) gu[n] = n <= T ? (gq[n] - dot) / s.S : 0.0;
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            if (k < T) {
+                // u_k = (1-p_k) P[k];  u_n (n>k, n<T) = (1-p_n) P[k] p_k R_n with R_n = prod_{k<j<n} p_j;  u_T = P[k] p_k R_T
+                double g = -gu[k] * s.P[k];
+                double R = 1.0;
+#pragma unroll
+                for (int n = k + 1; n <= MT; ++n) {
+                    if (n < T) g += gu[n] * (1.0 - s.p[n < MT ? n : 0]) * s.P[k] * R;
+                    else if (n == T) g += gu[n] * s.P[k] * R;
+                    if (n < MT) R *= s.p[n];
+                }
+                const size_t idx = (size_t)k * B + b;
+                const float sg = 1.0f / (1.0f + expf(-(logit[idx] + step_bias)));
+                float gg = (float)g;
+                if (eps >= 0.f) gg *= (1 - eps);
+                dlogit[idx] = gg * sg * (1.f - sg);
+            }
+        }
+    }
+}

@@ -1,0 +1,95 @@
+// Fused "heads" launches of the engine: two INDEPENDENT small kernels share one dispatch (blocks are split by role),
+// because at batch 64 the train step is bound by the number of dependent launches, not by work.
+//   forward : where ~ N(loc, softplus(raw))  (cell.py:129-133)   ||  presence + q(n) / KL / step weights (cell.py:137-151,
+//             prior.py:62-151)                 -- both only read the transform / steps MLP outputs
+//   backward: d where-parameters (needs dwhere from both ST kernels)  ||  d steps-logit (num-steps KL, step weights, REINFORCE)
+#include "engine_device.h"
+
+template <int MT>
+__global__ __launch_bounds__(PW_THREADS) void heads_fwd_kernel(
+    int gauss_blocks,
+    const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, float raw_offset, int loc_mode, float pl0,
+    float ps0, float pl1, float ps1, float *__restrict__ loc, float *__restrict__ scale, float *__restrict__ sample,
+    float *__restrict__ kl_row, int M, int D,
+    const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float explore_eps,
+    const double *__restrict__ prior, float *__restrict__ prob, float *__restrict__ pres, float *__restrict__ q,
+    float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
+    if ((int)blockIdx.x < gauss_blocks)
+        gauss_fwd_body(blockIdx.x, gauss_blocks, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale,
+                       sample, kl_row, M, D);
+    else
+        presence_numsteps_fwd_body<MT>(blockIdx.x - gauss_blocks, gridDim.x - gauss_blocks, logit, u, step_bias,
+                                       explore_eps, prior, prob, pres, q, kl_ps, logp, step_w, T, B);
+}
+
+template <int MT>
+__global__ __launch_bounds__(PW_THREADS) void heads_bwd_kernel(
+    int gauss_blocks,
+    const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, float raw_offset, int loc_mode, float pl0,
+    float ps0, float pl1, float ps1, const float *__restrict__ loc, const float *__restrict__ scale,
+    const float *__restrict__ dsample, const float *__restrict__ dsample2, const float *__restrict__ dkl_row,
+    float dkl_scale, float *__restrict__ dpre, int ld_dpre, int M, int D,
+    const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior, float kl_scale,
+    const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale, const float *__restrict__ dlogp,
+    const float *__restrict__ logit, float step_bias, float explore_eps, float *__restrict__ dlogit, int T, int B) {
+    if ((int)blockIdx.x < gauss_blocks)
+        gauss_bwd_body(blockIdx.x, gauss_blocks, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale,
+                       dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
+    else
+        numsteps_presence_bwd_body<MT>(blockIdx.x - gauss_blocks, gridDim.x - gauss_blocks, prob, presence, prior,
+                                       kl_scale, kl_a, kl_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
+}
+
+static inline int blocks_for(size_t n) {
+    size_t b = (n + PW_THREADS - 1) / PW_THREADS;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int air_heads_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                             float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd, float *loc,
+                             float *scale, float *sample, float *kl_row, int M, int D, const float *logit,
+                             const float *u, float step_bias, float explore_eps, const double *prior_f64,
+                             float *presence_prob, float *presence, float *q, float *kl_per_sample, float *logp,
+                             float *step_weight, int T, int B, void *stream) {
+    AIR_REQUIRE(pre && eps && loc && scale && sample && kl_row && logit && u && prior_f64 && presence_prob && presence &&
+                    q && kl_per_sample && logp && step_weight, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && T > 0 && T <= 32 && B > 0, AIR_E_SHAPE);
+    const int gb = blocks_for((size_t)M * 64), nb = air_cdiv(B, 64);
+    if (T <= 8)
+        hipLaunchKernelGGL(heads_fwd_kernel<8>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
+                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, sample,
+                           kl_row, M, D, logit, u, step_bias, explore_eps, prior_f64, presence_prob, presence, q,
+                           kl_per_sample, logp, step_weight, T, B);
+    else
+        hipLaunchKernelGGL(heads_fwd_kernel<32>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
+                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, sample,
+                           kl_row, M, D, logit, u, step_bias, explore_eps, prior_f64, presence_prob, presence, q,
+                           kl_per_sample, logp, step_weight, T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+extern "C" int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                             float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc,
+                             const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
+                             float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *presence_prob,
+                             const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
+                             const float *kl_row_b, float w_scale, const float *dlogp, const float *logit,
+                             float step_bias, float explore_eps, float *dlogit, int T, int B, void *stream) {
+    AIR_REQUIRE(pre && eps && loc && scale && dpre && presence_prob && prior_f64 && logit && dlogit, AIR_E_NULL);
+    AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D && T > 0 && T <= 32 && B > 0, AIR_E_SHAPE);
+    const int gb = blocks_for((size_t)M * D), nb = air_cdiv(B, 64);
+    if (T <= 8)
+        hipLaunchKernelGGL(heads_bwd_kernel<8>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
+                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
+                           dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, presence_prob, presence, prior_f64, kl_scale,
+                           kl_row_a, kl_row_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
+    else
+        hipLaunchKernelGGL(heads_bwd_kernel<32>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
+                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
+                           dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, presence_prob, presence, prior_f64, kl_scale,
+                           kl_row_a, kl_row_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}

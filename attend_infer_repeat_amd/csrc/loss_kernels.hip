@@ -129,70 +129,14 @@ extern "C" int air_numsteps_bwd(const float *presence_prob, const float *presenc
 // ---- fused forms used by the engine (one thread per image; the step is launch bound) -----------------------------
 // Templated on a compile-time bound MT >= T so that every per-image array lives in registers (the generic kernels
 // above index float64 arrays dynamically and run out of scratch memory: ~10 us for 64 images).
-template <int MT>
-struct NumStepsR {
-    double p[MT], P[MT + 1], q[MT + 1], S;   // p_t, prefix products P[n] = prod_{j<n} p_j, posterior q(n), normaliser
-    float q32[MT + 1];
-};
-template <int MT>
-__device__ __forceinline__ void posterior_r(const float *__restrict__ prob, int T, int B, int b, NumStepsR<MT> &s) {
-    s.P[0] = 1.0;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        s.p[t] = t < T ? (double)prob[(size_t)t * B + b] : 1.0;
-        s.P[t + 1] = s.P[t] * s.p[t];
-    }
-    double u[MT + 1];
-    s.S = 0.0;
-#pragma unroll
-    for (int n = 0; n <= MT; ++n) {
-        u[n] = n < T ? (1.0 - s.p[n < MT ? n : 0]) * s.P[n] : (n == T ? s.P[n] : 0.0);
-        if (n <= T) s.S += u[n];
-    }
-#pragma unroll
-    for (int n = 0; n <= MT; ++n) { s.q[n] = n <= T ? u[n] / s.S : 0.0; s.q32[n] = (float)s.q[n]; }
-}
-
-// presence (cell.py:137-151) + q(n) / KL / step weights / log q(n_sampled) in one launch
+#include "engine_device.h"
 template <int MT>
 __global__ __launch_bounds__(64) void presence_numsteps_fwd_kernel(
     const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float eps,
     const double *__restrict__ prior, float *__restrict__ prob, float *__restrict__ pres, float *__restrict__ q,
     float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
-    for (int b = blockIdx.x * 64 + threadIdx.x; b < B; b += gridDim.x * 64) {
-        float run = 1.0f, nsteps = 0.f;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            if (t < T) {
-                const size_t k = (size_t)t * B + b;
-                float p = 1.0f / (1.0f + expf(-(logit[k] + step_bias)));
-                if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
-                prob[k] = p;
-                run *= (u[k] < p) ? 1.0f : 0.0f;
-                pres[k] = run;
-                nsteps += run;
-            }
-        }
-        NumStepsR<MT> s;
-        posterior_r<MT>(prob, T, B, b, s);
-        float kl = 0.f, w = 0.f, qstar = 0.f;
-        const int nstar = (int)nsteps;
-#pragma unroll
-        for (int n = 0; n <= MT; ++n) {
-            if (n <= T) {
-                q[(size_t)b * (T + 1) + n] = s.q32[n];
-                const double pn = (double)s.q32[n];
-                kl += (pn > 0.0) ? (float)(pn * log(pn / prior[n])) : 0.f;
-                if (n == nstar) qstar = s.q32[n];
-            }
-        }
-        kl_ps[b] = kl;
-#pragma unroll
-        for (int t = MT - 1; t >= 0; --t) {
-            if (t < T) { w += s.q32[t + 1]; step_w[(size_t)t * B + b] = w; }
-        }
-        logp[b] = logf(fmaxf(qstar, 1e-32f));
-    }
+    presence_numsteps_fwd_body<MT>(blockIdx.x, gridDim.x, logit, u, step_bias, eps, prior, prob, pres, q, kl_ps, logp,
+                                   step_w, T, B);
 }
 extern "C" int air_presence_numsteps_fwd(const float *logit, const float *u, float step_bias, float explore_eps,
                                          const double *prior_f64, float *presence_prob, float *presence, float *q,
@@ -213,65 +157,14 @@ extern "C" int air_presence_numsteps_fwd(const float *logit, const float *u, flo
     return AIR_OK;
 }
 
-// backward of the above wrt the steps-predictor logit: the step-weight gradient is formed in place from the two
-// per-row KL buffers (dstep_w[t,b] = w_scale * (kl_a[t,b] + kl_b[t,b])), then d/dq -> d/du -> d/dp (products only, no
-// divisions: safe at p = 0 like the reference's scan-based cumprod), then sigmoid'.
 template <int MT>
 __global__ __launch_bounds__(64) void numsteps_presence_bwd_kernel(
     const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
     float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
     const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
     float *__restrict__ dlogit, int T, int B) {
-    for (int b = blockIdx.x * 64 + threadIdx.x; b < B; b += gridDim.x * 64) {
-        NumStepsR<MT> s;
-        posterior_r<MT>(prob, T, B, b, s);
-        int nstar = -1;
-        if (dlogp) {
-            float ns = 0.f;
-#pragma unroll
-            for (int t = 0; t < MT; ++t) if (t < T) ns += presence[(size_t)t * B + b];
-            nstar = (int)ns;
-        }
-        double gq[MT + 1], wsum = 0.0, dot = 0.0;
-#pragma unroll
-        for (int n = 0; n <= MT; ++n) {
-            double g = 0.0;
-            if (n <= T) {
-                const double pn = (double)s.q32[n];
-                g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
-                if (n >= 1) {
-                    const size_t k = (size_t)(n - 1) * B + b;
-                    wsum += (double)(w_scale * ((kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f)));
-                }
-                g += wsum;
-                if (n == nstar) g += (double)dlogp[b] / (double)fmaxf(s.q32[n], 1e-32f);
-                dot += g * s.q[n];
-            }
-            gq[n] = g;
-        }
-        double gu[MT + 1];
-#pragma unroll
-        for (int n = 0; n <= MT; ++n) gu[n] = n <= T ? (gq[n] - dot) / s.S : 0.0;
-#pragma unroll
-        for (int k = 0; k < MT; ++k) {
-            if (k < T) {
-                // u_k = (1-p_k) P[k];  u_n (n>k, n<T) = (1-p_n) P[k] p_k R_n with R_n = prod_{k<j<n} p_j;  u_T = P[k] p_k R_T
-                double g = -gu[k] * s.P[k];
-                double R = 1.0;
-#pragma unroll
-                for (int n = k + 1; n <= MT; ++n) {
-                    if (n < T) g += gu[n] * (1.0 - s.p[n < MT ? n : 0]) * s.P[k] * R;
-                    else if (n == T) g += gu[n] * s.P[k] * R;
-                    if (n < MT) R *= s.p[n];
-                }
-                const size_t idx = (size_t)k * B + b;
-                const float sg = 1.0f / (1.0f + expf(-(logit[idx] + step_bias)));
-                float gg = (float)g;
-                if (eps >= 0.f) gg *= (1 - eps);
-                dlogit[idx] = gg * sg * (1.f - sg);
-            }
-        }
-    }
+    numsteps_presence_bwd_body<MT>(blockIdx.x, gridDim.x, prob, presence, prior, kl_scale, kl_a, kl_b, w_scale, dlogp,
+                                   logit, step_bias, eps, dlogit, T, B);
 }
 extern "C" int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
                                          float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,

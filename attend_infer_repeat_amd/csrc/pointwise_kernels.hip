@@ -81,36 +81,15 @@ extern "C" int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev
 }
 
 // ---- reparameterised Gaussian + KL (cell.py:130-133,154-156; modules.py:17-24,41-46,58-63; model.py:174-209) ----
-__device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps) {
-    const float ratio = (s * s) / (ps * ps);
-    const float d = mu - pm;
-    return d * d / (2.f * ps * ps) + 0.5f * (ratio - 1.f - logf(ratio));
-}
-// one 64-lane wave per row: D elements strided over lanes, KL reduced with a wave reduction
+#include "engine_device.h"
 __global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, float raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                float *__restrict__ loc, float *__restrict__ scale,
                                                                float *__restrict__ sample, float *__restrict__ kl_row,
                                                                int M, int D) {
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (int)((blockIdx.x * (size_t)PW_THREADS + threadIdx.x) >> 6);
-    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
-    for (int m = wave_global; m < M; m += nwaves) {
-        const float *pr = pre + (size_t)m * ld_pre;
-        float kl = 0.f;
-        for (int d = lane; d < D; d += 64) {
-            float mu = pr[d];
-            if (loc_mode == 1) mu = (d & 1) ? tanhf(mu) : sigmoid_acc(mu);
-            const float s = softplus_acc(pr[D + d] + raw_offset);
-            const size_t o = (size_t)m * D + d;
-            loc[o] = mu; scale[o] = s;
-            if (sample) sample[o] = mu + s * eps[o];
-            kl += (d & 1) ? normal_kl(mu, s, pl1, ps1) : normal_kl(mu, s, pl0, ps0);
-        }
-        kl = wave_sum(kl);
-        if (kl_row && lane == 0) kl_row[m] = kl;
-    }
+    gauss_fwd_body(blockIdx.x, gridDim.x, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, sample,
+                   kl_row, M, D);
 }
 __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, float raw_offset,
@@ -121,22 +100,8 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__re
                                                                const float *__restrict__ dsample2,
                                                                const float *__restrict__ dkl_row, float dkl_scale,
                                                                float *__restrict__ dpre, int ld_dpre, int M, int D) {
-    const size_t n = (size_t)M * D;
-    PW_LOOP(e, n) {
-        const size_t m = e / D;
-        const int d = (int)(e - m * D);
-        const float mu = loc[e], s = scale[e];
-        const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
-        const float ds = (dsample ? dsample[e] : 0.f) + (dsample2 ? dsample2[e] : 0.f);
-        const float dk = dkl_row ? dkl_row[m] * dkl_scale : 0.f;
-        float dmu = ds + dk * (mu - pm) / (ps * ps);
-        const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + dk * (s / (ps * ps) - 1.f / s);
-        if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
-        const float raw = pre[m * ld_pre + D + d] + raw_offset;
-        const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus
-        dpre[m * ld_dpre + d] = dmu;
-        dpre[m * ld_dpre + D + d] = dsc * dsp;
-    }
+    gauss_bwd_body(blockIdx.x, gridDim.x, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
+                   dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
 }
 extern "C" int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                                     float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,

@@ -387,14 +387,13 @@ class AIREngine:
         h_all = self.h_seq[1:]                                                              # [T,B,Hd] contiguous
         mlp_fwd_multi(fwd, [(self.tr, h_all, Hd), (self.st, h_all, Hd)])                    # cell.py:129,138
         sp, shp = cfg.where_scale_prior, cfg.where_shift_prior
-        fwd.append((L.air_gauss_sample_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
-                                             sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
-                                             p(self.where), p(self.kl_where_row), M, 4), "air_gauss_sample_fwd"))
         eps = -1.0 if cfg.explore_eps is None else float(cfg.explore_eps)
-        fwd.append((L.air_presence_numsteps_fwd, (p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps,
-                                                  p(self.prior_dev), p(self.presence_prob), p(self.presence),
-                                                  p(self.q_n), p(self.kl_n), p(self.logp), p(self.step_w), T, B),
-                    "air_presence_numsteps_fwd"))                                           # cell.py:137-151, prior.py
+        fwd.append((L.air_heads_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
+                                      sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
+                                      p(self.where), p(self.kl_where_row), M, 4,                 # cell.py:129-133
+                                      p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
+                                      p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n), p(self.logp),
+                                      p(self.step_w), T, B), "air_heads_fwd"))                   # cell.py:137-151, prior.py
         fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
                     "air_st_read_fwd"))                                                     # cell.py:135
         mlp_fwd_multi(fwd, [(self.ge, self.glimpse_in, hw)])                                # cell.py:153
@@ -447,15 +446,14 @@ class AIREngine:
         mlp_bwd_multi(bwd, [dict(m=self.ge, x=self.glimpse_in, ldx=hw, g_last=self.ge.g[-1], dx_out=self.d_glimpse_in)])
         bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
                                         B, Hi, Wi, hc, wc), "air_st_read_bwd"))
-        bwd.append((L.air_gauss_sample_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
-                                             sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
-                                             p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
-                                             p(self.tr.g[-1]), 8, M, 4), "air_gauss_sample_bwd"))
-        bwd.append((L.air_numsteps_presence_bwd, (p(self.presence_prob), p(self.presence), p(self.prior_dev),
-                                                  pw * inv_b, p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
-                                                  p(self.dlogp) if cfg.use_reinforce else None, p(self.st.out[-1]),
-                                                  cfg.step_bias, eps, p(self.st.g[-1]), T, B),
-                    "air_numsteps_presence_bwd"))
+        bwd.append((L.air_heads_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
+                                      sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
+                                      p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
+                                      p(self.tr.g[-1]), 8, M, 4,
+                                      p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                      p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
+                                      p(self.dlogp) if cfg.use_reinforce else None, p(self.st.out[-1]), cfg.step_bias,
+                                      eps, p(self.st.g[-1]), T, B), "air_heads_bwd"))
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
                             dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)])
         # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)

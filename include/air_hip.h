@@ -197,6 +197,23 @@ int air_numsteps_presence_bwd(const float *presence_prob, const float *presence,
                               const float *dlogp, const float *logit, float step_bias, float explore_eps,
                               float *dlogit, int T, int B, void *stream);
 
+/* "Heads" launches: two independent small ops in ONE dispatch (blocks split by role).
+ *   air_heads_fwd = air_gauss_sample_fwd (the where sample)  ||  air_presence_numsteps_fwd
+ *   air_heads_bwd = air_gauss_sample_bwd (the where sample)  ||  air_numsteps_presence_bwd
+ * Argument meaning exactly as in the four constituent entry points.                                                  */
+int air_heads_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
+                  float p_scale_even, float p_loc_odd, float p_scale_odd, float *loc, float *scale, float *sample,
+                  float *kl_row, int M, int D, const float *logit, const float *u, float step_bias, float explore_eps,
+                  const double *prior_f64, float *presence_prob, float *presence, float *q, float *kl_per_sample,
+                  float *logp, float *step_weight, int T, int B, void *stream);
+int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
+                  float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
+                  const float *dsample, const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
+                  int ld_dpre, int M, int D, const float *presence_prob, const float *presence,
+                  const double *prior_f64, float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
+                  const float *dlogp, const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B,
+                  void *stream);
+
 /* Annealed geometric prior over the number of steps, entirely on device (model.py:106-124,139-146; prior.py:26-32):
  *   step' = max(*global_step_dev - hold_for, 0);  anneal_type 0: s = init; 1 ("exp"): s = max(final, init *
  *   ((final/init)^(steps_div/anneal_steps))^(step'/steps_div)); 2 ("linear"): s = max(final, final + (init-final) *
