@@ -435,6 +435,7 @@ class AIREngine:
         if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
             chains.append(dict(m=self.bl, x=self.base_in, ldx=cfg.baseline_in, g_last=self.dbase))
         mlp_bwd_multi(bwd, chains)
+        marks = [(len(bwd), "glimpse_decoder/0/w")]      # gradients of [glimpse_decoder .. baseline] are final here
         bwd.append((L.air_gauss_sample_bwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
                                              wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale),
                                              p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M,
@@ -444,6 +445,7 @@ class AIREngine:
                      desc(0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
                           aux=ge_out, ldaux=G)])
         mlp_bwd_multi(bwd, [dict(m=self.ge, x=self.glimpse_in, ldx=hw, g_last=self.ge.g[-1], dx_out=self.d_glimpse_in)])
+        marks.append((len(bwd), "glimpse_encoder/0/w"))        # + [glimpse_encoder, what]
         bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
                                         B, Hi, Wi, hc, wc), "air_st_read_bwd"))
         bwd.append((L.air_heads_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
@@ -456,6 +458,7 @@ class AIREngine:
                                       eps, p(self.st.g[-1]), T, B), "air_heads_bwd"))
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
                             dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)])
+        marks.append((len(bwd), "transform/0/w"))              # + [transform, steps]
         # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)
         gw = self.grads["lstm/w_gates"]
         dc_in, dc_out = None, self.dc_a
@@ -492,6 +495,13 @@ class AIREngine:
         self._plan_fwd_noise = [prologue(True)] + fwd
         self._plan_fwd = [prologue(False)] + fwd
         self._plan_bwd = bwd
+        # data-parallel gradient buckets: (end index in the backward plan, [lo, hi) slice of the flat gradient buffer that
+        # is final once the plan has run up to that index); contiguous, from the tail of the buffer to its head
+        self._grad_buckets, hi = [], self.n_total
+        for idx, first in marks:
+            lo = self.param_offsets[first]
+            self._grad_buckets.append((idx, lo, hi)); hi = lo
+        self._grad_buckets.append((len(bwd), 0, hi))
         self._plan_opt = self._opt_calls_factory(1.0)
 
     def _run(self, plan, stream_ptr):
@@ -551,41 +561,51 @@ class AIREngine:
         self._run(plan, self._sp())
         self.global_step += 1
 
-    def capture(self, split_optimizer: bool = False):
-        """Capture noise + forward + backward (+ optimiser) into hipGraphs.  With split_optimizer the update is a
-        second graph so that a gradient all-reduce can run between the two (data-parallel)."""
+    def _capture_plans(self, plans):
         L = H.lib()
-        self.release_graphs()
-        self.stream.synchronize()
         sp = self._sp()
         _lib.check(L.air_graph_begin_capture(sp), "air_graph_begin_capture")
         try:
-            self._run(self._plan_fwd_noise, sp)
-            self._run(self._plan_bwd, sp)
-            if not split_optimizer:
-                self._run(self._plan_opt, sp)
+            for pl in plans:
+                self._run(pl, sp)
         finally:
             exe = ctypes.c_void_p()
             st = L.air_graph_end_capture(sp, ctypes.byref(exe))
         _lib.check(st, "air_graph_end_capture")
-        self._graph = exe
+        return exe
+
+    def capture(self, split_optimizer: bool = False, bucketed: bool = False):
+        """Capture noise + forward + backward (+ optimiser) into hipGraphs.
+        split_optimizer: the update is its own graph so a gradient all-reduce can run before it (data parallel).
+        bucketed (implies split_optimizer): the backward is cut at the points where a contiguous slice of the flat
+        gradient buffer becomes final, so each slice can be all-reduced while the rest of the backward still runs."""
+        self.release_graphs()
+        self.stream.synchronize()
+        self._graph_segments = None
+        if bucketed:
+            segs, start = [], 0
+            for i, (end, lo, hi) in enumerate(self._grad_buckets):
+                plans = ([self._plan_fwd_noise] if i == 0 else []) + [self._plan_bwd[start:end]]
+                segs.append((self._capture_plans(plans), lo, hi))
+                start = end
+            self._graph_segments = segs
+            self._graph = segs[0][0]
+            self._graph_has_opt = False
+            self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
+            return
+        self._graph = self._capture_plans([self._plan_fwd_noise, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
         self._graph_has_opt = not split_optimizer
         if split_optimizer:
-            _lib.check(L.air_graph_begin_capture(sp), "air_graph_begin_capture")
-            try:
-                self._run(self._opt_calls_factory(1.0 / self.world_size), sp)
-            finally:
-                exe2 = ctypes.c_void_p()
-                st = L.air_graph_end_capture(sp, ctypes.byref(exe2))
-            _lib.check(st, "air_graph_end_capture")
-            self._graph_opt = exe2
+            self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
 
     def release_graphs(self):
         L = H.lib()
-        for g in (self._graph, self._graph_opt):
+        segs = getattr(self, "_graph_segments", None) or []
+        for g in [self._graph_opt] + ([x[0] for x in segs] if segs else [self._graph]):
             if g is not None:
                 L.air_graph_destroy(g)
         self._graph = self._graph_opt = None
+        self._graph_segments = None
 
     def train_step(self, obs=None, allreduce=None):
         """One full update: fresh noise, forward, backward, (all-reduce), centred RMSProp x2.
@@ -593,7 +613,22 @@ class AIREngine:
         if obs is not None:
             self.set_obs(obs)
         sp = self._sp()
-        if self._graph is not None:
+        if getattr(self, "_graph_segments", None):
+            # bucketed data parallel: segment i produces the final gradients of slice i; its all-reduce is issued at once
+            # (asynchronously, on the communicator's stream) and overlaps the remaining backward segments
+            pending = []
+            for exe, lo, hi in self._graph_segments:
+                _lib.check(H.lib().air_graph_launch(exe, sp), "air_graph_launch")
+                if allreduce is not None:
+                    with torch.cuda.stream(self.stream):
+                        w = allreduce(self.flat_grads[lo:hi])
+                    if w is not None:
+                        pending.append(w)
+            with torch.cuda.stream(self.stream):
+                for w in pending:
+                    w.wait()                      # stream-level wait: the update graph is ordered after every bucket
+            _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
+        elif self._graph is not None:
             _lib.check(H.lib().air_graph_launch(self._graph, sp), "air_graph_launch")
             if not self._graph_has_opt:
                 if allreduce is not None:

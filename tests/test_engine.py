@@ -172,5 +172,23 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
         eng_a.synchronize(); eng_b.synchronize()
         assert calls == [eng_b.n_total] * 3           # exactly one collective per step over the whole flat bucket
         assert torch.equal(eng_a.flat_params, eng_b.flat_params)
+        # bucketed variant: backward cut into segments, one asynchronous all-reduce per contiguous gradient slice
+        eng_c, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+        eng_c.world_size = 1
+        eng_c.capture(split_optimizer=True, bucketed=True)
+        slices = []
+
+        def allreduce_async(g):
+            slices.append((g.data_ptr() - eng_c.flat_grads.data_ptr()) // 4)
+            return dist.all_reduce(g, async_op=True)
+
+        for _ in range(3):
+            eng_c.train_step(allreduce=allreduce_async)
+        eng_c.synchronize()
+        buckets = eng_c._grad_buckets
+        assert len(buckets) == 4 and buckets[-1][1] == 0 and buckets[0][2] == eng_c.n_total
+        assert all(buckets[i][1] == buckets[i + 1][2] for i in range(3))          # contiguous cover of the flat buffer
+        assert slices[:4] == [b[1] for b in buckets]
+        assert torch.equal(eng_a.flat_params, eng_c.flat_params)
     finally:
         dist.destroy_process_group()
