@@ -29,3 +29,49 @@ def synthetic_multi_mnist(batch, img_size=(50, 50), max_objects=2, seed=0):
             d = np.sqrt((px - tt * dxs) ** 2 + (py - tt * dys) ** 2)
             imgs[b] = np.maximum(imgs[b], np.clip(1.6 - d, 0, 1))          # anti-aliased stroke
     return imgs, nums
+
+
+# ---- feeders (reference: data/data.py:110-158) -------------------------------------------------------------------------
+def load_data(path):
+    """data.py:110-118 for Python-3 pickles: dict(imgs uint8 [N,H,W], nums [max_objects+1,N,1], ...) -> float32 arrays."""
+    import pickle
+    with open(path, "rb") as f:
+        data = pickle.load(f)
+    data["imgs"] = data["imgs"].astype(np.float32) / 255.0
+    data["nums"] = data["nums"].astype(np.float32)
+    return data
+
+
+def synthetic_dataset(n_samples, img_size=(50, 50), max_objects=2, seed=0):
+    imgs, nums = synthetic_multi_mnist(n_samples, img_size, max_objects, seed)
+    return dict(imgs=imgs, nums=nums)
+
+
+class DeviceFeeder(object):
+    """HBM-resident counterpart of `tensors_from_data` (data.py:121-158).  The reference feeds every step through
+    tf.py_func (a host round trip per step); here the whole dataset lives on the GPU and a batch is an index gather.
+    shuffle=True samples with replacement like `np.random.choice(n, batch_size)` (data.py:131-132); shuffle=False walks
+    the data in order (the reference's non-shuffled feeder always returns the FIRST batch -- SURVEY B-8 -- which is a bug
+    we do not reproduce)."""
+
+    def __init__(self, data, batch_size, device, shuffle=False, seed=0):
+        import torch
+        self.torch = torch
+        self.imgs = torch.as_tensor(data["imgs"], dtype=torch.float32, device=device)
+        self.nums = torch.as_tensor(data["nums"], dtype=torch.float32, device=device)      # [max_objects+1, N, 1]
+        self.n = self.imgs.shape[0]
+        self.batch_size, self.shuffle, self._pos = int(batch_size), shuffle, 0
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    @property
+    def num_batches(self):
+        return self.n // self.batch_size
+
+    def __call__(self):
+        torch = self.torch
+        if self.shuffle:
+            idx = torch.randint(0, self.n, (self.batch_size,), device=self.imgs.device, generator=self.gen)
+        else:
+            idx = (torch.arange(self.batch_size, device=self.imgs.device) + self._pos) % self.n
+            self._pos = (self._pos + self.batch_size) % self.n
+        return self.imgs.index_select(0, idx), self.nums.index_select(1, idx)

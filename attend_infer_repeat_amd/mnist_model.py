@@ -126,6 +126,18 @@ class AIRonMNIST(AIRModel):
         self._train_step = train_step_fn
         return self._train_step, self.global_step
 
+    def evaluate(self, obs=None, nums=None, noise=None):
+        """Engine-backed evaluation pass (fresh noise, no update); falls back to the generic path without an engine."""
+        if self._engine is None:
+            return super(AIRonMNIST, self).evaluate(obs, nums, noise)
+        if obs is not None:
+            self.obs = obs
+        if nums is not None:
+            self.nums = nums
+        self._engine.forward(self.obs, sample_noise=True)
+        self._refresh_from_engine()
+        return self
+
     def _refresh_from_engine(self):
         """Expose the engine's buffers under the reference's attribute names (model.py:86-104,319-343)."""
         eng, T, B = self._engine, self.max_steps, self.batch_size
@@ -137,6 +149,15 @@ class AIRonMNIST(AIRModel):
             if k in o:
                 setattr(self, k, o[k])
         self.num_step = self.num_step_per_sample.mean()
+        from .ops import Loss
+        from .prior import NumStepsDistribution
+        self.prior_loss = Loss(); self.prior_loss.add(o["prior_loss"], o["kl_num_steps_per_sample"]
+                                                      + o["kl_what_per_sample"] + o["kl_where_per_sample"])
+        self.loss = Loss(); self.loss.add(o["loss"], o["rec_loss_per_sample"]
+                                          + self.prior_weight * self.prior_loss.per_sample)
+        if "baseline" in o:
+            self.importance_weight = o["rec_loss_per_sample"][None, :] - o["baseline"]       # [B,B] quirk, model.py:230
+        self.num_steps_distrib = NumStepsDistribution(o["presence_prob"].reshape(T, B).t())
         self.steps_prior_success_prob = eng.steps_prior_success_prob(max(eng.global_step - 1, 0))
         if self.nums is not None:
             self.gt_num_steps = self.nums.sum(0).reshape(-1)

@@ -204,6 +204,14 @@ class AIRModel(object):
             self.num_step_accuracy = (self.gt_num_steps == self.num_step_per_sample).float().mean()
         return opt_loss
 
+    def evaluate(self, obs=None, nums=None, noise=None):
+        """Forward pass + every loss attribute on (obs, nums) WITHOUT an update -- what `sess.run(exprs, feed_dict)` did
+        in the reference's logger (evaluation.py:137-164).  Requires `train_step(...)` to have been called (priors)."""
+        with torch.no_grad():
+            self.forward(obs, nums, noise)
+            self._losses(self.global_step)
+        return self
+
     def toggle_prior(self):
         self.use_prior = not self.use_prior
         return self.use_prior

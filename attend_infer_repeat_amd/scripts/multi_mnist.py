@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Counterpart of the reference's training script (attend_infer_repeat/scripts/multi_mnist.py:24-147): same
+hyper-parameters, same loop structure (train / periodic log / periodic figure + checkpoint), on the MI355X engine.
+
+Data: `--data-dir` with mnist_train.pickle / mnist_validation.pickle (Python-3 pickles with the reference's layout) if
+present; otherwise a synthetic multi-MNIST-shaped dataset (no network here, so no MNIST download).  The dataset lives
+in HBM and batches are index gathers (data.DeviceFeeder) instead of a tf.py_func host round trip per step.
+"""
+import argparse
+import json
+import os
+import os.path as osp
+import sys
+import time
+
+ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from attend_infer_repeat_amd.data import DeviceFeeder, load_data, synthetic_dataset  # noqa: E402
+from attend_infer_repeat_amd.evaluation import make_fig, make_logger  # noqa: E402
+from attend_infer_repeat_amd.mnist_model import AIRonMNIST  # noqa: E402
+from attend_infer_repeat_amd.utils import AttrDict  # noqa: E402
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=int(3e5))            # multi_mnist.py:134
+    ap.add_argument("--log-every", type=int, default=10000)           # :142
+    ap.add_argument("--save-every", type=int, default=5000)           # :145
+    ap.add_argument("--results-dir", default="../results")
+    ap.add_argument("--run-name", default="multi_mnist")
+    ap.add_argument("--data-dir", default="data")
+    ap.add_argument("--synthetic-samples", type=int, default=60000)
+    ap.add_argument("--eval-batches", type=int, default=10)
+    ap.add_argument("--figures", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    learning_rate, n_steps, batch_size = 1e-4, 3, 64                  # multi_mnist.py:24-25,37
+    num_steps_prior = AttrDict(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3)
+    appearance_prior = AttrDict(loc=0., scale=1.)
+    where_scale_prior = AttrDict(loc=0., scale=1.)
+    where_shift_prior = AttrDict(loc=0., scale=1.)
+    step_bias, transform_var_bias, output_multiplier, init_explore_eps, l2_weight = .75, .5, .5, 1e-3, 0.
+
+    device = torch.device("cuda", 0)
+    logdir = osp.join(args.results_dir, args.run_name)
+    os.makedirs(logdir, exist_ok=True)
+    tr, va = osp.join(args.data_dir, "mnist_train.pickle"), osp.join(args.data_dir, "mnist_validation.pickle")
+    if osp.exists(tr) and osp.exists(va):
+        train_data, valid_data = load_data(tr), load_data(va)
+    else:
+        print("no multi-MNIST pickles under {!r}: using a synthetic dataset".format(args.data_dir))
+        train_data = synthetic_dataset(args.synthetic_samples, seed=args.seed)
+        valid_data = synthetic_dataset(max(args.synthetic_samples // 6, batch_size), seed=args.seed + 1)
+    train_feed = DeviceFeeder(train_data, batch_size, device, shuffle=True, seed=args.seed)
+    valid_feed = DeviceFeeder(valid_data, batch_size, device, shuffle=False)
+    x, y = train_feed()
+
+    n_hiddens = [32 * 8] * 2
+    air = AIRonMNIST(x, y, max_steps=n_steps, explore_eps=init_explore_eps, inpt_encoder_hidden=n_hiddens,
+                     glimpse_encoder_hidden=n_hiddens, glimpse_decoder_hidden=n_hiddens,
+                     transform_estimator_hidden=n_hiddens, steps_pred_hidden=[128, 64], baseline_hidden=[256, 128],
+                     transform_var_bias=transform_var_bias, step_bias=step_bias, output_multiplier=output_multiplier)
+    train_step, global_step = air.train_step(learning_rate, l2_weight, appearance_prior, where_scale_prior,
+                                             where_shift_prior, num_steps_prior)
+    writer = open(osp.join(logdir, "log.jsonl"), "a")
+    log = make_logger(air, train_feed, args.eval_batches, valid_feed, args.eval_batches, writer)
+
+    train_itr = int(global_step)
+    print('Starting training at iter = {}'.format(train_itr))
+    if train_itr == 0:
+        log(0)
+    t0, last = time.time(), train_itr
+    while train_itr < args.iters:
+        xb, yb = train_feed()
+        train_itr = int(train_step(xb, yb))
+        if train_itr % args.log_every == 0:
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            print("iter {}: {:.0f} images/s".format(train_itr, (train_itr - last) * batch_size / max(dt, 1e-9)))
+            log(train_itr)
+            t0, last = time.time(), train_itr
+        if train_itr % args.save_every == 0:
+            torch.save({"flat_params": air._engine.flat_params.cpu(), "global_step": train_itr,
+                        "param_offsets": air._engine.param_offsets, "param_shapes": air._engine.param_shapes},
+                       osp.join(logdir, "model_{}.pt".format(train_itr)))
+            if args.figures:
+                make_fig(air, logdir, train_itr)
+    writer.close()
+    return air
+
+
+if __name__ == "__main__":
+    main()

@@ -190,3 +190,18 @@ def test_aironmnist_engine_backed_training(amd):
                            u_pres=eng.u_pres.clone().unsqueeze(-1)))
     assert torch.equal(air.presence.reshape(3, B), eo["presence"].reshape(3, B))
     assert rel(air.where, eo["where"]) < 1e-4 and rel(air.final_canvas, eo["final_canvas"]) < 1e-4
+
+
+def test_training_script_counterpart_runs(amd, tmp_path):
+    """scripts/multi_mnist.py counterpart: a short run trains, logs the reference's scalar set and checkpoints."""
+    from attend_infer_repeat_amd.scripts import multi_mnist
+    air = multi_mnist.main(["--iters", "40", "--log-every", "20", "--save-every", "40", "--synthetic-samples", "512",
+                            "--eval-batches", "2", "--results-dir", str(tmp_path)])
+    import json, os
+    lines = [json.loads(l) for l in open(os.path.join(tmp_path, "multi_mnist", "log.jsonl"))]
+    assert {l["data"] for l in lines} == {"train", "test"} and {l["step"] for l in lines} == {0, 20, 40}
+    for k in ("loss", "rec_loss", "num_step_acc", "num_step", "prior_loss", "kl_num_steps", "kl_what", "kl_where",
+              "baseline_loss", "reinforce_loss", "imp_weight"):
+        assert all(np.isfinite(l[k]) for l in lines), k
+    assert os.path.exists(os.path.join(tmp_path, "multi_mnist", "model_40.pt"))
+    assert int(air.global_step) == 40
