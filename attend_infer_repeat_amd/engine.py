@@ -647,6 +647,27 @@ class AIREngine:
     def synchronize(self):
         self.stream.synchronize()
 
+    # ---- checkpoint / resume (the reference only ever *saves*, multi_mnist.py:116,145-146) ---------------
+    def state_dict(self):
+        """Everything needed to resume bit-exactly: flat parameters, the three RMSProp slot buffers, the step counter and
+        the Philox state; plus the name -> (offset, shape) map so the flat buffer can be read without this class."""
+        self.synchronize()
+        return {"flat_params": self.flat_params.detach().cpu().clone(), "flat_ms": self.flat_ms.cpu().clone(),
+                "flat_mg": self.flat_mg.cpu().clone(), "flat_mom": self.flat_mom.cpu().clone(),
+                "global_step": int(self.step_dev.item()), "rng_state": self.rng_state.cpu().clone(),
+                "learning_rate": float(self.lr_dev.item()),
+                "param_offsets": dict(self.param_offsets), "param_shapes": {k: tuple(v) for k, v in self.param_shapes.items()}}
+
+    def load_state_dict(self, sd):
+        if dict(sd["param_offsets"]) != dict(self.param_offsets):
+            raise _lib.AirHipError("checkpoint was written for a different architecture (parameter layout differs)")
+        with torch.cuda.stream(self.stream):
+            self.flat_params.copy_(sd["flat_params"]); self.flat_ms.copy_(sd["flat_ms"])
+            self.flat_mg.copy_(sd["flat_mg"]); self.flat_mom.copy_(sd["flat_mom"])
+            self.rng_state.copy_(sd["rng_state"]); self.lr_dev.fill_(float(sd["learning_rate"]))
+        self.set_global_step(int(sd["global_step"]))
+        self.synchronize()
+
     # ---- read-outs (plumbing; not part of the timed step) ---------------------------------------------------------
     def outputs(self) -> Dict[str, torch.Tensor]:
         """The reference's model attributes (model.py:86-104, 319-343) as tensors, time-major."""

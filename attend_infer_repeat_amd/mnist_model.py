@@ -111,16 +111,23 @@ class AIRonMNIST(AIRModel):
             eng.capture()
         self._engine = eng
 
-        def train_step_fn(obs=None, nums=None):
-            """One fused update (fresh noise, forward, backward, both RMSProp updates) as a hipGraph replay."""
+        state = {"lr": None}
+
+        def train_step_fn(obs=None, nums=None, refresh=True):
+            """One fused update (fresh noise, forward, backward, both RMSProp updates) as a hipGraph replay.
+            refresh=False skips re-exposing the engine buffers as model attributes (a device sync + a handful of torch
+            ops per call): use it in tight training loops and call `air.refresh()` / `air.evaluate(...)` when needed."""
             if obs is not None:
                 self.obs = obs
             if nums is not None:
                 self.nums = nums
-            eng.set_learning_rate(float(self.learning_rate))
+            lr = float(self.learning_rate)
+            if lr != state["lr"]:
+                eng.set_learning_rate(lr); state["lr"] = lr
             eng.train_step(obs)
             self.global_step += 1
-            self._refresh_from_engine()
+            if refresh:
+                self._refresh_from_engine()
             return self.global_step
 
         self._train_step = train_step_fn
@@ -136,6 +143,12 @@ class AIRonMNIST(AIRModel):
             self.nums = nums
         self._engine.forward(self.obs, sample_noise=True)
         self._refresh_from_engine()
+        return self
+
+    def refresh(self):
+        """Re-expose the engine's current buffers under the reference's attribute names."""
+        if self._engine is not None:
+            self._refresh_from_engine()
         return self
 
     def _refresh_from_engine(self):

@@ -77,7 +77,7 @@ def main(argv=None):
     t0, last = time.time(), train_itr
     while train_itr < args.iters:
         xb, yb = train_feed()
-        train_itr = int(train_step(xb, yb))
+        train_itr = int(train_step(xb, yb, refresh=False))
         if train_itr % args.log_every == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0

@@ -205,3 +205,8 @@ def test_training_script_counterpart_runs(amd, tmp_path):
         assert all(np.isfinite(l[k]) for l in lines), k
     assert os.path.exists(os.path.join(tmp_path, "multi_mnist", "model_40.pt"))
     assert int(air.global_step) == 40
+    # progress figure (evaluation.py:31-65): inputs / per-step canvases with attention boxes / glimpses
+    from attend_infer_repeat_amd.evaluation import make_fig
+    air.refresh()
+    make_fig(air, str(tmp_path), 40, n_samples=4)
+    assert os.path.getsize(os.path.join(tmp_path, "progress_fig_40.png")) > 10_000
