@@ -171,8 +171,19 @@ class AIRModel(object):
                                                  self.presence.detach(), parts)            # sampled presence, :227
             self.baseline_vars = list(self.baseline_module.parameters())
         if decay_rate is not None:
-            raise NotImplementedError("moving-average normalisation of the importance weight (decay_rate) is off in "
-                                      "the reference script; not wired into the HIP path yet")
+            # EMA normalisation of the [B,B] importance weight (model.py:232-239, ops.py:46-64).  Off in the reference
+            # script; evaluated with torch glue on the generic path (the fused air_nvil kernel covers decay_rate=None).
+            iw = importance_weight.detach()[None, :] - self.baseline                      # [B,B]: (i,j) = imp_j - b_i
+            mean, var = iw.detach().mean(), iw.detach().var(unbiased=False)
+            self.imp_weight_moving_mean = make_moving_average('imp_weight_moving_mean', mean, 0., decay_rate)
+            self.imp_weight_moving_var = make_moving_average('imp_weight_moving_var', var, 1., decay_rate)
+            factor = torch.clamp(torch.sqrt(self.imp_weight_moving_var), min=1.)
+            iwn = (iw - self.imp_weight_moving_mean) / factor
+            self.importance_weight = iwn.detach()
+            self.imp_weight_mean, self.imp_weight_var = iwn.detach().mean(), iwn.detach().var(unbiased=False)
+            self.reinforce_loss = (iwn.detach() * log_prob[None, :]).mean()
+            self.baseline_loss = 0.5 * ((importance_weight.detach()[None, :] - self.baseline) ** 2).mean()
+            return self.reinforce_loss
         # [B] - [B,1] -> [B,B] broadcast of the reference (SURVEY B-1), evaluated in closed form by air_nvil
         rl, bl, m, v = F.nvil(importance_weight.detach(), self.baseline, log_prob)
         self.importance_weight = importance_weight.detach()[None, :] - self.baseline.detach()
@@ -198,6 +209,11 @@ class AIRModel(object):
             if not getattr(self.num_steps_prior, 'analytic', True):
                 self.reinforce_imp_weight = self.reinforce_imp_weight + self.prior_loss.per_sample
             opt_loss = opt_loss + self._reinforce(self.reinforce_imp_weight, self._decay_rate)
+        if self.l2_weight and self.l2_weight > 0.:                                            # model.py:346-353
+            bset = {id(p) for p in getattr(self, 'baseline_vars', [])}
+            weights = [p for p in self.cell.parameters() if p.dim() == 2 and id(p) not in bset]   # incl. the [1,H] initial state, like len(shape)==2 in the reference
+            self.l2_loss = self.l2_weight * sum((w * w).sum() / 2 for w in weights)
+            opt_loss = opt_loss + self.l2_loss
         self.loss = loss
         self.opt_loss = opt_loss
         if self.nums is not None:
@@ -236,8 +252,6 @@ class AIRModel(object):
         self._decay_rate = decay_rate
         self.learning_rate = torch.tensor(float(learning_rate))
         self.global_step = torch.zeros((), dtype=torch.int64)
-        if l2_weight and l2_weight > 0.:
-            raise NotImplementedError("l2_weight > 0 (0 in the reference script)")
         self._losses(self.global_step)                       # builds the baseline, exposes the loss attributes
         self._slots = {}
         lr_dev = torch.tensor([float(learning_rate)], device=self.obs.device)

@@ -76,6 +76,8 @@ class AIRConfig:
     nsp_analytic: bool = True
     use_prior: bool = True
     use_reinforce: bool = True
+    decay_rate: Optional[float] = None          # model.py:232-239 (None in the script)
+    l2_weight: float = 0.0                      # model.py:346-353 (0 in the script)
     # optimiser (model.py:265, multi_mnist.py:24)
     learning_rate: float = 1e-4
     baseline_lr_mult: float = 10.0              # model.py:363
@@ -582,9 +584,20 @@ def objective(params, cfg: AIRConfig, obs: Tensor, noise, global_step=0) -> Dict
                                     tuple(t.detach() for t in o["final_state"]) if isinstance(o["final_state"], tuple)
                                     else o["final_state"].detach())             # [B,1]
         importance_weight = imp - baseline                                       # [B,B]: (i,j) = imp_j - b_i
+        if cfg.decay_rate is not None:                                           # model.py:232-239 + ops.py:46-64
+            ema = noise.setdefault("_ema", {"mean": torch.zeros((), dtype=dt), "var": torch.ones((), dtype=dt)})
+            mean, var = importance_weight.detach().mean(), importance_weight.detach().var(unbiased=False)
+            mm, mv = ema["mean"].clone(), ema["var"].clone()                     # variable value BEFORE this step's update
+            ema["mean"] = cfg.decay_rate * ema["mean"] + (1 - cfg.decay_rate) * mean
+            ema["var"] = cfg.decay_rate * ema["var"] + (1 - cfg.decay_rate) * var
+            importance_weight = (importance_weight - mm) / torch.clamp(torch.sqrt(mv), min=1.0)
         reinforce_loss = (importance_weight.detach() * log_prob).mean()          # model.py:247-248
         baseline_loss = 0.5 * ((imp.detach() - baseline) ** 2).mean()            # model.py:253-256
         opt_loss = opt_loss + reinforce_loss
+        if cfg.l2_weight > 0:                                                    # model.py:346-353: 2-D model weights only
+            l2 = sum((v * v).sum() / 2 for k, v in params.items() if v.dim() == 2 and not is_baseline_param(k))
+            res["l2_loss"] = cfg.l2_weight * l2
+            opt_loss = opt_loss + res["l2_loss"]
         res.update(baseline=baseline, importance_weight=importance_weight, reinforce_loss=reinforce_loss,
                    baseline_loss=baseline_loss, num_steps_log_prob=log_prob,
                    imp_weight_mean=importance_weight.mean(), imp_weight_var=importance_weight.var(unbiased=False))

@@ -210,3 +210,42 @@ def test_training_script_counterpart_runs(amd, tmp_path):
     air.refresh()
     make_fig(air, str(tmp_path), 40, n_samples=4)
     assert os.path.getsize(os.path.join(tmp_path, "progress_fig_40.png")) > 10_000
+
+
+def test_generic_path_decay_rate_and_l2_match_oracle(amd):
+    """ops.make_moving_average / decay_rate (model.py:232-239) and l2_weight (model.py:346-353): off in the reference
+    script, implemented on the generic path; two consecutive steps so the EMA state matters."""
+    from attend_infer_repeat_amd import ops
+    ops._moving_averages.clear()
+    ocfg = O.AIRConfig(img_size=(12, 10), crop_size=(5, 4), n_appearance=6, n_hidden=16, inpt_encoder_hidden=(24,),
+                       glimpse_encoder_hidden=(20,), glimpse_decoder_hidden=(18,), transform_estimator_hidden=(14,),
+                       steps_pred_hidden=(9,), baseline_hidden=(12, 7), max_steps=3, decay_rate=0.8, l2_weight=1e-2)
+    B = 9
+    params = O.init_params(ocfg, seed=7, bias_std=0.2)
+    obs = torch.rand(B, *ocfg.img_size)
+    AD = amd.utils.AttrDict
+    model = _build_model(amd, ocfg, obs.cuda(), "lstm")
+    baseline = amd.modules.BaselineMLP(list(ocfg.baseline_hidden))
+    nsp = AD(anneal='exp', init=ocfg.nsp_init, final=ocfg.nsp_final, steps_div=ocfg.nsp_steps_div,
+             steps=ocfg.nsp_steps, hold_init=ocfg.nsp_hold_init)
+    train_step, _ = model.train_step(ocfg.learning_rate, ocfg.l2_weight, AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                                     AD(loc=0., scale=1.), nsp, baseline=baseline, decay_rate=ocfg.decay_rate)
+    _load_oracle_params(amd, model.cell, model.baseline_module, params, "lstm")
+    ops._moving_averages.clear()                                  # train_step() above already consumed one EMA update
+    p64 = {k: v.double() for k, v in params.items()}
+    slots = O.rmsprop_init(p64)
+    ema_holder = {}
+    for it in range(2):
+        noise = O.make_noise(ocfg, B, seed=30 + it)
+        train_step(noise={k: v.cuda() for k, v in noise.items()})
+        n64 = {k: v.double() for k, v in noise.items()}
+        n64.update(ema_holder)
+        res, grads = O.forward_backward(p64, ocfg, obs.double(), n64, global_step=it)
+        ema_holder = {"_ema": n64["_ema"]}
+        assert abs(model.reinforce_loss.item() - res["reinforce_loss"].item()) < 2e-4 * (abs(res["reinforce_loss"].item()) + 1)
+        assert abs(model.l2_loss.item() - res["l2_loss"].item()) < 1e-4 * (abs(res["l2_loss"].item()) + 1)
+        assert abs(model.opt_loss.item() - res["opt_loss"].item()) < 2e-4 * (abs(res["opt_loss"].item()) + 1)
+        O.rmsprop_centered_step(p64, grads, slots, ocfg)
+    w = model.cell._glimpse_decoder.mlp.layers[1].w
+    assert rel(w.data.cpu().double() - params["glimpse_decoder/1/w"].double(),
+               p64["glimpse_decoder/1/w"] - params["glimpse_decoder/1/w"].double()) < 5e-3

@@ -43,6 +43,7 @@ CONFIGS = {
     "mnist_b8": (O.AIRConfig(), 8),
     "tiny": (O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3,
                            transform_var_bias=0.5), 10),
+    "c4_b4": (O.AIRConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5), 4),       # BASELINE configs[3] shapes
     "rect_t5": (O.AIRConfig(img_size=(28, 36), crop_size=(9, 12), n_appearance=12, n_hidden=40,
                             inpt_encoder_hidden=(48,), glimpse_encoder_hidden=(33, 21), glimpse_decoder_hidden=(30,),
                             transform_estimator_hidden=(24,), steps_pred_hidden=(16, 8), baseline_hidden=(20,),
