@@ -96,6 +96,33 @@ def st_rooflines(eng, reps=200):
     return out
 
 
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
+
+
+def gemm_roofline(eng, reps=50):
+    """MFMA utilisation of the dense layers: 2*M*N*K summed over every GEMM problem of the step / the summed isolated
+    launch time of those launches (HIP events).  At batch 64 this is a latency statement, not a throughput one."""
+    from attend_infer_repeat_amd import hip as H
+    lib = H.lib()
+    sp = eng._sp()
+    flops, us, launches = 0.0, 0.0, 0
+    for plan in (eng._plan_fwd_noise, eng._plan_bwd):
+        for fn, a, name in plan:
+            if name == "air_gemm":
+                f = 2.0 * a[2] * a[3] * a[4]
+            elif name == "air_gemm_grouped":
+                f = sum(2.0 * d.M * d.N * d.K for d in a[0])
+            else:
+                continue
+            flops += f
+            us += event_time_ms(lib, sp, lambda: fn(*a, sp), reps) * 1e3
+            launches += 1
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 5), "traffic": None, "gemm_launches": launches,
+            "gemm_flops_per_step": int(flops), "gemm_us_per_step_isolated": round(us, 1)}
+
+
 def plan_breakdown(eng, reps=100):
     """Per-launch steady-state cost (launch + execution) of each entry of the step plan, run back-to-back in isolation."""
     from attend_infer_repeat_amd import hip as H
@@ -269,6 +296,7 @@ def main():
                        "params_finite_after_run": finite},
             "roofline": roof["st_read_fwd"],
             "roofline_other_kernels": {k: v for k, v in roof.items() if k != "st_read_fwd"},
+            "roofline_gemm": gemm_roofline(eng),
         }
         if not args.no_sweep and world == 1:
             # T glimpses per staged image (as in the train step) and the 1:1 case (one image per glimpse)
