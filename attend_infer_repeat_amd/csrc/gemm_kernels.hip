@@ -463,8 +463,8 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     ga.count = count;
     // long K on a handful of tiles (the BPTT products, 64x256x1024): 16 waves split K inside the workgroup, so every wave
     // still needs only one or two memory round trips and no second (split-K epilogue) launch is paid
-    bool long_k = tiles16 <= 256;
-    for (int i = 0; i < count; ++i) long_k = long_k && descs[i].K >= 512;
+    bool long_k = tiles16 <= 1024;
+    for (int i = 0; i < count; ++i) long_k = long_k && descs[i].K >= 512 && descs[i].K >= 8 * (descs[i].M < descs[i].N ? descs[i].M : descs[i].N);
     if (long_k) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 16>), dim3(tiles), dim3(1024), 0, air_stream(stream), ga);
     else if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
     else hipLaunchKernelGGL((gemm_grouped_kernel<2, 2, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);

@@ -304,11 +304,20 @@ class AIREngine:
                 plan.append((L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
                                           d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, wsp, wsb), "air_gemm"))
                 return
-            for i in range(0, len(descs), 8):
-                chunk = descs[i:i + 8]
-                arr = (_lib.AirGemmDesc * len(chunk))(*chunk)
-                self._keep.append(arr)
-                plan.append((L.air_gemm_grouped, (arr, len(chunk)), "air_gemm_grouped"))
+            t16 = lambda d: ((d.M + 15) // 16) * ((d.N + 15) // 16)
+            groups = [descs]
+            if tiles16 > 1536 and len(descs) > 1:
+                # large batch: launches are cheap relative to the work, and the library picks ONE tile shape / K-split per
+                # launch -- keep the long-K few-tile problems (weight gradients: K = T*B) apart from the many-tile ones
+                long_k = [d for d in descs if d.K >= 1024 and t16(d) <= 1024]
+                rest = [d for d in descs if not (d.K >= 1024 and t16(d) <= 1024)]
+                groups = [g for g in (long_k, rest) if g]
+            for grp in groups:
+                for i in range(0, len(grp), 8):
+                    chunk = grp[i:i + 8]
+                    arr = (_lib.AirGemmDesc * len(chunk))(*chunk)
+                    self._keep.append(arr)
+                    plan.append((L.air_gemm_grouped, (arr, len(chunk)), "air_gemm_grouped"))
 
         def fwd_desc(m: _Mlp, i, x, ldx):
             k, n = m.shapes[i]
