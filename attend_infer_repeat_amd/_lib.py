@@ -18,7 +18,7 @@ class AirGemmDesc(ctypes.Structure):
     _fields_ = [("ta", c_int), ("tb", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
                 ("bias", c_void_p), ("epilogue", c_int), ("aux", c_void_p), ("ldaux", c_int), ("beta", c_float),
-                ("colsum", c_void_p)]
+                ("colsum", c_void_p), ("precision", c_int)]
 
 
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
@@ -35,6 +35,8 @@ SIGNATURES = {
                                       c_float, c_float, P]),
     "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
                          c_float, P, P, c_size_t, P]),
+    "air_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
+                              c_float, P, P, c_size_t, P]),
     "air_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "air_gemm_grouped": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, P]),
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),

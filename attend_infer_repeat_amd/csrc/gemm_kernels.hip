@@ -21,6 +21,43 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const float __attribute__((address_space(1))) *gcf;
 typedef float __attribute__((address_space(1))) *gf;
 typedef const f32x4 __attribute__((address_space(1))) *gcf4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// bf16 operand mode (BASELINE config 5, "bf16 MFMA MLP path"): storage stays fp32; the four k-values a lane holds for a
+// 16-deep chunk are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers and ONE v_mfma_f32_16x16x16_bf16 replaces the
+// four v_mfma_f32_16x16x4_f32 -- same lane->k mapping (k = 4g..4g+3), fp32 accumulate.  1/8 of the MFMA issue cycles.
+__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
+    const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
+    const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+    const u32x2 p = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    return __builtin_bit_cast(s16x4, p);
+}
+template <int MT, int NT, bool BF>
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MT][NT], const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
+    if (BF) {
+        s16x4 ha[MT], hb[NT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) ha[a] = to_bf16x4(fa[a]);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) hb[b] = to_bf16x4(fb[b]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha[a], hb[b], acc[a][b], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    }
+}
 
 struct GemmArgs {
     const float *A, *B, *bias, *aux;
@@ -96,7 +133,7 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // MT x NT 16x16 MFMA tiles per wave.  KW = 4 / 16: the workgroup's KW waves split K for ONE tile (LDS reduce; 16
 // waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, bool BF>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
@@ -193,13 +230,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (c + u * c_step >= full_end) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][a][j], fb[u][b][j], acc[a][b], 0, 0, 0);
+            mfma_chunk<MT, NT, BF>(acc, fa[u], fb[u]);
             if (want_colsum) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
@@ -220,13 +251,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
         for (int b = 0; b < NT; ++b)
             fb[b] = g.tb ? ld_kcontig(gB, g.ldb, colB[b], okB[b], k, g.K, g.vecB != 0)
                          : ld_kstrided(gB, g.ldb, colB[b], okB[b], k, g.K);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        mfma_chunk<MT, NT, BF>(acc, fa, fb);
         if (want_colsum) {
 #pragma unroll
             for (int b = 0; b < NT; ++b) csum[b] += (fb[b].x + fb[b].y) + (fb[b].z + fb[b].w);
@@ -306,9 +331,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     }
 }
 
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, bool BF>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_f32_mfma_kernel(GemmArgs g) {
-    gemm_body<MT, NT, KW>(g, blockIdx.x, blockIdx.y);
+    gemm_body<MT, NT, KW, BF>(g, blockIdx.x, blockIdx.y);
 }
 
 // Several independent GEMMs in ONE launch (the step is launch/latency bound: a dW / dX pair, or the two heads that
@@ -319,7 +344,7 @@ struct GroupArgs {
     int tile_start[AIR_GEMM_GROUP_MAX + 1];
     int count;
 };
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, bool BF>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(GroupArgs ga) {
     int p = 0;
 #pragma unroll
@@ -332,14 +357,14 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(G
     // (blockIdx.y is always 0 here, but passing it instead of a literal 0 keeps hipcc from restructuring the K loop
     //  around a known start, which doubles the live registers: 94 -> 194 VGPRs, measured)
     switch (p) {
-        case 0: gemm_body<MT, NT, KW>(ga.g[0], (int)blockIdx.x - ga.tile_start[0], blockIdx.y); break;
-        case 1: gemm_body<MT, NT, KW>(ga.g[1], (int)blockIdx.x - ga.tile_start[1], blockIdx.y); break;
-        case 2: gemm_body<MT, NT, KW>(ga.g[2], (int)blockIdx.x - ga.tile_start[2], blockIdx.y); break;
-        case 3: gemm_body<MT, NT, KW>(ga.g[3], (int)blockIdx.x - ga.tile_start[3], blockIdx.y); break;
-        case 4: gemm_body<MT, NT, KW>(ga.g[4], (int)blockIdx.x - ga.tile_start[4], blockIdx.y); break;
-        case 5: gemm_body<MT, NT, KW>(ga.g[5], (int)blockIdx.x - ga.tile_start[5], blockIdx.y); break;
-        case 6: gemm_body<MT, NT, KW>(ga.g[6], (int)blockIdx.x - ga.tile_start[6], blockIdx.y); break;
-        default: gemm_body<MT, NT, KW>(ga.g[7], (int)blockIdx.x - ga.tile_start[7], blockIdx.y); break;
+        case 0: gemm_body<MT, NT, KW, BF>(ga.g[0], (int)blockIdx.x - ga.tile_start[0], blockIdx.y); break;
+        case 1: gemm_body<MT, NT, KW, BF>(ga.g[1], (int)blockIdx.x - ga.tile_start[1], blockIdx.y); break;
+        case 2: gemm_body<MT, NT, KW, BF>(ga.g[2], (int)blockIdx.x - ga.tile_start[2], blockIdx.y); break;
+        case 3: gemm_body<MT, NT, KW, BF>(ga.g[3], (int)blockIdx.x - ga.tile_start[3], blockIdx.y); break;
+        case 4: gemm_body<MT, NT, KW, BF>(ga.g[4], (int)blockIdx.x - ga.tile_start[4], blockIdx.y); break;
+        case 5: gemm_body<MT, NT, KW, BF>(ga.g[5], (int)blockIdx.x - ga.tile_start[5], blockIdx.y); break;
+        case 6: gemm_body<MT, NT, KW, BF>(ga.g[6], (int)blockIdx.x - ga.tile_start[6], blockIdx.y); break;
+        default: gemm_body<MT, NT, KW, BF>(ga.g[7], (int)blockIdx.x - ga.tile_start[7], blockIdx.y); break;
     }
 }
 
@@ -354,11 +379,11 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
     }
 }
 
-template <int MT, int NT, int KW>
+template <int MT, int NT, int KW, bool BF>
 static int launch_gemm(const GemmArgs &g, hipStream_t st) {
     constexpr int TM = 16 * MT, TN = 16 * NT * ((KW == 1) ? 4 : 1);
     const int tiles = air_cdiv(g.M, TM) * air_cdiv(g.N, TN);
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT, NT, KW>), dim3(tiles, g.S), dim3(KW == 1 ? 256 : 64 * KW), 0, st, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT, NT, KW, BF>), dim3(tiles, g.S), dim3(KW == 1 ? 256 : 64 * KW), 0, st, g);
     AIR_LAUNCH_CHECK();
     if (g.S > 1) {
         const size_t total = (size_t)g.M * g.N;
@@ -376,9 +401,10 @@ extern "C" size_t air_gemm_workspace_bytes(int M, int N, int K) {
     return (size_t)16 * (size_t)M * (size_t)N * sizeof(float);     // up to 16 split-K slabs
 }
 
-extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                        float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
-                        float *colsum, void *ws, size_t ws_bytes, void *stream) {
+template <bool BF>
+static int gemm_dispatch(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                         float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
+                         float *colsum, void *ws, size_t ws_bytes, void *stream) {
     AIR_REQUIRE(A && B && C, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && N > 0 && K > 0, AIR_E_SHAPE);
     AIR_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, AIR_E_SHAPE);
@@ -401,7 +427,7 @@ extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int
     hipStream_t st = air_stream(stream);
     if (tiles22 >= 2048) {
         g.S = 1; g.chunks_per_split = chunks;
-        return launch_gemm<2, 2, 1>(g, st);
+        return launch_gemm<2, 2, 1, BF>(g, st);
     }
     // latency regime (the whole problem fits a fraction of the chip): 16x16 tiles, one per workgroup, 4 waves split K,
     // 8 chunks in flight -- every wave does one or two memory round trips whatever the shape
@@ -422,7 +448,20 @@ extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int
     g.chunks_per_split = (chunks + S - 1) / S;
     g.S = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;       // drop empty tail splits
     (void)narrow;
-    return launch_gemm<1, 1, 4>(g, st);
+    return launch_gemm<1, 1, 4, BF>(g, st);
+}
+
+extern "C" int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                        float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
+                        float *colsum, void *ws, size_t ws_bytes, void *stream) {
+    return gemm_dispatch<false>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, beta, colsum, ws,
+                                ws_bytes, stream);
+}
+extern "C" int air_gemm_bf16(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                             float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
+                             float *colsum, void *ws, size_t ws_bytes, void *stream) {
+    return gemm_dispatch<true>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, beta, colsum, ws,
+                               ws_bytes, stream);
 }
 
 static int fill_gemm_args(GemmArgs &g, const AirGemmDesc &d) {
@@ -465,9 +504,21 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     // still needs only one or two memory round trips and no second (split-K epilogue) launch is paid
     bool long_k = tiles16 <= 1024;
     for (int i = 0; i < count; ++i) long_k = long_k && descs[i].K >= 512 && descs[i].K >= 8 * (descs[i].M < descs[i].N ? descs[i].M : descs[i].N);
-    if (long_k) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 16>), dim3(tiles), dim3(1024), 0, air_stream(stream), ga);
-    else if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
-    else hipLaunchKernelGGL((gemm_grouped_kernel<2, 2, 4>), dim3(tiles), dim3(256), 0, air_stream(stream), ga);
+    const bool bf = descs[0].precision == AIR_PREC_BF16;
+    for (int i = 0; i < count; ++i) {
+        AIR_REQUIRE(descs[i].precision == AIR_PREC_F32 || descs[i].precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+        AIR_REQUIRE((descs[i].precision == AIR_PREC_BF16) == bf, AIR_E_UNSUPPORTED);   // one precision per launch
+    }
+    hipStream_t st = air_stream(stream);
+#define AIR_GROUP_LAUNCH(MT_, NT_, KW_, NTH_)                                                                        \
+    do {                                                                                                             \
+        if (bf) hipLaunchKernelGGL((gemm_grouped_kernel<MT_, NT_, KW_, true>), dim3(tiles), dim3(NTH_), 0, st, ga);   \
+        else hipLaunchKernelGGL((gemm_grouped_kernel<MT_, NT_, KW_, false>), dim3(tiles), dim3(NTH_), 0, st, ga);     \
+    } while (0)
+    if (long_k) AIR_GROUP_LAUNCH(1, 1, 16, 1024);
+    else if (T_ == 16) AIR_GROUP_LAUNCH(1, 1, 4, 256);
+    else AIR_GROUP_LAUNCH(2, 2, 4, 256);
+#undef AIR_GROUP_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

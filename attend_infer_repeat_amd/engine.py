@@ -60,6 +60,10 @@ class EngineConfig:
     rms_decay: float = 0.9
     rms_momentum: float = 0.9
     rms_eps: float = 1e-10
+    # "f32": exact fp32 MFMA everywhere.  "bf16": every dense product (MLPs, LSTM gates, their dX / dW) rounds its operands
+    # to bf16 in registers and multiplies on the bf16 MFMA with fp32 accumulate; parameters, activations, gradients and the
+    # optimiser stay fp32 (BASELINE.json configs[4], "bf16 MFMA MLP path").
+    mfma_dtype: str = "f32"
 
     @property
     def n_pix(self):
@@ -287,6 +291,9 @@ class AIREngine:
         p = H._p
         wsp, wsb = p(self.ws), ctypes.c_size_t(self.ws.numel() * 4)
         fwd, bwd, rng = [], [], []
+        if cfg.mfma_dtype not in ("f32", "bf16"):
+            raise ValueError("mfma_dtype must be 'f32' or 'bf16', got %r" % (cfg.mfma_dtype,))
+        prec = 1 if cfg.mfma_dtype == "bf16" else 0
         self._keep = []
         NONE, BIAS, BELU, MDELU, ADDAUX = H.EPI_NONE, H.EPI_BIAS, H.EPI_BIAS_ELU, H.EPI_MUL_DELU, H.EPI_ADD_AUX
         dp = lambda t: (t.data_ptr() if t is not None else None)
@@ -294,14 +301,14 @@ class AIREngine:
         def desc(ta, tb, Mm, Nn, Kk, Aa, lda, Bb, ldb, Cc, ldc, bias=None, epi=NONE, aux=None, ldaux=0, beta=0.0,
                  colsum=None):
             return _lib.AirGemmDesc(int(ta), int(tb), Mm, Nn, Kk, dp(Aa), lda, dp(Bb), ldb, dp(Cc), ldc, dp(bias), epi,
-                                    dp(aux), ldaux, float(beta), dp(colsum))
+                                    dp(aux), ldaux, float(beta), dp(colsum), prec)
 
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
             tiles16 = sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in descs)
             if len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256:
                 d = descs[0]
-                plan.append((L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
+                plan.append((L.air_gemm_bf16 if prec else L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
                                           d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, wsp, wsb), "air_gemm"))
                 return
             t16 = lambda d: ((d.M + 15) // 16) * ((d.N + 15) // 16)

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--breakdown", action="store_true",
                     help="time every launch of the step plan in isolation (HIP events, back-to-back repeats) -> stderr")
+    ap.add_argument("--mfma", default="f32", choices=["f32", "bf16"],
+                    help="dense-product precision: exact fp32 MFMA (headline) or bf16 operands / fp32 accumulate (configs[4])")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2: 50x50/20x20/T=3 (headline); c4: 100x100/28x28/T=5 (bandwidth study)")
     return ap.parse_args()
@@ -118,8 +120,11 @@ def gemm_roofline(eng, reps=50):
             us += event_time_ms(lib, sp, lambda: fn(*a, sp), reps) * 1e3
             launches += 1
     tf = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 5), "traffic": None, "gemm_launches": launches,
+    # bf16 mode: v_mfma_f32_16x16x16_bf16, half the K per instruction of the gfx950 16x16x32 form -> price against the
+    # dense bf16 peak of MI355X_MICROARCH.md (2.5 PF) all the same; the operands are still fetched as fp32
+    peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.mfma_dtype == "f32" else 2516.6
+    return {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(tf / peak, 5), "traffic": None, "gemm_launches": launches,
             "gemm_flops_per_step": int(flops), "gemm_us_per_step_isolated": round(us, 1)}
 
 
@@ -246,7 +251,7 @@ def main():
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
 
     cfg_kw = {} if args.config == "c2" else dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5)
-    cfg = EngineConfig(**cfg_kw)
+    cfg = EngineConfig(mfma_dtype=args.mfma, **cfg_kw)
     B = args.batch
     eng = AIREngine(cfg, B, device=device, seed=D.rank_seed(1, rank), keep_canvas_steps=False)
     imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=2 if args.config == "c2" else 4, seed=rank)
@@ -287,7 +292,7 @@ def main():
                       else "images/sec (train step, ELBO backward) 100x100 canvas, 5-step AIR, glimpse 28x28",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "bf16 operands / f32 accumulate+storage", "data": "synthetic",
             "config": {"workload": ("multi-MNIST 50x50, max_steps=3, glimpse 20x20, batch=64 per GPU (BASELINE configs[1])"
                                     if args.config == "c2" else
                                     "canvas 100x100, 0-4 objects, max_steps=5, glimpse 28x28 (BASELINE configs[3])"),

@@ -93,11 +93,18 @@ int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float 
 int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
              float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
              float *colsum, void *ws, size_t ws_bytes, void *stream);
+/* Same contract with the operands rounded to bf16 (round-to-nearest-even) in registers and multiplied on
+ * v_mfma_f32_16x16x16_bf16 (fp32 accumulate, fp32 storage everywhere): BASELINE.json configs[4], "bf16 MFMA MLP path".
+ * colsum (the bias gradient) is summed from the un-rounded fp32 values.                                             */
+int air_gemm_bf16(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+             float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
+             float *colsum, void *ws, size_t ws_bytes, void *stream);
 size_t air_gemm_workspace_bytes(int M, int N, int K);
 
 /* Up to 8 INDEPENDENT GEMMs in one launch (same semantics as air_gemm, no split-K).  The step is launch/latency
  * bound at batch 64, so e.g. the dW and dX products of one layer, or the transform / steps heads that share h_t,
  * are dispatched together.  `descs` is a HOST array; outputs must not alias another problem's inputs.              */
+enum { AIR_PREC_F32 = 0, AIR_PREC_BF16 = 1 };
 typedef struct AirGemmDesc {
     int ta, tb, M, N, K;
     const float *A; int lda;
@@ -107,6 +114,7 @@ typedef struct AirGemmDesc {
     const float *aux; int ldaux;
     float beta;
     float *colsum;
+    int precision;           /* AIR_PREC_F32 (exact fp32 MFMA) or AIR_PREC_BF16 (operands rounded to bf16, fp32 accumulate) */
 } AirGemmDesc;
 int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
 

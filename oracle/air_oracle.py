@@ -227,9 +227,52 @@ def synthetic_batch(cfg: AIRConfig, batch: int, seed: int = 0, max_objects: int 
 # --------------------------------------------------------------------------------------
 # layers (neural.py:42-102)
 # --------------------------------------------------------------------------------------
+_MM_MODE = ["f32"]
+
+
+class matmul_mode:
+    """`with matmul_mode("bf16"):` makes every dense product of the oracle emulate the product's optional bf16-MFMA mode
+    (EngineConfig.mfma_dtype="bf16", BASELINE.json configs[4]): both operands rounded to bf16 (round-to-nearest-even),
+    exact products, fp32 accumulation -- forward, dX and dW alike.  Not part of the reference (TF1 fp32 only); it exists
+    so that the bf16 path is checked against the same arithmetic rather than against a loose tolerance."""
+
+    def __init__(self, mode: str):
+        assert mode in ("f32", "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _MM_MODE[0]
+        _MM_MODE[0] = self.mode
+
+    def __exit__(self, *exc):
+        _MM_MODE[0] = self.prev
+
+
+def _r16(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Bf16MatMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        xr, wr = _r16(x), _r16(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr = _r16(dy)
+        return dyr @ wr.t(), xr.t() @ dyr
+
+
+def mm(x: Tensor, w: Tensor) -> Tensor:
+    return _Bf16MatMul.apply(x, w) if _MM_MODE[0] == "bf16" else x @ w
+
+
 def affine(x: Tensor, w: Tensor, b: Tensor, elu: bool) -> Tensor:
     """Affine = transfer(x.W + b), neural.py:56-60."""
-    y = x @ w + b
+    y = mm(x, w) + b
     return F.elu(y) if elu else y
 
 
@@ -243,7 +286,7 @@ def mlp(x: Tensor, params: Dict[str, Tensor], prefix: str, n_layers: int, last_l
 
 def lstm_step(x: Tensor, h: Tensor, c: Tensor, w: Tensor, b: Tensor, forget_bias: float = 1.0):
     """Sonnet v1 LSTM (mnist_model.py:35, cell.py:127): gates=[x,h].W+b; i,j,f,o."""
-    g = torch.cat([x, h], -1) @ w + b
+    g = mm(torch.cat([x, h], -1), w) + b
     i, j, f, o = torch.chunk(g, 4, -1)
     c2 = torch.sigmoid(f + forget_bias) * c + torch.sigmoid(i) * torch.tanh(j)
     h2 = torch.tanh(c2) * torch.sigmoid(o)
@@ -396,7 +439,7 @@ def cell_step(params, cfg: AIRConfig, state, eps_where: Tensor, eps_what: Tensor
         presence = presence_prob                                                                    # cell.py:150-151
 
     g = mlp(cropped.reshape(B, -1), params, "glimpse_encoder", len(cfg.glimpse_encoder_hidden), last_linear=False)
-    q = g @ params["what/w"] + params["what/b"]                                                     # modules.py:20-21
+    q = mm(g, params["what/w"]) + params["what/b"]                                                     # modules.py:20-21
     A = cfg.n_appearance
     what_loc, what_raw = q[:, :A], q[:, A:]
     what_scale = F.softplus(what_raw + cfg.what_scale_offset)                                       # modules.py:23

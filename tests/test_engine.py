@@ -15,10 +15,10 @@ from oracle import air_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(ocfg: O.AIRConfig, B, seed=1, gstep=20000, bias_std=0.1):
+def make_pair(ocfg: O.AIRConfig, B, seed=1, gstep=20000, bias_std=0.1, mfma_dtype="f32"):
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
     fields = {f.name for f in dataclasses.fields(EngineConfig)}
-    ecfg = EngineConfig(**{k: v for k, v in dataclasses.asdict(ocfg).items() if k in fields})
+    ecfg = EngineConfig(mfma_dtype=mfma_dtype, **{k: v for k, v in dataclasses.asdict(ocfg).items() if k in fields})
     eng = AIREngine(ecfg, B, seed=seed)
     params = O.init_params(ocfg, seed=seed, bias_std=bias_std)
     eng.load_parameters(params)
@@ -77,6 +77,46 @@ def test_forward_and_gradients_match_oracle(gpu_device, name):
         worst[k] = rel_err(g[k], ref)
     bad = {k: v for k, v in worst.items() if not v < 2e-3}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["mnist_b8", "rect_t5"])
+def test_bf16_mfma_path_matches_bf16_emulating_oracle(gpu_device, name):
+    """BASELINE configs[4]: dense products with bf16-rounded operands on the bf16 MFMA, fp32 accumulate.  The oracle
+    emulates exactly that arithmetic (O.matmul_mode), so the tolerance stays tight: what is left is summation order plus
+    the rare operand that sits within fp32 noise of a bf16 rounding boundary (one bf16 ulp = 2^-8 relative on that
+    element).  Outputs 2e-3, gradients 1e-2 of each tensor's max; the plain-fp32 oracle is ~10x further away."""
+    ocfg, B = CONFIGS[name]
+    eng, params, obs, noise = make_pair(ocfg, B, mfma_dtype="bf16")
+    eng.forward(sample_noise=False)
+    eng.backward()
+    out = eng.outputs()
+    with O.matmul_mode("bf16"):
+        res, grads = O.forward_backward(f64(params), ocfg, obs.double(), f64(noise), global_step=20000)
+    res32, _ = O.forward_backward(f64(params), ocfg, obs.double(), f64(noise), global_step=20000)
+    assert torch.equal(out["presence"].cpu().double(), res["presence"])
+    for k in ["what", "where", "presence_prob", "final_canvas", "rec_loss_per_sample", "kl_what_per_sample",
+              "kl_where_per_sample", "num_steps_posterior", "baseline"]:
+        assert rel_err(out[k].reshape(res[k].shape), res[k]) < 2e-3, (k, rel_err(out[k].reshape(res[k].shape), res[k]))
+    for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
+        assert abs(out[k].item() - res[k].item()) <= 2e-3 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
+    g = eng.named_grads()
+    bad = {k: rel_err(g[k], ref) for k, ref in grads.items() if not rel_err(g[k], ref) < 1e-2}
+    assert not bad, bad
+    # the mode is really on: the result differs from exact fp32 by a bf16-sized amount, not by fp32 noise
+    d32 = rel_err(out["what"].reshape(res32["what"].shape), res32["what"])
+    assert 1e-4 < d32 < 5e-2, d32
+
+
+def test_bf16_graph_train_step_runs_and_learns(gpu_device):
+    ocfg, B = O.AIRConfig(), 32
+    eng, params, obs, noise = make_pair(ocfg, B, bias_std=0.0, mfma_dtype="bf16")
+    eng.forward(); first = eng.outputs()["loss"].item()
+    eng.capture()
+    for _ in range(200):
+        eng.train_step()
+    eng.forward(); last = eng.outputs()["loss"].item()
+    assert torch.isfinite(eng.flat_params).all() and torch.isfinite(eng.flat_grads).all()
+    assert np.isfinite(last) and last < first - 50.0, (first, last)
 
 
 def test_train_step_updates_match_oracle(gpu_device):
