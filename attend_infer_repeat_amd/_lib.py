@@ -41,6 +41,8 @@ SIGNATURES = {
     "air_gemm_grouped": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, P]),
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "air_lstm_step_fwd": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int, P]),
+    "air_lstm_step_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_gauss_sample_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,

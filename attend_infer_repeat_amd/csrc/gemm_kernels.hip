@@ -20,6 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // operand access a FLAT load with a 64-bit VGPR address (+100 VGPRs, half the occupancy)
 typedef const float __attribute__((address_space(1))) *gcf;
 typedef float __attribute__((address_space(1))) *gf;
+typedef gf gf_t;
 typedef const f32x4 __attribute__((address_space(1))) *gcf4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -125,6 +126,11 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
             v += g.aux[(size_t)m * g.ldaux + n];
             if (g.bias) v += g.bias[n];
             break;
+        case AIR_EPI_ADD_AUX_ELU:
+            v += g.aux[(size_t)m * g.ldaux + n];
+            if (g.bias) v += g.bias[n];
+            v = elu_acc(v);
+            break;
         default: break;
     }
     return v;
@@ -186,7 +192,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
             const int m = m0 + r, n = n0 + cidx;
             const bool ok = (e < TM * TN) && m < g.M && n < g.N;
             e_bias[i] = (ok && g.bias != nullptr) ? gBias[n] : 0.f;
-            e_aux[i] = (ok && (g.epi == AIR_EPI_MUL_DELU || g.epi == AIR_EPI_ADD_AUX)) ? gAux[(size_t)m * g.ldaux + n] : 0.f;
+            e_aux[i] = (ok && g.epi >= AIR_EPI_MUL_DELU) ? gAux[(size_t)m * g.ldaux + n] : 0.f;
             e_c[i] = (ok && g.beta != 0.f) ? gC[(size_t)m * g.ldc + n] : 0.f;
         }
     }
@@ -299,6 +305,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                     case AIR_EPI_BIAS_ELU: v = elu_acc(v + e_bias[i]); break;
                     case AIR_EPI_MUL_DELU: v *= (e_aux[i] > 0.f ? 1.f : e_aux[i] + 1.f); break;
                     case AIR_EPI_ADD_AUX: v += e_aux[i] + e_bias[i]; break;
+                    case AIR_EPI_ADD_AUX_ELU: v = elu_acc(v + e_aux[i] + e_bias[i]); break;
                     default: break;
                 }
                 gC[(size_t)m * g.ldc + n] = v;
@@ -408,9 +415,9 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const float *A, in
     AIR_REQUIRE(A && B && C, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && N > 0 && K > 0, AIR_E_SHAPE);
     AIR_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, AIR_E_SHAPE);
-    AIR_REQUIRE(epilogue >= AIR_EPI_NONE && epilogue <= AIR_EPI_ADD_AUX, AIR_E_UNSUPPORTED);
+    AIR_REQUIRE(epilogue >= AIR_EPI_NONE && epilogue <= AIR_EPI_ADD_AUX_ELU, AIR_E_UNSUPPORTED);
     if (epilogue == AIR_EPI_BIAS || epilogue == AIR_EPI_BIAS_ELU) AIR_REQUIRE(bias, AIR_E_NULL);
-    if (epilogue == AIR_EPI_MUL_DELU || epilogue == AIR_EPI_ADD_AUX) AIR_REQUIRE(aux && ldaux >= N, AIR_E_NULL);
+    if (epilogue >= AIR_EPI_MUL_DELU) AIR_REQUIRE(aux && ldaux >= N, AIR_E_NULL);
     AIR_REQUIRE(!colsum || ta, AIR_E_UNSUPPORTED);
 
     GemmArgs g;
@@ -468,9 +475,9 @@ static int fill_gemm_args(GemmArgs &g, const AirGemmDesc &d) {
     AIR_REQUIRE(d.A && d.B && d.C, AIR_E_NULL);
     AIR_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, AIR_E_SHAPE);
     AIR_REQUIRE(d.lda >= (d.ta ? d.M : d.K) && d.ldb >= (d.tb ? d.K : d.N) && d.ldc >= d.N, AIR_E_SHAPE);
-    AIR_REQUIRE(d.epilogue >= AIR_EPI_NONE && d.epilogue <= AIR_EPI_ADD_AUX, AIR_E_UNSUPPORTED);
+    AIR_REQUIRE(d.epilogue >= AIR_EPI_NONE && d.epilogue <= AIR_EPI_ADD_AUX_ELU, AIR_E_UNSUPPORTED);
     if (d.epilogue == AIR_EPI_BIAS || d.epilogue == AIR_EPI_BIAS_ELU) AIR_REQUIRE(d.bias, AIR_E_NULL);
-    if (d.epilogue == AIR_EPI_MUL_DELU || d.epilogue == AIR_EPI_ADD_AUX) AIR_REQUIRE(d.aux && d.ldaux >= d.N, AIR_E_NULL);
+    if (d.epilogue >= AIR_EPI_MUL_DELU) AIR_REQUIRE(d.aux && d.ldaux >= d.N, AIR_E_NULL);
     AIR_REQUIRE(!d.colsum || d.ta, AIR_E_UNSUPPORTED);
     g.A = d.A; g.B = d.B; g.C = d.C; g.bias = d.bias; g.aux = d.aux; g.colsum = d.colsum; g.ws = nullptr;
     g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldaux = d.ldaux;
@@ -521,6 +528,227 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
 #undef AIR_GROUP_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
+}
+
+// ---- LSTM recurrence with the gate math fused into the GEMM (snt.LSTM, mnist_model.py:35 / cell.py:126-127) -----------
+// The recurrence is the one truly sequential part of the step (T dependent products that cannot be batched over time),
+// and at batch 64 each link of that chain costs a launch (~4.5 us) far more than its flops.  Fusing the gate
+// non-linearities into the product halves the chain: forward T launches instead of 2T, backward T instead of 2T+1.
+//
+// One 16x16 accumulator tile per workgroup, KW waves interleave the 16-deep K chunks (as gemm_body<1,1,KW>); A is always
+// k-contiguous, B is k-strided (forward: W_h[K=Hd, 4Hd]) or k-contiguous (backward: W_h read as [N=Hd, K=4Hd]).
+template <int KW, bool BF, bool B_KCONTIG>
+__device__ __forceinline__ void tile16_kloop(f32x4 (&acc)[1][1], gcf gA, int lda, int rowA, bool okA, bool vecA, gcf gB,
+                                             int ldb, int colB, bool okB, bool vecB, int K, int limA, int limB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane >> 4;
+    constexpr int U = 4;
+    const int full_end = K >> 4;
+    const int rowAc = okA ? rowA : limA - 1, colBc = okB ? colB : limB;
+#pragma nounroll
+    for (int c = wave; c < full_end; c += U * KW) {
+        f32x4 fa[U][1], fb[U][1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = c + u * KW;
+            if (cu < full_end) {
+                const int k = (cu << 4) + 4 * lg;
+                fa[u][0] = ld_kcontig_full(gA, lda, rowAc, k, vecA);
+                fb[u][0] = B_KCONTIG ? ld_kcontig_full(gB, ldb, colBc, k, vecB) : ld_kstrided_full(gB, ldb, colBc, k);
+            } else {
+                fa[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                fb[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW >= full_end) break;
+            mfma_chunk<1, 1, BF>(acc, fa[u], fb[u]);
+        }
+    }
+    const int pc = K >> 4;
+    if ((K & 15) && (pc % KW) == wave) {
+        const int k = (pc << 4) + 4 * lg;
+        f32x4 fa[1], fb[1];
+        fa[0] = ld_kcontig(gA, lda, rowA, okA, k, K, vecA);
+        fb[0] = B_KCONTIG ? ld_kcontig(gB, ldb, colB, okB, k, K, vecB) : ld_kstrided(gB, ldb, colB, okB, k, K);
+        mfma_chunk<1, 1, BF>(acc, fa, fb);
+    }
+}
+
+struct LstmFwdArgs {
+    const float *h_prev, *w_h, *gx, *c_prev;
+    float *h, *c, *gate_act;
+    int M, Hd, ldw, ldgx, vecA;
+    float fb;
+};
+// tile = 16 batch rows x 4 hidden units: its 16 accumulator columns are the i,j,f,o gates of those 4 units (column
+// 4*gate + unit  <->  W_h column gate*Hd + unit), so the gate math of a unit never leaves the workgroup
+template <bool BF>
+__global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(LstmFwdArgs g) {
+    constexpr int KW = 4, LDT = 20;
+    __shared__ float s_tile[KW][16 * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_u = (g.Hd + 3) >> 2;
+    const int tm = blockIdx.x / tiles_u, tu = blockIdx.x - tm * tiles_u;
+    const int m0 = tm * 16, u0 = tu * 4;
+    const int ub = u0 + (li & 3);
+    const bool okB = ub < g.Hd;
+    const int colB = (li >> 2) * g.Hd + ub;
+    const int rowA = m0 + li;
+    const bool okA = rowA < g.M;
+    // epilogue operands of thread (r, uu): fetched before the K loop so their round trip overlaps the operand loads
+    const int er = threadIdx.x >> 2, eu = u0 + (threadIdx.x & 3), em = m0 + er;
+    const bool e_ok = threadIdx.x < 64 && em < g.M && eu < g.Hd;
+    float e_gx[4] = {0.f, 0.f, 0.f, 0.f}, e_c = 0.f;
+    if (e_ok) {
+        const gcf gx = (gcf)g.gx + (size_t)em * g.ldgx + eu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_gx[q] = gx[(size_t)q * g.Hd];
+        e_c = ((gcf)g.c_prev)[(size_t)em * g.Hd + eu];
+    }
+    f32x4 acc[1][1];
+    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile16_kloop<KW, BF, false>(acc, (gcf)g.h_prev, g.Hd, rowA, okA, g.vecA != 0, (gcf)g.w_h, g.ldw, colB, okB, false, g.Hd,
+                                g.M, (li >> 2) * g.Hd + g.Hd - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_tile[wave][(4 * lg + r) * LDT + li] = acc[0][0][r];
+    __syncthreads();
+    if (e_ok) {
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = er * LDT + 4 * q + (threadIdx.x & 3);
+            pre[q] = ((s_tile[0][off] + s_tile[1][off]) + (s_tile[2][off] + s_tile[3][off])) + e_gx[q];
+        }
+        const float gi = sigmoid_acc(pre[0]);
+        const float gj = tanhf(pre[1]);
+        const float gf = sigmoid_acc(pre[2] + g.fb);
+        const float go = sigmoid_acc(pre[3]);
+        const float cn = gf * e_c + gi * gj;
+        const size_t e = (size_t)em * g.Hd + eu;
+        ((gf_t)g.c)[e] = cn;
+        ((gf_t)g.h)[e] = tanhf(cn) * go;
+        const gf_t ar = (gf_t)g.gate_act + (size_t)em * 4 * g.Hd + eu;
+        ar[0] = gi; ar[g.Hd] = gj; ar[2 * (size_t)g.Hd] = gf; ar[3 * (size_t)g.Hd] = go;
+    }
+}
+
+struct LstmBwdArgs {
+    const float *dgates_next, *w_h, *dh_a, *dh_b, *dc_in, *gate_act, *c_prev, *c, *dgx_in;
+    float *dgates, *dc_prev, *dgx_out;
+    int M, Hd, vecA, vecB;
+};
+// dh[m,u] = sum_k dgates_{t+1}[m,k] W_h[u,k]  (+ the direct dh terms of step t), then the pointwise backward of step t for
+// that (m,u): dgates_t (4 values), dc_{t-1}, and the running sum over time of dgates (what x.W_x receives) -- all
+// element-wise in (m,u), so the 16x16 output tile finishes everything it owns
+template <int KW, bool BF>
+__global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g) {
+    constexpr int LDT = 20;
+    __shared__ float s_tile[KW][16 * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_n = (g.Hd + 15) >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 16, n0 = tn * 16;
+    const int rowA = m0 + li, colB = n0 + li;
+    const bool okA = rowA < g.M, okB = colB < g.Hd;
+    const int K = 4 * g.Hd;
+    const int er = threadIdx.x >> 4, ec = threadIdx.x & 15, em = m0 + er, eu = n0 + ec;
+    const bool e_ok = threadIdx.x < 256 && em < g.M && eu < g.Hd;
+    float gi = 0.f, gj = 0.f, gff = 0.f, go = 0.f, cp = 0.f, cc = 0.f, dha = 0.f, dhb = 0.f, dci = 0.f, sx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e_ok) {
+        const size_t e = (size_t)em * g.Hd + eu;
+        const gcf ar = (gcf)g.gate_act + (size_t)em * K + eu;
+        gi = ar[0]; gj = ar[g.Hd]; gff = ar[2 * (size_t)g.Hd]; go = ar[3 * (size_t)g.Hd];
+        cp = ((gcf)g.c_prev)[e];
+        cc = ((gcf)g.c)[e];
+        if (g.dh_a) dha = ((gcf)g.dh_a)[e];
+        if (g.dh_b) dhb = ((gcf)g.dh_b)[e];
+        if (g.dc_in) dci = ((gcf)g.dc_in)[e];
+        if (g.dgx_in) {
+            const gcf sr = (gcf)g.dgx_in + (size_t)em * K + eu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sx[q] = sr[(size_t)q * g.Hd];
+        }
+    }
+    f32x4 acc[1][1];
+    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile16_kloop<KW, BF, true>(acc, (gcf)g.dgates_next, K, rowA, okA, g.vecA != 0, (gcf)g.w_h, K, colB, okB, g.vecB != 0, K,
+                               g.M, g.Hd - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_tile[wave][(4 * lg + r) * LDT + li] = acc[0][0][r];
+    __syncthreads();
+    if (e_ok) {
+        const int off = er * LDT + ec;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KW; q += 4)
+            v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
+        // same order as the unfused pair: the product accumulates ONTO the direct dh term (beta = 1), then + dh_b
+        const float dh = (v + dha) + dhb;
+        const float tc = tanhf(cc);
+        const float dct = dci + dh * go * (1.f - tc * tc);
+        float d[4];
+        d[0] = dct * gj * gi * (1.f - gi);
+        d[1] = dct * gi * (1.f - gj * gj);
+        d[2] = dct * cp * gff * (1.f - gff);
+        d[3] = dh * tc * go * (1.f - go);
+        const gf_t dr = (gf_t)g.dgates + (size_t)em * K + eu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dr[(size_t)q * g.Hd] = d[q];
+        ((gf_t)g.dc_prev)[(size_t)em * g.Hd + eu] = dct * gff;
+        if (g.dgx_out) {
+            const gf_t so = (gf_t)g.dgx_out + (size_t)em * K + eu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) so[(size_t)q * g.Hd] = sx[q] + d[q];
+        }
+    }
+}
+
+template <bool BF>
+static int lstm_fwd_launch(const LstmFwdArgs &g, hipStream_t st) {
+    const int tiles = air_cdiv(g.M, 16) * air_cdiv(g.Hd, 4);
+    hipLaunchKernelGGL((lstm_fwd_fused_kernel<BF>), dim3(tiles), dim3(256), 0, st, g);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_lstm_step_fwd(const float *h_prev, const float *c_prev, const float *w_h, int ldw, const float *gx,
+                                 int ldgx, float *h, float *c, float *gate_act, int M, int Hd, float forget_bias,
+                                 int precision, void *stream) {
+    AIR_REQUIRE(h_prev && c_prev && w_h && gx && h && c && gate_act, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0 && ldw >= 4 * Hd && ldgx >= 4 * Hd, AIR_E_SHAPE);
+    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+    LstmFwdArgs g;
+    g.h_prev = h_prev; g.w_h = w_h; g.gx = gx; g.c_prev = c_prev; g.h = h; g.c = c; g.gate_act = gate_act;
+    g.M = M; g.Hd = Hd; g.ldw = ldw; g.ldgx = ldgx; g.fb = forget_bias;
+    g.vecA = ((Hd % 4) == 0 && air_aligned16(h_prev)) ? 1 : 0;
+    return precision == AIR_PREC_BF16 ? lstm_fwd_launch<true>(g, air_stream(stream))
+                                      : lstm_fwd_launch<false>(g, air_stream(stream));
+}
+
+template <bool BF>
+static int lstm_bwd_launch(const LstmBwdArgs &g, hipStream_t st) {
+    const int tiles = air_cdiv(g.M, 16) * air_cdiv(g.Hd, 16);
+    // few tiles (batch 64: 64 of them): 16 waves share the 4Hd-deep contraction of a tile; many tiles: 4 waves
+    if (tiles <= 512) hipLaunchKernelGGL((lstm_bwd_fused_kernel<16, BF>), dim3(tiles), dim3(1024), 0, st, g);
+    else hipLaunchKernelGGL((lstm_bwd_fused_kernel<4, BF>), dim3(tiles), dim3(256), 0, st, g);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_lstm_step_bwd(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
+                                 const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
+                                 const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd,
+                                 int precision, void *stream) {
+    AIR_REQUIRE(dgates_next && w_h && gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
+    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+    LstmBwdArgs g;
+    g.dgates_next = dgates_next; g.w_h = w_h; g.dh_a = dh_a; g.dh_b = dh_b; g.dc_in = dc_in; g.gate_act = gate_act;
+    g.c_prev = c_prev; g.c = c; g.dgx_in = dgx_in; g.dgates = dgates; g.dc_prev = dc_prev; g.dgx_out = dgx_out;
+    g.M = M; g.Hd = Hd;
+    g.vecA = air_aligned16(dgates_next) ? 1 : 0;          // row stride 4*Hd floats is always a multiple of 16 bytes
+    g.vecB = air_aligned16(w_h) ? 1 : 0;
+    return precision == AIR_PREC_BF16 ? lstm_bwd_launch<true>(g, air_stream(stream))
+                                      : lstm_bwd_launch<false>(g, air_stream(stream));
 }
 
 // ---- linear layer wrappers (neural.py:56-60) ------------------------------------------------------------------

@@ -317,9 +317,9 @@ __global__ __launch_bounds__(PW_THREADS) void baseline_pack_kernel(const float *
 extern "C" int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
                                  const float *state0, const float *state1, float *out, int T, int B, int P, int A,
                                  int S0, int S1, void *stream) {
-    AIR_REQUIRE(img && what && where && presence && out, AIR_E_NULL);
-    AIR_REQUIRE((S0 == 0 || state0) && (S1 == 0 || state1), AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && B > 0 && P > 0 && A > 0 && S0 >= 0 && S1 >= 0, AIR_E_SHAPE);
+    AIR_REQUIRE(what && where && presence && out, AIR_E_NULL);
+    AIR_REQUIRE((P == 0 || img) && (S0 == 0 || state0) && (S1 == 0 || state1), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && P >= 0 && A > 0 && S0 >= 0 && S1 >= 0, AIR_E_SHAPE);
     const size_t n = (size_t)B * (P + T * A + T * 4 + T + S0 + S1);
     hipLaunchKernelGGL(baseline_pack_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), img, what,
                        where, presence, state0, state1, out, T, B, P, A, S0, S1);

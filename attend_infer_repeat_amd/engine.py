@@ -247,7 +247,7 @@ class AIREngine:
         self.step_dev = b("global_step", (1,), torch.int64)
         self.enc = _Mlp(self, "input_encoder", B, P, cfg.inpt_encoder_hidden, None)
         self.gx = b("gx", (B, 4 * Hd))
-        self.gates = b("gates", (T, B, 4 * Hd)); self.gate_act = b("gate_act", (T, B, 4 * Hd))
+        self.gate_act = b("gate_act", (T, B, 4 * Hd))
         self.h_seq = b("h_seq", (T + 1, B, Hd)); self.c_seq = b("c_seq", (T + 1, B, Hd))
         self.tr = _Mlp(self, "transform", M, Hd, cfg.transform_estimator_hidden, 8)
         self.st = _Mlp(self, "steps", M, Hd, cfg.steps_pred_hidden, 1)
@@ -264,7 +264,11 @@ class AIREngine:
         self.final_canvas = b("final_canvas", (B, P)); self.rec = b("rec", (B,))
         self.q_n = b("q_n", (B, T + 1)); self.kl_n = b("kl_n", (B,)); self.logp = b("logp", (B,))
         self.step_w = b("step_w", (T, B))
-        self.base_in = b("base_in", (B, cfg.baseline_in))
+        # baseline input [obs | what | where | presence | h | c] (modules.py:131-139) is never materialised: the obs columns
+        # of the first layer are multiplied straight from obs (in the same launch as the input encoder's first layer),
+        # only the latent columns are packed
+        self.base_lat = b("base_lat", (B, cfg.baseline_in - P))
+        self.bl_obs = b("bl_obs", (B, _mlp_shapes(cfg.baseline_in, cfg.baseline_hidden, 1)[0][1]))
         self.bl = _Mlp(self, "baseline", B, cfg.baseline_in, cfg.baseline_hidden, 1)
         self.nvil_out = b("nvil_out", (4,)); self.dlogp = b("dlogp", (B,)); self.dbase = b("dbase", (B,))
         # backward scratch
@@ -296,6 +300,7 @@ class AIREngine:
         prec = 1 if cfg.mfma_dtype == "bf16" else 0
         self._keep = []
         NONE, BIAS, BELU, MDELU, ADDAUX = H.EPI_NONE, H.EPI_BIAS, H.EPI_BIAS_ELU, H.EPI_MUL_DELU, H.EPI_ADD_AUX
+        ADDAUX_ELU = H.EPI_ADD_AUX_ELU
         dp = lambda t: (t.data_ptr() if t is not None else None)
 
         def desc(ta, tb, Mm, Nn, Kk, Aa, lda, Bb, ldb, Cc, ldc, bias=None, epi=NONE, aux=None, ldaux=0, beta=0.0,
@@ -358,6 +363,11 @@ class AIREngine:
                         continue
                     k, n = m.shapes[i]
                     g = gcur[id(m)]
+                    if i == 0 and "x_parts" in c:           # first layer fed by a concat: one dW problem per part
+                        for j, (xp, ldp, k0, kn) in enumerate(c["x_parts"]):
+                            descs.append(desc(1, 0, kn, n, m.rows, xp, ldp, g, n, m.dw[0][k0:k0 + kn], n,
+                                              colsum=m.db[0] if j == 0 else None))
+                        continue
                     xin, ld_in = (m.out[i - 1], m.shapes[i - 1][1]) if i > 0 else (c["x"], c["ldx"])
                     descs.append(desc(1, 0, k, n, m.rows, xin, ld_in, g, n, m.dw[i], n, colsum=m.db[i]))
                     if i > 0:
@@ -389,12 +399,36 @@ class AIREngine:
                      float(cfg.nsp_steps_div), p(self.prior_dev), T, p(self.params["lstm/h0"]),
                      p(self.params["lstm/c0"]), p(self.h_seq[0]), p(self.c_seq[0]), B, Hd), "air_step_prologue")
 
-        mlp_fwd_multi(fwd, [(self.enc, self.obs, P)], splitk_first=True)                    # cell.py:125 (hoisted)
+        # cell.py:125 (hoisted out of the time loop) + the obs columns of the baseline's first layer (modules.py:131-143):
+        # both contract over the P pixels of obs
+        lvl0 = [fwd_desc(self.enc, 0, self.obs, P)]
+        if cfg.use_reinforce:
+            n0 = self.bl.shapes[0][1]
+            lvl0.append(desc(0, 0, B, n0, P, self.obs, P, self.bl.w[0][:P], n0, self.bl_obs, n0, bias=self.bl.b[0],
+                             epi=BIAS))
+        if ((B + 15) // 16) * ((max(d.N for d in lvl0) + 15) // 16) <= 256:
+            launch(fwd, lvl0)                               # few tiles: one launch, 16 waves per tile share the long K
+        else:
+            for d in lvl0:
+                launch(fwd, [d], allow_splitk=True)
+        for i in range(1, self.enc.n):
+            launch(fwd, [fwd_desc(self.enc, i, None, 0)])
         enc_out, E = self.enc.out[-1], self.enc.shapes[-1][1]
         wg, bg = self.params["lstm/w_gates"], self.params["lstm/b_gates"]
         w_x, w_h = wg[:E], wg[E:]
         launch(fwd, [desc(0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)])
+        # Recurrent product + gate math in ONE launch per step while the chain is latency bound (it is the only truly
+        # sequential part of the step); at large batch the 32x32-tile GEMM + a pointwise pass re-reads less (measured:
+        # B=1024 0.938 vs 0.954 ms/step), so the pair is kept there.
+        fuse_lstm = ((B + 15) // 16) * ((Hd + 15) // 16) <= 512
+        if not fuse_lstm:
+            self.gates = self._buf("gates", (T, B, 4 * Hd))
         for t in range(T):                                                                  # cell.py:126-127
+            if fuse_lstm:
+                fwd.append((L.air_lstm_step_fwd, (p(self.h_seq[t]), p(self.c_seq[t]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,
+                                                  p(self.h_seq[t + 1]), p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd,
+                                                  1.0, prec), "air_lstm_step_fwd"))
+                continue
             launch(fwd, [desc(0, 0, B, 4 * Hd, Hd, self.h_seq[t], Hd, w_h, 4 * Hd, self.gates[t], 4 * Hd, epi=ADDAUX,
                               aux=self.gx, ldaux=4 * Hd)])
             fwd.append((L.air_lstm_pointwise_fwd, (p(self.gates[t]), p(self.c_seq[t]), p(self.h_seq[t + 1]),
@@ -421,11 +455,15 @@ class AIREngine:
                                              wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale), p(self.what),
                                              p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
         if cfg.use_reinforce:                                                               # model.py:218-259
-            fwd.append((L.air_baseline_pack, (p(self.obs), p(self.what), p(self.where), p(self.presence),
-                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_in), T, B, P, A, Hd,
+            KL = cfg.baseline_in - P
+            fwd.append((L.air_baseline_pack, (None, p(self.what), p(self.where), p(self.presence),
+                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_lat), T, B, 0, A, Hd,
                                               Hd), "air_baseline_pack"))
-            launch(fwd, [fwd_desc(self.bl, 0, self.base_in, cfg.baseline_in)], allow_splitk=True)
-            launch(fwd, [fwd_desc(self.gd, 0, self.what, A)])                               # cell.py:158
+            n0 = self.bl.shapes[0][1]
+            launch(fwd, [desc(0, 0, B, n0, KL, self.base_lat, KL, self.bl.w[0][P:], n0, self.bl.out[0], n0,
+                              epi=ADDAUX_ELU if self.bl.n > 1 or not self.bl.last_linear else ADDAUX,
+                              aux=self.bl_obs, ldaux=n0),
+                         fwd_desc(self.gd, 0, self.what, A)])                               # cell.py:158
             depth = max(self.gd.n, self.bl.n)
             for i in range(1, depth):
                 launch(fwd, [fwd_desc(m, i, None, 0) for m in (self.gd, self.bl) if i < m.n])
@@ -449,7 +487,8 @@ class AIREngine:
                     "air_canvas_unroll_bwd"))
         chains = [dict(m=self.gd, x=self.what, ldx=A, g_last=self.gd.g[-1], dx_out=self.d_what)]
         if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
-            chains.append(dict(m=self.bl, x=self.base_in, ldx=cfg.baseline_in, g_last=self.dbase))
+            chains.append(dict(m=self.bl, g_last=self.dbase,
+                               x_parts=[(self.obs, P, 0, P), (self.base_lat, cfg.baseline_in - P, P, cfg.baseline_in - P)]))
         mlp_bwd_multi(bwd, chains)
         marks = [(len(bwd), "glimpse_decoder/0/w")]      # gradients of [glimpse_decoder .. baseline] are final here
         bwd.append((L.air_gauss_sample_bwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
@@ -478,23 +517,33 @@ class AIREngine:
         # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)
         gw = self.grads["lstm/w_gates"]
         dc_in, dc_out = None, self.dc_a
+        dgx = self.dgx if T > 1 else self.dgates[0]            # sum over time of dgates (what the hoisted x.W_x receives)
         for t in reversed(range(T)):
-            bwd.append((L.air_lstm_pointwise_bwd, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
-                                                   p(self.dH[t]), p(self.dH_b[t]),
-                                                   p(dc_in) if dc_in is not None else None,
-                                                   p(self.dgates[t]), p(dc_out), B, Hd), "air_lstm_pointwise_bwd"))
-            if t > 0:
-                launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, self.dH[t - 1], Hd,
-                                  beta=1.0)])
+            if t == T - 1 or not fuse_lstm:
+                bwd.append((L.air_lstm_pointwise_bwd, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
+                                                       p(self.dH[t]), p(self.dH_b[t]),
+                                                       p(dc_in) if dc_in is not None else None,
+                                                       p(self.dgates[t]), p(dc_out), B, Hd), "air_lstm_pointwise_bwd"))
+                if not fuse_lstm and t > 0:    # dgates_t . W_h^T accumulates into dH[t-1] (beta = 1)
+                    launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, self.dH[t - 1], Hd,
+                                      beta=1.0)])
+            else:
+                # one BPTT link per launch: dgates_{t+1}.W_h^T + direct dh terms -> gate backward of step t -> running dgx
+                bwd.append((L.air_lstm_step_bwd, (p(self.dgates[t + 1]), p(w_h), p(self.dH[t]), p(self.dH_b[t]), p(dc_in),
+                                                  p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
+                                                  p(self.dgates[T - 1]) if t == T - 2 else p(self.dgx),
+                                                  p(self.dgates[t]), p(dc_out), p(self.dgx), B, Hd, prec),
+                            "air_lstm_step_bwd"))
             dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
-        bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
-                    "air_sum_leading"))
+        if not fuse_lstm and T > 1:
+            bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
+                        "air_sum_leading"))
         launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[0], 4 * Hd, w_h, 4 * Hd, self.dh_init, Hd),   # d h_{-1}
-                     desc(0, 1, B, E, 4 * Hd, self.dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
+                     desc(0, 1, B, E, 4 * Hd, dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
                           ldaux=E)])                                                         # d enc_out (pre-activation)
         launch(bwd, [desc(1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
                           colsum=self.grads["lstm/b_gates"]),                                # dW_h, db_gates
-                     desc(1, 0, E, 4 * Hd, B, enc_out, E, self.dgx, 4 * Hd, gw[:E], 4 * Hd)])  # dW_x
+                     desc(1, 0, E, 4 * Hd, B, enc_out, E, dgx, 4 * Hd, gw[:E], 4 * Hd)])  # dW_x
         self._lstm_tail = [desc(1, 0, 1, Hd, B, self.ones_b, 1, self.dh_init, Hd, self.grads["lstm/h0"], Hd),   # dh0
                            desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)]          # dc0
         mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail)

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_ELU = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_ELU, EPI_MUL_DELU, EPI_ADD_AUX = 0, 1, 2, 3, 4
+EPI_NONE, EPI_BIAS, EPI_BIAS_ELU, EPI_MUL_DELU, EPI_ADD_AUX, EPI_ADD_AUX_ELU = 0, 1, 2, 3, 4, 5
 
 _WS = {}
 _WS_BYTES = 64 << 20
@@ -208,6 +208,31 @@ def lstm_pointwise_bwd(gate_act, c_prev, c, dh, dc):
     _lib.check(lib().air_lstm_pointwise_bwd(_p(gate_act), _p(c_prev), _p(c), _p(dh), None, _p(dc), _p(dgates),
                                             _p(dc_prev), M, Hd, _stream()), "air_lstm_pointwise_bwd")
     return dgates, dc_prev
+
+
+def lstm_step_fwd(h_prev, c_prev, w_h, gx, forget_bias=1.0, precision=0):
+    """fused recurrent product + gate math: (h, c, gate_act) from h_prev[M,Hd], c_prev[M,Hd], w_h[Hd,4Hd], gx[M,4Hd]"""
+    h_prev = _f32(h_prev, "h_prev", 2); c_prev = _f32(c_prev, "c_prev", 2); gx = _f32(gx, "gx", 2)
+    if not (w_h.is_cuda and w_h.dtype == torch.float32 and w_h.dim() == 2 and w_h.stride(1) == 1):
+        raise ValueError("w_h must be a row-major fp32 CUDA matrix (row stride allowed)")
+    M, Hd = c_prev.shape
+    h = torch.empty_like(c_prev); c = torch.empty_like(c_prev); act = torch.empty_like(gx)
+    _lib.check(lib().air_lstm_step_fwd(_p(h_prev), _p(c_prev), _p(w_h), w_h.stride(0), _p(gx), gx.stride(0), _p(h), _p(c),
+                                       _p(act), M, Hd, float(forget_bias), int(precision), _stream()), "air_lstm_step_fwd")
+    return h, c, act
+
+
+def lstm_step_bwd(dgates_next, w_h, dh_a, dh_b, dc_in, gate_act, c_prev, c, dgx_in=None, want_dgx=False, precision=0):
+    """fused BPTT link: dh = dgates_next . w_h^T + dh_a + dh_b, then the pointwise backward -> dgates, dc_prev[, dgx]"""
+    dgates_next = _f32(dgates_next, "dgates_next", 2); w_h = _f32(w_h, "w_h", 2)
+    gate_act = _f32(gate_act, "gate_act", 2); c_prev = _f32(c_prev, "c_prev", 2); c = _f32(c, "c", 2)
+    M, Hd = c_prev.shape
+    dgates = torch.empty_like(gate_act); dc_prev = torch.empty_like(c_prev)
+    dgx = torch.empty_like(gate_act) if want_dgx else None
+    _lib.check(lib().air_lstm_step_bwd(_p(dgates_next), _p(w_h), _p(dh_a), _p(dh_b), _p(dc_in), _p(gate_act), _p(c_prev),
+                                       _p(c), _p(dgx_in), _p(dgates), _p(dc_prev), _p(dgx), M, Hd, int(precision),
+                                       _stream()), "air_lstm_step_bwd")
+    return dgates, dc_prev, dgx
 
 
 # ---- stochastic nodes ----------------------------------------------------------------------------------------------

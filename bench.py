@@ -110,10 +110,14 @@ def gemm_roofline(eng, reps=50):
     flops, us, launches = 0.0, 0.0, 0
     for plan in (eng._plan_fwd_noise, eng._plan_bwd):
         for fn, a, name in plan:
-            if name == "air_gemm":
+            if name in ("air_gemm", "air_gemm_bf16"):
                 f = 2.0 * a[2] * a[3] * a[4]
             elif name == "air_gemm_grouped":
                 f = sum(2.0 * d.M * d.N * d.K for d in a[0])
+            elif name == "air_lstm_step_fwd":                      # h[M,Hd] . W_h[Hd,4Hd] with the gate math fused
+                f = 2.0 * a[9] * a[10] * 4 * a[10]
+            elif name == "air_lstm_step_bwd":                      # dgates[M,4Hd] . W_h^T
+                f = 2.0 * a[12] * a[13] * 4 * a[13]
             else:
                 continue
             flops += f
@@ -138,7 +142,7 @@ def plan_breakdown(eng, reps=100):
         for i, (fn, a, name) in enumerate(plan):
             ms = event_time_ms(lib, sp, lambda: fn(*a, sp), reps)
             desc = ""
-            if name == "air_gemm":
+            if name in ("air_gemm", "air_gemm_bf16"):
                 desc = f"ta={a[0]} tb={a[1]} M={a[2]} N={a[3]} K={a[4]} epi={a[12]}"
             elif name == "air_gemm_grouped":
                 desc = " | ".join(f"{'T' if d.ta else 'N'}{'T' if d.tb else 'N'} {d.M}x{d.N}x{d.K}" for d in a[0])

@@ -42,7 +42,8 @@ enum {
     AIR_EPI_BIAS = 1,        /* + bias[n]                                    snt.Linear, neural.py:56-60          */
     AIR_EPI_BIAS_ELU = 2,    /* elu(acc + bias[n])                           Affine(transfer=elu), neural.py:58-59 */
     AIR_EPI_MUL_DELU = 3,    /* acc * elu'(aux[m,n]) with aux = saved elu OUTPUT (y>0 ? 1 : y+1): backward of ELU  */
-    AIR_EPI_ADD_AUX = 4      /* acc + aux[m,n] (+ bias[n] if given)          LSTM: x.Wx hoisted, h.Wh added        */
+    AIR_EPI_ADD_AUX = 4,     /* acc + aux[m,n] (+ bias[n] if given)          LSTM: x.Wx hoisted, h.Wh added        */
+    AIR_EPI_ADD_AUX_ELU = 5  /* elu(acc + aux[m,n] (+ bias[n] if given))     layer whose input is a concat: parts summed */
 };
 
 int air_abi_version(void);
@@ -134,6 +135,22 @@ int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, fl
 int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
                            const float *dh2 /* optional second dh term, summed */, const float *dc, float *dgates,
                            float *dc_prev, int M, int Hd, void *stream);
+
+/* One LSTM time step with the gate math fused into the recurrent product (cell.py:126-127):
+ *   gates = h_prev[M,Hd] . w_h[Hd,4Hd](ldw) + gx[M,4Hd](ldgx)      (gx = x.W_x + b, hoisted out of the time loop)
+ *   then air_lstm_pointwise_fwd on `gates`; h, c [M,Hd] and gate_act [M,4Hd] are written, `gates` never exists.
+ * precision: AIR_PREC_F32 / AIR_PREC_BF16 for the product.                                                          */
+int air_lstm_step_fwd(const float *h_prev, const float *c_prev, const float *w_h, int ldw, const float *gx, int ldgx,
+                      float *h, float *c, float *gate_act, int M, int Hd, float forget_bias, int precision,
+                      void *stream);
+/* One BPTT link: dh = dgates_next[M,4Hd] . w_h[Hd,4Hd]^T + dh_a + dh_b (either may be NULL), then
+ * air_lstm_pointwise_bwd of the step that gate_act / c_prev / c belong to -> dgates[M,4Hd], dc_prev[M,Hd]; and, if
+ * dgx_out != NULL, dgx_out = dgx_in + dgates (the running sum over time that the hoisted x.W_x product receives;
+ * dgx_in may alias dgates_next or dgx_out, NULL = 0).                                                                */
+int air_lstm_step_bwd(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
+                      const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
+                      const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
+                      void *stream);
 
 /* ---- stochastic nodes ---------------------------------------------------------------------------------------*/
 
@@ -242,7 +259,8 @@ int air_nvil(const float *imp, const float *baseline, const float *logp, float *
 
 /* Baseline input assembly, modules.py:131-139: out[B, HW + T*A + T*4 + T + S] =
  * [img | what (batch-major) | where | presence | state] from time-major what[T,B,A], where[T,B,4], presence[T,B],
- * state[B,S] = concat of up to two state parts (h, c).                                                              */
+ * state[B,S] = concat of up to two state parts (h, c).  HW may be 0 (img NULL): only the latent columns are packed
+ * (the engine multiplies the image part of the first baseline layer straight from obs).                             */
 int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
                       const float *state0, const float *state1, float *out, int T, int B, int P, int A, int S0,
                       int S1, void *stream);

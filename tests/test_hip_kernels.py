@@ -255,6 +255,66 @@ def test_lstm_pointwise(hip):
     assert_close(dgates, gg, 1e-4, 1e-5, "dgates"); assert_close(dc_prev, gc, 1e-4, 1e-5, "dc_prev")
 
 
+@pytest.mark.parametrize("M,Hd", [(64, 256), (37, 50), (5, 7), (130, 40), (1024, 256)])
+def test_lstm_fused_step_matches_unfused_pair_and_fp64(hip, M, Hd):
+    """air_lstm_step_fwd / _bwd = recurrent product + gate math in one launch; must equal GEMM + pointwise (bitwise: same
+    K order, same reduction tree) and the fp64 formula."""
+    gen = torch.Generator().manual_seed(M * 7 + Hd)
+    h0 = torch.randn(M, Hd, generator=gen) * 0.5; c0 = torch.randn(M, Hd, generator=gen)
+    w_full = torch.randn(Hd + 3, 4 * Hd, generator=gen) / Hd ** 0.5
+    gx = torch.randn(M, 4 * Hd, generator=gen)
+    w_h_dev = w_full.cuda()[3:]                                     # row-offset view, like the engine's w_gates[E:]
+    h, c, act = hip.lstm_step_fwd(h0.cuda(), c0.cuda(), w_h_dev, gx.cuda(), 1.0)
+    g64 = h0.double() @ w_full[3:].double() + gx.double()
+    i, j, f, o = torch.chunk(g64, 4, -1)
+    c2 = torch.sigmoid(f + 1.0) * c0.double() + torch.sigmoid(i) * torch.tanh(j)
+    h2 = torch.tanh(c2) * torch.sigmoid(o)
+    assert_close(h, h2, 2e-5, 2e-5, "h"); assert_close(c, c2, 2e-5, 2e-5, "c")
+    gates = hip.gemm(h0.cuda(), w_h_dev, epilogue=hip.EPI_ADD_AUX, aux=gx.cuda())
+    hu, cu, actu = hip.lstm_pointwise_fwd(gates, c0.cuda(), 1.0)
+    assert_close(h, hu, 1e-6, 1e-6, "h vs unfused"); assert_close(act, actu, 1e-6, 1e-6, "act vs unfused")
+
+    # backward link: dh = dgn . W_h^T + dh_a + dh_b, then the pointwise backward of (act, c0, c)
+    dgn = torch.randn(M, 4 * Hd, generator=gen) * 0.3
+    dh_a = torch.randn(M, Hd, generator=gen); dh_b = torch.randn(M, Hd, generator=gen); dc = torch.randn(M, Hd, generator=gen)
+    dgx_in = torch.randn(M, 4 * Hd, generator=gen)
+    w_h_c = w_h_dev.contiguous()
+    dg, dcp, dgx = hip.lstm_step_bwd(dgn.cuda(), w_h_c, dh_a.cuda(), dh_b.cuda(), dc.cuda(), act, c0.cuda(), c,
+                                     dgx_in=dgx_in.cuda(), want_dgx=True)
+    dh_tot = dgn.double() @ w_full[3:].double().t() + dh_a.double() + dh_b.double()
+    a64 = act.cpu().double(); gi, gj, gf, go = torch.chunk(a64, 4, -1)
+    tc = torch.tanh(c.cpu().double())
+    dct = dc.double() + dh_tot * go * (1 - tc * tc)
+    ref = torch.cat([dct * gj * gi * (1 - gi), dct * gi * (1 - gj * gj), dct * c0.double() * gf * (1 - gf),
+                     dh_tot * tc * go * (1 - go)], -1)
+    assert_close(dg, ref, 1e-4, 2e-5, "dgates"); assert_close(dcp, dct * gf, 1e-4, 2e-5, "dc_prev")
+    assert_close(dgx, dgx_in.double() + ref, 1e-4, 2e-5, "dgx")
+    # NULL optional terms
+    dg2, dcp2, none = hip.lstm_step_bwd(dgn.cuda(), w_h_c, None, None, None, act, c0.cuda(), c)
+    dh0 = dgn.double() @ w_full[3:].double().t()
+    assert none is None
+    assert_close(dcp2, dh0 * go * (1 - tc * tc) * gf, 1e-4, 2e-5, "dc_prev (no dh/dc terms)")
+
+
+def test_lstm_fused_step_bf16(hip):
+    gen = torch.Generator().manual_seed(3)
+    M, Hd = 48, 64
+    r16 = lambda t: t.to(torch.bfloat16).double()
+    h0 = torch.randn(M, Hd, generator=gen); c0 = torch.randn(M, Hd, generator=gen)
+    w = torch.randn(Hd, 4 * Hd, generator=gen) / 8; gx = torch.randn(M, 4 * Hd, generator=gen)
+    h, c, act = hip.lstm_step_fwd(h0.cuda(), c0.cuda(), w.cuda(), gx.cuda(), 1.0, precision=1)
+    g64 = r16(h0) @ r16(w) + gx.double()
+    i, j, f, o = torch.chunk(g64, 4, -1)
+    c2 = torch.sigmoid(f + 1.0) * c0.double() + torch.sigmoid(i) * torch.tanh(j)
+    assert_close(c, c2, 2e-5, 2e-5, "c (bf16 operands)")
+    dgn = torch.randn(M, 4 * Hd, generator=gen)
+    dg, dcp, _ = hip.lstm_step_bwd(dgn.cuda(), w.cuda(), None, None, None, act, c0.cuda(), c, precision=1)
+    dh0 = r16(dgn) @ r16(w).t()
+    a64 = act.cpu().double(); gi, gj, gf, go = torch.chunk(a64, 4, -1)
+    tc = torch.tanh(c.cpu().double())
+    assert_close(dcp, dh0 * go * (1 - tc * tc) * gf, 1e-4, 2e-5, "dc_prev (bf16 operands)")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # stochastic nodes + objective
 # ---------------------------------------------------------------------------------------------------------------
