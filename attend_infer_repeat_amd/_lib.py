@@ -33,6 +33,8 @@ SIGNATURES = {
                                       c_float, P]),
     "air_canvas_unroll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_float, c_float, P]),
+    "air_canvas_unroll_bwd_nvil": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_float, c_float, P, P, P, P, P, P, P]),
     "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
                          c_float, P, P, c_size_t, P]),
     "air_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
@@ -41,6 +43,8 @@ SIGNATURES = {
     "air_gemm_grouped": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, P]),
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "air_what_sample_pack": (c_int, [P, c_int, P, c_float, c_float, c_float, P, P, P, P, c_int, P, P, P, P, P,
+                                     c_int, c_int, c_int, c_int, P]),
     "air_lstm_step_fwd": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int, P]),
     "air_lstm_step_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),

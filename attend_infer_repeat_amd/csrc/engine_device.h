@@ -21,7 +21,10 @@ __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const floa
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                float *__restrict__ loc, float *__restrict__ scale,
                                                                float *__restrict__ sample, float *__restrict__ kl_row,
-                                                               int M, int D) {
+                                                               int M, int D, float *__restrict__ sample_bm = nullptr,
+                                                               int B_bm = 1, int ld_bm = 0) {
+    // sample_bm (optional): a second, batch-major copy of the sample -- row m = t*B_bm + b lands at
+    // sample_bm[b*ld_bm + t*D + d] (the `what` columns of the baseline input, modules.py:131-139)
     const int lane = threadIdx.x & 63;
     const int wave_global = (int)((vblock * (size_t)PW_THREADS + threadIdx.x) >> 6);
     const int nwaves = (vgrid * PW_THREADS) >> 6;
@@ -34,7 +37,11 @@ __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const floa
             const float s = softplus_acc(pr[D + d] + raw_offset);
             const size_t o = (size_t)m * D + d;
             loc[o] = mu; scale[o] = s;
-            if (sample) sample[o] = mu + s * eps[o];
+            if (sample) {
+                const float v = mu + s * eps[o];
+                sample[o] = v;
+                if (sample_bm) { const int t = m / B_bm, b = m - t * B_bm; sample_bm[(size_t)b * ld_bm + t * D + d] = v; }
+            }
             kl += (d & 1) ? normal_kl(mu, s, pl1, ps1) : normal_kl(mu, s, pl0, ps0);
         }
         kl = wave_sum(kl);
@@ -65,6 +72,31 @@ __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const floa
         const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus
         dpre[m * ld_dpre + d] = dmu;
         dpre[m * ld_dpre + D + d] = dsc * dsp;
+    }
+}
+
+// Baseline input assembly (modules.py:131-139): out[B, P + T*A + T*4 + T + S0 + S1] = [img | what | where | presence | h | c]
+// from time-major what / where / presence; only columns >= c_begin are written (c_begin = P + T*A when the `what`
+// columns are filled by the sampling kernel itself).
+__device__ __forceinline__ void baseline_pack_body(int vblock, int vgrid, const float *__restrict__ img,
+                                                   const float *__restrict__ what, const float *__restrict__ where,
+                                                   const float *__restrict__ presence, const float *__restrict__ s0,
+                                                   const float *__restrict__ s1, float *__restrict__ out, int T, int B,
+                                                   int P, int A, int S0, int S1, int c_begin) {
+    const int width = P + T * A + T * 4 + T + S0 + S1, span = width - c_begin;
+    const size_t n = (size_t)B * span;
+    for (size_t e = (size_t)vblock * PW_THREADS + threadIdx.x; e < n; e += (size_t)vgrid * PW_THREADS) {
+        const size_t b = e / span;
+        const int col = c_begin + (int)(e - b * span);
+        int c = col;
+        float v;
+        if (c < P) v = img[b * P + c];
+        else if ((c -= P) < T * A) { const int t = c / A, a = c - t * A; v = what[((size_t)t * B + b) * A + a]; }
+        else if ((c -= T * A) < T * 4) { const int t = c / 4, a = c - t * 4; v = where[((size_t)t * B + b) * 4 + a]; }
+        else if ((c -= T * 4) < T) v = presence[(size_t)c * B + b];
+        else if ((c -= T) < S0) v = s0[b * S0 + c];
+        else v = s1[b * S1 + (c - S0)];
+        out[b * width + col] = v;
     }
 }
 

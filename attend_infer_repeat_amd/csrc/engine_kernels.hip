@@ -93,3 +93,36 @@ extern "C" int air_heads_bwd(const float *pre, int ld_pre, const float *eps, flo
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
+
+// ---- what ~ N(loc, softplus(raw + offset)) (cell.py:154-156) + KL rows, writing the sample twice: time-major for the
+// decoder and batch-major straight into the baseline input, whose remaining latent columns (where, presence, h, c -- all
+// final by now) are copied by a second group of workgroups.  Replaces air_gauss_sample_fwd + air_baseline_pack.
+__global__ __launch_bounds__(PW_THREADS) void what_sample_pack_kernel(
+    int gauss_blocks, const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, float raw_offset,
+    float pl, float ps, float *__restrict__ loc, float *__restrict__ scale, float *__restrict__ sample,
+    float *__restrict__ kl_row, int M, int D, const float *__restrict__ where, const float *__restrict__ presence,
+    const float *__restrict__ s0, const float *__restrict__ s1, float *__restrict__ pack, int T, int B, int S0, int S1) {
+    const int width = T * D + T * 4 + T + S0 + S1;
+    if ((int)blockIdx.x < gauss_blocks)
+        gauss_fwd_body(blockIdx.x, gauss_blocks, pre, ld_pre, eps, raw_offset, 0, pl, ps, pl, ps, loc, scale, sample, kl_row,
+                       M, D, pack, B, width);
+    else
+        baseline_pack_body(blockIdx.x - gauss_blocks, gridDim.x - gauss_blocks, nullptr, sample, where, presence, s0, s1,
+                           pack, T, B, 0, D, S0, S1, T * D);
+}
+
+extern "C" int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float raw_offset, float p_loc,
+                                    float p_scale, float *loc, float *scale, float *sample, float *kl_row, int D,
+                                    const float *where, const float *presence, const float *state0, const float *state1,
+                                    float *pack_out, int T, int B, int S0, int S1, void *stream) {
+    AIR_REQUIRE(pre && eps && loc && scale && sample && kl_row && where && presence && pack_out, AIR_E_NULL);
+    AIR_REQUIRE((S0 == 0 || state0) && (S1 == 0 || state1), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && D > 0 && ld_pre >= 2 * D && S0 >= 0 && S1 >= 0, AIR_E_SHAPE);
+    const int M = T * B;
+    const int gb = blocks_for((size_t)M * 64), pb = blocks_for((size_t)B * (T * 5 + S0 + S1));
+    hipLaunchKernelGGL(what_sample_pack_kernel, dim3(gb + pb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre, eps,
+                       raw_offset, p_loc, p_scale, loc, scale, sample, kl_row, M, D, where, presence, state0, state1,
+                       pack_out, T, B, S0, S1);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}

@@ -130,6 +130,7 @@ extern "C" int air_numsteps_bwd(const float *presence_prob, const float *presenc
 // Templated on a compile-time bound MT >= T so that every per-image array lives in registers (the generic kernels
 // above index float64 arrays dynamically and run out of scratch memory: ~10 us for 64 images).
 #include "engine_device.h"
+#include "nvil_device.h"
 template <int MT>
 __global__ __launch_bounds__(64) void presence_numsteps_fwd_kernel(
     const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float eps,
@@ -230,53 +231,13 @@ extern "C" int air_counter_add(int64_t *counter_dev, int64_t increment, void *st
 // ---- NVIL / REINFORCE (model.py:218-259) --------------------------------------------------------------------------
 // importance_weight[i,j] = imp[j] - baseline[i]  ([B]-[B,1] broadcast), so
 //   reinforce_loss = mean_j (imp_j - mean_i b_i) * logp_j ;  baseline_loss = 0.5 * mean_ij (imp_j - b_i)^2.
-__global__ __launch_bounds__(256) void nvil_kernel(const float *__restrict__ imp, const float *__restrict__ base,
-                                                   const float *__restrict__ logp, float *__restrict__ out,
-                                                   float *__restrict__ dlogp, float *__restrict__ dbase, int B) {
-    __shared__ double red[4][5];
-    __shared__ double tot[5];
-    double a[5] = {0, 0, 0, 0, 0};                  // sum imp, sum imp^2, sum b, sum b^2, sum imp*logp
-    double sl = 0.0;                                // sum logp
-    for (int i = threadIdx.x; i < B; i += 256) {
-        const double x = imp[i], b = base[i], l = logp[i];
-        a[0] += x; a[1] += x * x; a[2] += b; a[3] += b * b; a[4] += x * l; sl += l;
-    }
-    __shared__ double red_sl[4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) a[k] = wave_sum(a[k]);
-    sl = wave_sum(sl);
-    if (lane == 0) {
-        for (int k = 0; k < 5; ++k) red[wid][k] = a[k];
-        red_sl[wid] = sl;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t[5], tsl = 0.0;
-        for (int k = 0; k < 5; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-        tsl = red_sl[0] + red_sl[1] + red_sl[2] + red_sl[3];
-        const double n = (double)B;
-        const double mi = t[0] / n, mb = t[2] / n;
-        const double vi = t[1] / n - mi * mi, vb = t[3] / n - mb * mb;
-        out[0] = (float)((t[4] - mb * tsl) / n);                                  // reinforce_loss
-        out[1] = (float)(0.5 * (vi + vb + (mi - mb) * (mi - mb)));               // baseline_loss
-        out[2] = (float)(mi - mb);                                                // imp_weight_mean over [B,B]
-        out[3] = (float)(vi + vb);                                                // imp_weight_var  over [B,B]
-        tot[0] = mi; tot[1] = mb;
-    }
-    __syncthreads();
-    const double mi = tot[0], mb = tot[1];
-    for (int i = threadIdx.x; i < B; i += 256) {
-        if (dlogp) dlogp[i] = (float)(((double)imp[i] - mb) / (double)B);
-        if (dbase) dbase[i] = (float)(-(mi - (double)base[i]) / (double)B);
-    }
-}
+__global__ __launch_bounds__(256) void nvil_kernel(NvilArgs a) { nvil_body(a); }
 extern "C" int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
                         float *dbaseline, int B, void *stream) {
     AIR_REQUIRE(imp && baseline && logp && out, AIR_E_NULL);
     AIR_REQUIRE(B > 0, AIR_E_SHAPE);
-    hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), imp, baseline, logp, out, dlogp,
-                       dbaseline, B);
+    NvilArgs a = {imp, baseline, logp, out, dlogp, dbaseline, B};
+    hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -299,20 +299,7 @@ __global__ __launch_bounds__(PW_THREADS) void baseline_pack_kernel(const float *
                                                                    const float *__restrict__ s1,
                                                                    float *__restrict__ out, int T, int B, int P, int A,
                                                                    int S0, int S1) {
-    const int width = P + T * A + T * 4 + T + S0 + S1;
-    const size_t n = (size_t)B * width;
-    PW_LOOP(e, n) {
-        const size_t b = e / width;
-        int c = (int)(e - b * width);
-        float v;
-        if (c < P) v = img[b * P + c];
-        else if ((c -= P) < T * A) { const int t = c / A, a = c - t * A; v = what[((size_t)t * B + b) * A + a]; }
-        else if ((c -= T * A) < T * 4) { const int t = c / 4, a = c - t * 4; v = where[((size_t)t * B + b) * 4 + a]; }
-        else if ((c -= T * 4) < T) v = presence[(size_t)c * B + b];
-        else if ((c -= T) < S0) v = s0[b * S0 + c];
-        else v = s1[b * S1 + (c - S0)];
-        out[e] = v;
-    }
+    baseline_pack_body(blockIdx.x, gridDim.x, img, what, where, presence, s0, s1, out, T, B, P, A, S0, S1, 0);
 }
 extern "C" int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
                                  const float *state0, const float *state1, float *out, int T, int B, int P, int A,

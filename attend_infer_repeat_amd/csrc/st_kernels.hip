@@ -16,6 +16,7 @@
 #include <limits.h>
 #include <math.h>
 #include "air_common.h"
+#include "nvil_device.h"
 
 #define ST_THREADS 256
 #define ST_INVALID INT_MIN
@@ -382,14 +383,21 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
     float *__restrict__ dglimpse, float *__restrict__ dwhere, float *__restrict__ dpresence,
     int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, float loss_scale,
-    int vec4_glimpse) {
+    int vec4_glimpse, NvilArgs nv) {
     extern __shared__ __align__(16) float smem[];
+    // optional second role: the LAST workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
+    // has to precede the baseline / logit backward that follow this launch)
+    const int grid_st = nv.imp ? (int)gridDim.x - 1 : (int)gridDim.x;
+    if ((int)blockIdx.x >= grid_st) {
+        nvil_body(nv);
+        return;
+    }
     const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
     CarveBwd c = carve_bwd(smem, H, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
     const float coef = loss_scale * mult / (std * std);
     const int n = T * B;
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    for (int k = blockIdx.x; k < n; k += grid_st) {
         const int b = k % B;
         __syncthreads();
         stage_to_lds(c.src, glimpse + (size_t)k * hw, hw, vec4_glimpse != 0);
@@ -608,15 +616,17 @@ extern "C" int air_canvas_unroll_fwd(const float *glimpse, const float *where, c
 static int launch_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
                             const float *final_canvas, const float *obs, float *dglimpse, float *dwhere,
                             float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
-                            float loss_scale, void *stream) {
+                            float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
     const size_t lds = carve_bwd_bytes(H, W, h, w);
+    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (nvil) nv = *nvil;
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     { int st_ = st_allow_lds(st_write_bwd_kernel, lds); if (st_) return st_; }
     const int wr_threads = (long)B * T <= 4096 ? 1024 : ST_THREADS;
-    hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B)), dim3(wr_threads), lds, air_stream(stream), glimpse,
-                       where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
-                       lin_step(W), lin_step(H), mult, std, loss_scale, vec4g);
+    hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
+                       air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
+                       dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, nv);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -641,4 +651,19 @@ extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, c
     if (st) return st;
     return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
                             h, w, mult, std, loss_scale, stream);
+}
+
+extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence,
+                                          const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
+                                          int T, int B, int H, int W, int h, int w, float mult, float std,
+                                          float loss_scale, const float *imp, const float *baseline, const float *logp,
+                                          float *nvil_out, float *dlogp, float *dbaseline, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && final_canvas && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(imp && baseline && logp && nvil_out, AIR_E_NULL);
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    const NvilArgs nv = {imp, baseline, logp, nvil_out, dlogp, dbaseline, B};
+    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
+                            h, w, mult, std, loss_scale, stream, &nv);
 }

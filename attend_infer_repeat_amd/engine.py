@@ -349,7 +349,7 @@ class AIREngine:
                 else:
                     launch(plan, descs)
 
-        def mlp_bwd_multi(plan, chains, extra_first=()):
+        def mlp_bwd_multi(plan, chains, extra_first=(), extra_last=()):
             """chains: dicts(m, x, ldx, g_last, dx_out=None, dx_aux=None).  g_last = gradient wrt the last layer's
             pre-activation.  Per level one dispatch holding every chain's dW (+db) and dX."""
             depth = max(c["m"].n for c in chains)
@@ -380,6 +380,8 @@ class AIREngine:
                                           epi=MDELU if aux is not None else NONE, aux=aux, ldaux=k if aux is not None else 0))
                 if s_ == 0:
                     descs = list(extra_first) + descs
+                if s_ == depth - 1:
+                    descs = descs + list(extra_last)
                 launch(plan, descs)
 
         # ---- noise only (used when forward() is asked to keep injected noise: the prologue then draws nothing) -------
@@ -451,14 +453,13 @@ class AIREngine:
         launch(fwd, [desc(0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
                           bias=self.params["what/b"], epi=BIAS)])                           # modules.py:20-21
         wp = cfg.what_prior
-        fwd.append((L.air_gauss_sample_fwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
-                                             wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale), p(self.what),
-                                             p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
         if cfg.use_reinforce:                                                               # model.py:218-259
+            # sample `what` + assemble the latent columns of the baseline input in one launch
             KL = cfg.baseline_in - P
-            fwd.append((L.air_baseline_pack, (None, p(self.what), p(self.where), p(self.presence),
-                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_lat), T, B, 0, A, Hd,
-                                              Hd), "air_baseline_pack"))
+            fwd.append((L.air_what_sample_pack, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, wp[0], wp[1],
+                                                 p(self.what_loc), p(self.what_scale), p(self.what), p(self.kl_what_row),
+                                                 A, p(self.where), p(self.presence), p(self.h_seq[T]), p(self.c_seq[T]),
+                                                 p(self.base_lat), T, B, Hd, Hd), "air_what_sample_pack"))
             n0 = self.bl.shapes[0][1]
             launch(fwd, [desc(0, 0, B, n0, KL, self.base_lat, KL, self.bl.w[0][P:], n0, self.bl.out[0], n0,
                               epi=ADDAUX_ELU if self.bl.n > 1 or not self.bl.last_linear else ADDAUX,
@@ -468,23 +469,29 @@ class AIREngine:
             for i in range(1, depth):
                 launch(fwd, [fwd_desc(m, i, None, 0) for m in (self.gd, self.bl) if i < m.n])
         else:
+            fwd.append((L.air_gauss_sample_fwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
+                                                 wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale), p(self.what),
+                                                 p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
             mlp_fwd_multi(fwd, [(self.gd, self.what, A)])
         decoded = self.gd.out[-1]
         fwd.append((L.air_canvas_unroll_fwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
                                               p(self.canvas_steps), p(self.final_canvas), p(self.rec), T, B, Hi, Wi,
                                               hc, wc, cfg.output_multiplier, cfg.output_std),
                     "air_canvas_unroll_fwd"))                                               # cell.py:159-165, model.py:319-324
-        if cfg.use_reinforce:
-            fwd.append((L.air_nvil, (p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out), p(self.dlogp),
-                                     p(self.dbase), B), "air_nvil"))
+        # NVIL (model.py:218-259): forward() alone finishes with it so that outputs() is complete; a train step evaluates it
+        # as one extra workgroup of the canvas backward launch instead (independent work, one launch fewer)
+        nvil_args = (p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out), p(self.dlogp), p(self.dbase))
+        fwd_tail = [(L.air_nvil, nvil_args + (B,), "air_nvil")] if cfg.use_reinforce else []
 
         # ---- backward of opt_loss = mean(rec) + pw*(mean kl_n + mean sum_t w*(kl_what+kl_where)) + reinforce -------
         pw = 1.0 if cfg.use_prior else 0.0
         inv_b = 1.0 / B
-        bwd.append((L.air_canvas_unroll_bwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
-                                              p(self.final_canvas), p(self.gd.g[-1]), p(self.dwhere_w), T, B, Hi, Wi,
-                                              hc, wc, cfg.output_multiplier, cfg.output_std, inv_b),
-                    "air_canvas_unroll_bwd"))
+        cu_args = (p(decoded), p(self.where), p(self.presence), p(self.obs), p(self.final_canvas), p(self.gd.g[-1]),
+                   p(self.dwhere_w), T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std, inv_b)
+        if cfg.use_reinforce:
+            bwd.append((L.air_canvas_unroll_bwd_nvil, cu_args + nvil_args, "air_canvas_unroll_bwd_nvil"))
+        else:
+            bwd.append((L.air_canvas_unroll_bwd, cu_args, "air_canvas_unroll_bwd"))
         chains = [dict(m=self.gd, x=self.what, ldx=A, g_last=self.gd.g[-1], dx_out=self.d_what)]
         if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
             chains.append(dict(m=self.bl, g_last=self.dbase,
@@ -541,12 +548,15 @@ class AIREngine:
         launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[0], 4 * Hd, w_h, 4 * Hd, self.dh_init, Hd),   # d h_{-1}
                      desc(0, 1, B, E, 4 * Hd, dgx, 4 * Hd, w_x, 4 * Hd, self.enc.g[-1], E, epi=MDELU, aux=enc_out,
                           ldaux=E)])                                                         # d enc_out (pre-activation)
-        launch(bwd, [desc(1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
-                          colsum=self.grads["lstm/b_gates"]),                                # dW_h, db_gates
-                     desc(1, 0, E, 4 * Hd, B, enc_out, E, dgx, 4 * Hd, gw[:E], 4 * Hd)])  # dW_x
+        # dW_h (+ db_gates) and dW_x have no dependants before the optimiser: they ride along with the last launch of the
+        # chain (the input encoder's first-layer dW, another wide throughput-type problem) instead of costing their own
+        lstm_dw = [desc(1, 0, Hd, 4 * Hd, M, self.h_seq[:T], Hd, self.dgates, 4 * Hd, gw[E:], 4 * Hd,
+                        colsum=self.grads["lstm/b_gates"]),                                  # dW_h, db_gates
+                   desc(1, 0, E, 4 * Hd, B, enc_out, E, dgx, 4 * Hd, gw[:E], 4 * Hd)]        # dW_x
         self._lstm_tail = [desc(1, 0, 1, Hd, B, self.ones_b, 1, self.dh_init, Hd, self.grads["lstm/h0"], Hd),   # dh0
                            desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)]          # dc0
-        mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail)
+        mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail,
+                      extra_last=lstm_dw)
 
         # ---- optimiser: both centred-RMSProp updates + device counters in one launch ---------------------------------
         tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
@@ -557,8 +567,9 @@ class AIREngine:
                                    p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
              "air_step_epilogue")]
         self._plan_rng = rng
-        self._plan_fwd_noise = [prologue(True)] + fwd
-        self._plan_fwd = [prologue(False)] + fwd
+        self._plan_fwd_noise = [prologue(True)] + fwd + fwd_tail      # forward(): complete outputs
+        self._plan_fwd = [prologue(False)] + fwd + fwd_tail
+        self._plan_fwd_train = [prologue(True)] + fwd                 # train step: NVIL rides in the first backward launch
         self._plan_bwd = bwd
         # data-parallel gradient buckets: (end index in the backward plan, [lo, hi) slice of the flat gradient buffer that
         # is final once the plan has run up to that index); contiguous, from the tail of the buffer to its head
@@ -650,7 +661,7 @@ class AIREngine:
         if bucketed:
             segs, start = [], 0
             for i, (end, lo, hi) in enumerate(self._grad_buckets):
-                plans = ([self._plan_fwd_noise] if i == 0 else []) + [self._plan_bwd[start:end]]
+                plans = ([self._plan_fwd_train] if i == 0 else []) + [self._plan_bwd[start:end]]
                 segs.append((self._capture_plans(plans), lo, hi))
                 start = end
             self._graph_segments = segs
@@ -658,7 +669,7 @@ class AIREngine:
             self._graph_has_opt = False
             self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
             return
-        self._graph = self._capture_plans([self._plan_fwd_noise, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
+        self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
         self._graph_has_opt = not split_optimizer
         if split_optimizer:
             self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
@@ -701,7 +712,7 @@ class AIREngine:
                         allreduce(self.flat_grads)
                 _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
         else:
-            self._run(self._plan_fwd_noise, sp)
+            self._run(self._plan_fwd_train, sp)
             self._run(self._plan_bwd, sp)
             if allreduce is not None:
                 with torch.cuda.stream(self.stream):
@@ -779,4 +790,4 @@ class AIREngine:
         return dict(self.grads)
 
     def kernel_launch_count(self) -> Dict[str, int]:
-        return {"forward": len(self._plan_fwd_noise), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}
+        return {"forward": len(self._plan_fwd_train), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}

@@ -108,7 +108,7 @@ def gemm_roofline(eng, reps=50):
     lib = H.lib()
     sp = eng._sp()
     flops, us, launches = 0.0, 0.0, 0
-    for plan in (eng._plan_fwd_noise, eng._plan_bwd):
+    for plan in (eng._plan_fwd_train, eng._plan_bwd):
         for fn, a, name in plan:
             if name in ("air_gemm", "air_gemm_bf16"):
                 f = 2.0 * a[2] * a[3] * a[4]
@@ -138,7 +138,7 @@ def plan_breakdown(eng, reps=100):
     lib = H.lib()
     sp = eng._sp()
     rows = []
-    for phase, plan in (("fwd", eng._plan_fwd_noise), ("bwd", eng._plan_bwd), ("opt", eng._plan_opt)):
+    for phase, plan in (("fwd", eng._plan_fwd_train), ("bwd", eng._plan_bwd), ("opt", eng._plan_opt)):
         for i, (fn, a, name) in enumerate(plan):
             ms = event_time_ms(lib, sp, lambda: fn(*a, sp), reps)
             desc = ""

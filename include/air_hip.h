@@ -83,6 +83,13 @@ int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float 
                           const float *final_canvas, float *dglimpse, float *dwhere,
                           int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                           void *stream);
+/* The same launch with one extra workgroup that evaluates air_nvil(imp, baseline, logp, nvil_out, dlogp, dbaseline, B)
+ * (the two are independent; the step is bound by the number of dependent launches).                                  */
+int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence, const float *obs,
+                               const float *final_canvas, float *dglimpse, float *dwhere,
+                               int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
+                               const float *imp, const float *baseline, const float *logp, float *nvil_out,
+                               float *dlogp, float *dbaseline, void *stream);
 
 /* ---- dense layers -------------------------------------------------------------------------------------------
  * Replaces the TF MatMul/BiasAdd/Elu nodes under snt.Linear (neural.py:42-60) and snt.LSTM (mnist_model.py:35).   */
@@ -264,6 +271,13 @@ int air_nvil(const float *imp, const float *baseline, const float *logp, float *
 int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
                       const float *state0, const float *state1, float *out, int T, int B, int P, int A, int S0,
                       int S1, void *stream);
+/* air_gauss_sample_fwd for `what` (loc_mode 0, one prior) and the latent part of air_baseline_pack (HW = 0) in ONE launch:
+ * pre[T*B, ld_pre] -> loc, scale, sample [T*B, D] time-major, kl_row[T*B]; pack_out[B, T*D + T*4 + T + S0 + S1] =
+ * [what | where | presence | state0 | state1] batch-major (the sample is written to both places as it is drawn).      */
+int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float raw_offset, float p_loc, float p_scale,
+                         float *loc, float *scale, float *sample, float *kl_row, int D, const float *where,
+                         const float *presence, const float *state0, const float *state1, float *pack_out,
+                         int T, int B, int S0, int S1, void *stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------------
  * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;
