@@ -164,6 +164,32 @@ def gemm(A, B, ta=False, tb=False, bias=None, epilogue=EPI_NONE, aux=None, beta=
     return (out, cs) if colsum else out
 
 
+def gemm_grouped(problems, precision=0):
+    """Several independent GEMMs in one launch (air_gemm_grouped).  problems: dicts with A, B and optional ta, tb, bias,
+    epilogue, aux, beta, out, colsum (bool).  Returns [(C, colsum|None)]."""
+    descs, outs, keep = [], [], []
+    for pr in problems:
+        A, B = pr["A"], pr["B"]
+        ta, tb = bool(pr.get("ta", False)), bool(pr.get("tb", False))
+        M = A.shape[1] if ta else A.shape[0]
+        K = A.shape[0] if ta else A.shape[1]
+        N = B.shape[0] if tb else B.shape[1]
+        out = pr.get("out")
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        aux, bias = pr.get("aux"), pr.get("bias")
+        cs = torch.empty((N,), dtype=torch.float32, device=A.device) if pr.get("colsum") else None
+        ld = lambda t: t.stride(0) if t.shape[0] > 1 else t.shape[1]
+        d = _lib.AirGemmDesc(int(ta), int(tb), M, N, K, A.data_ptr(), ld(A), B.data_ptr(), ld(B), out.data_ptr(), ld(out),
+                             bias.data_ptr() if bias is not None else None, int(pr.get("epilogue", EPI_NONE)),
+                             aux.data_ptr() if aux is not None else None, ld(aux) if aux is not None else 0,
+                             float(pr.get("beta", 0.0)), cs.data_ptr() if cs is not None else None, int(precision))
+        descs.append(d); outs.append((out, cs)); keep.append((A, B, aux, bias))
+    arr = (_lib.AirGemmDesc * len(descs))(*descs)
+    _lib.check(lib().air_gemm_grouped(arr, len(descs), _stream()), "air_gemm_grouped")
+    return outs
+
+
 def linear_fwd(x, w, b, act):
     x = _f32(x, "x", 2); w = _f32(w, "w", 2); b = _f32(b, "b")
     M, K = x.shape

@@ -170,7 +170,8 @@ def test_canvas_unroll_fwd_bwd(hip):
 # GEMM / linear / LSTM
 # ---------------------------------------------------------------------------------------------------------------
 GEMM_SHAPES = [(64, 256, 2500), (192, 256, 400), (10, 5, 9), (64, 8, 256), (192, 1, 64), (64, 100, 256),
-               (64, 400, 256), (3, 17, 3), (64, 256, 3177), (192, 256, 50), (33, 47, 129), (2048, 256, 400)]
+               (64, 400, 256), (3, 17, 3), (64, 256, 3177), (192, 256, 50), (33, 47, 129), (2048, 256, 400),
+               (3072, 100, 256), (1000, 130, 70), (3177, 256, 1024)]          # the last three: large-batch shapes
 
 
 def _gemm_ref(A, B, ta, tb):
@@ -189,6 +190,34 @@ def test_gemm_all_layouts(hip, M, N, K, ta, tb):
     assert_close(out, ref, 1e-5, 2e-6 * K ** 0.5 * 4, f"gemm {M}x{N}x{K} ta={ta} tb={tb}")
     out2 = hip.gemm(A, B, ta=bool(ta), tb=bool(tb), use_workspace=False)       # no split-K path
     assert_close(out2, ref, 1e-5, 2e-6 * K ** 0.5 * 4, "gemm no-workspace")
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gemm_grouped_throughput_regime(hip, precision):
+    """One launch in the throughput regime (thousands of 16x16 tiles -> 32x32 tiles per wave): the dW / dX pair of a layer at
+    batch 1024, an odd-sized problem with unaligned leading dimensions, every epilogue, colsum."""
+    gen = torch.Generator().manual_seed(5 + precision)
+    r = (lambda t: t.to(torch.bfloat16).double()) if precision else (lambda t: t.double())
+    M, K, N = 3072, 256, 400
+    x = torch.randn(M, K, generator=gen).cuda(); g = torch.randn(M, N, generator=gen).cuda()
+    w = (torch.randn(K, N, generator=gen) / 16).cuda(); y = torch.randn(M, K, generator=gen).cuda()
+    big = torch.randn(1001, 77, generator=gen).cuda(); a2 = big[:, 5:75]                 # [1001, 70], ld 77, unaligned
+    b2 = torch.randn(70, 131, generator=gen).cuda(); bias2 = torch.randn(131, generator=gen).cuda()
+    outs = hip.gemm_grouped([
+        dict(A=x, B=g, ta=True, colsum=True),                                            # dW[K,N] = x^T g, db
+        dict(A=g, B=w, tb=True, epilogue=hip.EPI_MUL_DELU, aux=y),                       # dX[M,K] = (g w^T) * elu'(y)
+        dict(A=a2, B=b2, bias=bias2, epilogue=hip.EPI_BIAS_ELU),
+        dict(A=b2, B=a2, ta=True, tb=True),                                              # [131, 1001] = b2^T a2^T
+    ], precision=precision)
+    tol = dict(rtol=1e-5, atol=3e-4) if not precision else dict(rtol=1e-5, atol=3e-4)
+    xc, gc, wc, yc = x.cpu(), g.cpu(), w.cpu(), y.cpu()
+    assert_close(outs[0][0], r(xc).t() @ r(gc), tol["rtol"], tol["atol"] * 10, "dW")
+    assert_close(outs[0][1], gc.double().sum(0), 1e-5, 1e-3, "db")
+    d = torch.where(yc > 0, torch.ones_like(yc), yc + 1).double()
+    assert_close(outs[1][0], (r(gc) @ r(wc).t()) * d, tol["rtol"], tol["atol"], "dX")
+    ref2 = r(a2.cpu()) @ r(b2.cpu())
+    assert_close(outs[2][0], torch.nn.functional.elu(ref2 + bias2.cpu().double()), 1e-5, 3e-4, "odd bias+elu")
+    assert_close(outs[3][0], ref2.t(), 1e-5, 3e-4, "TT")
 
 
 def test_gemm_transpose_detecting_identity(hip):
@@ -272,7 +301,7 @@ def test_lstm_fused_step_matches_unfused_pair_and_fp64(hip, M, Hd):
     assert_close(h, h2, 2e-5, 2e-5, "h"); assert_close(c, c2, 2e-5, 2e-5, "c")
     gates = hip.gemm(h0.cuda(), w_h_dev, epilogue=hip.EPI_ADD_AUX, aux=gx.cuda())
     hu, cu, actu = hip.lstm_pointwise_fwd(gates, c0.cuda(), 1.0)
-    assert_close(h, hu, 1e-6, 1e-6, "h vs unfused"); assert_close(act, actu, 1e-6, 1e-6, "act vs unfused")
+    assert_close(h, hu, 1e-5, 1e-5, "h vs unfused"); assert_close(act, actu, 1e-5, 1e-5, "act vs unfused")
 
     # backward link: dh = dgn . W_h^T + dh_a + dh_b, then the pointwise backward of (act, c0, c)
     dgn = torch.randn(M, 4 * Hd, generator=gen) * 0.3
