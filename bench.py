@@ -88,13 +88,21 @@ def st_rooflines(eng, reps=200):
                                                                  Ww, h, w, cfg.output_multiplier, cfg.output_std,
                                                                  1.0 / B, sp), 4 * (HW + 2 * hw + 4 + 4 + 1) * M),
     }
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes at exactly these shapes (null for other shapes)
+    pmc = {}
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_d_instep_pmc.json")))
+        if (Hh, Ww, h, w, T, B) == (50, 50, 20, 20, 3, d["batch"]):
+            pmc = d["kernels"]
+    except Exception:
+        pmc = {}
     out = {}
     for name, (fn, nbytes) in calls.items():
         ms = event_time_ms(lib, sp, fn, reps)
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "us_per_launch": round(ms * 1e3, 3),
-                     "algorithmic_bytes_per_launch": nbytes}
+                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc.get(name, {}).get("traffic_bytes"),
+                     "us_per_launch": round(ms * 1e3, 3), "algorithmic_bytes_per_launch": nbytes}
     return out
 
 
@@ -220,6 +228,14 @@ def cpu_baseline(cfg_kw, batch, seconds):
         if dt < best[1]:
             best = (th, dt)
     cores = best[0]
+    # per-core figure: the same step on ONE thread, a few steps only
+    torch.set_num_threads(1)
+    O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=80), global_step=0)
+    t0, n1 = time.perf_counter(), 0
+    while n1 < 20 and (n1 < 3 or time.perf_counter() - t0 < 3.0):
+        O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=81 + n1), global_step=0)
+        n1 += 1
+    one_thread = batch * n1 / (time.perf_counter() - t0)
     torch.set_num_threads(cores)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -229,6 +245,7 @@ def cpu_baseline(cfg_kw, batch, seconds):
         if el >= seconds or n >= 400:
             break
     return {"value": round(batch * n / el, 1), "unit": "images/sec", "cores": cores, "kind": "port",
+            "one_thread_value": round(one_thread, 1), "host_cpus": avail,
             "sample": f"{n} full train steps at batch {batch} ({el:.1f} s) of the torch-CPU fp32 oracle "
                       f"(oracle/air_oracle.py); threads={cores} chosen as the fastest of a sweep on this {avail}-cpu host"}
 
