@@ -48,6 +48,13 @@ CONFIGS = {
                             inpt_encoder_hidden=(48,), glimpse_encoder_hidden=(33, 21), glimpse_decoder_hidden=(30,),
                             transform_estimator_hidden=(24,), steps_pred_hidden=(16, 8), baseline_hidden=(20,),
                             max_steps=5), 6),
+    # edge shapes: a single time step (no BPTT link, dgx aliases dgates[0]) with a batch that is not a multiple of anything;
+    # one image; a batch just past a multiple of the 16-row MFMA tile
+    "t1_b5": (O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3,
+                            transform_var_bias=0.5, max_steps=1), 5),
+    "b1": (O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3,
+                         transform_var_bias=0.5), 1),
+    "mnist_b17": (O.AIRConfig(), 17),
 }
 
 
