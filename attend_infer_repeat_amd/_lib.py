@@ -45,6 +45,12 @@ SIGNATURES = {
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_what_sample_pack": (c_int, [P, c_int, P, c_float, c_float, c_float, P, P, P, P, c_int, P, P, P, P, P,
                                      c_int, c_int, c_int, c_int, P]),
+    "air_attend_fwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, c_float, c_float, c_float, c_float, c_float,
+                               P, P, P, P, P, c_float, c_float, P, P, P, P, P, P, P, P, P,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_attend_bwd": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, P, c_float, P,
+                               P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
+                               c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "air_lstm_step_fwd": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int, P]),
     "air_lstm_step_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),

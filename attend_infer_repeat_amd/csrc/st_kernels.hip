@@ -667,3 +667,305 @@ extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *whe
     return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
                             h, w, mult, std, loss_scale, stream, &nv);
 }
+
+// ============================================================================================================
+// "attend": the last (tiny) layers of the transform / steps MLPs, where-sampling, presence + num-steps posterior and the
+// glimpse read of all T steps in ONE launch (cell.py:129-151 + modules.py:104-109).  At batch 64 these were three
+// dependent launches (a 192x8x256 | 192x1x64 GEMM pair, the heads kernel, the ST read) of ~4-5 us each with almost no work.
+//   role A, one workgroup per image b: its image is prefetched into registers first (nothing depends on it), then
+//           pre[t*B+b, 0:8] = h2 . W + bias for every t (one wave per row), where ~ N(loc, softplus(raw)) + KL row, and the
+//           T glimpses are resampled out of the LDS-staged image with `where` taken straight from LDS;
+//   role B, one workgroup per 64 batch columns: logit = s2 . w + b (64-deep dots), then the sequential presence chain and
+//           the float64 num-steps posterior / KL / step weights / log q(n) (presence_numsteps_fwd_body).
+// The two roles share nothing but the launch.
+// ============================================================================================================
+#include "engine_device.h"
+
+struct AttendFwdArgs {
+    const float *tr_h, *tr_w, *tr_b; int tr_k;       // [M, tr_k] . [tr_k, 8] + [8]   -> pre[M, 8]
+    const float *st_h, *st_w, *st_b; int st_k;       // [M, st_k] . [st_k, 1] + [1]   -> logit[M]
+    float *pre, *logit;
+    const float *eps; float raw_offset, pl0, ps0, pl1, ps1;
+    float *loc, *scale, *where, *kl_row;
+    const float *u; float step_bias, explore_eps; const double *prior;
+    float *prob, *pres, *q, *kl_ps, *logp, *step_w;
+    const float *img; float *glimpse;
+    int T, B, H, W, h, w, bf16;
+    double stepx, stepy;
+};
+// operand of a dense product: as is, or rounded to bf16 (EngineConfig.mfma_dtype = "bf16": same arithmetic as the MFMA path)
+__device__ __forceinline__ float opnd(float v, int bf16) { return bf16 ? (float)(__bf16)v : v; }
+
+template <int MT>
+__global__ __launch_bounds__(1024) void attend_fwd_kernel(AttendFwdArgs g) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int T = g.T, B = g.B;
+    if ((int)blockIdx.x >= B) {
+        // ---- role B: steps-predictor output layer + presence / num-steps for 64 batch columns ----------------------
+        const int vb = (int)blockIdx.x - B, vgrid = (int)gridDim.x - B;
+        // steps-predictor output layer for this block's 64 columns x T rows.  Thread (c = tid & 63, part = tid >> 6) sums a
+        // quarter of the K range of row (t, c) for every t -- all its loads are independent, so the whole layer is ONE memory
+        // round trip (a row-at-a-time loop measured 8 us: a dozen dependent round trips) -- then the 4 parts meet in LDS.
+        __shared__ float s_part[4][MT][64];
+        const float bias = g.st_b[0];
+        const int cc = tid & 63, part = tid >> 6;
+        const int chunk = (g.st_k + 3) >> 2, k0 = part * chunk, k1 = (k0 + chunk < g.st_k) ? k0 + chunk : g.st_k;
+        for (int base = vb * 64; base < B; base += vgrid * 64) {
+            const int b = base + cc;
+            if (part < 4) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    float acc = 0.f;
+                    if (t < T && b < B) {
+                        const float *x = g.st_h + ((size_t)t * B + b) * g.st_k;
+#pragma unroll 16
+                        for (int k = k0; k < k1; ++k) acc += opnd(x[k], g.bf16) * opnd(g.st_w[k], g.bf16);
+                    }
+                    s_part[part][t][cc] = acc;
+                }
+            }
+            __syncthreads();
+            if (tid < 64 && b < B) {
+                for (int t = 0; t < T; ++t)
+                    g.logit[(size_t)t * B + b] = ((s_part[0][t][cc] + s_part[1][t][cc]) + (s_part[2][t][cc] + s_part[3][t][cc])) + bias;
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                       // (same thread re-reads what it wrote; compiler fence)
+        presence_numsteps_fwd_body<MT>(vb, vgrid, g.logit, g.u, g.step_bias, g.explore_eps, g.prior, g.prob, g.pres, g.q,
+                                       g.kl_ps, g.logp, g.step_w, T, B);
+        return;
+    }
+    // ---- role A: image b ------------------------------------------------------------------------------------------
+    const int b = blockIdx.x;
+    const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w, nq = HW >> 2;
+    Carve c = carve_lds(smem, HW, 0, w, h);
+    float *s_where = c.scratch;                                // [T][4] (the carve reserves 128 floats; T <= 28)
+    const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    const int q0 = tid < nq ? tid : nq - 1, q1 = tid + nt < nq ? tid + nt : nq - 1;
+    const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
+    const float4 *s4 = reinterpret_cast<const float4 *>(g.img + (size_t)b * HW);
+    const float4 p0 = s4[q0], p1 = s4[q1], p2 = s4[q2];       // in flight while the output layer below runs
+    for (int a = tid; a < w + h; a += nt) {
+        if (a < w) c.X[a] = lin_m11(a, w, g.stepx); else c.Y[a - w] = lin_m11(a - w, h, g.stepy);
+    }
+    // transform output layer: one wave per time step (row t*B + b)
+    for (int t = wave; t < T; t += nw) {
+        const size_t m = (size_t)t * B + b;
+        const float *x = g.tr_h + m * g.tr_k;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = lane; k < g.tr_k; k += 64) {
+            const float xv = opnd(x[k], g.bf16);
+            float4 wa = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)k * 8);
+            float4 wb = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)k * 8 + 4);
+            if (g.bf16) {
+                wa.x = opnd(wa.x, 1); wa.y = opnd(wa.y, 1); wa.z = opnd(wa.z, 1); wa.w = opnd(wa.w, 1);
+                wb.x = opnd(wb.x, 1); wb.y = opnd(wb.y, 1); wb.z = opnd(wb.z, 1); wb.w = opnd(wb.w, 1);
+            }
+            acc[0] += xv * wa.x; acc[1] += xv * wa.y; acc[2] += xv * wa.z; acc[3] += xv * wa.w;
+            acc[4] += xv * wb.x; acc[5] += xv * wb.y; acc[6] += xv * wb.z; acc[7] += xv * wb.w;
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = wave_sum_all(acc[o]);
+        if (lane < 4) {
+            const int d = lane;
+            const float e_loc = (d == 0 ? acc[0] : d == 1 ? acc[1] : d == 2 ? acc[2] : acc[3]) + g.tr_b[d];
+            const float e_raw = (d == 0 ? acc[4] : d == 1 ? acc[5] : d == 2 ? acc[6] : acc[7]) + g.tr_b[4 + d];
+            g.pre[m * 8 + d] = e_loc;
+            g.pre[m * 8 + 4 + d] = e_raw;
+            const float mu = (d & 1) ? tanhf(e_loc) : sigmoid_acc(e_loc);                    // modules.py:41-46
+            const float s = softplus_acc(e_raw + g.raw_offset);
+            const size_t o = m * 4 + d;
+            const float v = mu + s * g.eps[o];                                              // cell.py:130-133
+            g.loc[o] = mu; g.scale[o] = s; g.where[o] = v;
+            s_where[4 * t + d] = v;
+            float kl = (d & 1) ? normal_kl(mu, s, g.pl1, g.ps1) : normal_kl(mu, s, g.pl0, g.ps0);
+            kl += __shfl_xor(kl, 1, 64);
+            kl += __shfl_xor(kl, 2, 64);
+            if (d == 0) g.kl_row[m] = kl;
+        }
+    }
+    float4 *d4 = reinterpret_cast<float4 *>(c.src);
+    if (tid < nq) d4[tid] = p0;
+    if (tid + nt < nq) d4[tid + nt] = p1;
+    if (tid + 2 * nt < nq) d4[tid + 2 * nt] = p2;
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();                                       // image + s_where visible / previous tables consumed
+        const float sx = s_where[4 * t + 0], tx = s_where[4 * t + 1], sy = s_where[4 * t + 2], ty = s_where[4 * t + 3];
+        for (int a = tid; a < w + h; a += nt) {
+            if (a < w) axis_entry(grid_coord(sx, c.X[a], tx, cxs), W, &c.fx[a], &c.dx[a]);
+            else axis_entry(grid_coord(sy, c.Y[a - w], ty, cys), H, &c.fy[a - w], &c.dy[a - w]);
+        }
+        __syncthreads();
+        float *o = g.glimpse + ((size_t)t * B + b) * hw;
+        for (int p = tid; p < hw; p += nt) {
+            const int i = p / w, j = p - i * w;
+            const int fx = c.fx[j], fy = c.fy[i];
+            float v = 0.f;
+            if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, H, W, fy, fx), c.dx[j], c.dy[i]);
+            o[p] = v;
+        }
+    }
+}
+
+extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int tr_k, const float *st_h,
+                              const float *st_w, const float *st_b, int st_k, float *pre, float *logit,
+                              const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
+                              float p_scale_odd, float *loc, float *scale, float *where, float *kl_row, const float *u,
+                              float step_bias, float explore_eps, const double *prior_f64, float *presence_prob,
+                              float *presence, float *q, float *kl_per_sample, float *logp, float *step_weight,
+                              const float *img, float *glimpse, int T, int B, int H, int W, int h, int w, int precision,
+                              void *stream) {
+    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+    AIR_REQUIRE(tr_h && tr_w && tr_b && st_h && st_w && st_b && pre && logit && eps && loc && scale && where && kl_row &&
+                    u && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight && img &&
+                    glimpse, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= 28 && tr_k > 0 && st_k > 0, AIR_E_SHAPE);   // s_where lives in the 128-float carve pad
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    const int nq = (H * W) / 4;
+    // the register-prefetch staging needs a 16-byte addressable image of at most 3 float4 per thread
+    AIR_REQUIRE((H * W) % 4 == 0 && air_aligned16(img) && nq <= 3 * 1024 && air_aligned16(tr_w), AIR_E_UNSUPPORTED);
+    const size_t lds = carve_bytes(H * W, 0, w, h);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    AttendFwdArgs g;
+    g.tr_h = tr_h; g.tr_w = tr_w; g.tr_b = tr_b; g.tr_k = tr_k; g.st_h = st_h; g.st_w = st_w; g.st_b = st_b; g.st_k = st_k;
+    g.pre = pre; g.logit = logit; g.eps = eps; g.raw_offset = raw_offset;
+    g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
+    g.loc = loc; g.scale = scale; g.where = where; g.kl_row = kl_row; g.u = u; g.step_bias = step_bias;
+    g.explore_eps = explore_eps; g.prior = prior_f64; g.prob = presence_prob; g.pres = presence; g.q = q;
+    g.kl_ps = kl_per_sample; g.logp = logp; g.step_w = step_weight; g.img = img; g.glimpse = glimpse;
+    g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w; g.stepx = lin_step(w); g.stepy = lin_step(h);
+    g.bf16 = precision == AIR_PREC_BF16 ? 1 : 0;
+    const int threads = nq <= 3 * 256 ? 256 : 1024;
+    const int grid = B + air_cdiv(B, 64);
+    if (T <= 8) {
+        { int st_ = st_allow_lds(attend_fwd_kernel<8>, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(attend_fwd_kernel<8>, dim3(grid), dim3(threads), lds, air_stream(stream), g);
+    } else {
+        { int st_ = st_allow_lds(attend_fwd_kernel<32>, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(attend_fwd_kernel<32>, dim3(grid), dim3(threads), lds, air_stream(stream), g);
+    }
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// Backward counterpart: role A, one workgroup per glimpse k = t*B + b: d where (through the read) by the same staging /
+// tables / fixed-order reduction as st_read_bwd_kernel, then -- in the same workgroup -- the where-sampling backward of row k
+// (needs dwhere from the canvas write AND from the read, plus the KL term): d pre[k, 0:8].  Role B: backward of the
+// num-steps KL / step weights / REINFORCE term wrt the steps logit (numsteps_presence_bwd_body).
+struct AttendBwdArgs {
+    const float *img, *where, *dglimpse; float *dwhere_r;
+    const float *pre, *eps; float raw_offset, pl0, ps0, pl1, ps1;
+    const float *loc, *scale, *dwhere_w, *dkl_row; float dkl_scale; float *dpre;
+    const float *prob, *presence; const double *prior; float kl_scale; const float *kl_a, *kl_b; float w_scale;
+    const float *dlogp, *logit; float step_bias, explore_eps; float *dlogit;
+    int T, B, H, W, h, w, vec4;
+    double stepx, stepy;
+};
+
+template <int MT>
+__global__ __launch_bounds__(1024) void attend_bwd_kernel(AttendBwdArgs g) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int T = g.T, B = g.B, n = T * B;
+    if ((int)blockIdx.x >= n) {
+        numsteps_presence_bwd_body<MT>((int)blockIdx.x - n, (int)gridDim.x - n, g.prob, g.presence, g.prior, g.kl_scale,
+                                       g.kl_a, g.kl_b, g.w_scale, g.dlogp, g.logit, g.step_bias, g.explore_eps, g.dlogit,
+                                       T, B);
+        return;
+    }
+    const int k = blockIdx.x, b = k % B;
+    const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w;
+    Carve c = carve_lds(smem, HW, 0, w, h);
+    const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    stage_to_lds(c.src, g.img + (size_t)b * HW, HW, g.vec4 != 0);
+    const float sx = g.where[4 * (size_t)k + 0], tx = g.where[4 * (size_t)k + 1];
+    const float sy = g.where[4 * (size_t)k + 2], ty = g.where[4 * (size_t)k + 3];
+    for (int a = tid; a < w + h; a += nt) {
+        if (a < w) {
+            const float X = lin_m11(a, w, g.stepx);
+            c.X[a] = X;
+            axis_entry(grid_coord(sx, X, tx, cxs), W, &c.fx[a], &c.dx[a]);
+        } else {
+            const float Y = lin_m11(a - w, h, g.stepy);
+            c.Y[a - w] = Y;
+            axis_entry(grid_coord(sy, Y, ty, cys), H, &c.fy[a - w], &c.dy[a - w]);
+        }
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *go_p = g.dglimpse + (size_t)k * hw;
+    for (int p = tid; p < hw; p += nt) {
+        const int i = p / w, j = p - i * w;
+        const int fx = c.fx[j], fy = c.fy[i];
+        if (fx == ST_INVALID || fy == ST_INVALID) continue;
+        const float dx = c.dx[j], dy = c.dy[i], go = go_p[p];
+        const Taps t = load_taps(c.src, H, W, fy, fx);
+        const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
+        const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
+        const float ax = go * gx * cxs, ay = go * gy * cys;
+        acc[0] += ax * c.X[j]; acc[1] += ax;
+        acc[2] += ay * c.Y[i]; acc[3] += ay;
+    }
+    block_sum<4>(acc, c.scratch);                              // valid in wave 0 (every lane after its wave_sum? no: lane 0)
+    if (tid == 0) {
+        float *d = g.dwhere_r + 4 * (size_t)k;
+        d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
+        // where-sampling backward of row k (gauss_bwd_body with D = 4, loc_mode = 1), four dims by this one thread
+#pragma unroll
+        for (int d_ = 0; d_ < 4; ++d_) {
+            const size_t e = (size_t)k * 4 + d_;
+            const float mu = g.loc[e], s = g.scale[e];
+            const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
+            const float ds = g.dwhere_w[e] + acc[d_];
+            const float dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
+            float dmu = ds + dk * (mu - pm) / (ps * ps);
+            const float dsc = ds * g.eps[e] + dk * (s / (ps * ps) - 1.f / s);
+            dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
+            const float raw = g.pre[(size_t)k * 8 + 4 + d_] + g.raw_offset;
+            const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);
+            g.dpre[(size_t)k * 8 + d_] = dmu;
+            g.dpre[(size_t)k * 8 + 4 + d_] = dsc * dsp;
+        }
+    }
+}
+
+extern "C" int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r,
+                              const float *pre, const float *eps, float raw_offset, float p_loc_even, float p_scale_even,
+                              float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
+                              const float *dwhere_w, const float *dkl_row, float dkl_scale, float *dpre,
+                              const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
+                              const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
+                              const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
+                              int W, int h, int w, void *stream) {
+    AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
+                    prior_f64 && logit && dlogit, AIR_E_NULL);
+    AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= 32, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    const size_t lds = carve_bytes(H * W, 0, w, h);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    AttendBwdArgs g;
+    g.img = img; g.where = where; g.dglimpse = dglimpse; g.dwhere_r = dwhere_r; g.pre = pre; g.eps = eps;
+    g.raw_offset = raw_offset; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
+    g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
+    g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
+    g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
+    g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;
+    g.vec4 = (((H * W) % 4 == 0) && air_aligned16(img)) ? 1 : 0;
+    g.stepx = lin_step(w); g.stepy = lin_step(h);
+    const int grid = T * B + air_cdiv(B, 64);
+    if (T <= 8) {
+        { int st_ = st_allow_lds(attend_bwd_kernel<8>, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(attend_bwd_kernel<8>, dim3(grid), dim3(ST_THREADS), lds, air_stream(stream), g);
+    } else {
+        { int st_ = st_allow_lds(attend_bwd_kernel<32>, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(attend_bwd_kernel<32>, dim3(grid), dim3(ST_THREADS), lds, air_stream(stream), g);
+    }
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}

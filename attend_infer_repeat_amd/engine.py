@@ -437,17 +437,35 @@ class AIREngine:
                                                    p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd, 1.0),
                         "air_lstm_pointwise_fwd"))
         h_all = self.h_seq[1:]                                                              # [T,B,Hd] contiguous
-        mlp_fwd_multi(fwd, [(self.tr, h_all, Hd), (self.st, h_all, Hd)])                    # cell.py:129,138
         sp, shp = cfg.where_scale_prior, cfg.where_shift_prior
         eps = -1.0 if cfg.explore_eps is None else float(cfg.explore_eps)
-        fwd.append((L.air_heads_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
-                                      sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
-                                      p(self.where), p(self.kl_where_row), M, 4,                 # cell.py:129-133
-                                      p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
-                                      p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n), p(self.logp),
-                                      p(self.step_w), T, B), "air_heads_fwd"))                   # cell.py:137-151, prior.py
-        fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
-                    "air_st_read_fwd"))                                                     # cell.py:135
+        # "attend" fusion: output layers of the transform / steps MLPs + where sampling + presence / num-steps + the glimpse
+        # read in ONE launch (three dependent launches otherwise).  Needs a 16-byte addressable image that fits the
+        # register-prefetch staging, and (backward) one workgroup per glimpse.
+        fuse_attend = (P % 4 == 0) and (P // 4 <= 3 * 1024) and T <= 28 and M <= 2048
+        if fuse_attend:
+            for i in range(max(self.tr.n, self.st.n) - 1):
+                launch(fwd, [fwd_desc(m, i, h_all, Hd) for m in (self.tr, self.st) if i < m.n - 1])
+            tr_in, tr_k = (self.tr.out[-2], self.tr.shapes[-1][0]) if self.tr.n > 1 else (h_all, Hd)
+            st_in, st_k = (self.st.out[-2], self.st.shapes[-1][0]) if self.st.n > 1 else (h_all, Hd)
+            fwd.append((L.air_attend_fwd, (p(tr_in), p(self.tr.w[-1]), p(self.tr.b[-1]), tr_k, p(st_in),
+                                           p(self.st.w[-1]), p(self.st.b[-1]), st_k, p(self.tr.out[-1]),
+                                           p(self.st.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
+                                           shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.where),
+                                           p(self.kl_where_row), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
+                                           p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n),
+                                           p(self.logp), p(self.step_w), p(self.obs), p(self.glimpse_in), T, B, Hi, Wi,
+                                           hc, wc, prec), "air_attend_fwd"))                      # cell.py:129-151
+        else:
+            mlp_fwd_multi(fwd, [(self.tr, h_all, Hd), (self.st, h_all, Hd)])                # cell.py:129,138
+            fwd.append((L.air_heads_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
+                                          sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
+                                          p(self.where), p(self.kl_where_row), M, 4,             # cell.py:129-133
+                                          p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
+                                          p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n), p(self.logp),
+                                          p(self.step_w), T, B), "air_heads_fwd"))               # cell.py:137-151, prior.py
+            fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
+                        "air_st_read_fwd"))                                                 # cell.py:135
         mlp_fwd_multi(fwd, [(self.ge, self.glimpse_in, hw)])                                # cell.py:153
         ge_out, G = self.ge.out[-1], self.ge.shapes[-1][1]
         launch(fwd, [desc(0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
@@ -508,16 +526,27 @@ class AIREngine:
                           aux=ge_out, ldaux=G)])
         mlp_bwd_multi(bwd, [dict(m=self.ge, x=self.glimpse_in, ldx=hw, g_last=self.ge.g[-1], dx_out=self.d_glimpse_in)])
         marks.append((len(bwd), "glimpse_encoder/0/w"))        # + [glimpse_encoder, what]
-        bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
-                                        B, Hi, Wi, hc, wc), "air_st_read_bwd"))
-        bwd.append((L.air_heads_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
-                                      sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
-                                      p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
-                                      p(self.tr.g[-1]), 8, M, 4,
-                                      p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
-                                      p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
-                                      p(self.dlogp) if cfg.use_reinforce else None, p(self.st.out[-1]), cfg.step_bias,
-                                      eps, p(self.st.g[-1]), T, B), "air_heads_bwd"))
+        dlogp_p = p(self.dlogp) if cfg.use_reinforce else None
+        if fuse_attend:
+            bwd.append((L.air_attend_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r),
+                                           p(self.tr.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
+                                           shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w),
+                                           p(self.step_w), pw * inv_b, p(self.tr.g[-1]),
+                                           p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                           p(self.kl_what_row), p(self.kl_where_row), pw * inv_b, dlogp_p,
+                                           p(self.st.out[-1]), cfg.step_bias, eps, p(self.st.g[-1]), T, B, Hi, Wi, hc, wc),
+                        "air_attend_bwd"))
+        else:
+            bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
+                                            B, Hi, Wi, hc, wc), "air_st_read_bwd"))
+            bwd.append((L.air_heads_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
+                                          sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
+                                          p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
+                                          p(self.tr.g[-1]), 8, M, 4,
+                                          p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                          p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
+                                          dlogp_p, p(self.st.out[-1]), cfg.step_bias,
+                                          eps, p(self.st.g[-1]), T, B), "air_heads_bwd"))
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
                             dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)])
         marks.append((len(bwd), "transform/0/w"))              # + [transform, steps]

@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 T
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)     # 0.5 s timed: long enough to average clock / scheduling hiccups
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager C-ABI launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")

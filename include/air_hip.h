@@ -279,6 +279,31 @@ int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float r
                          const float *presence, const float *state0, const float *state1, float *pack_out,
                          int T, int B, int S0, int S1, void *stream);
 
+/* ---- "attend": fused engine launches around the glimpse read (cell.py:129-151, modules.py:104-109) ------------------
+ * Forward, one launch: the output layers of the transform MLP (tr_h[T*B,tr_k] . tr_w[tr_k,8] + tr_b -> pre[T*B,8]) and of the
+ * steps predictor (st_h[T*B,st_k] . st_w[st_k,1] + st_b -> logit[T*B]), then everything air_heads_fwd computes from them
+ * (where ~ N(loc, softplus(raw + raw_offset)), its KL rows, presence, q(n), KL, log q(n), step weights) and
+ * air_st_read_fwd(img[B,H,W], where) -> glimpse[T*B,h,w] with `where` handed over inside the workgroup.
+ * Needs H*W % 4 == 0, H*W <= 12288, 16-byte aligned img / tr_w (AIR_E_UNSUPPORTED otherwise: use the separate entries). */
+int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int tr_k, const float *st_h,
+                   const float *st_w, const float *st_b, int st_k, float *pre, float *logit, const float *eps,
+                   float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
+                   float *loc, float *scale, float *where, float *kl_row, const float *u, float step_bias,
+                   float explore_eps, const double *prior_f64, float *presence_prob, float *presence, float *q,
+                   float *kl_per_sample, float *logp, float *step_weight, const float *img, float *glimpse,
+                   int T, int B, int H, int W, int h, int w, int precision /* of the two output-layer products */,
+                   void *stream);
+/* Backward, one launch: air_st_read_bwd (d where through the read, one workgroup per glimpse) followed in the same
+ * workgroup by the where-sampling backward of that row (dsample = dwhere_w + dwhere_r, KL term dkl_row*dkl_scale) ->
+ * dpre[T*B,8]; and, in separate workgroups, the steps-logit backward of air_heads_bwd -> dlogit[T*B].                */
+int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
+                   const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
+                   float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w,
+                   const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
+                   const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
+                   const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
+                   float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, void *stream);
+
 /* ---- optimiser ----------------------------------------------------------------------------------------------
  * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;
  * mom<-m*mom + lr*g/sqrt(ms-mg^2+eps); p<-p-mom.  lr = *lr_dev * lr_mult (lr_dev: device float, graph-safe).
