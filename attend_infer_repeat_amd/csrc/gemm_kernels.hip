@@ -522,9 +522,21 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         if (bf) hipLaunchKernelGGL((gemm_grouped_kernel<MT_, NT_, KW_, true>), dim3(tiles), dim3(NTH_), 0, st, ga);   \
         else hipLaunchKernelGGL((gemm_grouped_kernel<MT_, NT_, KW_, false>), dim3(tiles), dim3(NTH_), 0, st, ga);     \
     } while (0)
-    if (long_k) AIR_GROUP_LAUNCH(1, 1, 16, 1024);
+    // a lone problem goes through the single-GEMM kernel: its descriptor sits directly in the kernarg SGPRs, so the
+    // tile_start lookup (one more dependent scalar-memory round trip before the first operand load) is skipped
+#define AIR_SINGLE_LAUNCH(MT_, NT_, KW_, NTH_)                                                                       \
+    do {                                                                                                             \
+        if (bf) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT_, NT_, KW_, true>), dim3(tiles, 1), dim3(NTH_), 0, st, ga.g[0]);  \
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT_, NT_, KW_, false>), dim3(tiles, 1), dim3(NTH_), 0, st, ga.g[0]);    \
+    } while (0)
+    if (count == 1) {
+        if (long_k) AIR_SINGLE_LAUNCH(1, 1, 16, 1024);
+        else if (T_ == 16) AIR_SINGLE_LAUNCH(1, 1, 4, 256);
+        else AIR_SINGLE_LAUNCH(2, 2, 4, 256);
+    } else if (long_k) AIR_GROUP_LAUNCH(1, 1, 16, 1024);
     else if (T_ == 16) AIR_GROUP_LAUNCH(1, 1, 4, 256);
     else AIR_GROUP_LAUNCH(2, 2, 4, 256);
+#undef AIR_SINGLE_LAUNCH
 #undef AIR_GROUP_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
