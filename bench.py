@@ -88,6 +88,12 @@ def st_rooflines(eng, reps=200):
                                                                  Ww, h, w, cfg.output_multiplier, cfg.output_std,
                                                                  1.0 / B, sp), 4 * (HW + 2 * hw + 4 + 4 + 1) * M),
     }
+    # the fused attend launches of the step (glimpse read + the tiny heads around it): charged with the read's bytes only
+    for pname, plan, key, nb in (("attend_fwd", eng._plan_fwd_train, "air_attend_fwd", 4 * (HW + hw + 4) * M),
+                                 ("attend_bwd", eng._plan_bwd, "air_attend_bwd", 4 * (HW + hw + 4 + 4) * M)):
+        for fn, a, name in plan:
+            if name == key:
+                calls[pname] = ((lambda fn=fn, a=a: fn(*a, sp)), nb)
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes at exactly these shapes (null for other shapes)
     pmc = {}
     try:
@@ -320,7 +326,9 @@ def main():
                        "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
                        "params_finite_after_run": finite},
-            "roofline": roof["st_read_fwd"],
+            "roofline": dict(roof["st_read_fwd"], kernel="st_read_fwd_pipe_kernel: the glimpse read as its own launch at the "
+                             "in-step shape; inside the train step the same read runs fused in attend_fwd_kernel "
+                             "(roofline_other_kernels.attend_fwd) whenever T*B <= 2048"),
             "roofline_other_kernels": {k: v for k, v in roof.items() if k != "st_read_fwd"},
             "roofline_gemm": gemm_roofline(eng),
         }

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 PY="python $ROOT/bench.py"
 $PY --no-cpu-baseline > "$OUT/${TAG}_bench_c2_b64_unprofiled_nocpu.json" 2> "$OUT/bench_nocpu.log"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $PY --no-cpu-baseline --no-sweep > "$OUT/${TAG}_bench_c2_b64_profiled.json" 2> "$OUT/trace.log"
-python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --steps 220 > "$OUT/${TAG}_bench_c2_b64_kernel_stats.txt"
+python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --steps 2200 > "$OUT/${TAG}_bench_c2_b64_kernel_stats.txt"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_')
   rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$N" -o r -- $PY --no-cpu-baseline --no-sweep --steps 20 --warmup 5 > /dev/null 2> "$OUT/pmc_$N.log"
