@@ -14,6 +14,7 @@
 // Arbitrary M/N/K and leading dimensions are handled with masked edge loads (test/cell_test.py uses 3x3 images and
 // hidden sizes 5/7/11/13/17).
 #include "air_common.h"
+#include "prologue_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // explicit global address space: descriptors that travel through memory (grouped launch) would otherwise make every
@@ -591,14 +592,20 @@ struct LstmFwdArgs {
     const float *h_prev, *w_h, *gx, *c_prev;
     float *h, *c, *gate_act;
     int M, Hd, ldw, ldgx, vecA;
+    int ldh, ldc;            // row strides of h_prev / c_prev: Hd, or 0 = one row broadcast over the batch (trainable h0, c0)
+    int tiles;               // workgroups [tiles, gridDim.x) run the step prologue instead (first step of a train step)
     float fb;
 };
 // tile = 16 batch rows x 4 hidden units: its 16 accumulator columns are the i,j,f,o gates of those 4 units (column
 // 4*gate + unit  <->  W_h column gate*Hd + unit), so the gate math of a unit never leaves the workgroup
 template <bool BF>
-__global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(LstmFwdArgs g) {
+__global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(LstmFwdArgs g, PrologueArgs pro) {
     constexpr int KW = 4, LDT = 20;
     __shared__ float s_tile[KW][16 * LDT];
+    if ((int)blockIdx.x >= g.tiles) {       // independent role: noise / prior / tiled initial state for the rest of the step
+        step_prologue_body(pro, (int)blockIdx.x - g.tiles, (int)gridDim.x - g.tiles);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int tiles_u = (g.Hd + 3) >> 2;
     const int tm = blockIdx.x / tiles_u, tu = blockIdx.x - tm * tiles_u;
@@ -616,11 +623,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(LstmFwdArgs g) {
         const gcf gx = (gcf)g.gx + (size_t)em * g.ldgx + eu;
 #pragma unroll
         for (int q = 0; q < 4; ++q) e_gx[q] = gx[(size_t)q * g.Hd];
-        e_c = ((gcf)g.c_prev)[(size_t)em * g.Hd + eu];
+        e_c = ((gcf)g.c_prev)[(size_t)em * g.ldc + eu];
     }
     f32x4 acc[1][1];
     acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile16_kloop<KW, BF, false>(acc, (gcf)g.h_prev, g.Hd, rowA, okA, g.vecA != 0, (gcf)g.w_h, g.ldw, colB, okB, false, g.Hd,
+    tile16_kloop<KW, BF, false>(acc, (gcf)g.h_prev, g.ldh, rowA, okA, g.vecA != 0, (gcf)g.w_h, g.ldw, colB, okB, false, g.Hd,
                                 g.M, (li >> 2) * g.Hd + g.Hd - 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_tile[wave][(4 * lg + r) * LDT + li] = acc[0][0][r];
@@ -717,24 +724,56 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g) 
 }
 
 template <bool BF>
-static int lstm_fwd_launch(const LstmFwdArgs &g, hipStream_t st) {
-    const int tiles = air_cdiv(g.M, 16) * air_cdiv(g.Hd, 4);
-    hipLaunchKernelGGL((lstm_fwd_fused_kernel<BF>), dim3(tiles), dim3(256), 0, st, g);
+static int lstm_fwd_launch(const LstmFwdArgs &g, const PrologueArgs &pro, int extra_blocks, hipStream_t st) {
+    hipLaunchKernelGGL((lstm_fwd_fused_kernel<BF>), dim3(g.tiles + extra_blocks), dim3(256), 0, st, g, pro);
     AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+static int lstm_fwd_fill(LstmFwdArgs &g, const float *h_prev, int ldh, const float *c_prev, int ldc, const float *w_h,
+                         int ldw, const float *gx, int ldgx, float *h, float *c, float *gate_act, int M, int Hd,
+                         float forget_bias, int precision) {
+    AIR_REQUIRE(h_prev && c_prev && w_h && gx && h && c && gate_act, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0 && ldw >= 4 * Hd && ldgx >= 4 * Hd, AIR_E_SHAPE);
+    AIR_REQUIRE((ldh == 0 || ldh >= Hd) && (ldc == 0 || ldc >= Hd), AIR_E_SHAPE);
+    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+    g.h_prev = h_prev; g.w_h = w_h; g.gx = gx; g.c_prev = c_prev; g.h = h; g.c = c; g.gate_act = gate_act;
+    g.M = M; g.Hd = Hd; g.ldw = ldw; g.ldgx = ldgx; g.fb = forget_bias; g.ldh = ldh; g.ldc = ldc;
+    g.vecA = ((ldh % 4) == 0 && air_aligned16(h_prev)) ? 1 : 0;
+    g.tiles = air_cdiv(M, 16) * air_cdiv(Hd, 4);
     return AIR_OK;
 }
 extern "C" int air_lstm_step_fwd(const float *h_prev, const float *c_prev, const float *w_h, int ldw, const float *gx,
                                  int ldgx, float *h, float *c, float *gate_act, int M, int Hd, float forget_bias,
                                  int precision, void *stream) {
-    AIR_REQUIRE(h_prev && c_prev && w_h && gx && h && c && gate_act, AIR_E_NULL);
-    AIR_REQUIRE(M > 0 && Hd > 0 && ldw >= 4 * Hd && ldgx >= 4 * Hd, AIR_E_SHAPE);
-    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
     LstmFwdArgs g;
-    g.h_prev = h_prev; g.w_h = w_h; g.gx = gx; g.c_prev = c_prev; g.h = h; g.c = c; g.gate_act = gate_act;
-    g.M = M; g.Hd = Hd; g.ldw = ldw; g.ldgx = ldgx; g.fb = forget_bias;
-    g.vecA = ((Hd % 4) == 0 && air_aligned16(h_prev)) ? 1 : 0;
-    return precision == AIR_PREC_BF16 ? lstm_fwd_launch<true>(g, air_stream(stream))
-                                      : lstm_fwd_launch<false>(g, air_stream(stream));
+    int st = lstm_fwd_fill(g, h_prev, Hd, c_prev, Hd, w_h, ldw, gx, ldgx, h, c, gate_act, M, Hd, forget_bias, precision);
+    if (st) return st;
+    PrologueArgs pro = {};
+    return precision == AIR_PREC_BF16 ? lstm_fwd_launch<true>(g, pro, 0, air_stream(stream))
+                                      : lstm_fwd_launch<false>(g, pro, 0, air_stream(stream));
+}
+// First LSTM step of a train step with the step prologue riding along: h0 / c0 [1,Hd] are read with a broadcast row stride
+// by the step itself, while extra workgroups draw the step's noise, evaluate the annealed prior and write the tiled
+// initial state (needed only by later launches: the backward reads h_tiled / c_tiled).
+extern "C" int air_lstm_step_fwd_prologue(const float *h0, const float *c0, const float *w_h, int ldw, const float *gx,
+                                          int ldgx, float *h, float *c, float *gate_act, int M, int Hd, float forget_bias,
+                                          int precision, float *normal, size_t n_normal, float *uniform, size_t n_uniform,
+                                          const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
+                                          double init, double final_value, double anneal_steps, double hold_for,
+                                          double steps_div, double *prior_out_f64, int T, float *h_tiled, float *c_tiled,
+                                          void *stream) {
+    AIR_REQUIRE(rng_state_dev && global_step_dev && prior_out_f64 && h_tiled && c_tiled, AIR_E_NULL);
+    AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && anneal_type >= 0 && anneal_type <= 2, AIR_E_SHAPE);
+    LstmFwdArgs g;
+    int st = lstm_fwd_fill(g, h0, 0, c0, 0, w_h, ldw, gx, ldgx, h, c, gate_act, M, Hd, forget_bias, precision);
+    if (st) return st;
+    const PrologueArgs pro = make_prologue_args(normal, n_normal, uniform, n_uniform, rng_state_dev, global_step_dev,
+                                                anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
+                                                prior_out_f64, T, h0, c0, h_tiled, c_tiled, M, Hd);
+    const int extra = prologue_blocks(pro);
+    return precision == AIR_PREC_BF16 ? lstm_fwd_launch<true>(g, pro, extra, air_stream(stream))
+                                      : lstm_fwd_launch<false>(g, pro, extra, air_stream(stream));
 }
 
 template <bool BF>

@@ -342,24 +342,7 @@ extern "C" int air_rmsprop_centered(float *p, const float *g, float *ms, float *
 }
 
 // ---- Philox4x32-10 noise ----------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32(uint64_t ctr, uint64_t stream_id, uint64_t seed, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }          // [0,1)
-__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+#include "prologue_device.h"
 
 __global__ __launch_bounds__(PW_THREADS) void rng_fill_kernel(float *__restrict__ normal, size_t n_normal,
                                                               float *__restrict__ uniform, size_t n_uniform,
@@ -412,59 +395,8 @@ extern "C" int air_rng_advance(uint64_t *state_dev, uint64_t increment, void *st
 // ---- fused step prologue / epilogue (the train step is launch bound: 6 tiny launches become 2) -------------------
 // prologue: Philox noise for the whole step + annealed geometric prior (float64) + tiling of the trainable LSTM
 //           initial state over the batch.  Roles are split by block index.
-__global__ __launch_bounds__(PW_THREADS) void step_prologue_kernel(
-    float *__restrict__ normal, size_t n_normal, float *__restrict__ uniform, size_t n_uniform,
-    const uint64_t *__restrict__ rng_state, int rng_blocks,
-    const int64_t *__restrict__ gstep, int anneal_type, double init, double fin, double anneal_steps, double hold_for,
-    double steps_div, double *__restrict__ prior, int T,
-    const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ h_out, float *__restrict__ c_out,
-    int B, int Hd) {
-    const int bid = blockIdx.x;
-    if (bid < rng_blocks) {
-        const uint64_t seed = rng_state[0], offset = rng_state[1];
-        const size_t q_normal = (n_normal + 3) / 4, q_uniform = (n_uniform + 3) / 4;
-        for (size_t q = (size_t)bid * PW_THREADS + threadIdx.x; q < q_normal + q_uniform; q += (size_t)rng_blocks * PW_THREADS) {
-            uint32_t r[4];
-            philox4x32(offset + q, 0, seed, r);
-            if (q < q_normal) {
-                float z[4];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * k])));
-                    float sn, cs;
-                    sincosf(6.283185307179586f * u01(r[2 * k + 1]), &sn, &cs);
-                    z[2 * k] = rad * cs; z[2 * k + 1] = rad * sn;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (4 * q + k < n_normal) normal[4 * q + k] = z[k];
-            } else {
-                const size_t qq = q - q_normal;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (4 * qq + k < n_uniform) uniform[4 * qq + k] = u01(r[k]);
-            }
-        }
-    } else if (bid == rng_blocks) {
-        if (threadIdx.x == 0) {
-            double s = init;
-            if (anneal_type != 0) {
-                double step = (double)gstep[0] - hold_for;
-                if (step < 0.0) step = 0.0;
-                double val = (anneal_type == 1) ? init * pow(pow(fin / init, steps_div / anneal_steps), step / steps_div)
-                                                : fin + (init - fin) * (1.0 - step / anneal_steps);
-                s = val > fin ? val : fin;
-            }
-            s = s < 1e-7 ? 1e-7 : (s > 1.0 - 1e-15 ? 1.0 - 1e-15 : s);
-            const double probs = 1.0 - s;
-            for (int n = 0; n <= T; ++n) prior[n] = exp((double)n * log1p(-probs) + log(probs));
-        }
-    } else {
-        const int tb = bid - rng_blocks - 1, ntb = gridDim.x - rng_blocks - 1;
-        const size_t n = (size_t)B * Hd;
-        for (size_t i = (size_t)tb * PW_THREADS + threadIdx.x; i < n; i += (size_t)ntb * PW_THREADS) {
-            h_out[i] = h0[i % Hd];
-            c_out[i] = c0[i % Hd];
-        }
-    }
+__global__ __launch_bounds__(PW_THREADS) void step_prologue_kernel(PrologueArgs a) {
+    step_prologue_body(a, blockIdx.x, gridDim.x);
 }
 extern "C" int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_uniform,
                                  const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
@@ -474,13 +406,10 @@ extern "C" int air_step_prologue(float *normal, size_t n_normal, float *uniform,
     AIR_REQUIRE(rng_state_dev && global_step_dev && prior_out_f64 && h0 && c0 && h_tiled && c_tiled, AIR_E_NULL);
     AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
     AIR_REQUIRE(T > 0 && B > 0 && Hd > 0 && anneal_type >= 0 && anneal_type <= 2, AIR_E_SHAPE);
-    const size_t q = (n_normal + 3) / 4 + (n_uniform + 3) / 4;
-    const int rng_blocks = q ? pw_blocks(q) : 1;
-    const int tile_blocks = pw_blocks((size_t)B * Hd);
-    hipLaunchKernelGGL(step_prologue_kernel, dim3(rng_blocks + 1 + tile_blocks), dim3(PW_THREADS), 0,
-                       air_stream(stream), normal, n_normal, uniform, n_uniform, rng_state_dev, rng_blocks,
-                       global_step_dev, anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
-                       prior_out_f64, T, h0, c0, h_tiled, c_tiled, B, Hd);
+    const PrologueArgs a = make_prologue_args(normal, n_normal, uniform, n_uniform, rng_state_dev, global_step_dev,
+                                              anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
+                                              prior_out_f64, T, h0, c0, h_tiled, c_tiled, B, Hd);
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(prologue_blocks(a)), dim3(PW_THREADS), 0, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

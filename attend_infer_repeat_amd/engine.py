@@ -426,6 +426,10 @@ class AIREngine:
         if not fuse_lstm:
             self.gates = self._buf("gates", (T, B, 4 * Hd))
         for t in range(T):                                                                  # cell.py:126-127
+            if fuse_lstm and t == 0:
+                fwd.append(None)        # placeholder: the first step carries the step prologue (filled in per plan below)
+                lstm0_index = len(fwd) - 1
+                continue
             if fuse_lstm:
                 fwd.append((L.air_lstm_step_fwd, (p(self.h_seq[t]), p(self.c_seq[t]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,
                                                   p(self.h_seq[t + 1]), p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd,
@@ -596,9 +600,24 @@ class AIREngine:
                                    p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
              "air_step_epilogue")]
         self._plan_rng = rng
-        self._plan_fwd_noise = [prologue(True)] + fwd + fwd_tail      # forward(): complete outputs
-        self._plan_fwd = [prologue(False)] + fwd + fwd_tail
-        self._plan_fwd_train = [prologue(True)] + fwd                 # train step: NVIL rides in the first backward launch
+        def fwd_plan(with_noise):
+            """the forward list with its prologue: a launch of its own, or -- with the fused LSTM steps -- extra workgroups
+            of the first LSTM step, which then reads h0 / c0 with a broadcast row stride"""
+            if not fuse_lstm:
+                return [prologue(with_noise)] + fwd
+            lstm0 = (L.air_lstm_step_fwd_prologue,
+                     (p(self.params["lstm/h0"]), p(self.params["lstm/c0"]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,
+                      p(self.h_seq[1]), p(self.c_seq[1]), p(self.gate_act[0]), B, Hd, 1.0, prec,
+                      p(self.noise_normal), ctypes.c_size_t(n_norm if with_noise else 0), p(self.u_pres),
+                      ctypes.c_size_t(n_uni if with_noise else 0), p(self.rng_state), p(self.step_dev), anneal,
+                      float(cfg.nsp_init), float(cfg.nsp_final), float(cfg.nsp_steps), float(cfg.nsp_hold_init),
+                      float(cfg.nsp_steps_div), p(self.prior_dev), T, p(self.h_seq[0]), p(self.c_seq[0])),
+                     "air_lstm_step_fwd_prologue")
+            return fwd[:lstm0_index] + [lstm0] + fwd[lstm0_index + 1:]
+
+        self._plan_fwd_noise = fwd_plan(True) + fwd_tail              # forward(): complete outputs
+        self._plan_fwd = fwd_plan(False) + fwd_tail
+        self._plan_fwd_train = fwd_plan(True)                         # train step: NVIL rides in the first backward launch
         self._plan_bwd = bwd
         # data-parallel gradient buckets: (end index in the backward plan, [lo, hi) slice of the flat gradient buffer that
         # is final once the plan has run up to that index); contiguous, from the tail of the buffer to its head

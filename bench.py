@@ -128,7 +128,7 @@ def gemm_roofline(eng, reps=50):
                 f = 2.0 * a[2] * a[3] * a[4]
             elif name == "air_gemm_grouped":
                 f = sum(2.0 * d.M * d.N * d.K for d in a[0])
-            elif name == "air_lstm_step_fwd":                      # h[M,Hd] . W_h[Hd,4Hd] with the gate math fused
+            elif name in ("air_lstm_step_fwd", "air_lstm_step_fwd_prologue"):   # h[M,Hd] . W_h[Hd,4Hd], gate math fused
                 f = 2.0 * a[9] * a[10] * 4 * a[10]
             elif name == "air_lstm_step_bwd":                      # dgates[M,4Hd] . W_h^T
                 f = 2.0 * a[12] * a[13] * 4 * a[13]

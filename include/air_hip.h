@@ -150,6 +150,15 @@ int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const flo
 int air_lstm_step_fwd(const float *h_prev, const float *c_prev, const float *w_h, int ldw, const float *gx, int ldgx,
                       float *h, float *c, float *gate_act, int M, int Hd, float forget_bias, int precision,
                       void *stream);
+/* The first LSTM step of a train step with air_step_prologue riding along as extra workgroups: h0 / c0 [1,Hd] are read
+ * with a broadcast row stride; the noise, the annealed prior and the tiled initial state (h_tiled, c_tiled [M,Hd]) are
+ * written for the launches that follow.  Argument meaning as in air_lstm_step_fwd and air_step_prologue (B = M).        */
+int air_lstm_step_fwd_prologue(const float *h0, const float *c0, const float *w_h, int ldw, const float *gx, int ldgx,
+                               float *h, float *c, float *gate_act, int M, int Hd, float forget_bias, int precision,
+                               float *normal, size_t n_normal, float *uniform, size_t n_uniform,
+                               const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
+                               double init, double final_value, double anneal_steps, double hold_for, double steps_div,
+                               double *prior_out_f64, int T, float *h_tiled, float *c_tiled, void *stream);
 /* One BPTT link: dh = dgates_next[M,4Hd] . w_h[Hd,4Hd]^T + dh_a + dh_b (either may be NULL), then
  * air_lstm_pointwise_bwd of the step that gate_act / c_prev / c belong to -> dgates[M,4Hd], dc_prev[M,Hd]; and, if
  * dgx_out != NULL, dgx_out = dgx_in + dgates (the running sum over time that the hoisted x.W_x product receives;
