@@ -126,6 +126,28 @@ def test_bf16_graph_train_step_runs_and_learns(gpu_device):
     assert np.isfinite(last) and last < first - 50.0, (first, last)
 
 
+def test_large_batch_plan_matches_oracle(gpu_device):
+    """B = 704 (T*B = 2112 > 2048 glimpses, 44 x 16 LSTM tiles > 512): the plan switches to its throughput variants -- separate
+    heads / glimpse-read launches instead of the fused attend kernels, GEMM + pointwise LSTM steps, 32x32 GEMM tiles, long-K
+    weight gradients in their own launches.  Same parity bar as the latency-regime plan."""
+    ocfg, B = O.AIRConfig(), 704
+    eng, params, obs, noise = make_pair(ocfg, B)
+    names = [n for _, _, n in eng._plan_fwd_train + eng._plan_bwd]
+    assert "air_attend_fwd" not in names and "air_heads_fwd" in names and "air_lstm_pointwise_fwd" in names
+    eng.forward(sample_noise=False)
+    eng.backward()
+    out = eng.outputs()
+    res, grads = O.forward_backward(params, ocfg, obs, noise, global_step=20000)        # fp32 oracle: 704 images in fp64 is slow
+    assert torch.equal(out["presence"].cpu(), res["presence"])
+    for k in ["what", "where", "presence_prob", "final_canvas", "rec_loss_per_sample", "kl_what_per_sample", "baseline"]:
+        assert rel_err(out[k].reshape(res[k].shape), res[k]) < 5e-4, (k, rel_err(out[k].reshape(res[k].shape), res[k]))
+    for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
+        assert abs(out[k].item() - res[k].item()) <= 5e-4 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
+    g = eng.named_grads()
+    bad = {k: rel_err(g[k], ref) for k, ref in grads.items() if not rel_err(g[k], ref) < 5e-3}
+    assert not bad, bad
+
+
 def test_train_step_updates_match_oracle(gpu_device):
     ocfg, B = CONFIGS["mnist_b8"]
     eng, params, obs, noise = make_pair(ocfg, B, gstep=3)
