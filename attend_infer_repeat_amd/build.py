@@ -24,10 +24,12 @@ def _hipcc():
 
 
 def _digest(paths):
+    """Content hash of the build inputs.  File NAMES enter relative to the package (the repo lives under different roots in the
+    build container and on the GPU box: an absolute path in the hash would force a rebuild -- by every rank at once -- there)."""
     h = hashlib.sha256()
-    for p in sorted(paths):
+    for p in sorted(paths, key=os.path.basename):
         with open(p, "rb") as f:
-            h.update(p.encode()); h.update(f.read())
+            h.update(os.path.basename(p).encode()); h.update(f.read())
     return h.hexdigest()
 
 
@@ -35,30 +37,56 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _deps():
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    return sources() + headers + [os.path.join(PKG, "..", "include", "air_hip.h")]
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared object.  Returns the library path."""
+    """Compile every HIP source for gfx950 into one shared object.  Returns the library path.
+    Safe to call from several processes at once (one rank per GPU): an exclusive file lock serialises them, objects are
+    compiled in a private temporary directory and the library is moved into place atomically."""
+    import fcntl
+    import shutil
+    import tempfile
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = sources()
-    deps = srcs + [os.path.join(CSRC, "air_common.h"), os.path.join(PKG, "..", "include", "air_hip.h")]
     stamp = os.path.join(LIBDIR, "libair_hip.sha256")
-    digest = _digest([os.path.abspath(d) for d in deps])
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+    digest = _digest([os.path.abspath(d) for d in _deps()])
+
+    def fresh():
+        return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+
+    if not force and fresh():
         return LIB
-    objs = []
-    for s in srcs:
-        o = os.path.join(LIBDIR, os.path.basename(s).replace(".hip", ".o"))
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
-               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(o)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    with open(stamp, "w") as f:
-        f.write(digest)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():          # another process built it while this one waited for the lock
+                return LIB
+            tmp = tempfile.mkdtemp(prefix="air_build_", dir=LIBDIR)
+            try:
+                objs = []
+                for s in sources():
+                    o = os.path.join(tmp, os.path.basename(s).replace(".hip", ".o"))
+                    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
+                           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+                    if verbose:
+                        print(" ".join(cmd), file=sys.stderr)
+                    subprocess.check_call(cmd)
+                    objs.append(o)
+                out = os.path.join(tmp, "libair_hip.so")
+                cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                subprocess.check_call(cmd)
+                os.replace(out, LIB)
+                with open(stamp + ".tmp", "w") as f:
+                    f.write(digest)
+                os.replace(stamp + ".tmp", stamp)
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
