@@ -264,6 +264,35 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
         dist.destroy_process_group()
 
 
+def test_data_parallel_semantics_two_virtual_ranks(gpu_device):
+    """the data-parallel update equals centred RMSProp on the MEAN of the per-rank gradients of independent
+    per-rank reference steps.  Two ranks are emulated on one GPU: two engines with the same weights, each with its own batch
+    and noise; their flat gradient buffers are summed (what the RCCL all-reduce does) and the update runs with
+    grad_scale = 1/2 -- against the oracle's mean-gradient step."""
+    ocfg, B = CONFIGS["mnist_b8"]
+    e0, params, obs0, noise0 = make_pair(ocfg, B, seed=1, gstep=3)
+    e1, _, obs1, noise1 = make_pair(ocfg, B, seed=1, gstep=3)
+    obs1, _ = O.synthetic_batch(ocfg, B, seed=77)
+    noise1 = O.make_noise(ocfg, B, seed=78)
+    e1.set_obs(obs1.cuda()); e1.set_noise(noise1["eps_where"].cuda(), noise1["eps_what"].cuda(), noise1["u_pres"].cuda())
+    for e in (e0, e1):
+        e.forward(sample_noise=False); e.backward()
+    e0.synchronize(); e1.synchronize()
+    e0.flat_grads.add_(e1.flat_grads)                                # all_reduce(SUM) over the two ranks
+    e0.optimizer_step(grad_scale=0.5)
+    e0.synchronize()
+    p64 = f64(params)
+    _, g0 = O.forward_backward(p64, ocfg, obs0.double(), f64(noise0), global_step=3)
+    _, g1 = O.forward_backward(p64, ocfg, obs1.double(), f64(noise1), global_step=3)
+    mean = {k: 0.5 * (g0[k] + g1[k]) for k in g0}
+    slots = O.rmsprop_init(p64)
+    O.rmsprop_centered_step(p64, mean, slots, ocfg)
+    for k, ref in p64.items():
+        delta_ref = ref - params[k].double()
+        delta = e0.params[k].cpu().double() - params[k].double()
+        assert rel_err(delta, delta_ref) < 5e-3, (k, rel_err(delta, delta_ref))
+
+
 def test_checkpoint_resume_is_bit_exact(gpu_device, tmp_path):
     """Save after 3 steps, resume in a fresh engine, run 3 more: identical to 6 uninterrupted steps (params, optimiser
     slots, step counter and noise stream all restored)."""
