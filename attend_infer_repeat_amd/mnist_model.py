@@ -92,7 +92,10 @@ class AIRonMNIST(AIRModel):
 
     def train_step(self, learning_rate, l2_weight=0., what_prior=None, where_scale_prior=None,
                    where_shift_prior=None, num_steps_prior=None, use_prior=True, use_reinforce=True, baseline=None,
-                   decay_rate=None, optimizer=None, opt_kwargs=None, use_engine=True, capture_graph=True):
+                   decay_rate=None, optimizer=None, opt_kwargs=None, use_engine=True, capture_graph=True,
+                   mfma_dtype="f32"):
+        """model.py:261-376 on the fused engine.  Extras over the reference signature: `use_engine` / `capture_graph`, and
+        `mfma_dtype` ("f32" exact fp32 MFMA, "bf16" = bf16-rounded operands with fp32 accumulate in every dense product)."""
         fn, gs = super(AIRonMNIST, self).train_step(learning_rate, l2_weight, what_prior, where_scale_prior,
                                                     where_shift_prior, num_steps_prior, use_prior, use_reinforce,
                                                     baseline, decay_rate, optimizer, opt_kwargs)
@@ -100,6 +103,7 @@ class AIRonMNIST(AIRModel):
                     and decay_rate is None and not l2_weight)
         if not standard:
             return fn, gs
+        self._hyper["mfma_dtype"] = mfma_dtype
         cfg = self.engine_config(learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior)
         eng = AIREngine(cfg, self.batch_size, device=self.obs.device)
         named = self._named_module_params()

@@ -192,6 +192,30 @@ def test_aironmnist_engine_backed_training(amd):
     assert rel(air.where, eo["where"]) < 1e-4 and rel(air.final_canvas, eo["final_canvas"]) < 1e-4
 
 
+def test_aironmnist_bf16_mfma_option(amd):
+    """BASELINE configs[4] through the reference's surface: train_step(..., mfma_dtype="bf16") runs the engine with
+    bf16-rounded operands; a few updates stay finite and close to the fp32 run from the same weights and noise stream."""
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    AD = amd.utils.AttrDict
+    B = 16
+    imgs, nums = synthetic_multi_mnist(B, (50, 50), 2, seed=0)
+    x, y = torch.from_numpy(imgs).cuda(), torch.from_numpy(nums).cuda()
+    losses = {}
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(0)
+        air = amd.mnist_model.AIRonMNIST(x, y, max_steps=3, explore_eps=1e-3, steps_pred_hidden=[128, 64],
+                                         transform_var_bias=.5, step_bias=.75, output_multiplier=.5)
+        nsp = AD(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3)
+        train_step, _ = air.train_step(1e-4, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.), AD(loc=0., scale=1.), nsp,
+                                       mfma_dtype=mode)
+        assert air._engine.cfg.mfma_dtype == mode
+        for _ in range(3):
+            train_step()
+        losses[mode] = air.rec_loss.item()
+        assert np.isfinite(losses[mode]) and torch.isfinite(air._engine.flat_params).all()
+    assert abs(losses["bf16"] - losses["f32"]) < 0.05 * abs(losses["f32"]) + 1.0, losses
+
+
 def test_training_script_counterpart_runs(amd, tmp_path):
     """scripts/multi_mnist.py counterpart: a short run trains, logs the reference's scalar set and checkpoints."""
     from attend_infer_repeat_amd.scripts import multi_mnist
