@@ -75,3 +75,118 @@ class DeviceFeeder(object):
             idx = (torch.arange(self.batch_size, device=self.imgs.device) + self._pos) % self.n
             self._pos = (self._pos + self.batch_size) % self.n
         return self.imgs.index_select(0, idx), self.nums.index_select(1, idx)
+
+
+# ---- multi-MNIST synthesis from digit templates (reference: data/data.py:19-107) ----------------------------------------
+def _tight_box(template):
+    """(y0, x0), (height, width) of the non-zero support of a template (data.py:19-32: first..last non-zero row / column)."""
+    rows = np.flatnonzero(template.sum(1) > 0)
+    cols = np.flatnonzero(template.sum(0) > 0)
+    if rows.size == 0 or cols.size == 0:
+        return (0, 0), (0, 0)
+    return (int(rows[0]), int(cols[0])), (int(rows[-1] - rows[0] + 1), int(cols[-1] - cols[0] + 1))
+
+
+def _resize_templates(templates, obj_size):
+    if tuple(templates.shape[1:]) == tuple(obj_size):
+        return templates
+    import torch
+    t = torch.as_tensor(templates, dtype=torch.float32)[:, None]
+    t = torch.nn.functional.interpolate(t, size=tuple(obj_size), mode="bilinear", align_corners=False)
+    return t[:, 0].clamp_(0, 255).round_().numpy().astype(templates.dtype)
+
+
+def create_multi_mnist(templates, labels=None, canvas_size=(50, 50), obj_size=(28, 28), n_objects=(0, 2), n_samples=None,
+                       dtype=np.uint8, expand_nums=True, with_overlap=False, seed=0, max_tries=5):
+    """Multi-digit canvases from single-digit templates, the generator of the reference's dataset script (data.py:35-107).
+
+    templates [N, h, w] (uint8 0..255 or float 0..1 -- MNIST digits when available; the container has no network, so the
+    caller supplies them, e.g. `load_mnist_idx`), labels [N] optional.  Per sample: n ~ U{0..max(n_objects)} distinct templates,
+    each cropped to the tight bounding box of its non-zero pixels and pasted at a uniformly random position where the box fits;
+    without overlap a position is redrawn while the box hits an occupied box, at most `max_tries` redraws per SAMPLE, after
+    which the whole sample is started again (data.py:84-97).  Returns dict(imgs [n,H,W] dtype, labels [n,max] uint8,
+    nums [max+1,n,1] cumulative one-hot (data.py:101-105) or [n] counts)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    templates = np.asarray(templates)
+    if templates.dtype != np.uint8 and dtype == np.uint8:
+        templates = np.clip(np.round(templates * 255.0), 0, 255).astype(np.uint8)
+    templates = _resize_templates(templates, obj_size)
+    n_templates = templates.shape[0]
+    n_samples = n_templates if n_samples is None else int(n_samples)
+    max_objects = int(max(np.atleast_1d(n_objects)))
+    H, W = canvas_size
+    imgs = np.zeros((n_samples, H, W), dtype=dtype)
+    lab = np.zeros((n_samples, max_objects), dtype=np.uint8)
+    nums = rng.integers(0, max_objects + 1, size=n_samples).astype(np.uint8)
+    boxes = [_tight_box(t) for t in templates]
+    occupancy = np.zeros((H, W), dtype=bool)
+
+    def position(size):
+        return np.round(rng.random(2) * (np.asarray([H, W]) - np.asarray(size))).astype(np.int64)
+
+    i = 0
+    while i < n_samples:
+        n, tries, retry = int(nums[i]), 0, False
+        occupancy[...] = False
+        idx = rng.choice(n_templates, size=n, replace=False) if n > 0 else []
+        for j, k in enumerate(idx):
+            (y0, x0), (sh, sw) = boxes[k]
+            if sh > H or sw > W:
+                raise ValueError("template box %s does not fit the canvas %s" % ((sh, sw), (H, W)))
+            p = position((sh, sw))
+            if not with_overlap:
+                while occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw].any() and tries < max_tries:
+                    p = position((sh, sw))
+                    tries += 1
+                if tries == max_tries and occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw].any():
+                    retry = True
+                    break
+            imgs[i, p[0]:p[0] + sh, p[1]:p[1] + sw] = templates[k, y0:y0 + sh, x0:x0 + sw]
+            occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw] = True
+            if labels is not None:
+                lab[i, j] = labels[k]
+        if retry:
+            imgs[i] = 0
+            lab[i] = 0
+        else:
+            i += 1
+    if expand_nums:
+        expanded = np.zeros((max_objects + 1, n_samples, 1), dtype=np.uint8)
+        for s, n in enumerate(nums):
+            expanded[:n, s] = 1
+        nums = expanded
+    return dict(imgs=imgs, labels=lab, nums=nums)
+
+
+def load_mnist_idx(directory, partition="train"):
+    """MNIST digits from the standard idx-ubyte files (train-images-idx3-ubyte[.gz], ...), for create_multi_mnist.
+    (The reference downloads them through tensorflow.examples.tutorials.mnist, data.py:38; there is no network here.)"""
+    import gzip
+    import os
+    import struct
+    stem = {"train": "train", "validation": "train", "test": "t10k"}[partition]
+
+    def read(name):
+        for cand in (name, name + ".gz"):
+            path = os.path.join(directory, cand)
+            if os.path.exists(path):
+                opener = gzip.open if cand.endswith(".gz") else open
+                with opener(path, "rb") as f:
+                    return f.read()
+        raise FileNotFoundError(os.path.join(directory, name))
+
+    raw = read("%s-images-idx3-ubyte" % stem)
+    magic, n, h, w = struct.unpack(">IIII", raw[:16])
+    if magic != 2051:
+        raise ValueError("not an idx3 image file")
+    images = np.frombuffer(raw, np.uint8, offset=16).reshape(n, h, w)
+    raw = read("%s-labels-idx1-ubyte" % stem)
+    magic, n2 = struct.unpack(">II", raw[:8])
+    if magic != 2049 or n2 != n:
+        raise ValueError("label file does not match the image file")
+    labels = np.frombuffer(raw, np.uint8, offset=8)
+    if partition == "train":           # tensorflow's read_data_sets holds out the first 5000 training digits for validation
+        return images[5000:], labels[5000:]
+    if partition == "validation":
+        return images[:5000], labels[:5000]
+    return images, labels
