@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     // ---- main loop: U chunks in flight per wave.  The problem is latency bound (operands sit in L2 / Infinity
     // Cache, each wave owns only a handful of 16-deep chunks), so all loads of U chunks are issued before the first
     // MFMA: one memory round trip per U chunks instead of one per chunk.
-    constexpr int U = (MT * NT == 1) ? 8 : 4;             // chunks in flight: small tiles can afford more registers
+    constexpr int U = (MT * NT == 1) ? (KW == 16 ? 10 : 8) : 4;   // chunks in flight: small tiles can afford more registers
     int full_end = g.K >> 4;                               // chunks [0, full_end) need no k masking
     if (full_end > c_end) full_end = c_end;
     int rowAc[MT], colBc[NT];
