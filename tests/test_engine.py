@@ -148,6 +148,40 @@ def test_large_batch_plan_matches_oracle(gpu_device):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("B,mfma", [(64, "f32"), (1024, "f32"), (1024, "bf16")])
+def test_batch_permutation_equivariance_at_full_size(gpu_device, B, mfma):
+    """Size-independent property at BASELINE sizes (configs[1]: B=64; configs[4]: B=1024, where the oracle is too slow to be
+    the checker): images are independent through the whole forward, so permuting the batch (images and their noise) must
+    permute every per-sample output EXACTLY -- each output row / canvas is accumulated in the same order wherever its tile
+    sits -- and leave the batch-summed gradients unchanged up to summation order."""
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+    ocfg = O.AIRConfig()
+    obs, _ = O.synthetic_batch(ocfg, B, seed=3)
+    noise = O.make_noise(ocfg, B, seed=4)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5))
+    params = O.init_params(ocfg, seed=1, bias_std=0.1)
+    outs, grads = [], []
+    for pm in (None, perm):
+        eng = AIREngine(EngineConfig(mfma_dtype=mfma), B, seed=1)
+        eng.load_parameters(params)
+        o, nz = (obs, noise) if pm is None else (obs[pm], {k: v[:, pm] for k, v in noise.items()})
+        eng.set_obs(o.cuda())
+        eng.set_noise(nz["eps_where"].cuda(), nz["eps_what"].cuda(), nz["u_pres"].cuda())
+        eng.set_global_step(20000)
+        eng.forward(sample_noise=False); eng.backward()
+        outs.append({k: v.clone() for k, v in eng.outputs().items() if torch.is_tensor(v)})
+        grads.append({k: v.clone() for k, v in eng.named_grads().items()})
+    a, b = outs
+    pc = perm.cuda()
+    for k in ["what", "where", "presence", "presence_prob", "glimpse"]:                 # [T, B, ...]
+        assert torch.equal(a[k].reshape(ocfg.max_steps, B, -1)[:, pc], b[k].reshape(ocfg.max_steps, B, -1)), k
+    for k in ["final_canvas", "rec_loss_per_sample", "kl_what_per_sample", "kl_where_per_sample", "kl_num_steps_per_sample",
+              "num_steps_log_prob", "baseline"]:                                        # [B, ...]
+        assert torch.equal(a[k].reshape(B, -1)[pc], b[k].reshape(B, -1)), k
+    for k in grads[0]:
+        assert rel_err(grads[1][k], grads[0][k]) < 2e-4, (k, rel_err(grads[1][k], grads[0][k]))
+
+
 def test_train_step_updates_match_oracle(gpu_device):
     ocfg, B = CONFIGS["mnist_b8"]
     eng, params, obs, noise = make_pair(ocfg, B, gstep=3)
