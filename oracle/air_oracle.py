@@ -20,7 +20,11 @@ PARITY STATUS
                  assumptions are listed in tests/golden/ASSUMPTIONS.md.  The ST is
                  cross-checked by two further independent codings
                  (oracle/st_loops.c scalar loops, torch grid_sample) and fp64
-                 finite differences.
+                 finite differences; affine/ELU, the LSTM step, Gaussian
+                 sampling + KL, the num-steps math and centred RMSProp by a
+                 scalar-loop C coding (oracle/net_loops.c,
+                 tests/test_oracle_net_loops.py).  Independent codings catch
+                 slips, they do not pin the third-party semantics.
 
 Reference citations are `file:line` under /root/reference/attend_infer_repeat/.
 Weights use Sonnet layout: Linear w[in, out]; LSTM w_gates[in+hid, 4*hid], gate
