@@ -57,6 +57,41 @@ def model_case(name, cfg, B, gstep):
     np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
 
 
+def digest_indices(n, k=512):
+    """fixed, evenly spread sample positions of a flattened tensor (all of it when it is small)"""
+    return np.arange(n) if n <= k else np.linspace(0, n - 1, k).round().astype(np.int64)
+
+
+def model_case_full_size(name, cfg, B, gstep, param_seed=11, bias_std=0.15):
+    """BASELINE-size fixture (configs[1]: 50x50 / 20x20 / T=3 at batch 64).  The 2.6 M parameters and their gradients would
+    be 20 MB as raw arrays, so the fixture holds: the seed the parameters are drawn from plus a float64 checksum per tensor
+    (the test regenerates them with O.init_params and verifies the checksums), obs, noise, every per-sample output, the
+    scalar losses, and per gradient tensor a 512-point evenly spread sample + its sum and abs-sum in float64."""
+    params = O.init_params(cfg, seed=param_seed, bias_std=bias_std)
+    obs, _ = O.synthetic_batch(cfg, B, seed=12)
+    noise = O.make_noise(cfg, B, seed=13)
+    p64 = {k: v.double() for k, v in params.items()}
+    res, grads = O.forward_backward(p64, cfg, obs.double(), {k: v.double() for k, v in noise.items()}, global_step=gstep)
+    out = {"obs": obs.numpy(), "global_step": np.int64(gstep), "param_seed": np.int64(param_seed),
+           "param_bias_std": np.float64(bias_std)}
+    out.update({f"param_sum/{k}": np.float64(v.double().sum().item()) for k, v in params.items()})
+    out.update({f"param_abs/{k}": np.float64(v.double().abs().sum().item()) for k, v in params.items()})
+    out.update({f"noise/{k}": v.numpy() for k, v in noise.items()})
+    keep = ["glimpse", "what", "what_loc", "what_scale", "where", "where_loc", "where_scale", "presence_prob",
+            "presence", "final_canvas", "rec_loss_per_sample", "kl_num_steps_per_sample", "kl_what_per_sample",
+            "kl_where_per_sample", "num_steps_posterior", "prior_step_weight", "num_steps_log_prob", "baseline",
+            "rec_loss", "kl_num_steps", "kl_what", "kl_where", "loss", "reinforce_loss", "baseline_loss", "opt_loss"]
+    out.update({f"out/{k}": res[k].numpy().astype(np.float32) for k in keep})
+    for k, v in grads.items():
+        flat = v.numpy().reshape(-1)
+        idx = digest_indices(flat.size)
+        out[f"grad_sample/{k}"] = flat[idx].astype(np.float32)
+        out[f"grad_sum/{k}"] = np.float64(flat.sum())
+        out[f"grad_abs/{k}"] = np.float64(np.abs(flat).sum())
+        out[f"grad_max/{k}"] = np.float64(np.abs(flat).max())
+    np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
+
+
 def prior_known_answers():
     """The numbers held by the reference's own tests (test/prior_test.py:15-24, 100-120)."""
     np.savez(os.path.join(HERE, "prior_known_answers.npz"),
@@ -75,6 +110,7 @@ if __name__ == "__main__":
                                     inpt_encoder_hidden=(32, 24), glimpse_encoder_hidden=(28,),
                                     glimpse_decoder_hidden=(20, 16), transform_estimator_hidden=(18,),
                                     steps_pred_hidden=(12, 6), baseline_hidden=(16, 8), max_steps=3), 5, 1500)
+    model_case_full_size("c2_b64", O.AIRConfig(), 64, 20000)
     prior_known_answers()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -2,9 +2,13 @@
 C ABI) against the CPU oracle's literal per-step restatement with autograd.
 
 Tolerances: the oracle is evaluated in float64 on the same fp32 inputs; the engine computes in fp32 with a different
-summation order (batched over T, split-K).  Outputs agree to ~1e-5 relative, gradients to 2e-3 of each tensor's max
-magnitude (measured worst case ~2e-4; see DESIGN.md "Parity")."""
+summation order (batched over T, split-K).  Every tensor is checked two ways: the worst element against the tensor's max
+magnitude (fp32 cancellation noise scales with the tensor, not with the element) AND the relative L2 error of the whole
+tensor (so small-magnitude elements are not hidden behind one large one).  The bounds are ~10x the worst values measured
+on MI355X over all configurations below (profiles/r02_parity_margins.json): outputs 1e-4 / 3e-5, gradients 3e-4 / 1e-4."""
 import dataclasses
+import json
+import os
 
 import numpy as np
 import pytest
@@ -39,6 +43,34 @@ def rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
+def l2_err(a, b):
+    a = a.detach().cpu().double().reshape(-1); b = b.detach().cpu().double().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+OUT_TOL, OUT_L2 = 1e-4, 3e-5          # per-sample outputs: worst element / tensor max, relative L2
+GRAD_TOL, GRAD_L2 = 3e-4, 1e-4        # gradients
+_MARGINS = {}
+
+
+def record_margin(test, name, kind, key, value):
+    """AIR_PARITY_MARGINS=<path>: dump the worst observed errors so the tolerances above can be re-derived from a GPU run."""
+    path = os.environ.get("AIR_PARITY_MARGINS")
+    if not path:
+        return
+    slot = _MARGINS.setdefault(f"{test}[{name}]", {})
+    if value > slot.get(kind, (None, -1.0))[1]:
+        slot[kind] = (key, value)
+    with open(path, "w") as f:
+        json.dump(_MARGINS, f, indent=1, sort_keys=True)
+
+
+def check_tensor(test, name, kind, key, got, ref, tol, tol_l2):
+    e, e2 = rel_err(got, ref), l2_err(got, ref)
+    record_margin(test, name, kind + "_max", key, e); record_margin(test, name, kind + "_l2", key, e2)
+    assert e < tol and e2 < tol_l2, (key, e, e2)
+
+
 CONFIGS = {
     "mnist_b8": (O.AIRConfig(), 8),
     "tiny": (O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3,
@@ -55,6 +87,10 @@ CONFIGS = {
     "b1": (O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3,
                          transform_var_bias=0.5), 1),
     "mnist_b17": (O.AIRConfig(), 17),
+    # the sizes the metric is quoted on: BASELINE configs[1] (scripts/multi_mnist.py:24-37: 50x50 / 20x20 / T=3, batch 64) and
+    # configs[3] (100x100 canvas, 28x28 glimpse, T=5) at the same batch
+    "mnist_b64": (O.AIRConfig(), 64),
+    "c4_b64": (O.AIRConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5), 64),
 }
 
 
@@ -74,16 +110,15 @@ def test_forward_and_gradients_match_oracle(gpu_device, name):
               "kl_where_per_sample", "num_steps_posterior", "prior_step_weight", "num_steps_log_prob", "baseline"]:
         ref = res[k]
         got = out[k].reshape(ref.shape)
-        assert rel_err(got, ref) < 2e-4, (k, rel_err(got, ref))
+        check_tensor("fwd_bwd", name, "out", k, got, ref, OUT_TOL, OUT_L2)
     for k in ["rec_loss", "kl_num_steps", "kl_what", "kl_where", "loss", "reinforce_loss", "baseline_loss",
               "opt_loss", "imp_weight_mean", "imp_weight_var"]:
-        assert abs(out[k].item() - res[k].item()) <= 2e-4 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
+        err = abs(out[k].item() - res[k].item()) / (abs(res[k].item()) + 1.0)
+        record_margin("fwd_bwd", name, "scalar", k, err)
+        assert err <= 5e-5, (k, out[k].item(), res[k].item())
     g = eng.named_grads()
-    worst = {}
     for k, ref in grads.items():
-        worst[k] = rel_err(g[k], ref)
-    bad = {k: v for k, v in worst.items() if not v < 2e-3}
-    assert not bad, bad
+        check_tensor("fwd_bwd", name, "grad", k, g[k], ref, GRAD_TOL, GRAD_L2)
 
 
 @pytest.mark.parametrize("name", ["mnist_b8", "rect_t5"])
@@ -112,6 +147,71 @@ def test_bf16_mfma_path_matches_bf16_emulating_oracle(gpu_device, name):
     # the mode is really on: the result differs from exact fp32 by a bf16-sized amount, not by fp32 noise
     d32 = rel_err(out["what"].reshape(res32["what"].shape), res32["what"])
     assert 1e-4 < d32 < 5e-2, d32
+
+
+def test_bf16_path_at_batch_1024_matches_bf16_emulating_oracle(gpu_device):
+    """BASELINE configs[4] at its own size (batch 1024, 3072 glimpse rows: the throughput-regime plan) against the oracle that
+    emulates the bf16-operand arithmetic, evaluated in fp32 (0.6 s on the host)."""
+    ocfg, B = O.AIRConfig(), 1024
+    eng, params, obs, noise = make_pair(ocfg, B, mfma_dtype="bf16")
+    eng.forward(sample_noise=False)
+    eng.backward()
+    out = eng.outputs()
+    with O.matmul_mode("bf16"):
+        res, grads = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
+    # a Bernoulli draw whose probability sits within bf16 noise of its uniform variate may flip; such images are excluded
+    # from the per-sample comparison (there must be almost none) and the batch-summed gradients are compared regardless
+    same = (out["presence"].cpu().reshape(ocfg.max_steps, B) == res["presence"].reshape(ocfg.max_steps, B)).all(0)
+    assert same.float().mean().item() > 0.995, same.float().mean().item()
+    for k in ["what", "where", "presence_prob"]:                                                     # [T, B, ...]
+        a = out[k].cpu().reshape(ocfg.max_steps, B, -1)[:, same]; r = res[k].reshape(ocfg.max_steps, B, -1)[:, same]
+        record_margin("bf16_b1024", "c5", "out_max", k, rel_err(a, r))
+        assert rel_err(a, r) < 2e-3, (k, rel_err(a, r))
+    for k in ["final_canvas", "rec_loss_per_sample", "kl_what_per_sample", "kl_where_per_sample", "baseline"]:   # [B, ...]
+        a = out[k].cpu().reshape(B, -1)[same]; r = res[k].reshape(B, -1)[same]
+        record_margin("bf16_b1024", "c5", "out_max", k, rel_err(a, r))
+        assert rel_err(a, r) < 2e-3, (k, rel_err(a, r))
+    if bool(same.all()):
+        for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
+            assert abs(out[k].item() - res[k].item()) <= 2e-3 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
+        g = eng.named_grads()
+        for k, ref in grads.items():
+            record_margin("bf16_b1024", "c5", "grad_max", k, rel_err(g[k], ref))
+            assert rel_err(g[k], ref) < 1e-2, (k, rel_err(g[k], ref))
+
+
+def test_graph_captured_train_steps_at_batch_64_match_oracle(gpu_device):
+    """The thing bench.py times -- hipGraph replays of noise + forward + backward + both RMSProp updates at BASELINE
+    configs[1]'s batch 64 -- against O.train_step in float64.  The graph draws its own Philox noise on the device; after each
+    replay the noise it used is read back and handed to the oracle, so three consecutive updates are compared."""
+    ocfg, B = O.AIRConfig(), 64
+    eng, params, obs, noise = make_pair(ocfg, B, gstep=3)
+    p64 = f64(params)
+    slots = O.rmsprop_init(p64)
+    eng.capture()
+    prev = {k: v.clone() for k, v in p64.items()}
+    for it in range(3):
+        eng.train_step()
+        eng.synchronize()
+        used = {"eps_where": eng.eps_where.cpu().double(), "eps_what": eng.eps_what.cpu().double(),
+                "u_pres": eng.u_pres.cpu().double().reshape(ocfg.max_steps, B, 1)}
+        used = {k: v.reshape(noise[k].shape) for k, v in used.items()}
+        O.train_step(p64, slots, ocfg, obs.double(), used, global_step=3 + it)
+        for k, ref in p64.items():
+            d_ref = ref - prev[k]
+            d_got = eng.params[k].cpu().double() - prev[k]
+            record_margin("graph_train", f"step{it}", "delta_max", k, rel_err(d_got, d_ref))
+            assert rel_err(d_got, d_ref) < 2e-3, (it, k, rel_err(d_got, d_ref))
+        # continue from the ENGINE's parameters so that fp32 rounding of the state does not accumulate into the next comparison
+        for k in p64:
+            p64[k] = eng.params[k].cpu().double().clone()
+            prev[k] = p64[k].clone()
+        slots_dev = {"ms": eng.flat_ms, "mg": eng.flat_mg, "mom": eng.flat_mom}
+        for sk, flat in slots_dev.items():
+            for k in p64:
+                o, n = eng.param_offsets[k], eng.param_sizes[k]
+                slots[k][sk] = flat[o:o + n].view(eng.param_shapes[k]).cpu().double().clone()
+    assert eng.global_step == 6 and eng.step_dev.item() == 6
 
 
 def test_bf16_graph_train_step_runs_and_learns(gpu_device):
