@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
+ABI_VERSION = 2  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -25,6 +26,7 @@ class AirGemmDesc(ctypes.Structure):
 SIGNATURES = {
     "air_abi_version": (c_int, []),
     "air_status_string": (ctypes.c_char_p, [c_int]),
+    "air_build_digest": (ctypes.c_char_p, []),
     "air_st_read_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "air_st_read_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "air_st_write_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -129,8 +131,17 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.air_abi_version() != 1:
-        raise AirHipError("libair_hip.so ABI version mismatch")
+    if lib.air_abi_version() != ABI_VERSION:
+        raise AirHipError(f"libair_hip.so ABI version {lib.air_abi_version()} != binding {ABI_VERSION}: rebuild "
+                          "(python -m attend_infer_repeat_amd.build)")
+    # a binary compiled from other sources than the ones next to it (a checkout that changed csrc/ without a rebuild) would
+    # be called with possibly changed argument lists -- ctypes cannot notice -- so it is refused
+    from . import build as _build
+    if os.path.isdir(_build.CSRC) and os.environ.get("AIR_SKIP_DIGEST_CHECK") != "1":
+        built, have = lib.air_build_digest().decode(), _build.source_digest()
+        if built != have:
+            raise AirHipError(f"{LIB_PATH} was built from different sources (binary {built[:12]}, tree {have[:12]}): "
+                              "rebuild with `python -m attend_infer_repeat_amd.build`")
     _lib = lib
     return lib
 

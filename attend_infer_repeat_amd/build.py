@@ -42,6 +42,11 @@ def _deps():
     return sources() + headers + [os.path.join(PKG, "..", "include", "air_hip.h")]
 
 
+def source_digest():
+    """Digest of the build inputs as they are on disk now (what a fresh build would embed as air_build_digest())."""
+    return _digest([os.path.abspath(d) for d in _deps()])
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into one shared object.  Returns the library path.
     Safe to call from several processes at once (one rank per GPU): an exclusive file lock serialises them, objects are
@@ -69,7 +74,7 @@ def build(force=False, verbose=False):
                 for s in sources():
                     o = os.path.join(tmp, os.path.basename(s).replace(".hip", ".o"))
                     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
-                           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+                           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", f'-DAIR_BUILD_DIGEST="{digest}"']
                     if verbose:
                         print(" ".join(cmd), file=sys.stderr)
                     subprocess.check_call(cmd)

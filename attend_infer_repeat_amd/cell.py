@@ -68,6 +68,21 @@ class AIRCell(torch.nn.Module):
             return None
         return float(e.item()) if torch.is_tensor(e) else float(e)
 
+    def _validate(self, name, value, kind):
+        """debug=True (cell.py:66-67,130-131,144-145: `validate_args=self._debug, allow_nan_stats=not self._debug` on the
+        three distributions): TF then asserts a positive Normal scale and Bernoulli probabilities inside [0, 1], and NaNs
+        trip those assertions.  Eager counterpart: a device sync per check, so only in debug mode."""
+        if not self._debug:
+            return
+        ok = torch.isfinite(value).all()
+        if kind == "scale":
+            ok = ok & (value > 0).all()
+        elif kind == "prob":
+            ok = ok & (value >= 0).all() & (value <= 1).all()
+        if not bool(ok):
+            raise ValueError("AIRCell(debug=True): invalid %s parameter `%s` (non-finite or outside its support)"
+                             % ("Normal" if kind != "prob" else "Bernoulli", name))
+
     def initial_state(self, img):                                            # cell.py:101-114
         batch_size = img.shape[0]
         dev = img.device
@@ -100,6 +115,7 @@ class AIRCell(torch.nn.Module):
             where_distrib = NormalWithSoftplusScale(*est(hidden_output))
         where_code = where_distrib.sample(noise.get("eps_where"))
         where_loc, where_scale = where_distrib.loc, where_distrib.scale
+        self._validate("where_loc", where_loc, "loc"); self._validate("where_scale", where_scale, "scale")
 
         cropped = self._spatial_transformer(img, where_code)                 # cell.py:135
 
@@ -124,10 +140,12 @@ class AIRCell(torch.nn.Module):
             else:
                 presence = presence_prob
 
+        self._validate("presence_prob", presence_prob, "prob")
         what_params = self._glimpse_encoder(cropped)                         # cell.py:153-156
         what_distrib = self._what_distrib(what_params)
         what_code = what_distrib.sample(noise.get("eps_what"))
         what_loc, what_scale = what_distrib.loc, what_distrib.scale
+        self._validate("what_loc", what_loc, "loc"); self._validate("what_scale", what_scale, "scale")
 
         decoded = self._glimpse_decoder(what_code)                           # cell.py:158-165 (one fused kernel)
         canvas = F.st_write_acc(decoded.reshape((B,) + self._crop_size), where_code, presence,

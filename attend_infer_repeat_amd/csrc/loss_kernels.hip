@@ -291,6 +291,10 @@ extern "C" int air_event_destroy(void *event) {
 }
 
 extern "C" int air_abi_version(void) { return AIR_ABI_VERSION; }
+#ifndef AIR_BUILD_DIGEST
+#define AIR_BUILD_DIGEST "unstamped"
+#endif
+extern "C" const char *air_build_digest(void) { return AIR_BUILD_DIGEST; }
 extern "C" const char *air_status_string(int status) {
     switch (status) {
         case AIR_OK: return "ok";

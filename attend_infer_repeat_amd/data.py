@@ -76,6 +76,14 @@ class DeviceFeeder(object):
             self._pos = (self._pos + self.batch_size) % self.n
         return self.imgs.index_select(0, idx), self.nums.index_select(1, idx)
 
+    def state_dict(self):
+        """Position of the feeder (sampler state / cursor) so that a resumed run draws the batches an uninterrupted one would."""
+        return {"pos": int(self._pos), "gen": self.gen.get_state().cpu()}
+
+    def load_state_dict(self, sd):
+        self._pos = int(sd["pos"])
+        self.gen.set_state(sd["gen"])
+
 
 # ---- multi-MNIST synthesis from digit templates (reference: data/data.py:19-107) ----------------------------------------
 def _tight_box(template):

@@ -217,16 +217,43 @@ class AIREngine:
             if len(shape) == 2 and not k.endswith(("/h0", "/c0")):
                 w = torch.empty(shape, dtype=torch.float32)
                 torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
-                self.params[k].copy_(w * (1.0 / math.sqrt(shape[0])))
+                self._copy_in(self.params[k], w * (1.0 / math.sqrt(shape[0])))
             else:
-                self.params[k].zero_()
+                self._fill_in(self.params[k], 0.0)
+
+    # ---- stream discipline ------------------------------------------------------------------------------------------
+    # The engine runs on its own stream.  Everything that enters its buffers from outside (a batch gathered on the default
+    # stream, checkpoint tensors, injected noise) is ordered explicitly: the engine stream first waits for the producer's
+    # stream, the copy runs ON the engine stream, and a device-side source is marked as in use by the engine stream so the
+    # caching allocator cannot hand its block to a later allocation while the copy is still pending.
+    def _copy_in(self, dst: torch.Tensor, src):
+        src_t = src if torch.is_tensor(src) else torch.as_tensor(src)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            dst.copy_(src_t.reshape(dst.shape), non_blocking=True)
+        if src_t.is_cuda:
+            src_t.record_stream(self.stream)
+
+    def _fill_in(self, dst: torch.Tensor, value):
+        with torch.cuda.stream(self.stream):
+            dst.fill_(value)
+
+    def wait_for_engine(self):
+        """Order the CALLER's current stream after everything queued on the engine stream (before torch code on another
+        stream reads buffers the engine writes: the shared parameters, outputs)."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def wait_for_caller(self):
+        """Order the engine stream after the caller's current stream (after torch code on another stream touched buffers
+        the next engine launch reads or overwrites)."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def load_parameters(self, named: Dict[str, torch.Tensor]):
         for k, v in named.items():
-            self.params[k].copy_(torch.as_tensor(v, dtype=torch.float32).reshape(self.param_shapes[k]))
+            self._copy_in(self.params[k], torch.as_tensor(v).to(torch.float32))
 
     def reset_optimizer(self):
-        self.flat_ms.fill_(1.0); self.flat_mg.zero_(); self.flat_mom.zero_()
+        self._fill_in(self.flat_ms, 1.0); self._fill_in(self.flat_mg, 0.0); self._fill_in(self.flat_mom, 0.0)
 
     def _buf(self, name, shape, dtype=torch.float32):
         if name not in self._bufs:
@@ -641,17 +668,15 @@ class AIREngine:
         return ctypes.c_void_p(self.stream.cuda_stream)
 
     def set_learning_rate(self, lr: float):
-        self.lr_dev.fill_(float(lr))
+        self._fill_in(self.lr_dev, float(lr))
 
     def set_obs(self, obs: torch.Tensor):
-        with torch.cuda.stream(self.stream):
-            self.obs.copy_(obs.reshape(self.B, -1), non_blocking=True)
+        self._copy_in(self.obs, obs)
 
     def set_noise(self, eps_where, eps_what, u_pres):
-        with torch.cuda.stream(self.stream):
-            self.eps_where.copy_(eps_where.reshape(self.T, self.B, 4))
-            self.eps_what.copy_(eps_what.reshape(self.T, self.B, -1))
-            self.u_pres.copy_(u_pres.reshape(self.T, self.B))
+        self._copy_in(self.eps_where, eps_where)
+        self._copy_in(self.eps_what, eps_what)
+        self._copy_in(self.u_pres, u_pres)
 
     def steps_prior_success_prob(self, global_step=None) -> float:
         cfg = self.cfg
@@ -664,8 +689,7 @@ class AIREngine:
     def set_global_step(self, step: int):
         """Host mirror + the device counter the captured graph reads (annealing schedule, model.py:106-124)."""
         self.global_step = int(step)
-        with torch.cuda.stream(self.stream):
-            self.step_dev.fill_(int(step))
+        self._fill_in(self.step_dev, int(step))
 
     def sample_noise(self):
         self._run(self._plan_rng, self._sp())
@@ -785,10 +809,10 @@ class AIREngine:
     def load_state_dict(self, sd):
         if dict(sd["param_offsets"]) != dict(self.param_offsets):
             raise _lib.AirHipError("checkpoint was written for a different architecture (parameter layout differs)")
-        with torch.cuda.stream(self.stream):
-            self.flat_params.copy_(sd["flat_params"]); self.flat_ms.copy_(sd["flat_ms"])
-            self.flat_mg.copy_(sd["flat_mg"]); self.flat_mom.copy_(sd["flat_mom"])
-            self.rng_state.copy_(sd["rng_state"]); self.lr_dev.fill_(float(sd["learning_rate"]))
+        for dst, key in ((self.flat_params, "flat_params"), (self.flat_ms, "flat_ms"), (self.flat_mg, "flat_mg"),
+                         (self.flat_mom, "flat_mom"), (self.rng_state, "rng_state")):
+            self._copy_in(dst, sd[key])
+        self.set_learning_rate(float(sd["learning_rate"]))
         self.set_global_step(int(sd["global_step"]))
         self.synchronize()
 

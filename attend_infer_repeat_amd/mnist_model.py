@@ -70,8 +70,31 @@ class AIRonMNIST(AIRModel):
         mlp("glimpse_encoder", c._glimpse_encoder.mlp)
         out["what/w"], out["what/b"] = c._what_distrib.w, c._what_distrib.b
         mlp("glimpse_decoder", c._glimpse_decoder.mlp)
-        mlp("baseline", self.baseline_module.mlp)
+        bm = getattr(self, "baseline_module", None)
+        if bm is not None and all(l.w is not None for l in bm.mlp.layers):   # built lazily by the first _reinforce call
+            mlp("baseline", bm.mlp)
         return out
+
+    def _engine_eligible(self, use_engine, l2_weight, what_prior, where_scale_prior, where_shift_prior, num_steps_prior,
+                         decay_rate):
+        """The fused engine implements the configuration of the reference script (scripts/multi_mnist.py:24-94) and its
+        plain switches.  Anything else the reference's train_step accepts (model.py:261-265) -- priors left at None, a shift
+        prior without `loc`, a weighted / non-analytic num-steps prior, EMA-normalised importance weights, L2, continuous
+        steps, a non-MLP baseline -- trains through the generic autograd path over the same kernels."""
+        nsp = num_steps_prior
+        has = lambda p, *keys: p is not None and all(k in p for k in keys)
+        if not (use_engine and self.discrete_steps and decay_rate is None and not l2_weight):
+            return False
+        if nsp is None or not getattr(nsp, 'analytic', True) or float(getattr(nsp, 'weight', 1.)) != 1.:
+            return False
+        if not (has(what_prior, 'loc', 'scale') and has(where_scale_prior, 'loc', 'scale')
+                and has(where_shift_prior, 'loc', 'scale')):
+            return False
+        if self.use_reinforce:
+            bm = getattr(self, "baseline_module", None)
+            if not isinstance(bm, BaselineMLP) or any(l.w is None for l in bm.mlp.layers):
+                return False
+        return True
 
     def engine_config(self, learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior):
         nsp = num_steps_prior
@@ -99,15 +122,15 @@ class AIRonMNIST(AIRModel):
         fn, gs = super(AIRonMNIST, self).train_step(learning_rate, l2_weight, what_prior, where_scale_prior,
                                                     where_shift_prior, num_steps_prior, use_prior, use_reinforce,
                                                     baseline, decay_rate, optimizer, opt_kwargs)
-        standard = (use_engine and self.discrete_steps and getattr(num_steps_prior, 'analytic', True)
-                    and decay_rate is None and not l2_weight)
-        if not standard:
+        if not self._engine_eligible(use_engine, l2_weight, what_prior, where_scale_prior, where_shift_prior,
+                                     num_steps_prior, decay_rate):
             return fn, gs
         self._hyper["mfma_dtype"] = mfma_dtype
         cfg = self.engine_config(learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior)
         eng = AIREngine(cfg, self.batch_size, device=self.obs.device)
         named = self._named_module_params()
         eng.load_parameters({k: v.detach() for k, v in named.items()})
+        eng.synchronize()
         for k, p in named.items():                           # share storage: modules now view the engine's flat buffer
             p.data = eng.params[k]
         eng.set_obs(self.obs)
@@ -136,6 +159,18 @@ class AIRonMNIST(AIRModel):
 
         self._train_step = train_step_fn
         return self._train_step, self.global_step
+
+    def forward(self, obs=None, nums=None, noise=None):
+        """Generic cell-by-cell unroll (model.py:66-104).  Once the engine owns the parameters the module tree aliases its
+        flat buffer, so this torch-stream pass is ordered after the engine's pending updates, and the engine's next launch
+        after this pass."""
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.wait_for_engine()
+        out = super(AIRonMNIST, self).forward(obs, nums, noise)
+        if eng is not None:
+            eng.wait_for_caller()
+        return out
 
     def evaluate(self, obs=None, nums=None, noise=None):
         """Engine-backed evaluation pass (fresh noise, no update); falls back to the generic path without an engine."""

@@ -53,6 +53,8 @@ class AIRModel(object):
         self.batch_size = shape[0]
         self.img_size = shape[1:]
         self._engine = None
+        self._moving_averages = {}           # state of make_moving_average (decay_rate), owned by this model
+        self._in_train_step = False
         self._build(transition, input_encoder, glimpse_encoder, glimpse_decoder, transform_estimator,
                     steps_predictor, kwargs)
 
@@ -144,13 +146,17 @@ class AIRModel(object):
             self.kl_what = what_kl_per_sample.mean()
             prior_loss.add(self.kl_what, what_kl_per_sample, weight=1.)
         if where_scale_prior is not None and where_shift_prior is not None:
-            if 'loc' in where_shift_prior:
-                shift_mean = where_shift_prior.loc
-            else:
-                raise NotImplementedError("where_shift_prior without `loc` (KL to its own mean)")
+            own_mean = 'loc' not in where_shift_prior
+            shift_mean = 0. if own_mean else where_shift_prior.loc
             where_kl = F.normal_kl_rows(self.where_loc, self.where_scale,
                                         (where_scale_prior.loc, where_scale_prior.scale, shift_mean,
                                          where_shift_prior.scale))
+            if own_mean:
+                # model.py:203-207: without `loc` the shift prior is centred on the posterior's own mean `ut`, so the
+                # (mu_a - mu_b)^2 / (2 s_b^2) term of the KL -- and its gradient, d/d ut of (ut - ut)^2 -- vanishes:
+                # remove exactly that term from the rows evaluated against a zero mean
+                ut = self.where_loc[..., 1::2]
+                where_kl = where_kl - (ut * ut).sum(-1) / (2. * float(where_shift_prior.scale) ** 2)
             where_kl_per_sample = (where_kl * step_weight).sum(0)
             self.kl_where = where_kl_per_sample.mean()
             prior_loss.add(self.kl_where, where_kl_per_sample, weight=1.)
@@ -175,8 +181,13 @@ class AIRModel(object):
             # script; evaluated with torch glue on the generic path (the fused air_nvil kernel covers decay_rate=None).
             iw = importance_weight.detach()[None, :] - self.baseline                      # [B,B]: (i,j) = imp_j - b_i
             mean, var = iw.detach().mean(), iw.detach().var(unbiased=False)
-            self.imp_weight_moving_mean = make_moving_average('imp_weight_moving_mean', mean, 0., decay_rate)
-            self.imp_weight_moving_var = make_moving_average('imp_weight_moving_var', var, 1., decay_rate)
+            # the EMA variables belong to THIS model and their update op runs only inside a train step (ops.py:46-64:
+            # UPDATE_OPS are control dependencies of apply_gradients, model.py:357-359); evaluate() only reads them
+            store, upd = self._moving_averages, self._in_train_step
+            self.imp_weight_moving_mean = make_moving_average('imp_weight_moving_mean', mean, 0., decay_rate,
+                                                              store=store, update=upd)
+            self.imp_weight_moving_var = make_moving_average('imp_weight_moving_var', var, 1., decay_rate,
+                                                             store=store, update=upd)
             factor = torch.clamp(torch.sqrt(self.imp_weight_moving_var), min=1.)
             iwn = (iw - self.imp_weight_moving_mean) / factor
             self.importance_weight = iwn.detach()
@@ -269,7 +280,11 @@ class AIRModel(object):
             """One update (== sess.run(train_step)): fresh forward, both gradient sets, both RMSProp updates."""
             lr_dev.fill_(float(self.learning_rate))
             self.forward(obs, nums, noise)
-            opt_loss = self._losses(self.global_step)
+            self._in_train_step = True
+            try:
+                opt_loss = self._losses(self.global_step)
+            finally:
+                self._in_train_step = False
             baseline_vars = list(getattr(self, 'baseline_vars', []))
             bset = {id(p) for p in baseline_vars}
             model_vars = [p for p in self.cell.parameters() if id(p) not in bset]

@@ -58,17 +58,20 @@ class MovingAverage(object):
         return self.var
 
 
-_moving_averages = {}
-
-
-def make_moving_average(name, value, init, decay, log=True):
-    """Exp-moving average of `value` (ops.py:46-64).  In the reference the update is an UPDATE_OP that runs with the
-    train step and the returned tensor is the *variable* (pre-update value on the first step = init)."""
-    ma = _moving_averages.get(name)
+def make_moving_average(name, value, init, decay, log=True, store=None, update=True):
+    """Exp-moving average of `value` (ops.py:46-64).  In the reference the update is an UPDATE_OP that runs only with the
+    train step and the returned tensor is the *variable* (pre-update value on the first step = init).
+    `store`: the dict that owns the state (a tf.Graph's variable collection in the reference; here the model instance's
+    `_moving_averages`, so two models never share statistics).  `update=False` reads the variable without running the
+    update op (evaluation passes)."""
+    if store is None:
+        store = {}
+    ma = store.get(name)
     if ma is None:
-        ma = _moving_averages[name] = MovingAverage(name, init, decay)
+        ma = store[name] = MovingAverage(name, init, decay)
     prev = ma.var if ma.var is not None else torch.full_like(value.detach(), float(init))
-    ma.update(value)
+    if update:
+        ma.update(value)
     return prev
 
 

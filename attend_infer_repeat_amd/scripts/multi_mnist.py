@@ -37,6 +37,9 @@ def main(argv=None):
     ap.add_argument("--eval-batches", type=int, default=10)
     ap.add_argument("--figures", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--resume", default=None,
+                    help="checkpoint written by this script (model_<iter>.pt): restores parameters, the RMSProp slots, "
+                         "the step counter, the learning rate, the Philox noise state and the feeders' positions")
     args = ap.parse_args(argv)
 
     learning_rate, n_steps, batch_size = 1e-4, 3, 64                  # multi_mnist.py:24-25,37
@@ -67,6 +70,15 @@ def main(argv=None):
                      transform_var_bias=transform_var_bias, step_bias=step_bias, output_multiplier=output_multiplier)
     train_step, global_step = air.train_step(learning_rate, l2_weight, appearance_prior, where_scale_prior,
                                              where_shift_prior, num_steps_prior)
+    if args.resume:
+        # the reference only ever saves (tf.train.Saver over every variable incl. the optimiser slots and global_step,
+        # multi_mnist.py:116,145-146); restoring is the counterpart a long run needs
+        ck = torch.load(args.resume, map_location="cpu")
+        air._engine.load_state_dict(ck["engine"])
+        air.global_step.fill_(int(ck["engine"]["global_step"]))
+        if "train_feed" in ck:
+            train_feed.load_state_dict(ck["train_feed"]); valid_feed.load_state_dict(ck["valid_feed"])
+        global_step = air.global_step
     writer = open(osp.join(logdir, "log.jsonl"), "a")
     log = make_logger(air, train_feed, args.eval_batches, valid_feed, args.eval_batches, writer)
 
@@ -85,9 +97,8 @@ def main(argv=None):
             log(train_itr)
             t0, last = time.time(), train_itr
         if train_itr % args.save_every == 0:
-            torch.save({"flat_params": air._engine.flat_params.cpu(), "global_step": train_itr,
-                        "param_offsets": air._engine.param_offsets, "param_shapes": air._engine.param_shapes},
-                       osp.join(logdir, "model_{}.pt".format(train_itr)))
+            torch.save({"engine": air._engine.state_dict(), "train_feed": train_feed.state_dict(),
+                        "valid_feed": valid_feed.state_dict()}, osp.join(logdir, "model_{}.pt".format(train_itr)))
             if args.figures:
                 make_fig(air, logdir, train_itr)
     writer.close()

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define AIR_ABI_VERSION 1
+/* bumped whenever a signature below changes (ctypes cannot check argument lists) */
+#define AIR_ABI_VERSION 2
 
 enum {
     AIR_OK = 0,
@@ -47,6 +48,10 @@ enum {
 };
 
 int air_abi_version(void);
+/* sha256 of the sources + headers this binary was compiled from (attend_infer_repeat_amd/build.py passes it at compile
+ * time); the loader compares it with the sources it finds next to the library, so a stale binary is refused instead of
+ * being called with a changed argument list. */
+const char *air_build_digest(void);
 const char *air_status_string(int status);
 
 /* ---- spatial transformer ------------------------------------------------------------------------------------

@@ -605,7 +605,9 @@ def objective(params, cfg: AIRConfig, obs: Tensor, noise, global_step=0) -> Dict
     ut, st = wl[..., [1, 3]], ws[..., [1, 3]]
     one = torch.ones((), dtype=dt)
     scale_kl = normal_kl(us, ss, cfg.where_scale_prior[0] * one, cfg.where_scale_prior[1] * one)
-    shift_kl = normal_kl(ut, st, cfg.where_shift_prior[0] * one, cfg.where_shift_prior[1] * one)
+    # model.py:203-207: a shift prior without `loc` (here: loc = None) is centred on the posterior's own mean `ut`
+    shift_mean = ut if cfg.where_shift_prior[0] is None else cfg.where_shift_prior[0] * one
+    shift_kl = normal_kl(ut, st, shift_mean, cfg.where_shift_prior[1] * one)
     where_kl = (scale_kl + shift_kl).sum(-1) * w
     kl_where_ps = where_kl.sum(0)
     kl_where = kl_where_ps.mean()

@@ -239,8 +239,6 @@ def test_training_script_counterpart_runs(amd, tmp_path):
 def test_generic_path_decay_rate_and_l2_match_oracle(amd):
     """ops.make_moving_average / decay_rate (model.py:232-239) and l2_weight (model.py:346-353): off in the reference
     script, implemented on the generic path; two consecutive steps so the EMA state matters."""
-    from attend_infer_repeat_amd import ops
-    ops._moving_averages.clear()
     ocfg = O.AIRConfig(img_size=(12, 10), crop_size=(5, 4), n_appearance=6, n_hidden=16, inpt_encoder_hidden=(24,),
                        glimpse_encoder_hidden=(20,), glimpse_decoder_hidden=(18,), transform_estimator_hidden=(14,),
                        steps_pred_hidden=(9,), baseline_hidden=(12, 7), max_steps=3, decay_rate=0.8, l2_weight=1e-2)
@@ -255,12 +253,18 @@ def test_generic_path_decay_rate_and_l2_match_oracle(amd):
     train_step, _ = model.train_step(ocfg.learning_rate, ocfg.l2_weight, AD(loc=0., scale=1.), AD(loc=0., scale=1.),
                                      AD(loc=0., scale=1.), nsp, baseline=baseline, decay_rate=ocfg.decay_rate)
     _load_oracle_params(amd, model.cell, model.baseline_module, params, "lstm")
-    ops._moving_averages.clear()                                  # train_step() above already consumed one EMA update
+    # the EMA variables belong to the model and only a train step updates them (ops.py:46-64: an UPDATE_OP): building the
+    # train step and evaluation passes leave them untouched
+    assert all(ma.var is None for ma in model._moving_averages.values())
     p64 = {k: v.double() for k, v in params.items()}
     slots = O.rmsprop_init(p64)
     ema_holder = {}
     for it in range(2):
         noise = O.make_noise(ocfg, B, seed=30 + it)
+        before = {k: (None if ma.var is None else ma.var.clone()) for k, ma in model._moving_averages.items()}
+        model.evaluate(noise={k: v.cuda() for k, v in noise.items()})
+        for k, ma in model._moving_averages.items():
+            assert (ma.var is None) if before[k] is None else torch.equal(ma.var, before[k]), k
         train_step(noise={k: v.cuda() for k, v in noise.items()})
         n64 = {k: v.double() for k, v in noise.items()}
         n64.update(ema_holder)
@@ -273,3 +277,123 @@ def test_generic_path_decay_rate_and_l2_match_oracle(amd):
     w = model.cell._glimpse_decoder.mlp.layers[1].w
     assert rel(w.data.cpu().double() - params["glimpse_decoder/1/w"].double(),
                p64["glimpse_decoder/1/w"] - params["glimpse_decoder/1/w"].double()) < 5e-3
+
+
+def test_second_model_does_not_share_moving_averages(amd):
+    """Two models in one process keep separate imp_weight EMA state (the reference's variables live in each model's graph)."""
+    ocfg = O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3, transform_var_bias=0.5,
+                         n_hidden=6)
+    AD = amd.utils.AttrDict
+    models = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = _build_model(amd, ocfg, torch.rand(7, *ocfg.img_size).cuda(), "lstm")
+        ts, _ = m.train_step(1e-3, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                             AD(anneal=None, init=0.5), baseline=amd.modules.BaselineMLP([6, 4]), decay_rate=0.9)
+        models.append((m, ts))
+    models[0][1](); models[0][1]()
+    assert models[0][0]._moving_averages["imp_weight_moving_var"].var is not None
+    assert all(ma.var is None for ma in models[1][0]._moving_averages.values())
+    assert models[0][0]._moving_averages is not models[1][0]._moving_averages
+
+
+def test_where_shift_prior_without_loc_matches_oracle(amd):
+    """model.py:203-207: `where_shift_prior` without `loc` centres the shift prior on the posterior's own mean."""
+    ocfg = O.AIRConfig(img_size=(12, 10), crop_size=(5, 4), n_appearance=6, n_hidden=16, inpt_encoder_hidden=(24,),
+                       glimpse_encoder_hidden=(20,), glimpse_decoder_hidden=(18,), transform_estimator_hidden=(14,),
+                       steps_pred_hidden=(9,), baseline_hidden=(12, 7), max_steps=3, where_shift_prior=(None, 0.7))
+    B = 9
+    params = O.init_params(ocfg, seed=7, bias_std=0.2)
+    obs = torch.rand(B, *ocfg.img_size)
+    noise = O.make_noise(ocfg, B, seed=8)
+    AD = amd.utils.AttrDict
+    model = _build_model(amd, ocfg, obs.cuda(), "lstm")
+    baseline = amd.modules.BaselineMLP(list(ocfg.baseline_hidden))
+    nsp = AD(anneal='exp', init=ocfg.nsp_init, final=ocfg.nsp_final, steps_div=ocfg.nsp_steps_div,
+             steps=ocfg.nsp_steps, hold_init=ocfg.nsp_hold_init)
+    train_step, _ = model.train_step(ocfg.learning_rate, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                                     AD(scale=0.7), nsp, baseline=baseline)
+    _load_oracle_params(amd, model.cell, model.baseline_module, params, "lstm")
+    train_step(noise={k: v.cuda() for k, v in noise.items()})
+    p64 = {k: v.double() for k, v in params.items()}
+    res, grads = O.forward_backward(p64, ocfg, obs.double(), {k: v.double() for k, v in noise.items()}, global_step=0)
+    assert abs(model.kl_where.item() - res["kl_where"].item()) < 1e-4 * (abs(res["kl_where"].item()) + 1)
+    assert abs(model.opt_loss.item() - res["opt_loss"].item()) < 1e-4 * (abs(res["opt_loss"].item()) + 1)
+    for k, p in {"transform/1/w": model.cell._transform_estimator.mlp.layers[1].w,
+                 "transform/0/b": model.cell._transform_estimator.mlp.layers[0].b,
+                 "lstm/w_gates": model.cell._transition.w_gates}.items():
+        assert rel(p.grad, grads[k]) < 1e-3, (k, rel(p.grad, grads[k]))
+
+
+def _mnist_model(amd, B=8, **kw):
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    imgs, nums = synthetic_multi_mnist(B, (50, 50), 2, seed=0)
+    x, y = torch.from_numpy(imgs).cuda(), torch.from_numpy(nums).cuda()
+    return amd.mnist_model.AIRonMNIST(x, y, max_steps=3, explore_eps=1e-3, steps_pred_hidden=[128, 64],
+                                      transform_var_bias=.5, step_bias=.75, output_multiplier=.5, **kw)
+
+
+def test_aironmnist_argument_combinations_the_reference_accepts(amd):
+    """model.py:261-265 accepts priors left at None, a shift prior without `loc`, use_reinforce=False and a weighted
+    num-steps prior.  The fused engine covers the script's configuration and its plain switches; everything else must fall
+    back to the generic path instead of crashing or silently ignoring an argument."""
+    AD = amd.utils.AttrDict
+    nsp = lambda **kw: AD(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3, **kw)
+    N01 = lambda: AD(loc=0., scale=1.)
+    # use_reinforce=False: engine path, baseline never built, no REINFORCE term
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp(), use_reinforce=False)
+    assert air._engine is not None and air._engine.cfg.use_reinforce is False
+    ts(); ts()
+    assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(air._engine.flat_params).all()
+    assert abs(air.opt_loss.item() - air.loss.value.item()) < 1e-6 * abs(air.loss.value.item())
+    # priors left at None (the reference's defaults: the KL term is skipped) -> generic path
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-4, num_steps_prior=nsp())
+    assert air._engine is None
+    ts()
+    assert int(gs) == 1 and np.isfinite(float(air.opt_loss))
+    # shift prior without loc -> generic path
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-4, 0., N01(), N01(), AD(scale=1.), nsp())
+    assert air._engine is None
+    ts()
+    assert np.isfinite(float(air.kl_where))
+    # weighted num-steps KL -> generic path, and the weight is honoured
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp(weight=3.))
+    assert air._engine is None
+    expect = 3. * float(air.kl_num_steps) + float(air.kl_what) + float(air.kl_where)
+    assert abs(float(air.prior_loss.value) - expect) < 1e-4 * (abs(expect) + 1)
+
+
+def test_debug_flag_validates_distribution_parameters(amd):
+    """cell.py:66-67,130-131,144-145: debug=True turns on validate_args on the three distributions."""
+    air = amd.cell.AIRCell((3, 3), (2, 2), 10, debug=True, **make_modules(amd))
+    x = torch.rand(4, 3, 3).cuda()
+    state = air.initial_state(x)
+    air(None, state)                                                     # healthy parameters pass
+    with torch.no_grad():
+        air._what_distrib.b.fill_(float("nan"))
+    with pytest.raises(ValueError, match="what_"):
+        air(None, air.initial_state(x))
+    quiet = amd.cell.AIRCell((3, 3), (2, 2), 10, debug=False, **make_modules(amd))
+    quiet(None, quiet.initial_state(x))
+    with torch.no_grad():
+        quiet._what_distrib.b.fill_(float("nan"))
+    quiet(None, quiet.initial_state(x))                                  # debug=False: no check, like the reference
+
+
+def test_training_script_resume_is_bit_exact(amd, tmp_path):
+    """A run interrupted at a checkpoint and resumed with --resume ends with exactly the parameters of an uninterrupted run
+    (parameters, RMSProp slots, step counter, learning rate, Philox state and feeder positions all travel)."""
+    from attend_infer_repeat_amd.scripts import multi_mnist
+    common = ["--log-every", "1000", "--save-every", "20", "--synthetic-samples", "512", "--eval-batches", "1"]
+    a = multi_mnist.main(["--iters", "40", "--results-dir", str(tmp_path / "a")] + common)
+    multi_mnist.main(["--iters", "20", "--results-dir", str(tmp_path / "b")] + common)
+    b = multi_mnist.main(["--iters", "40", "--results-dir", str(tmp_path / "b"), "--resume",
+                          str(tmp_path / "b" / "multi_mnist" / "model_20.pt")] + common)
+    a._engine.synchronize(); b._engine.synchronize()
+    assert int(b.global_step) == 40
+    assert torch.equal(a._engine.flat_params, b._engine.flat_params)
+    assert torch.equal(a._engine.flat_mom, b._engine.flat_mom)

@@ -5,7 +5,9 @@ Tolerances: the oracle is evaluated in float64 on the same fp32 inputs; the engi
 summation order (batched over T, split-K).  Every tensor is checked two ways: the worst element against the tensor's max
 magnitude (fp32 cancellation noise scales with the tensor, not with the element) AND the relative L2 error of the whole
 tensor (so small-magnitude elements are not hidden behind one large one).  The bounds are ~10x the worst values measured
-on MI355X over all configurations below (profiles/r02_parity_margins.json): outputs 1e-4 / 3e-5, gradients 3e-4 / 1e-4."""
+on MI355X over all configurations below (profiles/r02_parity_margins.json): outputs 1e-4 / 3e-5, gradients 3e-4 / 2e-4
+(typical gradient error is 1e-5..3e-5; the B=17 case is ill-conditioned for this seed -- the ORACLE evaluated in fp32
+deviates from its own fp64 evaluation by 8e-4 there, the engine by 1.7e-4)."""
 import dataclasses
 import json
 import os
@@ -49,7 +51,7 @@ def l2_err(a, b):
 
 
 OUT_TOL, OUT_L2 = 1e-4, 3e-5          # per-sample outputs: worst element / tensor max, relative L2
-GRAD_TOL, GRAD_L2 = 3e-4, 1e-4        # gradients
+GRAD_TOL, GRAD_L2 = 3e-4, 2e-4        # gradients
 _MARGINS = {}
 
 
@@ -68,6 +70,8 @@ def record_margin(test, name, kind, key, value):
 def check_tensor(test, name, kind, key, got, ref, tol, tol_l2):
     e, e2 = rel_err(got, ref), l2_err(got, ref)
     record_margin(test, name, kind + "_max", key, e); record_margin(test, name, kind + "_l2", key, e2)
+    if os.environ.get("AIR_PARITY_RECORD_ONLY") == "1":     # measurement run (tools/profile_round.sh): collect, do not judge
+        return
     assert e < tol and e2 < tol_l2, (key, e, e2)
 
 
@@ -115,7 +119,7 @@ def test_forward_and_gradients_match_oracle(gpu_device, name):
               "opt_loss", "imp_weight_mean", "imp_weight_var"]:
         err = abs(out[k].item() - res[k].item()) / (abs(res[k].item()) + 1.0)
         record_margin("fwd_bwd", name, "scalar", k, err)
-        assert err <= 5e-5, (k, out[k].item(), res[k].item())
+        assert err <= 2e-5, (k, out[k].item(), res[k].item())
     g = eng.named_grads()
     for k, ref in grads.items():
         check_tensor("fwd_bwd", name, "grad", k, g[k], ref, GRAD_TOL, GRAD_L2)
@@ -163,21 +167,31 @@ def test_bf16_path_at_batch_1024_matches_bf16_emulating_oracle(gpu_device):
     # from the per-sample comparison (there must be almost none) and the batch-summed gradients are compared regardless
     same = (out["presence"].cpu().reshape(ocfg.max_steps, B) == res["presence"].reshape(ocfg.max_steps, B)).all(0)
     assert same.float().mean().item() > 0.995, same.float().mean().item()
+    def close(k, a, r):
+        """bf16 mode at 3072 rows: an operand that sits within fp32 noise of a bf16 rounding boundary flips one bf16 ulp on
+        that element, and through `where` that moves a glimpse by a fraction of a pixel -- a handful of canvas pixels next to
+        sharp edges then differ by percents.  So the bulk is bounded tightly (relative L2, 99.9th percentile of the absolute
+        error against the tensor's max) and the worst single element loosely."""
+        a, r = a.double().reshape(-1), r.double().reshape(-1)
+        err = (a - r).abs() / (r.abs().max() + 1e-12)
+        p999 = torch.quantile(err[:: max(1, err.numel() // 4_000_000)], 0.999).item()
+        record_margin("bf16_b1024", "c5", "out_max", k, err.max().item())
+        record_margin("bf16_b1024", "c5", "out_p999", k, p999)
+        record_margin("bf16_b1024", "c5", "out_l2", k, l2_err(a, r))
+        assert l2_err(a, r) < 2e-3 and p999 < 2e-3 and err.max().item() < 0.1, (k, l2_err(a, r), p999, err.max().item())
+
     for k in ["what", "where", "presence_prob"]:                                                     # [T, B, ...]
-        a = out[k].cpu().reshape(ocfg.max_steps, B, -1)[:, same]; r = res[k].reshape(ocfg.max_steps, B, -1)[:, same]
-        record_margin("bf16_b1024", "c5", "out_max", k, rel_err(a, r))
-        assert rel_err(a, r) < 2e-3, (k, rel_err(a, r))
+        close(k, out[k].cpu().reshape(ocfg.max_steps, B, -1)[:, same], res[k].reshape(ocfg.max_steps, B, -1)[:, same])
     for k in ["final_canvas", "rec_loss_per_sample", "kl_what_per_sample", "kl_where_per_sample", "baseline"]:   # [B, ...]
-        a = out[k].cpu().reshape(B, -1)[same]; r = res[k].reshape(B, -1)[same]
-        record_margin("bf16_b1024", "c5", "out_max", k, rel_err(a, r))
-        assert rel_err(a, r) < 2e-3, (k, rel_err(a, r))
+        close(k, out[k].cpu().reshape(B, -1)[same], res[k].reshape(B, -1)[same])
     if bool(same.all()):
         for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
             assert abs(out[k].item() - res[k].item()) <= 2e-3 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
         g = eng.named_grads()
         for k, ref in grads.items():
             record_margin("bf16_b1024", "c5", "grad_max", k, rel_err(g[k], ref))
-            assert rel_err(g[k], ref) < 1e-2, (k, rel_err(g[k], ref))
+            record_margin("bf16_b1024", "c5", "grad_l2", k, l2_err(g[k], ref))
+            assert rel_err(g[k], ref) < 1e-2 and l2_err(g[k], ref) < 1e-2, (k, rel_err(g[k], ref), l2_err(g[k], ref))
 
 
 def test_graph_captured_train_steps_at_batch_64_match_oracle(gpu_device):
@@ -201,7 +215,7 @@ def test_graph_captured_train_steps_at_batch_64_match_oracle(gpu_device):
             d_ref = ref - prev[k]
             d_got = eng.params[k].cpu().double() - prev[k]
             record_margin("graph_train", f"step{it}", "delta_max", k, rel_err(d_got, d_ref))
-            assert rel_err(d_got, d_ref) < 2e-3, (it, k, rel_err(d_got, d_ref))
+            assert rel_err(d_got, d_ref) < 5e-4, (it, k, rel_err(d_got, d_ref))
         # continue from the ENGINE's parameters so that fp32 rounding of the state does not accumulate into the next comparison
         for k in p64:
             p64[k] = eng.params[k].cpu().double().clone()
