@@ -36,7 +36,11 @@ SIGNATURES = {
     "air_canvas_unroll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_float, c_float, P]),
     "air_canvas_unroll_bwd_nvil": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                      c_float, c_float, P, P, P, P, P, P, P]),
+                                           c_float, c_float, P, c_int, P, P, P, P, P, P, P]),
+    "air_canvas_unroll_bands": (c_int, [c_int, c_int]),
+    "air_canvas_unroll_fwd_banded": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_float, c_float, P]),
+    "air_nvil_parts": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P]),
     "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
                          c_float, P, P, c_size_t, P]),
     "air_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,

@@ -11,7 +11,19 @@
 
 static inline hipStream_t air_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool air_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool air_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int air_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// A zero the compiler cannot see through.  Adding it to a wave-uniform index moves that load from the scalar path (s_load,
+// lgkmcnt) to the vector path (global_load, vmcnt).  Scalar loads return out of order, so the first use of ANY scalar-loaded
+// value -- the kernel-argument pointers every address needs -- waits lgkmcnt(0), i.e. also for a slow uniform load from
+// global memory issued next to them: seen in the ISA of the canvas backward as one full memory round trip in front of every
+// vector load of the prologue.  On the vector path the same load is just one more request in flight.
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
 
 // ---- wave / block reductions (64-wide wavefronts) -----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -28,6 +40,30 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;  // valid in every lane
+}
+
+// Eight per-lane partial sums -> the eight totals over the 64 lanes of a wave in 10 cross-lane moves (a plain butterfly per
+// value takes 48): every exchange step halves the number of live values.  Afterwards lane L holds the total of output
+// o(L) = 4*bit5(L) + 2*bit4(L) + bit3(L) (the eight lanes that share bits 3..5 hold the same number).  Fixed order.
+template <typename T>
+__device__ __forceinline__ T wave_reduce8(const T (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+    T a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (h5 ? v[i + 4] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 4], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = (h4 ? a[i + 2] : a[i]) + __shfl_xor(h4 ? a[i] : a[i + 2], 16, 64);
+    T c = (h3 ? b[1] : b[0]) + __shfl_xor(h3 ? b[0] : b[1], 8, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 1, 64);
+    return c;
+}
+// which of the eight outputs of wave_reduce8 this lane holds
+__device__ __forceinline__ int wave_reduce8_slot() {
+    const int lane = threadIdx.x & 63;
+    return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
 }
 
 // Sum NV values per thread across a block of up to 1024 threads; result valid in thread 0.

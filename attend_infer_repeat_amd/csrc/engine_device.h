@@ -105,12 +105,13 @@ struct NumStepsR {
     double p[MT], P[MT + 1], q[MT + 1], S;   // p_t, prefix products P[n] = prod_{j<n} p_j, posterior q(n), normaliser
     float q32[MT + 1];
 };
+// posterior from the T presence probabilities held in registers
 template <int MT>
-__device__ __forceinline__ void posterior_r(const float *__restrict__ prob, int T, int B, int b, NumStepsR<MT> &s) {
+__device__ __forceinline__ void posterior_p(const float (&p32)[MT], int T, NumStepsR<MT> &s) {
     s.P[0] = 1.0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        s.p[t] = t < T ? (double)prob[(size_t)t * B + b] : 1.0;
+        s.p[t] = t < T ? (double)p32[t] : 1.0;
         s.P[t + 1] = s.P[t] * s.p[t];
     }
     double u[MT + 1];
@@ -123,48 +124,75 @@ __device__ __forceinline__ void posterior_r(const float *__restrict__ prob, int 
 #pragma unroll
     for (int n = 0; n <= MT; ++n) { s.q[n] = n <= T ? u[n] / s.S : 0.0; s.q32[n] = (float)s.q[n]; }
 }
+template <int MT>
+__device__ __forceinline__ void posterior_r(const float *__restrict__ prob, int T, int B, int b, NumStepsR<MT> &s) {
+    float p32[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) p32[t] = t < T ? prob[(size_t)t * B + b] : 1.0f;
+    posterior_p<MT>(p32, T, s);
+}
+
+// presence (cell.py:137-151) + q(n) / KL / step weights / log q(n_sampled) in one launch
+// One batch column b with its T logits and uniform variates already in registers: nothing is read back from memory, so the
+// whole chain (sigmoid, Bernoulli chain, float64 posterior, KL, step weights, log q(n*)) is pure ALU after the operand loads.
+template <int MT>
+__device__ __forceinline__ void presence_numsteps_col(int b, const float (&lg)[MT], const float (&uu)[MT],
+    const double (&pri)[MT + 1], float step_bias, float eps, float *__restrict__ prob, float *__restrict__ pres,
+    float *__restrict__ q, float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
+    float run = 1.0f, nsteps = 0.f, p32[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        p32[t] = 1.0f;
+        if (t < T) {
+            const size_t k = (size_t)t * B + b;
+            float p = 1.0f / (1.0f + expf(-(lg[t] + step_bias)));
+            if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
+            p32[t] = p;
+            prob[k] = p;
+            run *= (uu[t] < p) ? 1.0f : 0.0f;
+            pres[k] = run;
+            nsteps += run;
+        }
+    }
+    NumStepsR<MT> s;
+    posterior_p<MT>(p32, T, s);
+    float kl = 0.f, w = 0.f, qstar = 0.f;
+    const int nstar = (int)nsteps;
+#pragma unroll
+    for (int n = 0; n <= MT; ++n) {
+        if (n <= T) {
+            q[(size_t)b * (T + 1) + n] = s.q32[n];
+            const double pn = (double)s.q32[n];
+            kl += (pn > 0.0) ? (float)(pn * log(pn / pri[n])) : 0.f;
+            if (n == nstar) qstar = s.q32[n];
+        }
+    }
+    kl_ps[b] = kl;
+#pragma unroll
+    for (int t = MT - 1; t >= 0; --t) {
+        if (t < T) { w += s.q32[t + 1]; step_w[(size_t)t * B + b] = w; }
+    }
+    logp[b] = logf(fmaxf(qstar, 1e-32f));
+}
 
 // presence (cell.py:137-151) + q(n) / KL / step weights / log q(n_sampled) in one launch
 template <int MT>
 __device__ __forceinline__ void presence_numsteps_fwd_body(int vblock, int vgrid,
-    
     const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float eps,
     const double *__restrict__ prior, float *__restrict__ prob, float *__restrict__ pres, float *__restrict__ q,
     float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
     for (int b = vblock * 64 + (int)threadIdx.x; b < B; b += vgrid * 64) {
         if (threadIdx.x >= 64) break;
-        float run = 1.0f, nsteps = 0.f;
+        float lg[MT], uu[MT];
+        double pri[MT + 1];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            if (t < T) {
-                const size_t k = (size_t)t * B + b;
-                float p = 1.0f / (1.0f + expf(-(logit[k] + step_bias)));
-                if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
-                prob[k] = p;
-                run *= (u[k] < p) ? 1.0f : 0.0f;
-                pres[k] = run;
-                nsteps += run;
-            }
+            lg[t] = t < T ? logit[(size_t)t * B + b] : 0.f;
+            uu[t] = t < T ? u[(size_t)t * B + b] : 0.f;
         }
-        NumStepsR<MT> s;
-        posterior_r<MT>(prob, T, B, b, s);
-        float kl = 0.f, w = 0.f, qstar = 0.f;
-        const int nstar = (int)nsteps;
 #pragma unroll
-        for (int n = 0; n <= MT; ++n) {
-            if (n <= T) {
-                q[(size_t)b * (T + 1) + n] = s.q32[n];
-                const double pn = (double)s.q32[n];
-                kl += (pn > 0.0) ? (float)(pn * log(pn / prior[n])) : 0.f;
-                if (n == nstar) qstar = s.q32[n];
-            }
-        }
-        kl_ps[b] = kl;
-#pragma unroll
-        for (int t = MT - 1; t >= 0; --t) {
-            if (t < T) { w += s.q32[t + 1]; step_w[(size_t)t * B + b] = w; }
-        }
-        logp[b] = logf(fmaxf(qstar, 1e-32f));
+        for (int n = 0; n <= MT; ++n) pri[n] = n <= T ? prior[n] : 1.0;
+        presence_numsteps_col<MT>(b, lg, uu, pri, step_bias, eps, prob, pres, q, kl_ps, logp, step_w, T, B);
     }
 }
 

@@ -236,7 +236,16 @@ extern "C" int air_nvil(const float *imp, const float *baseline, const float *lo
                         float *dbaseline, int B, void *stream) {
     AIR_REQUIRE(imp && baseline && logp && out, AIR_E_NULL);
     AIR_REQUIRE(B > 0, AIR_E_SHAPE);
-    NvilArgs a = {imp, baseline, logp, out, dlogp, dbaseline, B};
+    NvilArgs a = {imp, baseline, logp, out, dlogp, dbaseline, B, 1, nullptr};
+    hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), a);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline,
+                              const float *logp, float *out, float *dlogp, float *dbaseline, int B, void *stream) {
+    AIR_REQUIRE(imp_parts && baseline && logp && out, AIR_E_NULL);
+    AIR_REQUIRE(B > 0 && n_parts > 0, AIR_E_SHAPE);
+    NvilArgs a = {imp_parts, baseline, logp, out, dlogp, dbaseline, B, n_parts, imp_sum};
     hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

@@ -21,6 +21,25 @@
 #define ST_THREADS 256
 #define ST_INVALID INT_MIN
 
+// Developer tracing (tools/kbench/st_trace.cpp builds this file with -DAIR_TRACE): thread 0 of every workgroup stamps the
+// chip-wide 100 MHz counter at the marked phase boundaries.  Compiles to nothing in the product build.
+#ifdef AIR_TRACE
+#define AIR_TRACE_BLOCKS 512
+#define AIR_TRACE_PHASES 8
+__device__ unsigned long long air_trace[AIR_TRACE_BLOCKS * AIR_TRACE_PHASES];
+// stamps go to LDS (a global store in front of a barrier would add its own latency to the phase being measured) and are
+// flushed once when the workgroup is done
+#define AIR_TR_INIT() __shared__ unsigned long long air_tr_lds[AIR_TRACE_PHASES]; do { if (threadIdx.x < AIR_TRACE_PHASES) air_tr_lds[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define AIR_TRT(t_, i) do { if (threadIdx.x == (t_)) air_tr_lds[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define AIR_TR(i) AIR_TRT(0, i)
+#define AIR_TR_FLUSH() do { __syncthreads(); if (threadIdx.x < AIR_TRACE_PHASES && blockIdx.x < AIR_TRACE_BLOCKS) air_trace[blockIdx.x * AIR_TRACE_PHASES + threadIdx.x] = air_tr_lds[threadIdx.x]; } while (0)
+#else
+#define AIR_TR_INIT() do { } while (0)
+#define AIR_TRT(t_, i) do { } while (0)
+#define AIR_TR(i) do { } while (0)
+#define AIR_TR_FLUSH() do { } while (0)
+#endif
+
 struct Taps { float ff, fc, cf, cc; };
 
 // bilinear taps around (fy, fx) of an LDS-resident Hs x Ws source; out-of-range taps are zero
@@ -262,85 +281,151 @@ __global__ __launch_bounds__(1024) void st_read_bwd_kernel(
 // each thread walks its canvas pixels with the running canvas in a register (t inner, in order, so the accumulation is
 // the oracle's ((0 + p0*v0) + p1*v1) + ...).  One memory round trip per image instead of one per step.
 struct CarveWr {
-    float *glm, *dx, *dy, *X, *Y, *pres, *scratch;
-    int *fx, *fy;
+    float *glm, *pres, *scratch;
+    float2 *xe, *ye;                 // per (t, column) / (t, band row): {floor index as int bits | ST_INVALID, d}
     int hwp;
 };
-__device__ __forceinline__ CarveWr carve_wr(float *smem, int T, int H, int W, int h, int w) {
+__device__ __forceinline__ CarveWr carve_wr(float *smem, int T, int RB, int W, int h, int w) {
     CarveWr c;
     c.hwp = (h * w + 3) & ~3;
     float *p = smem;
     c.glm = p; p += (size_t)T * c.hwp;
-    c.fx = reinterpret_cast<int *>(p); p += T * W;
-    c.dx = p; p += T * W;
-    c.fy = reinterpret_cast<int *>(p); p += T * H;
-    c.dy = p; p += T * H;
-    c.X = p; p += W;
-    c.Y = p; p += H;
+    c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
+    c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * RB;
     c.pres = p; p += (T + 3) & ~3;
     c.scratch = p;
     return c;
 }
-static inline size_t carve_wr_bytes(int T, int H, int W, int h, int w) {
-    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + 2 * (size_t)T * (W + H) + W + H + ((T + 3) & ~3) + 128);
+static inline size_t carve_wr_bytes(int T, int RB, int W, int h, int w) {
+    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + 2 * (size_t)T * (W + RB) + ((T + 3) & ~3) + 128);
+}
+// one packed axis entry
+__device__ __forceinline__ float2 axis_entry2(float coord, int extent) {
+    int f; float d;
+    axis_entry(coord, extent, &f, &d);
+    return make_float2(__int_as_float(f), d);
+}
+// taps with unconditional (clamped) LDS reads and a select: no divergent branches around the four loads
+__device__ __forceinline__ Taps load_taps_sel(const float *s, int Hs, int Ws, int fy, int fx) {
+    const bool x0 = fx >= 0, x1 = fx + 1 <= Ws - 1, y0 = fy >= 0, y1 = fy + 1 <= Hs - 1;
+    const int cx0 = x0 ? fx : 0, cx1 = x1 ? fx + 1 : Ws - 1, cy0 = y0 ? fy : 0, cy1 = y1 ? fy + 1 : Hs - 1;
+    Taps t;
+    const float a = s[cy0 * Ws + cx0], b = s[cy0 * Ws + cx1], c = s[cy1 * Ws + cx0], d = s[cy1 * Ws + cx1];
+    t.ff = (x0 && y0) ? a : 0.f;
+    t.fc = (x1 && y0) ? b : 0.f;
+    t.cf = (x0 && y1) ? c : 0.f;
+    t.cc = (x1 && y1) ? d : 0.f;
+    return t;
 }
 
+// One workgroup per (image, row band): band `q` of `NB` covers canvas rows [q*RB, min(H, (q+1)*RB)).  A batch of 64 images in
+// 4 bands fills the 256 CUs (one workgroup per image left three quarters of the chip idle while each busy CU was bound by
+// VALU issue: 2500 pixels x T steps x ~45 instructions on 4 SIMDs).  Every global operand (all T glimpses, the `where` rows,
+// presence, this thread's observation pixels) is requested up front -- one memory round trip -- then ONE barrier, then each
+// thread walks its pixels with the running canvas in a register (t inner, in order, so the accumulation is the oracle's
+// ((0 + p0*v0) + p1*v1) + ...).  rec_parts[q*B + b] receives the band's share of the reconstruction term; with NB = 1 that
+// IS rec[b], with NB > 1 the consumer (air_nvil_parts / air_canvas_unroll_bwd_nvil / air_sum_leading) adds the NB shares
+// in band order (no float atomics: bitwise reproducible).
 __global__ __launch_bounds__(1024) void st_write_fwd_kernel(
     const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ canvas_in, const float *__restrict__ obs,
-    float *__restrict__ canvas_steps, float *__restrict__ final_canvas, float *__restrict__ rec,
-    int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, int vec4_canvas,
+    float *__restrict__ canvas_steps, float *__restrict__ final_canvas, float *__restrict__ rec_parts,
+    int T, int B, int NB, int RB, int H, int W, int h, int w, double stepX, double stepY, float mult, float std,
     int vec4_glimpse) {
     extern __shared__ __align__(16) float smem[];
+    AIR_TR_INIT();
     const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
-    CarveWr c = carve_wr(smem, T, H, W, h, w);
+    CarveWr c = carve_wr(smem, T, RB, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
     const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
-    for (int a = tid; a < W + H; a += nt) {           // linspace tables: image independent
-        if (a < W) c.X[a] = lin_m11(a, W, stepX); else c.Y[a - W] = lin_m11(a - W, H, stepY);
-    }
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        __syncthreads();                                      // previous image done (and X/Y visible)
-        for (int t = 0; t < T; ++t)
-            stage_to_lds(c.glm + (size_t)t * c.hwp, glimpse + ((size_t)t * B + b) * hw, hw, vec4_glimpse != 0);
-        for (int a = tid; a < T * (W + H); a += nt) {
-            const int t = a / (W + H), r = a - t * (W + H);
+    const int n_units = B * NB;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int b = unit % B, band = unit / B;
+        const int r0 = band * RB, r1 = (r0 + RB < H) ? r0 + RB : H, npx = (r1 - r0) * W, pbase = r0 * W;
+        AIR_TR(0);
+        // ---- every global load of this unit --------------------------------------------------------------------------
+        const float *ob = rec_parts ? obs + (size_t)b * HW + pbase : where;     // (any valid address when rec is not wanted)
+        const int ob_last = rec_parts ? npx - 1 : 0;
+        float xo[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                          // unconditional loads from clamped addresses (no branches)
+            const int p = tid + u * nt;
+            xo[u] = ob[p < ob_last ? p : ob_last];
+        }
+        if (unit != (int)blockIdx.x) __syncthreads();          // grid-stride reuse of the carve
+        if (vec4_glimpse) {
+            const int nq = hw >> 2;
+            for (int e = tid; e < T * nq; e += nt) {
+                const int t = e / nq, q = e - t * nq;
+                reinterpret_cast<float4 *>(c.glm + (size_t)t * c.hwp)[q] =
+                    reinterpret_cast<const float4 *>(glimpse + ((size_t)t * B + b) * hw)[q];
+            }
+        } else {
+            for (int e = tid; e < T * hw; e += nt) {
+                const int t = e / hw, q = e - t * hw;
+                c.glm[(size_t)t * c.hwp + q] = glimpse[((size_t)t * B + b) * hw + q];
+            }
+        }
+        const int nrow = r1 - r0;
+        for (int a = tid; a < T * (W + nrow); a += nt) {
+            const int t = a / (W + nrow), r = a - t * (W + nrow);
             const float *wk = where + 4 * ((size_t)t * B + b);
             if (r < W) {
                 const float sx = wk[0], tx = wk[1];
-                axis_entry(grid_coord(1.0f / sx, c.X[r], -tx / sx, cxs), w, &c.fx[t * W + r], &c.dx[t * W + r]);
+                c.xe[t * W + r] = axis_entry2(grid_coord(1.0f / sx, lin_m11(r, W, stepX), -tx / sx, cxs), w);
             } else {
                 const float sy = wk[2], ty = wk[3];
                 const int i = r - W;
-                axis_entry(grid_coord(1.0f / sy, c.Y[i], -ty / sy, cys), h, &c.fy[t * H + i], &c.dy[t * H + i]);
+                c.ye[t * RB + i] = axis_entry2(grid_coord(1.0f / sy, lin_m11(r0 + i, H, stepY), -ty / sy, cys), h);
             }
         }
         if (tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
+        AIR_TR(1);
         __syncthreads();
+        AIR_TR(2);
         float s[1] = {0.f};
-        for (int p = tid; p < HW; p += nt) {
-            const int I = p / W, J = p - I * W;
-            const float xo = rec ? obs[(size_t)b * HW + p] : 0.f;
-            float acc = canvas_in ? canvas_in[(size_t)b * HW + p] : 0.f;
-            for (int t = 0; t < T; ++t) {
-                const int fx = c.fx[t * W + J], fy = c.fy[t * H + I];
-                float v = 0.f;
-                if (fx != ST_INVALID && fy != ST_INVALID)
-                    v = bilerp(load_taps(c.glm + (size_t)t * c.hwp, h, w, fy, fx), c.dx[t * W + J], c.dy[t * H + I]);
-                acc = acc + c.pres[t] * v;
-                if (canvas_steps) canvas_steps[((size_t)t * B + b) * HW + p] = acc;
+        for (int p0 = tid; p0 < npx; p0 += 4 * nt) {
+            float xn[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p0 + 4 * nt < npx) {                           // next chunk's observations (bands above 4 pixels per thread)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + (4 + u) * nt;
+                    xn[u] = ob[p < ob_last ? p : ob_last];
+                }
             }
-            if (final_canvas) final_canvas[(size_t)b * HW + p] = acc;
-            if (rec) {
-                const float z = (xo - mult * acc) / std;
-                s[0] += 0.5f * z * z + cst;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * nt;
+                if (p >= npx) break;
+                const int Ib = p / W, J = p - Ib * W;
+                const size_t gp = (size_t)b * HW + pbase + p;
+                float acc = canvas_in ? canvas_in[gp] : 0.f;
+                for (int t = 0; t < T; ++t) {
+                    const float2 ex = c.xe[t * W + J], ey = c.ye[t * RB + Ib];
+                    const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);
+                    float v = 0.f;
+                    if (fx != ST_INVALID && fy != ST_INVALID)
+                        v = bilerp(load_taps_sel(c.glm + (size_t)t * c.hwp, h, w, fy, fx), ex.y, ey.y);
+                    acc = acc + c.pres[t] * v;
+                    if (canvas_steps) canvas_steps[((size_t)t * B + b) * HW + pbase + p] = acc;
+                }
+                if (final_canvas) final_canvas[gp] = acc;
+                if (rec_parts) {
+                    const float z = (xo[u] - mult * acc) / std;
+                    s[0] += 0.5f * z * z + cst;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xo[u] = xn[u];
         }
-        if (rec) {
+        AIR_TR(3);
+        if (rec_parts) {
             block_sum<1>(s, c.scratch);
-            if (tid == 0) rec[b] = s[0];
+            if (tid == 0) rec_parts[(size_t)band * B + b] = s[0];
         }
+        AIR_TR(4);
     }
+    AIR_TR_FLUSH();
 }
 
 // Backward of the write for every (t, b): dglimpse, dwhere, optional dpresence.
@@ -351,8 +436,9 @@ __global__ __launch_bounds__(1024) void st_write_fwd_kernel(
 //   T1[I,j] = sum_J g[I,J] * wx[J,j]   over the contiguous J-range that touches glimpse column j
 //   dG[i,j] = sum_I wy[I,i] * T1[I,j]  over the contiguous I-range that touches glimpse row i
 struct CarveBwd {
-    float *src, *g, *t1, *dx, *X, *dy, *Y, *scratch;
-    int *fx, *fy, *jlo, *jhi, *ilo, *ihi;
+    float *src, *g, *t1, *X, *Y, *scratch;
+    float2 *xe, *ye;
+    int2 *jr, *ir;               // exact [lo, hi] canvas column / row range that touches glimpse column j / row i
 };
 __device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, int w) {
     CarveBwd c;
@@ -360,151 +446,285 @@ __device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, 
     c.src = p; p += (h * w + 3) & ~3;
     c.g = p; p += (H * W + 3) & ~3;
     c.t1 = p; p += (H * w + 3) & ~3;
-    c.fx = reinterpret_cast<int *>(p); p += W;
-    c.dx = p; p += W;
+    c.xe = reinterpret_cast<float2 *>(p); p += 2 * W;
+    c.ye = reinterpret_cast<float2 *>(p); p += 2 * H;
+    c.jr = reinterpret_cast<int2 *>(p); p += 2 * w;
+    c.ir = reinterpret_cast<int2 *>(p); p += 2 * h;
     c.X = p; p += W;
-    c.fy = reinterpret_cast<int *>(p); p += H;
-    c.dy = p; p += H;
     c.Y = p; p += H;
-    c.jlo = reinterpret_cast<int *>(p); p += w;
-    c.jhi = reinterpret_cast<int *>(p); p += w;
-    c.ilo = reinterpret_cast<int *>(p); p += h;
-    c.ihi = reinterpret_cast<int *>(p); p += h;
     c.scratch = p;
     return c;
 }
 static inline size_t carve_bwd_bytes(int H, int W, int h, int w) {
-    return sizeof(float) * (size_t)(((h * w + 3) & ~3) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 3 * W + 3 * H +
-                                    2 * w + 2 * h + 128);
+    return sizeof(float) * (size_t)(((h * w + 3) & ~3) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 3 * W + 3 * H + 2 * w +
+                                    2 * h + 128 + 16);
+}
+// Canvas indices J (of n) whose source coordinate x(J) = cs*((a*X_J + b) + 1), X_J = -1 + 2J/(n-1), can land in [x0, x1].
+// The map is affine in J, so the set is an interval; it is obtained from the inverse map with a margin of one index on each
+// side (callers re-check every candidate exactly, so a superset is all that is needed) and degenerates to the full range for
+// non-finite or zero scales.
+__device__ __forceinline__ void src_range(float inv_a, float b, float inv_cs, float x0, float x1, int n, int *lo, int *hi) {
+    const float half = 0.5f * (float)(n - 1);
+    const float J0 = (((x0 * inv_cs - 1.0f) - b) * inv_a + 1.0f) * half;
+    const float J1 = (((x1 * inv_cs - 1.0f) - b) * inv_a + 1.0f) * half;
+    if (!(fabsf(J0) < 1e8f && fabsf(J1) < 1e8f)) { *lo = 0; *hi = n - 1; return; }     // NaN / inf / degenerate
+    const float l = fminf(J0, J1), u = fmaxf(J0, J1);
+    const int a0 = (int)floorf(l) - 1, a1 = (int)ceilf(u) + 1;
+    *lo = a0 < 0 ? 0 : (a0 > n - 1 ? n - 1 : a0);         // both ends inside the table (a superset of the true set is fine)
+    *hi = a1 > n - 1 ? n - 1 : (a1 < 0 ? 0 : a1);
+}
+// exact [lo, hi] of canvas indices whose taps touch source index j (floor == j-1 or j), from the LDS axis table; empty => lo > hi.
+// The candidate interval of src_range is at most a handful of indices: up to eight are tested with independent LDS reads
+// (one round trip); longer intervals (degenerate scales) fall back to a scan from both ends.
+__device__ __forceinline__ int2 touch_range(const float2 *tab, float b, float inv_a, float inv_cs, int j, int n) {
+    int lo, hi;
+    src_range(inv_a, b, inv_cs, (float)(j - 1), (float)(j + 1), n, &lo, &hi);
+    if (hi - lo < 8) {
+        unsigned mask = 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int J = lo + u;
+            const int f = __float_as_int(tab[J <= hi ? J : lo].x);
+            if (J <= hi && f != ST_INVALID && (f == j || f + 1 == j)) mask |= 1u << u;
+        }
+        if (!mask) return make_int2(1, 0);
+        return make_int2(lo + __ffs((int)mask) - 1, lo + 31 - __clz((int)mask));
+    }
+    while (lo <= hi) { const int f = __float_as_int(tab[lo].x); if (f != ST_INVALID && (f == j || f + 1 == j)) break; ++lo; }
+    while (hi >= lo) { const int f = __float_as_int(tab[hi].x); if (f != ST_INVALID && (f == j || f + 1 == j)) break; --hi; }
+    return make_int2(lo, hi);
+}
+// [first, last] index of an axis table with a valid entry (the valid set of a monotone map is an interval); every lane of the
+// wave gets the result; empty => first > last
+__device__ __forceinline__ int2 valid_span(const float2 *tab, int n) {
+    const int lane = threadIdx.x & 63;
+    int first = n, last = -1;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const bool v = k < n && __float_as_int(tab[k < n ? k : n - 1].x) != ST_INVALID;
+        const unsigned long long m = __ballot(v);
+        if (m) {
+            const int lo = base + (int)__ffsll((long long)m) - 1, hi = base + 63 - (int)__clzll((long long)m);
+            first = lo < first ? lo : first;
+            last = hi > last ? hi : last;
+        }
+    }
+    return make_int2(first, last);
 }
 
+// Workgroup barriers per unit: [operands staged + axis tables] | footprint pixel pass (+ exact contraction ranges) | column
+// contraction | row contraction.  What the r01 kernel spent its 10 us on (traced with tools/kbench/st_trace.cpp: 2.7 us in
+// three serialised load round trips, 2.3 us walking all H*W canvas pixels on one CU, 1.3 + 2.1 us in the two contractions
+// with data-dependent loop bounds behind LDS min/max atomics) is cut by: requesting every global operand first and building
+// the axis tables -- which only need `where`, the oldest request -- while the rest is in flight; walking only the glimpse's
+// FOOTPRINT on the canvas (the ~(W*sx)*(H*sy) pixels with a valid source coordinate; all others contribute exactly zero;
+// found with two ballots over the tables); exact per-column / per-row source ranges from the inverse affine map, re-checked
+// against the tables, computed by the idlest wave during the pixel pass; 4-wide predicated contraction loops (one LDS round
+// trip); and multi-value wave reductions.
 __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
     float *__restrict__ dglimpse, float *__restrict__ dwhere, float *__restrict__ dpresence,
     int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, float loss_scale,
-    int vec4_glimpse, NvilArgs nv) {
+    int vec4_glimpse, int vec4_canvas, NvilArgs nv) {
     extern __shared__ __align__(16) float smem[];
     // optional second role: the LAST workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
     // has to precede the baseline / logit backward that follow this launch)
+    AIR_TR_INIT();
     const int grid_st = nv.imp ? (int)gridDim.x - 1 : (int)gridDim.x;
     if ((int)blockIdx.x >= grid_st) {
+        AIR_TR(5);
         nvil_body(nv);
+        AIR_TR(6);
+        AIR_TR_FLUSH();
         return;
     }
-    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
+    AIR_TR(0);
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
     CarveBwd c = carve_bwd(smem, H, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
     const float coef = loss_scale * mult / (std * std);
     const int n = T * B;
     for (int k = blockIdx.x; k < n; k += grid_st) {
         const int b = k % B;
-        __syncthreads();
-        stage_to_lds(c.src, glimpse + (size_t)k * hw, hw, vec4_glimpse != 0);
-        {   // incoming canvas gradient -> LDS up front: these global loads do not depend on the tables, so their
-            // latency overlaps the table construction instead of sitting inside the per-pixel dependency chain
-            const float *dcp = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
-            const float *fcp = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
-            const float *obp = obs ? obs + (size_t)b * HW : nullptr;
-            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : coef * (mult * fcp[p] - obp[p]);
+        if (k != (int)blockIdx.x) __syncthreads();           // grid-stride reuse of the LDS carve
+        // ---- every global load of the unit is requested first; the axis tables (which only need `where`, the oldest
+        //      request) are built while the rest is still in flight, then the staged operands are written to LDS
+        const int z0 = opaque_zero();                          // vector-path loads of the wave-uniform operands (see opaque_zero)
+        const float sx = where[4 * (size_t)k + z0], tx = where[4 * (size_t)k + 1 + z0];
+        const float sy = where[4 * (size_t)k + 2 + z0], ty = where[4 * (size_t)k + 3 + z0];
+        const float pres = presence ? presence[k + z0] : 1.0f;
+        const float *dcp = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
+        const float *fcp = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
+        const float *obp = obs ? obs + (size_t)b * HW : nullptr;
+        const float *gsrc = glimpse + (size_t)k * hw;
+        // 16-byte requests from clamped addresses, all issued before anything waits (a per-element `if (p < HW) load` makes
+        // hipcc branch around every load and wait for each one separately -- eight serialised round trips, measured 4 us;
+        // dword requests cost four times the load and LDS-store instructions)
+        const bool v4 = vec4_canvas != 0;
+        const int nQ = HW >> 2;
+        const float *pa = dcp ? dcp : fcp, *pb = dcp ? dcp : obp;
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+        if (v4) {
+            const int q = tid < nQ ? tid : nQ - 1;
+            qa = reinterpret_cast<const float4 *>(pa)[q];
+            qb = reinterpret_cast<const float4 *>(pb)[q];
         }
-        for (int a = tid; a < w + h; a += nt) {               // empty index ranges (lo > hi)
-            if (a < w) { c.jlo[a] = W; c.jhi[a] = -1; } else { c.ilo[a - w] = H; c.ihi[a - w] = -1; }
-        }
-        const float sx = where[4 * (size_t)k + 0], tx = where[4 * (size_t)k + 1];
-        const float sy = where[4 * (size_t)k + 2], ty = where[4 * (size_t)k + 3];
+        const int nq = hw >> 2;
+        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec4_glimpse && tid < nq) gq = reinterpret_cast<const float4 *>(gsrc)[tid];
         const float ax = 1.0f / sx, bx = -tx / sx;
         const float ay = 1.0f / sy, by = -ty / sy;
-        __syncthreads();
-        // axis tables; each canvas column / row also registers itself in the contiguous source range of the (at most
-        // two) glimpse columns / rows it touches -- integer LDS min / max atomics: order independent, deterministic
-        for (int a = tid; a < W + H; a += nt) {
-            if (a < W) {
-                const float X = lin_m11(a, W, stepX);
-                c.X[a] = X;
-                int f; float d;
-                axis_entry(grid_coord(ax, X, bx, cxs), w, &f, &d);
-                c.fx[a] = f; c.dx[a] = d;
-                if (f != ST_INVALID) {
-                    if (f >= 0) { atomicMin(&c.jlo[f], a); atomicMax(&c.jhi[f], a); }
-                    if (f + 1 <= w - 1) { atomicMin(&c.jlo[f + 1], a); atomicMax(&c.jhi[f + 1], a); }
-                }
-            } else {
-                const int i = a - W;
-                const float Y = lin_m11(i, H, stepY);
-                c.Y[i] = Y;
-                int f; float d;
-                axis_entry(grid_coord(ay, Y, by, cys), h, &f, &d);
-                c.fy[i] = f; c.dy[i] = d;
-                if (f != ST_INVALID) {
-                    if (f >= 0) { atomicMin(&c.ilo[f], i); atomicMax(&c.ihi[f], i); }
-                    if (f + 1 <= h - 1) { atomicMin(&c.ilo[f + 1], i); atomicMax(&c.ihi[f + 1], i); }
+        {   // axis tables: columns by the first ceil(W/64) waves, rows by the next ceil(H/64) (no divergence inside a wave)
+            const int Wp = (W + 63) & ~63, Hp = (H + 63) & ~63;
+            for (int a = tid; a < Wp + Hp; a += nt) {
+                if (a < Wp) {
+                    if (a < W) {
+                        const float X = lin_m11(a, W, stepX);
+                        c.X[a] = X;
+                        c.xe[a] = axis_entry2(grid_coord(ax, X, bx, cxs), w);
+                    }
+                } else {
+                    const int i = a - Wp;
+                    if (i < H) {
+                        const float Y = lin_m11(i, H, stepY);
+                        c.Y[i] = Y;
+                        c.ye[i] = axis_entry2(grid_coord(ay, Y, by, cys), h);
+                    }
                 }
             }
         }
-        __syncthreads();
-        const float pres = presence ? presence[k] : 1.0f;
-        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence
-        for (int p = tid; p < HW; p += nt) {
-            const int I = p / W, J = p - I * W;
-            const int fx = c.fx[J], fy = c.fy[I];
-            float go = 0.f;
-            if (fx != ST_INVALID && fy != ST_INVALID) {
-                const float dc = c.g[p];
-                const float dx = c.dx[J], dy = c.dy[I];
-                const Taps t = load_taps(c.src, h, w, fy, fx);
-                const float v = bilerp(t, dx, dy);
-                const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
-                const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
-                go = pres * dc;
-                const float gax = go * gx * cxs, gay = go * gy * cys;
-                acc[0] += gax * c.X[J]; acc[1] += gax;
-                acc[2] += gay * c.Y[I]; acc[3] += gay;
-                acc[4] += dc * v;
+        AIR_TR(7);
+        if (vec4_glimpse) {
+            if (tid < nq) reinterpret_cast<float4 *>(c.src)[tid] = gq;
+            for (int q = tid + nt; q < nq; q += nt) reinterpret_cast<float4 *>(c.src)[q] = reinterpret_cast<const float4 *>(gsrc)[q];
+        } else {
+            for (int q = tid; q < hw; q += nt) c.src[q] = gsrc[q];
+        }
+        if (v4) {
+            if (tid < nQ) {
+                float4 gv = qa;
+                if (!dcp) { gv.x = coef * (mult * qa.x - qb.x); gv.y = coef * (mult * qa.y - qb.y);
+                            gv.z = coef * (mult * qa.z - qb.z); gv.w = coef * (mult * qa.w - qb.w); }
+                reinterpret_cast<float4 *>(c.g)[tid] = gv;
             }
+            for (int q = tid + nt; q < nQ; q += nt) {            // images above 4096 pixels
+                const float4 a4 = reinterpret_cast<const float4 *>(pa)[q], b4 = reinterpret_cast<const float4 *>(pb)[q];
+                float4 gv = a4;
+                if (!dcp) { gv.x = coef * (mult * a4.x - b4.x); gv.y = coef * (mult * a4.y - b4.y);
+                            gv.z = coef * (mult * a4.z - b4.z); gv.w = coef * (mult * a4.w - b4.w); }
+                reinterpret_cast<float4 *>(c.g)[q] = gv;
+            }
+        } else {
+            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : coef * (mult * fcp[p] - obp[p]);
+        }
+        AIR_TRT(128, 6);
+        __syncthreads();                                       // (1)
+        AIR_TR(1);
+        // footprint of the glimpse on the canvas (valid columns x valid rows): two ballots per wave over the tables
+        const int2 vx = valid_span(c.xe, W), vy = valid_span(c.ye, H);
+        const int J0 = vx.x, J1 = vx.y, I0 = vy.x, I1 = vy.y;
+        const int fw = J1 - J0 + 1, fh = I1 - I0 + 1;
+        const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence, -, -, -
+        for (int idx = tid; idx < npx; idx += nt) {
+            const int Ir = idx / fw, I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
+            const float2 ex = c.xe[J], ey = c.ye[I];
+            const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);       // valid by construction of the footprint
+            const float dc = c.g[p];
+            const float dx = ex.y, dy = ey.y;
+            const Taps t = load_taps_sel(c.src, h, w, fy, fx);
+            const float v = bilerp(t, dx, dy);
+            const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
+            const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
+            const float go = pres * dc;
+            const float gax = go * gx * cxs, gay = go * gy * cys;
+            acc[0] += gax * c.X[J]; acc[1] += gax;
+            acc[2] += gay * c.Y[I]; acc[3] += gay;
+            acc[4] += dc * v;
             c.g[p] = go;
         }
-        __syncthreads();
-        for (int e = tid; e < H * w; e += nt) {            // pass 1: contract canvas columns
-            const int I = e / w, j = e - I * w;
-            float s = 0.f;
-            if (c.fy[I] != ST_INVALID) {
-                const float *grow = c.g + I * W;
-                for (int J = c.jlo[j]; J <= c.jhi[j]; ++J) {
-                    const int fx = c.fx[J];
-                    if (fx == ST_INVALID) continue;
-                    const float dx = c.dx[J];
-                    const float wgt = (fx == j ? dx : 0.f) + (fx + 1 == j ? 1.f - dx : 0.f);
-                    s += grow[J] * wgt;
-                }
-            }
-            c.t1[e] = s;
+        {
+            const float r = wave_reduce8(acc);
+            if ((lane & 7) == 0) c.scratch[wid * 8 + wave_reduce8_slot()] = r;
         }
-        __syncthreads();
-        float *dg = dglimpse + (size_t)k * hw;
-        for (int e = tid; e < hw; e += nt) {               // pass 2: contract canvas rows
-            const int i = e / w, j = e - i * w;
+        // exact source ranges of the two contractions, by the two waves with the fewest footprint pixels
+        if (wid == nw - 1) for (int j = lane; j < w; j += 64) c.jr[j] = touch_range(c.xe, bx, sx, inv_cxs, j, W);   // 1/ax = sx
+        if (wid == (nw > 1 ? nw - 2 : 0)) for (int i = lane; i < h; i += 64) c.ir[i] = touch_range(c.ye, by, sy, inv_cys, i, H);
+        __syncthreads();                                       // (2)
+        AIR_TR(2);
+        // pass 1: T1[I, j] = sum_J go[I, J] * wx[J, j] over the exact column range of j, valid rows only
+        for (int e = tid; e < (fh > 0 ? fh : 0) * w; e += nt) {
+            const int Ir = e / w, I = I0 + Ir, j = e - Ir * w;
+            const int2 r = c.jr[j];
+            const float *grow = c.g + I * W;
             float s = 0.f;
-            for (int I = c.ilo[i]; I <= c.ihi[i]; ++I) {
-                const int fy = c.fy[I];
-                if (fy == ST_INVALID) continue;
-                const float dy = c.dy[I];
-                const float wgt = (fy == i ? dy : 0.f) + (fy + 1 == i ? 1.f - dy : 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                  // the first four candidates: loads issued together
+                const int J = r.x + u;
+                const bool in = J <= r.y;
+                const int Jc = in ? J : r.x <= r.y ? r.x : 0;
+                const float2 ex = c.xe[Jc];
+                const float gv = grow[Jc];
+                const int fx = __float_as_int(ex.x);
+                const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
+                if (in) s += gv * wgt;
+            }
+            for (int J = r.x + 4; J <= r.y; ++J) {
+                const float2 ex = c.xe[J];
+                const int fx = __float_as_int(ex.x);
+                const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
+                s += grow[J] * wgt;
+            }
+            c.t1[I * w + j] = s;
+        }
+        __syncthreads();                                       // (3)
+        AIR_TR(3);
+        float *dg = dglimpse + (size_t)k * hw;
+        for (int e = tid; e < hw; e += nt) {               // pass 2: dG[i, j] = sum_I wy[I, i] * T1[I, j]
+            const int i = e / w, j = e - i * w;
+            const int2 r = c.ir[i];
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int I = r.x + u;
+                const bool in = I <= r.y;
+                const int Ic = in ? I : r.x <= r.y ? r.x : 0;
+                const float2 ey = c.ye[Ic];
+                const float tv = in ? c.t1[Ic * w + j] : 0.f;
+                const int fy = __float_as_int(ey.x);
+                const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
+                if (in) s += tv * wgt;
+            }
+            for (int I = r.x + 4; I <= r.y; ++I) {
+                const float2 ey = c.ye[I];
+                const int fy = __float_as_int(ey.x);
+                const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
                 s += c.t1[I * w + j] * wgt;
             }
             dg[e] = s;
         }
-        block_sum<5>(acc, c.scratch);
-        if (tid == 0) {
-            // chain through a = 1/s, b = -t/s
-            float *d = dwhere + 4 * (size_t)k;
-            d[0] = acc[0] * (-1.0f / (sx * sx)) + acc[1] * (tx / (sx * sx));
-            d[1] = acc[1] * (-1.0f / sx);
-            d[2] = acc[2] * (-1.0f / (sy * sy)) + acc[3] * (ty / (sy * sy));
-            d[3] = acc[3] * (-1.0f / sy);
-            if (dpresence) dpresence[k] = acc[4];
+        if (wid == nw - 1) {                               // the per-wave dwhere partials (visible since barrier 2), fixed order;
+            float part[8];                                 // by the LAST wave: it has the least contraction work
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[lane * 8 + q] : 0.f;
+            const float tot = wave_reduce8(part);
+            const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64),
+                        r4 = __shfl(tot, 32, 64);
+            if (lane == 0) {
+                // chain through a = 1/s, b = -t/s
+                float *d = dwhere + 4 * (size_t)k;
+                d[0] = r0 * (-1.0f / (sx * sx)) + r1 * (tx / (sx * sx));
+                d[1] = r1 * (-1.0f / sx);
+                d[2] = r2 * (-1.0f / (sy * sy)) + r3 * (ty / (sy * sy));
+                d[3] = r3 * (-1.0f / sy);
+                if (dpresence) dpresence[k] = r4;
+            }
         }
+        AIR_TR(4);
     }
+    AIR_TR_FLUSH();
 }
 
 // ============================================================================================================
@@ -572,20 +792,34 @@ extern "C" int air_st_read_bwd(const float *img, const float *where, const float
     return AIR_OK;
 }
 
+// rows per band / number of bands actually used for a request of `want` bands
+static inline void wr_bands(int H, int want, int *NB, int *RB) {
+    int nb = want < 1 ? 1 : (want > H ? H : want);
+    const int rb = (H + nb - 1) / nb;
+    nb = (H + rb - 1) / rb;                                  // drop empty trailing bands
+    *NB = nb; *RB = rb;
+}
 static int launch_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
-                            const float *obs, float *canvas_steps, float *final_canvas, float *rec, int T, int B,
-                            int H, int W, int h, int w, float mult, float std, void *stream) {
-    const size_t lds = carve_wr_bytes(T, H, W, h, w);
+                            const float *obs, float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
+                            int T, int B, int H, int W, int h, int w, float mult, float std, void *stream) {
+    int NB, RB;
+    wr_bands(H, n_bands, &NB, &RB);
+    AIR_REQUIRE(NB == n_bands || !rec_parts, AIR_E_SHAPE);   // the caller sized rec_parts for exactly n_bands shares
+    const size_t lds = carve_wr_bytes(T, RB, W, h, w);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
-    const int vec4c = ((H * W) % 4 == 0) && (!canvas_in || air_aligned16(canvas_in)) &&
-                      (!final_canvas || air_aligned16(final_canvas));
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     { int st_ = st_allow_lds(st_write_fwd_kernel, lds); if (st_) return st_; }
-    // few images: the chip is mostly idle, so give each image 16 waves (4 per SIMD) to hide LDS / global latency
-    const int wr_threads = (long)B * T <= 4096 ? 1024 : ST_THREADS;
-    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid(B)), dim3(wr_threads), lds, air_stream(stream), glimpse, where,
-                       presence, canvas_in, obs, canvas_steps, final_canvas, rec, T, B, H, W, h, w, lin_step(W),
-                       lin_step(H), mult, std, vec4c, vec4g);
+    // one pixel per thread while the launch is far from filling the chip (latency regime), 256-thread workgroups beyond
+    const long units = (long)B * NB;
+    int wr_threads = ST_THREADS;
+    if (units * T <= 4096) {
+        const int px = RB * W;
+        wr_threads = px >= 1024 ? 1024 : ((px + 63) / 64) * 64;
+        if (wr_threads < 64) wr_threads = 64;
+    }
+    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid((int)units)), dim3(wr_threads), lds, air_stream(stream), glimpse,
+                       where, presence, canvas_in, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
+                       lin_step(W), lin_step(H), mult, std, vec4g);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -596,7 +830,7 @@ extern "C" int air_st_write_fwd(const float *glimpse, const float *where, const 
     AIR_REQUIRE(glimpse && where && canvas_out, AIR_E_NULL);
     int st = st_check_dims(n, H, W, h, w);
     if (st) return st;
-    return launch_write_fwd(glimpse, where, presence, canvas_in, nullptr, nullptr, canvas_out, nullptr, 1, n, H, W, h,
+    return launch_write_fwd(glimpse, where, presence, canvas_in, nullptr, nullptr, canvas_out, nullptr, 1, 1, n, H, W, h,
                             w, 1.0f, 1.0f, stream);
 }
 
@@ -609,7 +843,33 @@ extern "C" int air_canvas_unroll_fwd(const float *glimpse, const float *where, c
     AIR_REQUIRE(T > 0, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
-    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_per_sample, T, B,
+    // the complete per-sample reconstruction term needs the whole image in one workgroup; without it the bands are free
+    int nb = 1;
+    if (!rec_per_sample && (long)B * T <= 1024) nb = 256 / B < 1 ? 1 : 256 / B;
+    int NB, RB;
+    wr_bands(H, nb, &NB, &RB);
+    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_per_sample, NB, T, B,
+                            H, W, h, w, mult, std, stream);
+}
+
+extern "C" int air_canvas_unroll_bands(int B, int H) {
+    int nb = 256 / (B < 1 ? 1 : B);
+    if (nb > 8) nb = 8;
+    int NB, RB;
+    wr_bands(H, nb, &NB, &RB);
+    return NB;
+}
+
+extern "C" int air_canvas_unroll_fwd_banded(const float *glimpse, const float *where, const float *presence,
+                                            const float *obs, float *canvas_steps, float *final_canvas,
+                                            float *rec_parts, int n_bands, int T, int B, int H, int W, int h, int w,
+                                            float mult, float std, void *stream) {
+    AIR_REQUIRE(glimpse && where && (final_canvas || canvas_steps), AIR_E_NULL);
+    AIR_REQUIRE(!rec_parts || obs, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n_bands > 0, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, n_bands, T, B,
                             H, W, h, w, mult, std, stream);
 }
 
@@ -618,15 +878,16 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
                             float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
                             float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
     const size_t lds = carve_bwd_bytes(H, W, h, w);
-    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
     if (nvil) nv = *nvil;
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    const int vec4c = ((H * W) % 4 == 0) && (dcanvas ? air_aligned16(dcanvas) : (air_aligned16(final_canvas) && air_aligned16(obs)));
     { int st_ = st_allow_lds(st_write_bwd_kernel, lds); if (st_) return st_; }
     const int wr_threads = (long)B * T <= 4096 ? 1024 : ST_THREADS;
     hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
                        air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
-                       dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, nv);
+                       dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -656,14 +917,15 @@ extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, c
 extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence,
                                           const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
                                           int T, int B, int H, int W, int h, int w, float mult, float std,
-                                          float loss_scale, const float *imp, const float *baseline, const float *logp,
-                                          float *nvil_out, float *dlogp, float *dbaseline, void *stream) {
+                                          float loss_scale, const float *imp_parts, int n_parts, float *imp_sum,
+                                          const float *baseline, const float *logp, float *nvil_out, float *dlogp,
+                                          float *dbaseline, void *stream) {
     AIR_REQUIRE(glimpse && where && obs && final_canvas && dglimpse && dwhere, AIR_E_NULL);
-    AIR_REQUIRE(imp && baseline && logp && nvil_out, AIR_E_NULL);
-    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n_parts > 0, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
-    const NvilArgs nv = {imp, baseline, logp, nvil_out, dlogp, dbaseline, B};
+    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
     return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
                             h, w, mult, std, loss_scale, stream, &nv);
 }
@@ -696,63 +958,92 @@ struct AttendFwdArgs {
 // operand of a dense product: as is, or rounded to bf16 (EngineConfig.mfma_dtype = "bf16": same arithmetic as the MFMA path)
 __device__ __forceinline__ float opnd(float v, int bf16) { return bf16 ? (float)(__bf16)v : v; }
 
-template <int MT>
-__global__ __launch_bounds__(1024) void attend_fwd_kernel(AttendFwdArgs g) {
+// Role A runs one workgroup per GLIMPSE (t, b) -- T*B workgroups, so a batch of 64 already covers 192 of the 256 CUs (one
+// workgroup per image left three quarters of the chip idle and serialised the T reads behind 2T barriers).  Each workgroup
+// prefetches its image into registers, wave 0 forms the 8 outputs of the transform layer for row t*B+b (one memory round trip,
+// wave_reduce8) and samples `where`, which reaches the other waves through LDS behind the ONE barrier of the kernel; the
+// glimpse pixels then compute their own axis entries (no table phase) and gather four taps from the LDS-staged image.
+template <int MT, int NT, bool EXACT>
+__global__ __launch_bounds__(NT) void attend_fwd_kernel(AttendFwdArgs g) {
     extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    const int T = g.T, B = g.B;
-    if ((int)blockIdx.x >= B) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int T = EXACT ? MT : g.T, B = g.B, n = T * B;     // EXACT: T is a compile-time constant, every t-loop unrolls flat
+    AIR_TR_INIT();
+    if ((int)blockIdx.x >= n) {
         // ---- role B: steps-predictor output layer + presence / num-steps for 64 batch columns ----------------------
-        const int vb = (int)blockIdx.x - B, vgrid = (int)gridDim.x - B;
-        // steps-predictor output layer for this block's 64 columns x T rows.  Thread (c = tid & 63, part = tid >> 6) sums a
-        // quarter of the K range of row (t, c) for every t -- all its loads are independent, so the whole layer is ONE memory
-        // round trip (a row-at-a-time loop measured 8 us: a dozen dependent round trips) -- then the 4 parts meet in LDS.
-        __shared__ float s_part[4][MT][64];
-        const float bias = g.st_b[0];
-        const int cc = tid & 63, part = tid >> 6;
-        const int chunk = (g.st_k + 3) >> 2, k0 = part * chunk, k1 = (k0 + chunk < g.st_k) ? k0 + chunk : g.st_k;
+        // Four adjacent lanes per batch column: each sums a quarter of the K range of row (t, c) for every t with 16-byte
+        // loads (the four lanes of a column cover one contiguous row segment), two cross-lane adds finish the dot product in
+        // every lane, and the T logits stay in registers through the presence chain and the float64 posterior.  (The r01
+        // form -- one lane per column, scalar loads -- walked 64 different cache lines per load instruction and read the
+        // logits back from memory: 5.9 us for this role against 3.5 us for the glimpse role, traced.)
+        const int vb = (int)blockIdx.x - n, vgrid = (int)gridDim.x - n;
+        AIR_TR(4);
+        const int z0 = opaque_zero();                          // vector-path loads of wave-uniform operands (see opaque_zero)
+        const float bias = g.st_b[z0];
+        const int cc = tid >> 2, sl = tid & 3;
+        const bool vec = (g.st_k & 15) == 0 && air_aligned16_dev(g.st_h) && air_aligned16_dev(g.st_w);
+        const int kq = vec ? g.st_k >> 2 : (g.st_k + 3) >> 2, k0 = sl * kq, k1 = (k0 + kq < g.st_k) ? k0 + kq : g.st_k;
         for (int base = vb * 64; base < B; base += vgrid * 64) {
+            if (tid >= 256) break;
             const int b = base + cc;
-            if (part < 4) {
+            const bool live = b < B;
+            float uu[MT], lg[MT];
+            double pri[MT + 1];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    float acc = 0.f;
-                    if (t < T && b < B) {
-                        const float *x = g.st_h + ((size_t)t * B + b) * g.st_k;
-#pragma unroll 16
+            for (int t = 0; t < MT; ++t) uu[t] = (t < T && live) ? g.u[(size_t)t * B + b] : 0.f;
+#pragma unroll
+            for (int q = 0; q <= MT; ++q) pri[q] = q <= T ? g.prior[q + z0] : 1.0;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float acc = 0.f;
+                if (t < T && live) {
+                    const float *x = g.st_h + ((size_t)t * B + b) * g.st_k;
+                    if (vec) {
+                        const float4 *x4 = reinterpret_cast<const float4 *>(x + k0);
+                        const float4 *w4 = reinterpret_cast<const float4 *>(g.st_w + k0);
+#pragma unroll 4
+                        for (int q = 0; q < (kq >> 2); ++q) {
+                            const float4 xv = x4[q], wv = w4[q];
+                            acc += opnd(xv.x, g.bf16) * opnd(wv.x, g.bf16);
+                            acc += opnd(xv.y, g.bf16) * opnd(wv.y, g.bf16);
+                            acc += opnd(xv.z, g.bf16) * opnd(wv.z, g.bf16);
+                            acc += opnd(xv.w, g.bf16) * opnd(wv.w, g.bf16);
+                        }
+                    } else {
                         for (int k = k0; k < k1; ++k) acc += opnd(x[k], g.bf16) * opnd(g.st_w[k], g.bf16);
                     }
-                    s_part[part][t][cc] = acc;
                 }
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                lg[t] = acc + bias;
             }
-            __syncthreads();
-            if (tid < 64 && b < B) {
-                for (int t = 0; t < T; ++t)
-                    g.logit[(size_t)t * B + b] = ((s_part[0][t][cc] + s_part[1][t][cc]) + (s_part[2][t][cc] + s_part[3][t][cc])) + bias;
+            AIR_TR(5);
+            if (live && sl == 0) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) if (t < T) g.logit[(size_t)t * B + b] = lg[t];
+                presence_numsteps_col<MT>(b, lg, uu, pri, g.step_bias, g.explore_eps, g.prob, g.pres, g.q, g.kl_ps, g.logp,
+                                          g.step_w, T, B);
             }
-            __syncthreads();
         }
-        __syncthreads();                                       // (same thread re-reads what it wrote; compiler fence)
-        presence_numsteps_fwd_body<MT>(vb, vgrid, g.logit, g.u, g.step_bias, g.explore_eps, g.prior, g.prob, g.pres, g.q,
-                                       g.kl_ps, g.logp, g.step_w, T, B);
+        AIR_TR(6);
+        AIR_TR_FLUSH();
         return;
     }
-    // ---- role A: image b ------------------------------------------------------------------------------------------
-    const int b = blockIdx.x;
+    AIR_TR(0);
+    // ---- role A: glimpse (t, b) -----------------------------------------------------------------------------------
+    const int kk = blockIdx.x, b = kk % B;
+    const size_t m = (size_t)kk;                               // row t*B + b
     const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w, nq = HW >> 2;
     Carve c = carve_lds(smem, HW, 0, w, h);
-    float *s_where = c.scratch;                                // [T][4] (the carve reserves 128 floats; T <= 28)
+    float *s_where = c.scratch;                                // [4]
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
     const int q0 = tid < nq ? tid : nq - 1, q1 = tid + nt < nq ? tid + nt : nq - 1;
     const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
     const float4 *s4 = reinterpret_cast<const float4 *>(g.img + (size_t)b * HW);
-    const float4 p0 = s4[q0], p1 = s4[q1], p2 = s4[q2];       // in flight while the output layer below runs
-    for (int a = tid; a < w + h; a += nt) {
-        if (a < w) c.X[a] = lin_m11(a, w, g.stepx); else c.Y[a - w] = lin_m11(a - w, h, g.stepy);
-    }
-    // transform output layer: one wave per time step (row t*B + b)
-    for (int t = wave; t < T; t += nw) {
-        const size_t m = (size_t)t * B + b;
+    const float4 p0 = s4[q0], p1 = s4[q1], p2 = s4[q2];       // in flight while wave 0 forms `where`
+    if (wave == 0) {
+        const int o = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1), d = o & 3;
+        const float bias_o = g.tr_b[o], eps_d = g.eps[m * 4 + d];
         const float *x = g.tr_h + m * g.tr_k;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -767,47 +1058,46 @@ __global__ __launch_bounds__(1024) void attend_fwd_kernel(AttendFwdArgs g) {
             acc[0] += xv * wa.x; acc[1] += xv * wa.y; acc[2] += xv * wa.z; acc[3] += xv * wa.w;
             acc[4] += xv * wb.x; acc[5] += xv * wb.y; acc[6] += xv * wb.z; acc[7] += xv * wb.w;
         }
-#pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = wave_sum_all(acc[o]);
-        if (lane < 4) {
-            const int d = lane;
-            const float e_loc = (d == 0 ? acc[0] : d == 1 ? acc[1] : d == 2 ? acc[2] : acc[3]) + g.tr_b[d];
-            const float e_raw = (d == 0 ? acc[4] : d == 1 ? acc[5] : d == 2 ? acc[6] : acc[7]) + g.tr_b[4 + d];
-            g.pre[m * 8 + d] = e_loc;
-            g.pre[m * 8 + 4 + d] = e_raw;
+        const float e_o = wave_reduce8(acc) + bias_o;          // lanes < 32: e_loc[d]; lanes >= 32: e_raw[d]
+        const float e_partner = __shfl_xor(e_o, 32, 64);
+        if (lane < 32) {
+            const float e_loc = e_o, e_raw = e_partner;
             const float mu = (d & 1) ? tanhf(e_loc) : sigmoid_acc(e_loc);                    // modules.py:41-46
-            const float s = softplus_acc(e_raw + g.raw_offset);
-            const size_t o = m * 4 + d;
-            const float v = mu + s * g.eps[o];                                              // cell.py:130-133
-            g.loc[o] = mu; g.scale[o] = s; g.where[o] = v;
-            s_where[4 * t + d] = v;
-            float kl = (d & 1) ? normal_kl(mu, s, g.pl1, g.ps1) : normal_kl(mu, s, g.pl0, g.ps0);
-            kl += __shfl_xor(kl, 1, 64);
-            kl += __shfl_xor(kl, 2, 64);
-            if (d == 0) g.kl_row[m] = kl;
+            const float sc = softplus_acc(e_raw + g.raw_offset);
+            const float v = mu + sc * eps_d;                                                // cell.py:130-133
+            float kl = (d & 1) ? normal_kl(mu, sc, g.pl1, g.ps1) : normal_kl(mu, sc, g.pl0, g.ps0);
+            kl += __shfl_xor(kl, 8, 64);
+            kl += __shfl_xor(kl, 16, 64);
+            if ((lane & 7) == 0) {
+                g.pre[m * 8 + d] = e_loc;
+                g.pre[m * 8 + 4 + d] = e_raw;
+                const size_t oo = m * 4 + d;
+                g.loc[oo] = mu; g.scale[oo] = sc; g.where[oo] = v;
+                s_where[d] = v;
+                if (lane == 0) g.kl_row[m] = kl;
+            }
         }
+        AIR_TR(1);
     }
     float4 *d4 = reinterpret_cast<float4 *>(c.src);
     if (tid < nq) d4[tid] = p0;
     if (tid + nt < nq) d4[tid + nt] = p1;
     if (tid + 2 * nt < nq) d4[tid + 2 * nt] = p2;
-    for (int t = 0; t < T; ++t) {
-        __syncthreads();                                       // image + s_where visible / previous tables consumed
-        const float sx = s_where[4 * t + 0], tx = s_where[4 * t + 1], sy = s_where[4 * t + 2], ty = s_where[4 * t + 3];
-        for (int a = tid; a < w + h; a += nt) {
-            if (a < w) axis_entry(grid_coord(sx, c.X[a], tx, cxs), W, &c.fx[a], &c.dx[a]);
-            else axis_entry(grid_coord(sy, c.Y[a - w], ty, cys), H, &c.fy[a - w], &c.dy[a - w]);
-        }
-        __syncthreads();
-        float *o = g.glimpse + ((size_t)t * B + b) * hw;
-        for (int p = tid; p < hw; p += nt) {
-            const int i = p / w, j = p - i * w;
-            const int fx = c.fx[j], fy = c.fy[i];
-            float v = 0.f;
-            if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, H, W, fy, fx), c.dx[j], c.dy[i]);
-            o[p] = v;
-        }
+    __syncthreads();                                           // image + `where` visible
+    AIR_TR(2);
+    const float sx = s_where[0], tx = s_where[1], sy = s_where[2], ty = s_where[3];
+    float *o = g.glimpse + m * hw;
+    for (int p = tid; p < hw; p += nt) {
+        const int i = p / w, j = p - i * w;
+        int fx, fy; float dx, dy;
+        axis_entry(grid_coord(sx, lin_m11(j, w, g.stepx), tx, cxs), W, &fx, &dx);
+        axis_entry(grid_coord(sy, lin_m11(i, h, g.stepy), ty, cys), H, &fy, &dy);
+        float v = 0.f;
+        if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps_sel(c.src, H, W, fy, fx), dx, dy);
+        o[p] = v;
     }
+    AIR_TR(3);
+    AIR_TR_FLUSH();
 }
 
 extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int tr_k, const float *st_h,
@@ -822,7 +1112,7 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
     AIR_REQUIRE(tr_h && tr_w && tr_b && st_h && st_w && st_b && pre && logit && eps && loc && scale && where && kl_row &&
                     u && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight && img &&
                     glimpse, AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && T <= 28 && tr_k > 0 && st_k > 0, AIR_E_SHAPE);   // s_where lives in the 128-float carve pad
+    AIR_REQUIRE(T > 0 && T <= 32 && tr_k > 0 && st_k > 0, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
     const int nq = (H * W) / 4;
@@ -839,15 +1129,23 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
     g.kl_ps = kl_per_sample; g.logp = logp; g.step_w = step_weight; g.img = img; g.glimpse = glimpse;
     g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w; g.stepx = lin_step(w); g.stepy = lin_step(h);
     g.bf16 = precision == AIR_PREC_BF16 ? 1 : 0;
-    const int threads = nq <= 3 * 256 ? 256 : 1024;
-    const int grid = B + air_cdiv(B, 64);
-    if (T <= 8) {
-        { int st_ = st_allow_lds(attend_fwd_kernel<8>, lds); if (st_) return st_; }
-        hipLaunchKernelGGL(attend_fwd_kernel<8>, dim3(grid), dim3(threads), lds, air_stream(stream), g);
-    } else {
-        { int st_ = st_allow_lds(attend_fwd_kernel<32>, lds); if (st_) return st_; }
-        hipLaunchKernelGGL(attend_fwd_kernel<32>, dim3(grid), dim3(threads), lds, air_stream(stream), g);
-    }
+    const int grid = T * B + air_cdiv(B, 64);
+#define AIR_ATTEND_FWD_LAUNCH(MT_, NT_, EX_)                                                                         \
+    do {                                                                                                                \
+        int st_ = st_allow_lds(attend_fwd_kernel<MT_, NT_, EX_>, lds);                                                 \
+        if (st_) return st_;                                                                                            \
+        hipLaunchKernelGGL((attend_fwd_kernel<MT_, NT_, EX_>), dim3(grid), dim3(NT_), lds, air_stream(stream), g);     \
+    } while (0)
+#define AIR_ATTEND_FWD_BY_T(NT_)                                                                                      \
+    do {                                                                                                                \
+        if (T == 3) AIR_ATTEND_FWD_LAUNCH(3, NT_, true);                                                                \
+        else if (T == 5) AIR_ATTEND_FWD_LAUNCH(5, NT_, true);                                                           \
+        else if (T <= 8) AIR_ATTEND_FWD_LAUNCH(8, NT_, false);                                                          \
+        else AIR_ATTEND_FWD_LAUNCH(32, NT_, false);                                                                     \
+    } while (0)
+    if (nq <= 3 * 256) AIR_ATTEND_FWD_BY_T(256); else AIR_ATTEND_FWD_BY_T(1024);
+#undef AIR_ATTEND_FWD_BY_T
+#undef AIR_ATTEND_FWD_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -866,71 +1164,96 @@ struct AttendBwdArgs {
     double stepx, stepy;
 };
 
-template <int MT>
-__global__ __launch_bounds__(1024) void attend_bwd_kernel(AttendBwdArgs g) {
+template <int MT, int NT, bool EXACT>
+__global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
     extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int T = g.T, B = g.B, n = T * B;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+    const int T = EXACT ? MT : g.T, B = g.B, n = T * B;
+    AIR_TR_INIT();
     if ((int)blockIdx.x >= n) {
+        AIR_TR(4);
         numsteps_presence_bwd_body<MT>((int)blockIdx.x - n, (int)gridDim.x - n, g.prob, g.presence, g.prior, g.kl_scale,
                                        g.kl_a, g.kl_b, g.w_scale, g.dlogp, g.logit, g.step_bias, g.explore_eps, g.dlogit,
                                        T, B);
+        AIR_TR(6);
+        AIR_TR_FLUSH();
         return;
     }
+    AIR_TR(0);
     const int k = blockIdx.x, b = k % B;
     const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w;
     Carve c = carve_lds(smem, HW, 0, w, h);
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    // every operand of this unit is requested before anything waits: the image, the `where` row, the incoming glimpse
+    // gradient of this thread's (first four) pixels, and -- lanes 0..3 of wave 0 -- the operands of the where-sampling backward
+    const int z0 = opaque_zero();                              // vector-path loads of the wave-uniform `where` row (see opaque_zero)
+    const float sx = g.where[4 * (size_t)k + z0], tx = g.where[4 * (size_t)k + 1 + z0];
+    const float sy = g.where[4 * (size_t)k + 2 + z0], ty = g.where[4 * (size_t)k + 3 + z0];
+    const float *go_p = g.dglimpse + (size_t)k * hw;
+    float gov[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int p = tid + u * nt; gov[u] = go_p[p < hw ? p : hw - 1]; }     // clamped, branch-free
+    float s_mu = 0.f, s_sc = 1.f, s_dw = 0.f, s_eps = 0.f, s_raw = 0.f, s_dk = 0.f;
+    if (tid < 4) {
+        const size_t e = (size_t)k * 4 + tid;
+        s_mu = g.loc[e]; s_sc = g.scale[e]; s_dw = g.dwhere_w[e]; s_eps = g.eps[e];
+        s_raw = g.pre[(size_t)k * 8 + 4 + tid] + g.raw_offset;
+        s_dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
+    }
     stage_to_lds(c.src, g.img + (size_t)b * HW, HW, g.vec4 != 0);
-    const float sx = g.where[4 * (size_t)k + 0], tx = g.where[4 * (size_t)k + 1];
-    const float sy = g.where[4 * (size_t)k + 2], ty = g.where[4 * (size_t)k + 3];
-    for (int a = tid; a < w + h; a += nt) {
-        if (a < w) {
-            const float X = lin_m11(a, w, g.stepx);
-            c.X[a] = X;
-            axis_entry(grid_coord(sx, X, tx, cxs), W, &c.fx[a], &c.dx[a]);
-        } else {
-            const float Y = lin_m11(a - w, h, g.stepy);
-            c.Y[a - w] = Y;
-            axis_entry(grid_coord(sy, Y, ty, cys), H, &c.fy[a - w], &c.dy[a - w]);
+    __syncthreads();
+    AIR_TR(1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p0 = tid; p0 < hw; p0 += 4 * nt) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * nt;
+            if (p >= hw) break;
+            const float go = p0 == tid ? gov[u] : go_p[p];
+            const int i = p / w, j = p - i * w;
+            const float X = lin_m11(j, w, g.stepx), Y = lin_m11(i, h, g.stepy);
+            int fx, fy; float dx, dy;
+            axis_entry(grid_coord(sx, X, tx, cxs), W, &fx, &dx);
+            axis_entry(grid_coord(sy, Y, ty, cys), H, &fy, &dy);
+            if (fx == ST_INVALID || fy == ST_INVALID) continue;
+            const Taps t = load_taps_sel(c.src, H, W, fy, fx);
+            const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
+            const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
+            const float ax = go * gx * cxs, ay = go * gy * cys;
+            acc[0] += ax * X; acc[1] += ax;
+            acc[2] += ay * Y; acc[3] += ay;
         }
     }
-    __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float *go_p = g.dglimpse + (size_t)k * hw;
-    for (int p = tid; p < hw; p += nt) {
-        const int i = p / w, j = p - i * w;
-        const int fx = c.fx[j], fy = c.fy[i];
-        if (fx == ST_INVALID || fy == ST_INVALID) continue;
-        const float dx = c.dx[j], dy = c.dy[i], go = go_p[p];
-        const Taps t = load_taps(c.src, H, W, fy, fx);
-        const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
-        const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
-        const float ax = go * gx * cxs, ay = go * gy * cys;
-        acc[0] += ax * c.X[j]; acc[1] += ax;
-        acc[2] += ay * c.Y[i]; acc[3] += ay;
+    {
+        const float r = wave_reduce8(acc);
+        if ((lane & 7) == 0) c.scratch[wid * 8 + wave_reduce8_slot()] = r;
     }
-    block_sum<4>(acc, c.scratch);                              // valid in wave 0 (every lane after its wave_sum? no: lane 0)
-    if (tid == 0) {
-        float *d = g.dwhere_r + 4 * (size_t)k;
-        d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
-        // where-sampling backward of row k (gauss_bwd_body with D = 4, loc_mode = 1), four dims by this one thread
+    __syncthreads();
+    AIR_TR(2);
+    if (wid == 0) {
+        float part[8];
 #pragma unroll
-        for (int d_ = 0; d_ < 4; ++d_) {
-            const size_t e = (size_t)k * 4 + d_;
-            const float mu = g.loc[e], s = g.scale[e];
+        for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 4) ? c.scratch[lane * 8 + q] : 0.f;
+        const float tot = wave_reduce8(part);                  // lane 8*d holds the total of dimension d
+        const float accd = __shfl(tot, 8 * (lane & 3), 64);
+        if (lane < 4) {
+            // d where through the read, then the where-sampling backward of row k (gauss_bwd_body with D = 4, loc_mode = 1):
+            // one dimension per lane
+            const int d_ = lane;
+            g.dwhere_r[4 * (size_t)k + d_] = accd;
+            const float mu = s_mu, sc = s_sc;
             const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
-            const float ds = g.dwhere_w[e] + acc[d_];
-            const float dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
-            float dmu = ds + dk * (mu - pm) / (ps * ps);
-            const float dsc = ds * g.eps[e] + dk * (s / (ps * ps) - 1.f / s);
+            const float ds = s_dw + accd;
+            float dmu = ds + s_dk * (mu - pm) / (ps * ps);
+            const float dsc = ds * s_eps + s_dk * (sc / (ps * ps) - 1.f / sc);
             dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
-            const float raw = g.pre[(size_t)k * 8 + 4 + d_] + g.raw_offset;
-            const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);
+            const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
             g.dpre[(size_t)k * 8 + d_] = dmu;
             g.dpre[(size_t)k * 8 + 4 + d_] = dsc * dsp;
         }
     }
+    AIR_TR(3);
+    AIR_TR_FLUSH();
 }
 
 extern "C" int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r,
@@ -959,13 +1282,24 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
     g.vec4 = (((H * W) % 4 == 0) && air_aligned16(img)) ? 1 : 0;
     g.stepx = lin_step(w); g.stepy = lin_step(h);
     const int grid = T * B + air_cdiv(B, 64);
-    if (T <= 8) {
-        { int st_ = st_allow_lds(attend_bwd_kernel<8>, lds); if (st_) return st_; }
-        hipLaunchKernelGGL(attend_bwd_kernel<8>, dim3(grid), dim3(ST_THREADS), lds, air_stream(stream), g);
-    } else {
-        { int st_ = st_allow_lds(attend_bwd_kernel<32>, lds); if (st_) return st_; }
-        hipLaunchKernelGGL(attend_bwd_kernel<32>, dim3(grid), dim3(ST_THREADS), lds, air_stream(stream), g);
-    }
+    const int hw_ = h * w;
+#define AIR_ATTEND_BWD_LAUNCH(MT_, NT_, EX_)                                                                         \
+    do {                                                                                                                \
+        int st_ = st_allow_lds(attend_bwd_kernel<MT_, NT_, EX_>, lds);                                                 \
+        if (st_) return st_;                                                                                            \
+        hipLaunchKernelGGL((attend_bwd_kernel<MT_, NT_, EX_>), dim3(grid), dim3(NT_), lds, air_stream(stream), g);     \
+    } while (0)
+#define AIR_ATTEND_BWD_BY_T(NT_)                                                                                      \
+    do {                                                                                                                \
+        if (T == 3) AIR_ATTEND_BWD_LAUNCH(3, NT_, true);                                                                \
+        else if (T == 5) AIR_ATTEND_BWD_LAUNCH(5, NT_, true);                                                           \
+        else if (T <= 8) AIR_ATTEND_BWD_LAUNCH(8, NT_, false);                                                          \
+        else AIR_ATTEND_BWD_LAUNCH(32, NT_, false);                                                                     \
+    } while (0)
+    // about one glimpse pixel per thread
+    if (hw_ <= 256) AIR_ATTEND_BWD_BY_T(256); else if (hw_ <= 512) AIR_ATTEND_BWD_BY_T(512); else AIR_ATTEND_BWD_BY_T(1024);
+#undef AIR_ATTEND_BWD_BY_T
+#undef AIR_ATTEND_BWD_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

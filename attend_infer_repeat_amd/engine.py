@@ -289,6 +289,10 @@ class AIREngine:
         self.gd = _Mlp(self, "glimpse_decoder", M, A, cfg.glimpse_decoder_hidden, hw)
         self.canvas_steps = b("canvas_steps", (T, B, P)) if self.keep_canvas_steps else None
         self.final_canvas = b("final_canvas", (B, P)); self.rec = b("rec", (B,))
+        # the canvas unroll runs one workgroup per (image, row band) so that a small batch fills the chip; each band leaves
+        # its share of the reconstruction term here and the consumer (NVIL, or a plain sum) adds the shares in band order
+        self.n_bands = int(H.lib().air_canvas_unroll_bands(B, int(cfg.img_size[0])))
+        self.rec_parts = b("rec_parts", (self.n_bands, B))
         self.q_n = b("q_n", (B, T + 1)); self.kl_n = b("kl_n", (B,)); self.logp = b("logp", (B,))
         self.step_w = b("step_w", (T, B))
         # baseline input [obs | what | where | presence | h | c] (modules.py:131-139) is never materialised: the obs columns
@@ -523,14 +527,18 @@ class AIREngine:
                                                  p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
             mlp_fwd_multi(fwd, [(self.gd, self.what, A)])
         decoded = self.gd.out[-1]
-        fwd.append((L.air_canvas_unroll_fwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
-                                              p(self.canvas_steps), p(self.final_canvas), p(self.rec), T, B, Hi, Wi,
-                                              hc, wc, cfg.output_multiplier, cfg.output_std),
-                    "air_canvas_unroll_fwd"))                                               # cell.py:159-165, model.py:319-324
+        NB = self.n_bands
+        fwd.append((L.air_canvas_unroll_fwd_banded, (p(decoded), p(self.where), p(self.presence), p(self.obs),
+                                                     p(self.canvas_steps), p(self.final_canvas), p(self.rec_parts), NB,
+                                                     T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std),
+                    "air_canvas_unroll_fwd_banded"))                                        # cell.py:159-165, model.py:319-324
         # NVIL (model.py:218-259): forward() alone finishes with it so that outputs() is complete; a train step evaluates it
-        # as one extra workgroup of the canvas backward launch instead (independent work, one launch fewer)
-        nvil_args = (p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out), p(self.dlogp), p(self.dbase))
-        fwd_tail = [(L.air_nvil, nvil_args + (B,), "air_nvil")] if cfg.use_reinforce else []
+        # as one extra workgroup of the canvas backward launch instead (independent work, one launch fewer).  Either way it
+        # is the consumer that adds the per-band shares of rec_loss_per_sample (and stores the sum in self.rec).
+        nvil_args = (p(self.rec_parts), NB, p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out),
+                     p(self.dlogp), p(self.dbase))
+        rec_sum = (L.air_sum_leading, (p(self.rec_parts), p(self.rec), NB, ctypes.c_size_t(B)), "air_sum_leading")
+        fwd_tail = [(L.air_nvil_parts, nvil_args + (B,), "air_nvil_parts")] if cfg.use_reinforce else [rec_sum]
 
         # ---- backward of opt_loss = mean(rec) + pw*(mean kl_n + mean sum_t w*(kl_what+kl_where)) + reinforce -------
         pw = 1.0 if cfg.use_prior else 0.0
@@ -540,6 +548,7 @@ class AIREngine:
         if cfg.use_reinforce:
             bwd.append((L.air_canvas_unroll_bwd_nvil, cu_args + nvil_args, "air_canvas_unroll_bwd_nvil"))
         else:
+            bwd.append(rec_sum)          # nobody consumes rec in the step itself; keeps outputs() complete after train_step
             bwd.append((L.air_canvas_unroll_bwd, cu_args, "air_canvas_unroll_bwd"))
         chains = [dict(m=self.gd, x=self.what, ldx=A, g_last=self.gd.g[-1], dx_out=self.d_what)]
         if cfg.use_reinforce:                                                               # model.py:253-259, 362-367

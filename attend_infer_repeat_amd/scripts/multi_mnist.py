@@ -50,6 +50,7 @@ def main(argv=None):
     step_bias, transform_var_bias, output_multiplier, init_explore_eps, l2_weight = .75, .5, .5, 1e-3, 0.
 
     device = torch.device("cuda", 0)
+    torch.manual_seed(args.seed)                                      # parameter initialisation (Sonnet draws at build time)
     logdir = osp.join(args.results_dir, args.run_name)
     os.makedirs(logdir, exist_ok=True)
     tr, va = osp.join(args.data_dir, "mnist_train.pickle"), osp.join(args.data_dir, "mnist_validation.pickle")

@@ -79,10 +79,11 @@ def st_rooflines(eng, reps=200):
                         4 * (HW + hw + 4) * M),
         "st_read_bwd": (lambda: lib.air_st_read_bwd(p(eng.obs), p(eng.where), p(eng.d_glimpse_in), p(eng.dwhere_r), None,
                                                     M, B, Hh, Ww, h, w, sp), 4 * (HW + hw + 4 + 4) * M),
-        "canvas_unroll_fwd": (lambda: lib.air_canvas_unroll_fwd(p(dec), p(eng.where), p(eng.presence), p(eng.obs),
-                                                                 p(eng.canvas_steps), p(eng.final_canvas), p(eng.rec),
-                                                                 T, B, Hh, Ww, h, w, cfg.output_multiplier,
-                                                                 cfg.output_std, sp), 4 * (hw + 2 * HW + 4 + 1) * M),
+        "canvas_unroll_fwd": (lambda: lib.air_canvas_unroll_fwd_banded(p(dec), p(eng.where), p(eng.presence), p(eng.obs),
+                                                                        p(eng.canvas_steps), p(eng.final_canvas),
+                                                                        p(eng.rec_parts), eng.n_bands, T, B, Hh, Ww, h, w,
+                                                                        cfg.output_multiplier, cfg.output_std, sp),
+                              4 * (hw + 2 * HW + 4 + 1) * M),
         "canvas_unroll_bwd": (lambda: lib.air_canvas_unroll_bwd(p(dec), p(eng.where), p(eng.presence), p(eng.obs),
                                                                  p(eng.final_canvas), p(dgl), p(eng.dwhere_w), T, B, Hh,
                                                                  Ww, h, w, cfg.output_multiplier, cfg.output_std,

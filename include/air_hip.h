@@ -82,6 +82,15 @@ int air_st_write_bwd(const float *glimpse, const float *where, const float *pres
 int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence, const float *obs,
                           float *canvas_steps, float *final_canvas, float *rec_per_sample,
                           int T, int B, int H, int W, int h, int w, float mult, float std, void *stream);
+/* The same unroll with each image cut into `n_bands` horizontal row bands, one workgroup per (image, band): a small batch
+ * then fills the chip (64 images x 4 bands = 256 workgroups).  rec_parts[n_bands, B] receives each band's share of the
+ * reconstruction term; consumers add the shares in band order (air_nvil_parts, air_canvas_unroll_bwd_nvil, or
+ * air_sum_leading for the plain sum).  n_bands must be what air_canvas_unroll_bands(B, H) returns (or 1).            */
+int air_canvas_unroll_bands(int B, int H);
+int air_canvas_unroll_fwd_banded(const float *glimpse, const float *where, const float *presence, const float *obs,
+                                 float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
+                                 int T, int B, int H, int W, int h, int w, float mult, float std, void *stream);
+
 /* Backward of mean_b(rec_per_sample) * loss_scale through the fused op: dcanvas is formed on the fly from
  * (final_canvas, obs).  Outputs dglimpse[T,B,h,w], dwhere[T,B,4].                                                  */
 int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
@@ -93,9 +102,8 @@ int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float 
 int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence, const float *obs,
                                const float *final_canvas, float *dglimpse, float *dwhere,
                                int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
-                               const float *imp, const float *baseline, const float *logp, float *nvil_out,
-                               float *dlogp, float *dbaseline, void *stream);
-
+                               const float *imp_parts, int n_parts, float *imp_sum, const float *baseline,
+                               const float *logp, float *nvil_out, float *dlogp, float *dbaseline, void *stream);
 /* ---- dense layers -------------------------------------------------------------------------------------------
  * Replaces the TF MatMul/BiasAdd/Elu nodes under snt.Linear (neural.py:42-60) and snt.LSTM (mnist_model.py:35).   */
 
@@ -277,6 +285,11 @@ int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
  *   dlogp[B] = d reinforce_loss / d logp; dbaseline[B] = d baseline_loss / d baseline.                              */
 int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
              float *dbaseline, int B, void *stream);
+/* air_nvil with the importance weight given as n_parts shares per sample (imp_parts[n_parts, B], added in share order in
+ * fp32); the sum is also written to imp_sum[B] when given (the complete rec_loss_per_sample).                          */
+int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline, const float *logp,
+                   float *out, float *dlogp, float *dbaseline, int B, void *stream);
+
 
 /* Baseline input assembly, modules.py:131-139: out[B, HW + T*A + T*4 + T + S] =
  * [img | what (batch-major) | where | presence | state] from time-major what[T,B,A], where[T,B,4], presence[T,B],
