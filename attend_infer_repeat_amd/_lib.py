@@ -101,6 +101,12 @@ SIGNATURES = {
     "air_tile_rows": (c_int, [P, P, c_int, c_int, P]),
     "air_colsum": (c_int, [P, c_int, P, c_int, c_int, P]),
     "air_sum_leading": (c_int, [P, P, c_int, c_size_t, P]),
+    "air_comm_unique_id": (c_int, [P]),
+    "air_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, P]),
+    "air_comm_destroy": (c_int, [P]),
+    "air_allreduce_sum": (c_int, [P, c_size_t, P, P]),
+    "air_comm_last_error": (ctypes.c_char_p, []),
+    "air_stream_wait_event": (c_int, [P, P]),
     "air_graph_begin_capture": (c_int, [P]),
     "air_graph_end_capture": (c_int, [P, ctypes.POINTER(c_void_p)]),
     "air_graph_launch": (c_int, [P, P]),

@@ -12,7 +12,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libair_hip.so")
-SOURCES = ["st_kernels.hip", "gemm_kernels.hip", "pointwise_kernels.hip", "loss_kernels.hip", "engine_kernels.hip"]
+SOURCES = ["st_kernels.hip", "gemm_kernels.hip", "pointwise_kernels.hip", "loss_kernels.hip", "engine_kernels.hip",
+           "comm_rccl.hip"]
 ARCH = "gfx950"
 
 
@@ -80,7 +81,7 @@ def build(force=False, verbose=False):
                     subprocess.check_call(cmd)
                     objs.append(o)
                 out = os.path.join(tmp, "libair_hip.so")
-                cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+                cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
                 if verbose:
                     print(" ".join(cmd), file=sys.stderr)
                 subprocess.check_call(cmd)

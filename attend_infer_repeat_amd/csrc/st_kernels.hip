@@ -72,6 +72,25 @@ __device__ __forceinline__ void axis_entry(float coord, int extent, int *f_out, 
     *d_out = (fl + 1.0f) - coord;
 }
 
+// one packed axis entry
+__device__ __forceinline__ float2 axis_entry2(float coord, int extent) {
+    int f; float d;
+    axis_entry(coord, extent, &f, &d);
+    return make_float2(__int_as_float(f), d);
+}
+// taps with unconditional (clamped) LDS reads and a select: no divergent branches around the four loads
+__device__ __forceinline__ Taps load_taps_sel(const float *s, int Hs, int Ws, int fy, int fx) {
+    const bool x0 = fx >= 0, x1 = fx + 1 <= Ws - 1, y0 = fy >= 0, y1 = fy + 1 <= Hs - 1;
+    const int cx0 = x0 ? fx : 0, cx1 = x1 ? fx + 1 : Ws - 1, cy0 = y0 ? fy : 0, cy1 = y1 ? fy + 1 : Hs - 1;
+    Taps t;
+    const float a = s[cy0 * Ws + cx0], b = s[cy0 * Ws + cx1], c = s[cy1 * Ws + cx0], d = s[cy1 * Ws + cx1];
+    t.ff = (x0 && y0) ? a : 0.f;
+    t.fc = (x1 && y0) ? b : 0.f;
+    t.cf = (x0 && y1) ? c : 0.f;
+    t.cc = (x1 && y1) ? d : 0.f;
+    return t;
+}
+
 __device__ __forceinline__ void stage_to_lds(float *dst, const float *src, int count, bool vec4) {
     const int nt = blockDim.x;
     if (vec4) {
@@ -153,6 +172,24 @@ __device__ __forceinline__ void lds_barrier() {
 }
 // (three NAMED float4 registers per thread: an indexed register array is demoted to scratch by hipcc here, which
 //  serialises every load behind a scratch store; blockDim.x = 256 covers images up to 768 float4, 1024 up to 3072)
+// Streaming policy of the out-of-cache regime.  tools/kbench/stream_ceiling.cpp on this box (970 MB, "10 KB in, 4.8 KB out
+// per image"): plain loads + stores 5.0 TB/s, non-temporal loads AND stores 5.4-6.0 TB/s, read-only nt 7.0 TB/s; this kernel:
+// 4.4-4.6 TB/s plain -> 5.0-5.6 TB/s non-temporal with a 16 k-workgroup grid.  In cache-resident launches (the train step:
+// the glimpses are consumed by the next GEMM) the default policy is kept.
+template <bool NT>
+__device__ __forceinline__ float4 ld_stream4(const float4 *p) {
+    if (NT) {
+        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+        const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(float *p, float v) {
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT>
 __global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
     const float *__restrict__ img, const float *__restrict__ where, float *__restrict__ out,
     int n, int n_img, int H, int W, int h, int w, double stepx, double stepy) {
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
     int b = blockIdx.x;
     if (b < n_img) {
         const float4 *s4 = reinterpret_cast<const float4 *>(img + (size_t)b * HW);
-        p0 = s4[q0]; p1 = s4[q1]; p2 = s4[q2];
+        p0 = ld_stream4<NT>(s4 + q0); p1 = ld_stream4<NT>(s4 + q1); p2 = ld_stream4<NT>(s4 + q2);
     }
     float4 wnext = (b < n_img) ? where4[b] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = tid; a < w + h; a += nt) {                   // the linspace tables do not depend on the image
@@ -182,7 +219,7 @@ __global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
         const int nb = b + gridDim.x;
         if (nb < n_img) {                                     // next image: in flight during this image's compute
             const float4 *s4 = reinterpret_cast<const float4 *>(img + (size_t)nb * HW);
-            p0 = s4[q0]; p1 = s4[q1]; p2 = s4[q2];
+            p0 = ld_stream4<NT>(s4 + q0); p1 = ld_stream4<NT>(s4 + q1); p2 = ld_stream4<NT>(s4 + q2);
         }
         for (int k = b; k < n; k += n_img) {
             const float4 wk = wnext;
@@ -200,7 +237,7 @@ __global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
                 const int fx = c.fx[j], fy = c.fy[i];
                 float v = 0.f;
                 if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, H, W, fy, fx), c.dx[j], c.dy[i]);
-                o[p] = v;
+                st_stream<NT>(o + p, v);
             }
         }
     }
@@ -299,25 +336,6 @@ __device__ __forceinline__ CarveWr carve_wr(float *smem, int T, int RB, int W, i
 static inline size_t carve_wr_bytes(int T, int RB, int W, int h, int w) {
     return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + 2 * (size_t)T * (W + RB) + ((T + 3) & ~3) + 128);
 }
-// one packed axis entry
-__device__ __forceinline__ float2 axis_entry2(float coord, int extent) {
-    int f; float d;
-    axis_entry(coord, extent, &f, &d);
-    return make_float2(__int_as_float(f), d);
-}
-// taps with unconditional (clamped) LDS reads and a select: no divergent branches around the four loads
-__device__ __forceinline__ Taps load_taps_sel(const float *s, int Hs, int Ws, int fy, int fx) {
-    const bool x0 = fx >= 0, x1 = fx + 1 <= Ws - 1, y0 = fy >= 0, y1 = fy + 1 <= Hs - 1;
-    const int cx0 = x0 ? fx : 0, cx1 = x1 ? fx + 1 : Ws - 1, cy0 = y0 ? fy : 0, cy1 = y1 ? fy + 1 : Hs - 1;
-    Taps t;
-    const float a = s[cy0 * Ws + cx0], b = s[cy0 * Ws + cx1], c = s[cy1 * Ws + cx0], d = s[cy1 * Ws + cx1];
-    t.ff = (x0 && y0) ? a : 0.f;
-    t.fc = (x1 && y0) ? b : 0.f;
-    t.cf = (x0 && y1) ? c : 0.f;
-    t.cc = (x1 && y1) ? d : 0.f;
-    return t;
-}
-
 // One workgroup per (image, row band): band `q` of `NB` covers canvas rows [q*RB, min(H, (q+1)*RB)).  A batch of 64 images in
 // 4 bands fills the 256 CUs (one workgroup per image left three quarters of the chip idle while each busy CU was bound by
 // VALU issue: 2500 pixels x T steps x ~45 instructions on 4 SIMDs).  Every global operand (all T glimpses, the `where` rows,
@@ -731,8 +749,7 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
 // host side
 // ============================================================================================================
 static inline double lin_step(int n) { return n > 1 ? 2.0 / (double)(n - 1) : 0.0; }
-static inline int st_grid(int items) {
-    const int cap = 256 * 8;   // 256 CUs x up to 8 resident 256-thread workgroups; grid-stride beyond that
+static inline int st_grid(int items, int cap = 256 * 8) {   // 256 CUs x up to 8 resident 256-thread workgroups; grid-stride beyond that
     return items < cap ? items : cap;
 }
 static inline int st_check_dims(int n, int H, int W, int h, int w) {
@@ -760,9 +777,17 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
     const int nq = (H * W) / 4;
     if (vec4 && air_aligned16(where) && nq <= 3 * 1024) {
         const int threads = nq <= 3 * 256 ? 256 : 1024;
-        { int st_ = st_allow_lds(st_read_fwd_pipe_kernel, lds); if (st_) return st_; }
-        hipLaunchKernelGGL(st_read_fwd_pipe_kernel, dim3(st_grid(n_img)), dim3(threads), lds, air_stream(stream), img,
-                           where, glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h));
+        // out of cache (more than ~1/4 of the 256 MiB Infinity Cache touched once): streaming loads / stores, many short workgroups
+        const size_t touched = sizeof(float) * ((size_t)n_img * H * W + (size_t)n * h * w);
+        if (touched > ((size_t)64 << 20)) {
+            { int st_ = st_allow_lds(st_read_fwd_pipe_kernel<true>, lds); if (st_) return st_; }
+            hipLaunchKernelGGL(st_read_fwd_pipe_kernel<true>, dim3(st_grid(n_img, 16384)), dim3(threads), lds, air_stream(stream),
+                               img, where, glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h));
+        } else {
+            { int st_ = st_allow_lds(st_read_fwd_pipe_kernel<false>, lds); if (st_) return st_; }
+            hipLaunchKernelGGL(st_read_fwd_pipe_kernel<false>, dim3(st_grid(n_img)), dim3(threads), lds, air_stream(stream),
+                               img, where, glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h));
+        }
         AIR_LAUNCH_CHECK();
         return AIR_OK;
     }

@@ -168,6 +168,9 @@ class AIREngine:
         self.world_size = 1
         self._graph = None
         self._graph_opt = None
+        self._graph_has_opt = True
+        self._side_stream = None
+        self._side_events = None
         self._bufs: Dict[str, torch.Tensor] = {}
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.Stream(device=self.device)
@@ -719,36 +722,82 @@ class AIREngine:
         self.global_step += 1
 
     def _capture_plans(self, plans):
+        """Capture a list of plan entries into one hipGraph.  An entry is either a launch plan (list of (fn, args, name)) or
+        a callable taking the stream pointer (collectives, stream forks / joins)."""
         L = H.lib()
         sp = self._sp()
         _lib.check(L.air_graph_begin_capture(sp), "air_graph_begin_capture")
         try:
             for pl in plans:
-                self._run(pl, sp)
+                if callable(pl):
+                    pl(sp)
+                else:
+                    self._run(pl, sp)
         finally:
             exe = ctypes.c_void_p()
             st = L.air_graph_end_capture(sp, ctypes.byref(exe))
         _lib.check(st, "air_graph_end_capture")
         return exe
 
-    def capture(self, split_optimizer: bool = False, bucketed: bool = False):
-        """Capture noise + forward + backward (+ optimiser) into hipGraphs.
-        split_optimizer: the update is its own graph so a gradient all-reduce can run before it (data parallel).
-        bucketed (implies split_optimizer): the backward is cut at the points where a contiguous slice of the flat
-        gradient buffer becomes final, so each slice can be all-reduced while the rest of the backward still runs."""
+    def _allreduce_call(self, comm, lo, hi):
+        L = H.lib()
+        ptr = ctypes.c_void_p(self.flat_grads.data_ptr() + 4 * lo)
+
+        def call(sp):
+            st = L.air_allreduce_sum(ptr, ctypes.c_size_t(hi - lo), comm, sp)
+            if st != 0:
+                raise _lib.AirHipError("air_allreduce_sum failed: %s" % (L.air_comm_last_error() or b"").decode())
+        return call
+
+    def capture(self, split_optimizer: bool = False, comm=None, overlap: bool = False):
+        """Capture noise + forward + backward (+ gradient all-reduce) + both RMSProp updates into hipGraphs.
+        comm=None, split_optimizer=False : single GPU, ONE graph.
+        comm=<air_comm handle>           : data parallel, still ONE graph -- the RCCL all-reduce of the flat gradient buffer
+                                           is a captured node between the backward and the update (grad_scale = 1/world).
+                                           overlap=True additionally forks a captured side stream at the point of the backward
+                                           where the tail of the buffer (decoder / baseline / what / glimpse-encoder
+                                           gradients, ~half of the bytes) is final and all-reduces that slice there, while the
+                                           main stream finishes the backward and all-reduces the head.
+        split_optimizer=True             : forward+backward and the update as two graphs, so a host-issued collective
+                                           (torch.distributed) can run between them (fallback when RCCL cannot be captured)."""
         self.release_graphs()
         self.stream.synchronize()
-        self._graph_segments = None
-        if bucketed:
-            segs, start = [], 0
-            for i, (end, lo, hi) in enumerate(self._grad_buckets):
-                plans = ([self._plan_fwd_train] if i == 0 else []) + [self._plan_bwd[start:end]]
-                segs.append((self._capture_plans(plans), lo, hi))
-                start = end
-            self._graph_segments = segs
-            self._graph = segs[0][0]
-            self._graph_has_opt = False
-            self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
+        L = H.lib()
+        if comm is not None:
+            opt = self._opt_calls_factory(1.0 / self.world_size)
+            cut = None
+            if overlap and len(self._grad_buckets) >= 2:
+                # the latest cut whose tail holds at most ~60 % of the buffer: [lo, n_total) is final after plan index `end`
+                for end, lo, hi in self._grad_buckets:
+                    if self.n_total - lo <= 0.6 * self.n_total:
+                        cut = (end, lo)
+            if cut is None:
+                plans = [self._plan_fwd_train, self._plan_bwd, self._allreduce_call(comm, 0, self.n_total), opt]
+            else:
+                end, lo = cut
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=self.device)
+                    ev = [ctypes.c_void_p(), ctypes.c_void_p()]
+                    for e in ev:
+                        _lib.check(L.air_event_create(ctypes.byref(e)), "air_event_create")
+                    self._side_events = ev
+                side = ctypes.c_void_p(self._side_stream.cuda_stream)
+                ev_fork, ev_join = self._side_events
+                tail_reduce = self._allreduce_call(comm, lo, self.n_total)
+
+                def fork(sp):
+                    _lib.check(L.air_event_record(ev_fork, sp), "air_event_record")
+                    _lib.check(L.air_stream_wait_event(side, ev_fork), "air_stream_wait_event")
+                    tail_reduce(side)
+                    _lib.check(L.air_event_record(ev_join, side), "air_event_record")
+
+                def join(sp):
+                    _lib.check(L.air_stream_wait_event(sp, ev_join), "air_stream_wait_event")
+
+                plans = [self._plan_fwd_train, self._plan_bwd[:end], fork, self._plan_bwd[end:],
+                         self._allreduce_call(comm, 0, lo), join, opt]
+            self._graph = self._capture_plans(plans)
+            self._graph_has_opt = True
             return
         self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
         self._graph_has_opt = not split_optimizer
@@ -757,35 +806,23 @@ class AIREngine:
 
     def release_graphs(self):
         L = H.lib()
-        segs = getattr(self, "_graph_segments", None) or []
-        for g in [self._graph_opt] + ([x[0] for x in segs] if segs else [self._graph]):
+        for g in (self._graph_opt, self._graph):
             if g is not None:
                 L.air_graph_destroy(g)
         self._graph = self._graph_opt = None
-        self._graph_segments = None
+
+    def stream_context(self):
+        """torch stream context of the engine's stream (collectives issued through torch.distributed run inside it)."""
+        return torch.cuda.stream(self.stream)
 
     def train_step(self, obs=None, allreduce=None):
         """One full update: fresh noise, forward, backward, (all-reduce), centred RMSProp x2.
-        `allreduce(flat_grads)`: optional callable run on the engine stream between backward and the update."""
+        `allreduce(flat_grads)`: optional callable run on the engine stream between backward and the update (used when the
+        collective is NOT part of the captured graph)."""
         if obs is not None:
             self.set_obs(obs)
         sp = self._sp()
-        if getattr(self, "_graph_segments", None):
-            # bucketed data parallel: segment i produces the final gradients of slice i; its all-reduce is issued at once
-            # (asynchronously, on the communicator's stream) and overlaps the remaining backward segments
-            pending = []
-            for exe, lo, hi in self._graph_segments:
-                _lib.check(H.lib().air_graph_launch(exe, sp), "air_graph_launch")
-                if allreduce is not None:
-                    with torch.cuda.stream(self.stream):
-                        w = allreduce(self.flat_grads[lo:hi])
-                    if w is not None:
-                        pending.append(w)
-            with torch.cuda.stream(self.stream):
-                for w in pending:
-                    w.wait()                      # stream-level wait: the update graph is ordered after every bucket
-            _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
-        elif self._graph is not None:
+        if self._graph is not None:
             _lib.check(H.lib().air_graph_launch(self._graph, sp), "air_graph_launch")
             if not self._graph_has_opt:
                 if allreduce is not None:

@@ -369,6 +369,20 @@ int air_colsum(const float *x, int ld, float *out, int M, int N, void *stream); 
 int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream);
 
 /* ---- hipGraph capture + timing helpers (plumbing for bench / the fused train step) --------------------------*/
+/* ---- data parallel: RCCL all-reduce of the flat gradient bucket, capturable into the step's hipGraph ----------------
+ * The reference is single-process; SURVEY 8(e) shards the batch over one process per GPU with ONE all-reduce
+ * (sum) of the flat fp32 gradient buffer per step.  RCCL is bound at run time (dlopen of the instance already in the
+ * process).  air_comm_unique_id: 128 opaque bytes created on rank 0, handed to every rank's air_comm_init (a collective
+ * call; the thread's current device is the rank's GPU).  air_allreduce_sum: in place on `stream`, no allocation / host
+ * sync, legal inside a capture.  air_stream_wait_event = hipStreamWaitEvent (fork / join of a side stream in a capture).
+ * Failures return AIR_E_UNSUPPORTED; air_comm_last_error() has the RCCL message.                                      */
+int air_comm_unique_id(void *id_out_128_bytes);
+int air_comm_init(void **comm_out, int world_size, int rank, const void *id_128_bytes);
+int air_comm_destroy(void *comm);
+int air_allreduce_sum(float *buf, size_t n, void *comm, void *stream);
+const char *air_comm_last_error(void);
+int air_stream_wait_event(void *stream, void *event);
+
 int air_graph_begin_capture(void *stream);
 int air_graph_end_capture(void *stream, void **graph_exec_out);
 int air_graph_launch(void *graph_exec, void *stream);

@@ -66,6 +66,69 @@ def test_two_rank_gradient_allreduce(tmp_path):
     assert torch.isfinite(mean).all() and mean.abs().max() > 0
 
 
+class _StandInEngine(object):
+    """What DataParallelEngine needs from an engine, on CPU tensors: a flat parameter / gradient buffer, capture() and
+    train_step(obs, allreduce).  The "gradient" of step s on rank r is a known vector, so the update every replica must end
+    up with is known in closed form."""
+
+    def __init__(self, n, rank):
+        self.device = torch.device("cpu")
+        self.world_size = 1
+        self.flat_params = torch.full((n,), float(rank + 1))          # deliberately different before the broadcast
+        self.flat_grads = torch.zeros(n)
+        self.rank, self.step, self.captured, self.reduced = rank, 0, [], []
+
+    def capture(self, **kw):
+        self.captured.append(kw)
+
+    def synchronize(self):
+        pass
+
+    def train_step(self, obs=None, allreduce=None):
+        self.flat_grads.copy_(torch.arange(self.flat_grads.numel(), dtype=torch.float32) * (self.rank + 1) + self.step)
+        if allreduce is not None:
+            self.reduced.append(self.flat_grads.numel())
+            allreduce(self.flat_grads)
+        self.flat_params.sub_(0.1 * self.flat_grads / self.world_size)  # grad_scale = 1/world, like air_step_epilogue
+        self.step += 1
+
+
+def _dp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from attend_infer_repeat_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    eng = _StandInEngine(7, rank)
+    dp = D.DataParallelEngine(eng)
+    start = eng.flat_params.clone()
+    for _ in range(3):
+        dp.train_step()
+    torch.save(dict(start=start, params=eng.flat_params, captured=eng.captured, reduced=eng.reduced,
+                    collective=dp.collective, world=eng.world_size), os.path.join(out_dir, f"dp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_engine_control_flow_two_ranks(tmp_path):
+    """DataParallelEngine itself over gloo, world 2: parameters are broadcast from rank 0, the engine is told the world size
+    (-> grad_scale), a CPU engine gets the two-graph protocol (capture(split_optimizer=True)) with exactly ONE all-reduce of
+    the whole flat bucket per step, and both replicas apply the mean gradient."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"dp{r}.pt")) for r in range(world)]
+    for r in res:
+        assert r["collective"] == "torch-split" and r["world"] == 2
+        assert r["captured"] == [dict(split_optimizer=True)]
+        assert r["reduced"] == [7, 7, 7]
+        assert torch.equal(r["start"], torch.full((7,), 1.0))           # rank 0's parameters everywhere
+    expect = torch.full((7,), 1.0)
+    for s in range(3):
+        g = sum(torch.arange(7, dtype=torch.float32) * (rk + 1) + s for rk in range(world))
+        expect = expect - 0.1 * g / world
+    assert torch.allclose(res[0]["params"], expect, rtol=1e-6) and torch.equal(res[0]["params"], res[1]["params"])
+
+
 def test_shard_and_seed_helpers():
     from attend_infer_repeat_amd import distributed as D
     assert [D.shard_batch(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]

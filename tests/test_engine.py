@@ -369,53 +369,71 @@ def test_loss_decreases_on_fixed_batch(gpu_device):
 
 
 def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
-    """The multi-GPU step structure (graph A: fwd+bwd -> RCCL all-reduce of the flat bucket -> graph B: RMSProp) run
-    with a 1-rank nccl (RCCL) group: must equal the single-graph step bit for bit."""
+    """The multi-GPU step structures run with a 1-rank RCCL group; each must equal the single-GPU graph bit for bit:
+      * the collective CAPTURED in the step's graph (air_allreduce_sum on the engine stream: still one graph replay per step),
+        plain and with the tail slice all-reduced on a forked captured stream;
+      * the fallback: graph A (fwd+bwd) -> torch.distributed all-reduce -> graph B (RMSProp)."""
+    import ctypes
     import os
     import socket
     import torch.distributed as dist
     from attend_infer_repeat_amd import distributed as D
+    from attend_infer_repeat_amd import hip as H
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         ocfg, B = CONFIGS["mnist_b8"]
         eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
-        eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
         eng_a.capture()
+        for _ in range(3):
+            eng_a.train_step()
+        eng_a.synchronize()
+        # --- captured RCCL collective (the default of DataParallelEngine for world > 1) ---------------------------------
+        comm = D.create_rccl_comm(torch.device("cuda", 0))
+        for overlap in (False, True):
+            eng_c, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+            eng_c.world_size = 1
+            eng_c.capture(comm=comm, overlap=overlap)
+            assert eng_c._graph is not None and eng_c._graph_opt is None and eng_c._graph_has_opt      # ONE graph
+            for _ in range(3):
+                eng_c.train_step()
+            eng_c.synchronize()
+            assert torch.equal(eng_a.flat_params, eng_c.flat_params), overlap
+            assert torch.equal(eng_a.flat_mom, eng_c.flat_mom), overlap
+            eng_c.release_graphs()
+        # the stand-alone entry really sums: with one rank it must leave the buffer untouched
+        g = torch.arange(1000, dtype=torch.float32, device="cuda")
+        st = H.lib().air_allreduce_sum(H._p(g), ctypes.c_size_t(g.numel()), comm, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert st == 0 and torch.equal(g, torch.arange(1000, dtype=torch.float32, device="cuda"))
+        assert H.lib().air_comm_destroy(comm) == 0
+        # --- the wrapper: world 1 -> plain single graph, collective "none" ---------------------------------------------
+        eng_d, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+        dp = D.DataParallelEngine(eng_d)
+        assert dp.collective == "none" and dp.world == 1
+        for _ in range(3):
+            dp.train_step()
+        eng_d.synchronize()
+        assert torch.equal(eng_a.flat_params, eng_d.flat_params)
+        # --- fallback: two graphs with a host-issued collective in between ------------------------------------------------
+        eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
         eng_b.world_size = 1
         eng_b.capture(split_optimizer=True)
         calls = []
 
-        def allreduce(g):
-            calls.append(g.numel())
-            D.allreduce_gradients(g)                  # world 1 -> returns immediately
-            dist.all_reduce(g)                        # force the real RCCL call on the engine stream
+        def allreduce(gr):
+            calls.append(gr.numel())
+            dist.all_reduce(gr)                        # the real RCCL call on the engine stream
 
         for _ in range(3):
-            eng_a.train_step()
             eng_b.train_step(allreduce=allreduce)
-        eng_a.synchronize(); eng_b.synchronize()
+        eng_b.synchronize()
         assert calls == [eng_b.n_total] * 3           # exactly one collective per step over the whole flat bucket
         assert torch.equal(eng_a.flat_params, eng_b.flat_params)
-        # bucketed variant: backward cut into segments, one asynchronous all-reduce per contiguous gradient slice
-        eng_c, *_ = make_pair(ocfg, B, seed=3, gstep=0)
-        eng_c.world_size = 1
-        eng_c.capture(split_optimizer=True, bucketed=True)
-        slices = []
-
-        def allreduce_async(g):
-            slices.append((g.data_ptr() - eng_c.flat_grads.data_ptr()) // 4)
-            return dist.all_reduce(g, async_op=True)
-
-        for _ in range(3):
-            eng_c.train_step(allreduce=allreduce_async)
-        eng_c.synchronize()
-        buckets = eng_c._grad_buckets
-        assert len(buckets) == 4 and buckets[-1][1] == 0 and buckets[0][2] == eng_c.n_total
-        assert all(buckets[i][1] == buckets[i + 1][2] for i in range(3))          # contiguous cover of the flat buffer
-        assert slices[:4] == [b[1] for b in buckets]
-        assert torch.equal(eng_a.flat_params, eng_c.flat_params)
+        buckets = eng_b._grad_buckets                  # cut points for the overlapped variant: contiguous cover, tail first
+        assert buckets[-1][1] == 0 and buckets[0][2] == eng_b.n_total
+        assert all(buckets[i][1] == buckets[i + 1][2] for i in range(len(buckets) - 1))
     finally:
         dist.destroy_process_group()
 
