@@ -836,8 +836,8 @@ static int launch_write_fwd(const float *glimpse, const float *where, const floa
     { int st_ = st_allow_lds(st_write_fwd_kernel, lds); if (st_) return st_; }
     // one pixel per thread while the launch is far from filling the chip (latency regime), 256-thread workgroups beyond
     const long units = (long)B * NB;
-    int wr_threads = ST_THREADS;
-    if (units * T <= 4096) {
+    int wr_threads = units <= 512 ? 512 : ST_THREADS;          // (measured at 50x50: 512 units 14 us with 512 threads, 16 / 17.5 with 1024 / 256)
+    if (units <= 256) {
         const int px = RB * W;
         wr_threads = px >= 1024 ? 1024 : ((px + 63) / 64) * 64;
         if (wr_threads < 64) wr_threads = 64;
@@ -909,7 +909,9 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     const int vec4c = ((H * W) % 4 == 0) && (dcanvas ? air_aligned16(dcanvas) : (air_aligned16(final_canvas) && air_aligned16(obs)));
     { int st_ = st_allow_lds(st_write_bwd_kernel, lds); if (st_) return st_; }
-    const int wr_threads = (long)B * T <= 4096 ? 1024 : ST_THREADS;
+    // 512 threads (about one per footprint pixel) while the launch does not fill the chip: 7.5 us at 192 units against 8.2 with
+    // 1024; beyond that 256-thread workgroups, 8 per CU, hide each other's barriers (29 vs 74 us at 3072 units, 11 vs 21 at 768)
+    const int wr_threads = (long)B * T <= 512 ? 512 : ST_THREADS;
     hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
                        air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
                        dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
