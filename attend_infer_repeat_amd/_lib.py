@@ -57,6 +57,10 @@ SIGNATURES = {
     "air_attend_bwd": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, P, c_float, P,
                                P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
                                c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "air_attend_bwd_dx": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, P, c_float, P,
+                                  P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, c_int, c_int,
+                                  c_int, P]),
     "air_lstm_step_fwd": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int, P]),
     "air_lstm_step_fwd_prologue": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int,
                                            P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,

@@ -200,61 +200,73 @@ __device__ __forceinline__ void presence_numsteps_fwd_body(int vblock, int vgrid
 // per-row KL buffers (dstep_w[t,b] = w_scale * (kl_a[t,b] + kl_b[t,b])), then d/dq -> d/du -> d/dp (products only, no
 // divisions: safe at p = 0 like the reference's scan-based cumprod), then sigmoid'.
 template <int MT>
+__device__ __forceinline__ void numsteps_presence_bwd_col(int b,
+    const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
+    float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
+    const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
+    float (&dl)[MT], int T, int B) {
+    NumStepsR<MT> s;
+    posterior_r<MT>(prob, T, B, b, s);
+    int nstar = -1;
+    if (dlogp) {
+        float ns = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) if (t < T) ns += presence[(size_t)t * B + b];
+        nstar = (int)ns;
+    }
+    double gq[MT + 1], wsum = 0.0, dot = 0.0;
+#pragma unroll
+    for (int n = 0; n <= MT; ++n) {
+        double g = 0.0;
+        if (n <= T) {
+            const double pn = (double)s.q32[n];
+            g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
+            if (n >= 1) {
+                const size_t k = (size_t)(n - 1) * B + b;
+                wsum += (double)(w_scale * ((kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f)));
+            }
+            g += wsum;
+            if (n == nstar) g += (double)dlogp[b] / (double)fmaxf(s.q32[n], 1e-32f);
+            dot += g * s.q[n];
+        }
+        gq[n] = g;
+    }
+    double gu[MT + 1];
+#pragma unroll
+    for (int n = 0; n <= MT; ++n) gu[n] = n <= T ? (gq[n] - dot) / s.S : 0.0;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        dl[k] = 0.f;
+        if (k < T) {
+            // u_k = (1-p_k) P[k];  u_n (n>k, n<T) = (1-p_n) P[k] p_k R_n with R_n = prod_{k<j<n} p_j;  u_T = P[k] p_k R_T
+            double g = -gu[k] * s.P[k];
+            double R = 1.0;
+#pragma unroll
+            for (int n = k + 1; n <= MT; ++n) {
+                if (n < T) g += gu[n] * (1.0 - s.p[n < MT ? n : 0]) * s.P[k] * R;
+                else if (n == T) g += gu[n] * s.P[k] * R;
+                if (n < MT) R *= s.p[n];
+            }
+            const size_t idx = (size_t)k * B + b;
+            const float sg = 1.0f / (1.0f + expf(-(logit[idx] + step_bias)));
+            float gg = (float)g;
+            if (eps >= 0.f) gg *= (1 - eps);
+            dl[k] = gg * sg * (1.f - sg);
+        }
+    }
+}
+template <int MT>
 __device__ __forceinline__ void numsteps_presence_bwd_body(int vblock, int vgrid,
-    
     const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
     float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
     const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
     float *__restrict__ dlogit, int T, int B) {
     for (int b = vblock * 64 + (int)threadIdx.x; b < B; b += vgrid * 64) {
         if (threadIdx.x >= 64) break;
-        NumStepsR<MT> s;
-        posterior_r<MT>(prob, T, B, b, s);
-        int nstar = -1;
-        if (dlogp) {
-            float ns = 0.f;
+        float dl[MT];
+        numsteps_presence_bwd_col<MT>(b, prob, presence, prior, kl_scale, kl_a, kl_b, w_scale, dlogp, logit, step_bias, eps, dl,
+                                      T, B);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) if (t < T) ns += presence[(size_t)t * B + b];
-            nstar = (int)ns;
-        }
-        double gq[MT + 1], wsum = 0.0, dot = 0.0;
-#pragma unroll
-        for (int n = 0; n <= MT; ++n) {
-            double g = 0.0;
-            if (n <= T) {
-                const double pn = (double)s.q32[n];
-                g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
-                if (n >= 1) {
-                    const size_t k = (size_t)(n - 1) * B + b;
-                    wsum += (double)(w_scale * ((kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f)));
-                }
-                g += wsum;
-                if (n == nstar) g += (double)dlogp[b] / (double)fmaxf(s.q32[n], 1e-32f);
-                dot += g * s.q[n];
-            }
-            gq[n] = g;
-        }
-        double gu[MT + 1];
-#pragma unroll
-        for (int n = 0; n <= MT; ++n) gu[n] = n <= T ? (gq[n] - dot) / s.S : 0.0;
-#pragma unroll
-        for (int k = 0; k < MT; ++k) {
-            if (k < T) {
-                // u_k = (1-p_k) P[k];  u_n (n>k, n<T) = (1-p_n) P[k] p_k R_n with R_n = prod_{k<j<n} p_j;  u_T = P[k] p_k R_T
-                double g = -gu[k] * s.P[k];
-                double R = 1.0;
-#pragma unroll
-                for (int n = k + 1; n <= MT; ++n) {
-                    if (n < T) g += gu[n] * (1.0 - s.p[n < MT ? n : 0]) * s.P[k] * R;
-                    else if (n == T) g += gu[n] * s.P[k] * R;
-                    if (n < MT) R *= s.p[n];
-                }
-                const size_t idx = (size_t)k * B + b;
-                const float sg = 1.0f / (1.0f + expf(-(logit[idx] + step_bias)));
-                float gg = (float)g;
-                if (eps >= 0.f) gg *= (1 - eps);
-                dlogit[idx] = gg * sg * (1.f - sg);
-            }
-        }
+        for (int k = 0; k < MT; ++k) if (k < T) dlogit[(size_t)k * B + b] = dl[k];
     }
 }

@@ -122,7 +122,7 @@ __device__ __forceinline__ Carve carve_lds(float *smem, int cnt_src, int cnt_aux
     return c;
 }
 static inline size_t carve_bytes(int cnt_src, int cnt_aux, int nx, int ny) {
-    return sizeof(float) * (size_t)(((cnt_src + 3) & ~3) + ((cnt_aux + 3) & ~3) + 3 * nx + 3 * ny + 128);
+    return sizeof(float) * (size_t)(((cnt_src + 3) & ~3) + ((cnt_aux + 3) & ~3) + 3 * nx + 3 * ny + 160);
 }
 
 // ============================================================================================================
@@ -1189,6 +1189,13 @@ struct AttendBwdArgs {
     const float *dlogp, *logit; float step_bias, explore_eps; float *dlogit;
     int T, B, H, W, h, w, vec4;
     double stepx, stepy;
+    // optional: dX of the output layers of the transform / steps MLPs in the same launch (the two 8- and 1-deep products that
+    // otherwise need a launch of their own on the backward chain):
+    //   tr_dx[k, n] = (sum_o dpre[k, o] * tr_w[n, o]) * elu'(tr_y[k, n]),  n < tr_k   (tr_y = that layer's input activation;
+    //   st_dx[k, n] = dlogit[k] * st_w[n]              * elu'(st_y[k, n]),  n < st_k    NULL: the input is not an ELU output)
+    const float *tr_w, *tr_y; float *tr_dx; int tr_k, tr_ld;
+    const float *st_w, *st_y; float *st_dx; int st_k, st_ld;
+    int bf16;
 };
 
 template <int MT, int NT, bool EXACT>
@@ -1199,9 +1206,52 @@ __global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
     AIR_TR_INIT();
     if ((int)blockIdx.x >= n) {
         AIR_TR(4);
-        numsteps_presence_bwd_body<MT>((int)blockIdx.x - n, (int)gridDim.x - n, g.prob, g.presence, g.prior, g.kl_scale,
-                                       g.kl_a, g.kl_b, g.w_scale, g.dlogp, g.logit, g.step_bias, g.explore_eps, g.dlogit,
-                                       T, B);
+        if (g.st_dx == nullptr) {
+            numsteps_presence_bwd_body<MT>((int)blockIdx.x - n, (int)gridDim.x - n, g.prob, g.presence, g.prior, g.kl_scale,
+                                           g.kl_a, g.kl_b, g.w_scale, g.dlogp, g.logit, g.step_bias, g.explore_eps, g.dlogit,
+                                           T, B);
+        } else {
+            // 16 batch columns per workgroup: threads 0..15 run the float64 chain of their column, then all threads form
+            // st_dx for the 16 x T rows (their input activations were requested before the chain started)
+            __shared__ float s_dl[MT][16];
+            const int vb = (int)blockIdx.x - n, vgrid = (int)gridDim.x - n;
+            for (int base = vb * 16; base < B; base += vgrid * 16) {
+                const int nout = 16 * T * g.st_k;
+                float yv[4], wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                  // output e = (c, t, nn): column c, step t, unit nn
+                    const int e = tid + u * nt, ec = e < nout ? e : 0;
+                    const int nn = ec % g.st_k, ct = ec / g.st_k, t = ct % T, c = ct / T;
+                    const int b = base + c < B ? base + c : B - 1;
+                    yv[u] = g.st_y ? g.st_y[((size_t)t * B + b) * g.st_ld + nn] : 1.f;
+                    wv[u] = g.st_w[nn];
+                }
+                if (tid < 16 && base + tid < B) {
+                    float dl[MT];
+                    numsteps_presence_bwd_col<MT>(base + tid, g.prob, g.presence, g.prior, g.kl_scale, g.kl_a, g.kl_b, g.w_scale,
+                                                  g.dlogp, g.logit, g.step_bias, g.explore_eps, dl, T, B);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) if (t < T) { g.dlogit[(size_t)t * B + base + tid] = dl[t]; s_dl[t][tid] = dl[t]; }
+                }
+                __syncthreads();
+                for (int e0 = tid; e0 < nout; e0 += 4 * nt) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * nt;
+                        if (e >= nout) break;
+                        const int nn = e % g.st_k, ct = e / g.st_k, t = ct % T, c = ct / T;
+                        if (base + c >= B) continue;
+                        const size_t row = (size_t)t * B + base + c;
+                        const float y = e0 == tid ? yv[u] : (g.st_y ? g.st_y[row * g.st_ld + nn] : 1.f);
+                        const float w_ = e0 == tid ? wv[u] : g.st_w[nn];
+                        float v = opnd(s_dl[t][c], g.bf16) * opnd(w_, g.bf16);
+                        if (g.st_y) v *= (y > 0.f ? 1.f : y + 1.f);
+                        g.st_dx[row * g.st_ld + nn] = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
         AIR_TR(6);
         AIR_TR_FLUSH();
         return;
@@ -1220,6 +1270,18 @@ __global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
     float gov[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int p = tid + u * nt; gov[u] = go_p[p < hw ? p : hw - 1]; }     // clamped, branch-free
+    // fused transform-layer dX: this thread's weight row(s) and input activation(s), requested now
+    float4 twa[2], twb[2]; float tyv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        twa[u] = make_float4(0.f, 0.f, 0.f, 0.f); twb[u] = twa[u]; tyv[u] = 1.f;
+        if (g.tr_dx) {
+            const int nn = tid + u * nt, nc = nn < g.tr_k ? nn : g.tr_k - 1;
+            twa[u] = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)nc * 8);
+            twb[u] = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)nc * 8 + 4);
+            if (g.tr_y) tyv[u] = g.tr_y[(size_t)k * g.tr_ld + nc];
+        }
+    }
     float s_mu = 0.f, s_sc = 1.f, s_dw = 0.f, s_eps = 0.f, s_raw = 0.f, s_dk = 0.f;
     if (tid < 4) {
         const size_t e = (size_t)k * 4 + tid;
@@ -1277,10 +1339,61 @@ __global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
             const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
             g.dpre[(size_t)k * 8 + d_] = dmu;
             g.dpre[(size_t)k * 8 + 4 + d_] = dsc * dsp;
+            if (g.tr_dx) { c.scratch[128 + d_] = dmu; c.scratch[128 + 4 + d_] = dsc * dsp; }     // (scratch[0:128] holds the partial sums)
+        }
+    }
+    if (g.tr_dx) {
+        __syncthreads();
+        float dp[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) dp[o] = opnd(c.scratch[128 + o], g.bf16);
+        for (int n0 = tid; n0 < g.tr_k; n0 += 2 * nt) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int nn = n0 + u * nt;
+                if (nn >= g.tr_k) break;
+                float4 wa = twa[u], wb = twb[u]; float y = tyv[u];
+                if (n0 != tid) {
+                    wa = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)nn * 8);
+                    wb = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)nn * 8 + 4);
+                    if (g.tr_y) y = g.tr_y[(size_t)k * g.tr_ld + nn];
+                }
+                float v = dp[0] * opnd(wa.x, g.bf16);
+                v += dp[1] * opnd(wa.y, g.bf16); v += dp[2] * opnd(wa.z, g.bf16); v += dp[3] * opnd(wa.w, g.bf16);
+                v += dp[4] * opnd(wb.x, g.bf16); v += dp[5] * opnd(wb.y, g.bf16); v += dp[6] * opnd(wb.z, g.bf16);
+                v += dp[7] * opnd(wb.w, g.bf16);
+                if (g.tr_y) v *= (y > 0.f ? 1.f : y + 1.f);
+                g.tr_dx[(size_t)k * g.tr_ld + nn] = v;
+            }
         }
     }
     AIR_TR(3);
     AIR_TR_FLUSH();
+}
+
+static int attend_bwd_launch(AttendBwdArgs &g, int T, int B, int H, int W, int h, int w, size_t lds, void *stream) {
+    const int role_b = g.st_dx ? air_cdiv(B, 16) : air_cdiv(B, 64);
+    const int grid = T * B + role_b;
+    const int hw_ = h * w;
+#define AIR_ATTEND_BWD_LAUNCH(MT_, NT_, EX_)                                                                         \
+    do {                                                                                                                \
+        int st_ = st_allow_lds(attend_bwd_kernel<MT_, NT_, EX_>, lds);                                                 \
+        if (st_) return st_;                                                                                            \
+        hipLaunchKernelGGL((attend_bwd_kernel<MT_, NT_, EX_>), dim3(grid), dim3(NT_), lds, air_stream(stream), g);     \
+    } while (0)
+#define AIR_ATTEND_BWD_BY_T(NT_)                                                                                      \
+    do {                                                                                                                \
+        if (T == 3) AIR_ATTEND_BWD_LAUNCH(3, NT_, true);                                                                \
+        else if (T == 5) AIR_ATTEND_BWD_LAUNCH(5, NT_, true);                                                           \
+        else if (T <= 8) AIR_ATTEND_BWD_LAUNCH(8, NT_, false);                                                          \
+        else AIR_ATTEND_BWD_LAUNCH(32, NT_, false);                                                                     \
+    } while (0)
+    // about one glimpse pixel per thread
+    if (hw_ <= 256) AIR_ATTEND_BWD_BY_T(256); else if (hw_ <= 512) AIR_ATTEND_BWD_BY_T(512); else AIR_ATTEND_BWD_BY_T(1024);
+#undef AIR_ATTEND_BWD_BY_T
+#undef AIR_ATTEND_BWD_LAUNCH
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 extern "C" int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r,
@@ -1308,25 +1421,43 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
     g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;
     g.vec4 = (((H * W) % 4 == 0) && air_aligned16(img)) ? 1 : 0;
     g.stepx = lin_step(w); g.stepy = lin_step(h);
-    const int grid = T * B + air_cdiv(B, 64);
-    const int hw_ = h * w;
-#define AIR_ATTEND_BWD_LAUNCH(MT_, NT_, EX_)                                                                         \
-    do {                                                                                                                \
-        int st_ = st_allow_lds(attend_bwd_kernel<MT_, NT_, EX_>, lds);                                                 \
-        if (st_) return st_;                                                                                            \
-        hipLaunchKernelGGL((attend_bwd_kernel<MT_, NT_, EX_>), dim3(grid), dim3(NT_), lds, air_stream(stream), g);     \
-    } while (0)
-#define AIR_ATTEND_BWD_BY_T(NT_)                                                                                      \
-    do {                                                                                                                \
-        if (T == 3) AIR_ATTEND_BWD_LAUNCH(3, NT_, true);                                                                \
-        else if (T == 5) AIR_ATTEND_BWD_LAUNCH(5, NT_, true);                                                           \
-        else if (T <= 8) AIR_ATTEND_BWD_LAUNCH(8, NT_, false);                                                          \
-        else AIR_ATTEND_BWD_LAUNCH(32, NT_, false);                                                                     \
-    } while (0)
-    // about one glimpse pixel per thread
-    if (hw_ <= 256) AIR_ATTEND_BWD_BY_T(256); else if (hw_ <= 512) AIR_ATTEND_BWD_BY_T(512); else AIR_ATTEND_BWD_BY_T(1024);
-#undef AIR_ATTEND_BWD_BY_T
-#undef AIR_ATTEND_BWD_LAUNCH
-    AIR_LAUNCH_CHECK();
-    return AIR_OK;
+    g.tr_w = nullptr; g.tr_y = nullptr; g.tr_dx = nullptr; g.tr_k = 0; g.tr_ld = 0;
+    g.st_w = nullptr; g.st_y = nullptr; g.st_dx = nullptr; g.st_k = 0; g.st_ld = 0; g.bf16 = 0;
+    return attend_bwd_launch(g, T, B, H, W, h, w, lds, stream);
+}
+
+// air_attend_bwd + the dX of the two MLP output layers (see AttendBwdArgs): tr_dx[T*B, tr_k], st_dx[T*B, st_k]
+extern "C" int air_attend_bwd_dx(const float *img, const float *where, const float *dglimpse, float *dwhere_r,
+                              const float *pre, const float *eps, float raw_offset, float p_loc_even, float p_scale_even,
+                              float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
+                              const float *dwhere_w, const float *dkl_row, float dkl_scale, float *dpre,
+                              const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
+                              const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
+                              const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
+                              int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
+                                 const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision,
+                                 void *stream) {
+    AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
+                    prior_f64 && logit && dlogit, AIR_E_NULL);
+    AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && T <= 32, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    const size_t lds = carve_bytes(H * W, 0, w, h);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    AttendBwdArgs g;
+    g.img = img; g.where = where; g.dglimpse = dglimpse; g.dwhere_r = dwhere_r; g.pre = pre; g.eps = eps;
+    g.raw_offset = raw_offset; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
+    g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
+    g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
+    g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
+    g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;
+    g.vec4 = (((H * W) % 4 == 0) && air_aligned16(img)) ? 1 : 0;
+    g.stepx = lin_step(w); g.stepy = lin_step(h);
+    AIR_REQUIRE(tr_w && tr_dx && st_w && st_dx && tr_k > 0 && st_k > 0 && tr_ld >= tr_k && st_ld >= st_k, AIR_E_NULL);
+    AIR_REQUIRE(air_aligned16(tr_w), AIR_E_ALIGN);
+    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+    g.tr_w = tr_w; g.tr_y = tr_y; g.tr_dx = tr_dx; g.tr_k = tr_k; g.tr_ld = tr_ld;
+    g.st_w = st_w; g.st_y = st_y; g.st_dx = st_dx; g.st_k = st_k; g.st_ld = st_ld; g.bf16 = precision == AIR_PREC_BF16 ? 1 : 0;
+    return attend_bwd_launch(g, T, B, H, W, h, w, lds, stream);
 }

@@ -383,13 +383,17 @@ class AIREngine:
                 else:
                     launch(plan, descs)
 
-        def mlp_bwd_multi(plan, chains, extra_first=(), extra_last=()):
+        def mlp_bwd_multi(plan, chains, extra_first=(), extra_last=(), first_dx_done=False):
             """chains: dicts(m, x, ldx, g_last, dx_out=None, dx_aux=None).  g_last = gradient wrt the last layer's
-            pre-activation.  Per level one dispatch holding every chain's dW (+db) and dX."""
+            pre-activation.  Per level one dispatch holding every chain's dW (+db) and dX.
+            first_dx_done: the dX of every chain's LAST layer already exists (air_attend_bwd_dx); that level then only has
+            weight gradients, which ride in the next level's dispatch."""
             depth = max(c["m"].n for c in chains)
             gcur = {id(c["m"]): c["g_last"] for c in chains}
+            carry = []
             for s_ in range(depth):
-                descs = []
+                descs = carry
+                carry = []
                 for c in chains:
                     m = c["m"]
                     i = m.n - 1 - s_
@@ -404,11 +408,13 @@ class AIREngine:
                         continue
                     xin, ld_in = (m.out[i - 1], m.shapes[i - 1][1]) if i > 0 else (c["x"], c["ldx"])
                     descs.append(desc(1, 0, k, n, m.rows, xin, ld_in, g, n, m.dw[i], n, colsum=m.db[i]))
+                    skip_dx = first_dx_done and i == m.n - 1
                     if i > 0:
-                        descs.append(desc(0, 1, m.rows, k, n, g, n, m.w[i], n, m.g[i - 1], k, epi=MDELU,
-                                          aux=m.out[i - 1], ldaux=k))
+                        if not skip_dx:
+                            descs.append(desc(0, 1, m.rows, k, n, g, n, m.w[i], n, m.g[i - 1], k, epi=MDELU,
+                                              aux=m.out[i - 1], ldaux=k))
                         gcur[id(m)] = m.g[i - 1]
-                    elif c.get("dx_out") is not None:
+                    elif c.get("dx_out") is not None and not skip_dx:
                         aux = c.get("dx_aux")
                         descs.append(desc(0, 1, m.rows, k, n, g, n, m.w[0], n, c["dx_out"], k,
                                           epi=MDELU if aux is not None else NONE, aux=aux, ldaux=k if aux is not None else 0))
@@ -416,6 +422,9 @@ class AIREngine:
                     descs = list(extra_first) + descs
                 if s_ == depth - 1:
                     descs = descs + list(extra_last)
+                if first_dx_done and s_ == 0 and depth > 1 and not extra_first:
+                    carry = descs                  # only weight gradients at this level: dispatch them with the next one
+                    continue
                 launch(plan, descs)
 
         # ---- noise only (used when forward() is asked to keep injected noise: the prologue then draws nothing) -------
@@ -571,14 +580,24 @@ class AIREngine:
         marks.append((len(bwd), "glimpse_encoder/0/w"))        # + [glimpse_encoder, what]
         dlogp_p = p(self.dlogp) if cfg.use_reinforce else None
         if fuse_attend:
-            bwd.append((L.air_attend_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r),
-                                           p(self.tr.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
-                                           shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w),
-                                           p(self.step_w), pw * inv_b, p(self.tr.g[-1]),
-                                           p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
-                                           p(self.kl_what_row), p(self.kl_where_row), pw * inv_b, dlogp_p,
-                                           p(self.st.out[-1]), cfg.step_bias, eps, p(self.st.g[-1]), T, B, Hi, Wi, hc, wc),
-                        "air_attend_bwd"))
+            # ... including the dX of the two MLP output layers (K = 8 and 1): their launch disappears from the chain, their
+            # dW / bias gradients join the next level's launch
+            def last_dx(m, dx_top):
+                if m.n > 1:
+                    return m.out[-2], m.g[-2], m.shapes[-1][0], m.shapes[-1][0]
+                return None, dx_top, Hd, Hd
+            tr_y, tr_dx, tr_kk, tr_ld = last_dx(self.tr, self.dH)
+            st_y, st_dx, st_kk, st_ld = last_dx(self.st, self.dH_b)
+            bwd.append((L.air_attend_bwd_dx, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r),
+                                              p(self.tr.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
+                                              shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w),
+                                              p(self.step_w), pw * inv_b, p(self.tr.g[-1]),
+                                              p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                              p(self.kl_what_row), p(self.kl_where_row), pw * inv_b, dlogp_p,
+                                              p(self.st.out[-1]), cfg.step_bias, eps, p(self.st.g[-1]), T, B, Hi, Wi, hc, wc,
+                                              p(self.tr.w[-1]), p(tr_y) if tr_y is not None else None, p(tr_dx), tr_kk, tr_ld,
+                                              p(self.st.w[-1]), p(st_y) if st_y is not None else None, p(st_dx), st_kk, st_ld,
+                                              prec), "air_attend_bwd_dx"))
         else:
             bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
                                             B, Hi, Wi, hc, wc), "air_st_read_bwd"))
@@ -591,7 +610,8 @@ class AIREngine:
                                           dlogp_p, p(self.st.out[-1]), cfg.step_bias,
                                           eps, p(self.st.g[-1]), T, B), "air_heads_bwd"))
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
-                            dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)])
+                            dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)],
+                      first_dx_done=fuse_attend)
         marks.append((len(bwd), "transform/0/w"))              # + [transform, steps]
         # BPTT through the T recurrences (dgates_t . W_h^T accumulates into dH[t-1] with beta = 1)
         gw = self.grads["lstm/w_gates"]

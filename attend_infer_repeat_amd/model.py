@@ -246,10 +246,17 @@ class AIRModel(object):
     def train_step(self, learning_rate, l2_weight=0., what_prior=None, where_scale_prior=None,
                    where_shift_prior=None, num_steps_prior=None, use_prior=True, use_reinforce=True, baseline=None,
                    decay_rate=None, optimizer=None, opt_kwargs=None):
-        """Creates the train step and the global_step (model.py:261-376).  `optimizer`/`opt_kwargs`: only the
-        reference's default (centred RMSProp with momentum .9) is implemented by the HIP optimiser kernel."""
-        if optimizer is not None or (opt_kwargs is not None and dict(opt_kwargs) != dict(momentum=.9, centered=True)):
-            raise NotImplementedError("only RMSProp(momentum=.9, centered=True) (the reference default) is implemented")
+        """Creates the train step and the global_step (model.py:261-376).
+        `optimizer` / `opt_kwargs` (model.py:265: `optimizer=tf.train.RMSPropOptimizer, opt_kwargs=dict(momentum=.9,
+        centered=True)`, instantiated as optimizer(learning_rate, **opt_kwargs) and once more at 10x the rate for the
+        baseline, model.py:355-363): the default runs on the HIP centred-RMSProp kernel with TF's slot initialisation; any
+        other choice is given as a torch.optim class (same calling convention: optimizer(params, lr, **opt_kwargs)) and
+        steps the generic autograd path."""
+        custom_opt = optimizer is not None or (opt_kwargs is not None and dict(opt_kwargs) != dict(momentum=.9, centered=True))
+        if custom_opt and optimizer is None:
+            raise NotImplementedError("non-default opt_kwargs need an explicit torch.optim class in `optimizer` "
+                                      "(the built-in kernel is RMSProp(momentum=.9, centered=True))")
+        self._custom_optimizer = (optimizer, dict(opt_kwargs or {})) if custom_opt else None
         if num_steps_prior is not None and not hasattr(num_steps_prior, 'analytic'):
             num_steps_prior['analytic'] = True
         self.l2_weight = l2_weight
@@ -297,8 +304,20 @@ class AIRModel(object):
                 gb = torch.autograd.grad(self.baseline_loss, baseline_vars, allow_unused=True)
                 for p, g in zip(baseline_vars, gb):
                     p.grad = g
-            _update(model_vars, 1.0)
-            _update(baseline_vars, 10.0)                      # model.py:363
+            if self._custom_optimizer is None:
+                _update(model_vars, 1.0)
+                _update(baseline_vars, 10.0)                  # model.py:363
+            else:
+                cls, kw = self._custom_optimizer
+                if "model" not in self._slots:                # built on the first step: the baseline is created lazily
+                    self._slots["model"] = cls(model_vars, lr=float(self.learning_rate), **kw)
+                    if baseline_vars:
+                        self._slots["baseline"] = cls(baseline_vars, lr=10.0 * float(self.learning_rate), **kw)
+                for key, mult in (("model", 1.0), ("baseline", 10.0)):
+                    if key in self._slots:
+                        for grp in self._slots[key].param_groups:
+                            grp["lr"] = mult * float(self.learning_rate)
+                        self._slots[key].step()
             self.global_step += 1
             return self.global_step
 

@@ -330,6 +330,19 @@ int air_attend_bwd(const float *img, const float *where, const float *dglimpse, 
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
                    const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
                    float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, void *stream);
+/* The same launch plus the dX of the two MLP OUTPUT layers (transform: [.., 8], steps: [.., 1]) whose dpre / dlogit it has just
+ * formed -- the 8- and 1-deep products that otherwise need a launch of their own on the backward chain:
+ *   tr_dx[k, n] = (sum_o dpre[k, o] * tr_w[n, o]) * elu'(tr_y[k, n]),  n < tr_k;   st_dx[k, n] = dlogit[k] * st_w[n] * elu'(st_y[k, n]).
+ * tr_y / st_y: the layer's input activation (an ELU output) or NULL when the input is not an ELU output (no factor).
+ * Their dW (and bias gradients) remain ordinary air_gemm problems over dpre / dlogit.                                        */
+int air_attend_bwd_dx(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
+                   const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
+                   float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w,
+                   const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
+                   const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
+                   const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
+                   float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
+                      const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision, void *stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------------
  * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;

@@ -397,3 +397,24 @@ def test_training_script_resume_is_bit_exact(amd, tmp_path):
     assert int(b.global_step) == 40
     assert torch.equal(a._engine.flat_params, b._engine.flat_params)
     assert torch.equal(a._engine.flat_mom, b._engine.flat_mom)
+
+
+def test_custom_optimizer_runs_on_the_generic_path(amd):
+    """model.py:265: `optimizer` / `opt_kwargs` are free; anything but the default centred RMSProp is taken as a torch.optim
+    class and steps the autograd path (the engine stays out of it)."""
+    AD = amd.utils.AttrDict
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-3, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                            AD(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3),
+                            optimizer=torch.optim.Adam, opt_kwargs=dict(betas=(0.9, 0.99)))
+    assert air._engine is None
+    w0 = air.cell._input_encoder.mlp.layers[0].w.detach().clone()
+    b0 = air.baseline_module.mlp.layers[0].w.detach().clone()
+    ts(); ts()
+    assert int(gs) == 2 and np.isfinite(float(air.opt_loss))
+    assert not torch.equal(w0, air.cell._input_encoder.mlp.layers[0].w) and not torch.equal(b0, air.baseline_module.mlp.layers[0].w)
+    # Adam's first steps move every touched weight by ~lr (model) and ~10 lr (baseline, model.py:363)
+    dm = (air.cell._input_encoder.mlp.layers[1].w - 0).abs().max()   # finite
+    assert torch.isfinite(dm)
+    with pytest.raises(NotImplementedError):
+        _mnist_model(amd).train_step(1e-3, num_steps_prior=AD(anneal=None, init=0.5), opt_kwargs=dict(momentum=0.5))
