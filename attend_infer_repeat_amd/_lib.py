@@ -12,14 +12,15 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 2  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 3  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
     _fields_ = [("ta", c_int), ("tb", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
                 ("bias", c_void_p), ("epilogue", c_int), ("aux", c_void_p), ("ldaux", c_int), ("beta", c_float),
-                ("colsum", c_void_p), ("precision", c_int)]
+                ("colsum", c_void_p), ("precision", c_int),
+                ("A2", c_void_p), ("a_bias", c_void_p), ("a_elu", c_int), ("a_out", c_void_p)]
 
 
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h

@@ -10,6 +10,10 @@
 #define PW_THREADS 256
 #endif
 
+// float64 log as ONE out-of-line copy: inlined, each call is ~1.5 KB of straight-line code, and in the train step every kernel
+// starts with a cold instruction cache (36 different kernels per step share 64 KB per CU pair), so code size is latency
+__device__ __noinline__ double air_log_f64(double x) { return log(x); }
+
 __device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps) {
     const float ratio = (s * s) / (ps * ps);
     const float d = mu - pm;
@@ -163,7 +167,7 @@ __device__ __forceinline__ void presence_numsteps_col(int b, const float (&lg)[M
         if (n <= T) {
             q[(size_t)b * (T + 1) + n] = s.q32[n];
             const double pn = (double)s.q32[n];
-            kl += (pn > 0.0) ? (float)(pn * log(pn / pri[n])) : 0.f;
+            kl += (pn > 0.0) ? (float)(pn * air_log_f64(pn / pri[n])) : 0.f;
             if (n == nstar) qstar = s.q32[n];
         }
     }
@@ -220,7 +224,7 @@ __device__ __forceinline__ void numsteps_presence_bwd_col(int b,
         double g = 0.0;
         if (n <= T) {
             const double pn = (double)s.q32[n];
-            g = (pn > 0.0) ? (double)kl_scale * (log(pn / prior[n]) + 1.0) : 0.0;
+            g = (pn > 0.0) ? (double)kl_scale * (air_log_f64(pn / prior[n]) + 1.0) : 0.0;
             if (n >= 1) {
                 const size_t k = (size_t)(n - 1) * B + b;
                 wsum += (double)(w_scale * ((kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f)));

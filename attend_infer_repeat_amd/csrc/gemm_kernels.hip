@@ -61,6 +61,13 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MT][NT], const f32x4 (&f
     }
 }
 
+// consumer-side reduction of a K-split producer (AirGemmDesc.A2 ...): a separate kernel argument of the one kernel that uses it --
+// every field added to GemmArgs is loaded by EVERY GEMM launch (x8 in a grouped launch): five more cost 7 us per step, measured
+struct AproArgs {
+    const float *A2, *a_bias;
+    float *a_out;
+    int a_elu;
+};
 struct GemmArgs {
     const float *A, *B, *bias, *aux;
     float *C, *colsum, *ws;
@@ -140,8 +147,8 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // MT x NT 16x16 MFMA tiles per wave.  KW = 4 / 16: the workgroup's KW waves split K for ONE tile (LDS reduce; 16
 // waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
-template <int MT, int NT, int KW, bool BF>
-__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split) {
+template <int MT, int NT, int KW, bool BF, bool APRO = false>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split, const AproArgs pro = AproArgs()) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
     constexpr int NWV = (KW == 1) ? 4 : KW;               // waves per workgroup
@@ -214,15 +221,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 #pragma nounroll
     for (; c < full_end; c += U * c_step) {   // (unrolling this loop doubles the live operand registers: 94 -> 194 VGPRs)
         f32x4 fa[U][MT], fb[U][NT];
+        f32x4 fa2[APRO ? U : 1][APRO ? MT : 1], fab[APRO ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int cu = c + u * c_step;
             if (cu < full_end) {                           // wave-uniform: a short tail group issues fewer loads
                 const int k = (cu << 4) + 4 * lg;
 #pragma unroll
-                for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MT; ++a) {
                     fa[u][a] = g.ta ? ld_kstrided_full(gA, g.lda, rowAc[a], k)
                                     : ld_kcontig_full(gA, g.lda, rowAc[a], k, g.vecA != 0);
+                    if (APRO) {       // second K-split slab + bias of the producing layer: requested with the operand itself
+                        fa2[u][a] = ld_kcontig_full((gcf)pro.A2, g.lda, rowAc[a], k, g.vecA != 0);
+                        fab[u] = ld_kcontig_full((gcf)pro.a_bias, 0, 0, k, g.vecA != 0);
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
                     fb[u][b] = g.tb ? ld_kcontig_full(gB, g.ldb, colBc[b], k, g.vecB != 0)
@@ -237,6 +250,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (c + u * c_step >= full_end) break;
+            if (APRO) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    f32x4 v = (fa[u][a] + fa2[u][a]) + fab[u];
+                    if (pro.a_elu) { v.x = elu_acc(v.x); v.y = elu_acc(v.y); v.z = elu_acc(v.z); v.w = elu_acc(v.w); }
+                    fa[u][a] = v;
+                    if (pro.a_out != nullptr && tn == 0 && okA[a])        // the reduced activation, for the backward pass
+                        *(f32x4 *)(pro.a_out + (size_t)rowA[a] * g.lda + (((c + u * c_step) << 4) + 4 * lg)) = v;
+                }
+            }
             mfma_chunk<MT, NT, BF>(acc, fa[u], fb[u]);
             if (want_colsum) {
 #pragma unroll
@@ -342,6 +365,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 template <int MT, int NT, int KW, bool BF>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_f32_mfma_kernel(GemmArgs g) {
     gemm_body<MT, NT, KW, BF>(g, blockIdx.x, blockIdx.y);
+}
+// the same body with the A-operand prologue (consumer-side reduction of a K-split producer) compiled in
+template <int MT, int NT, int KW, bool BF>
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_f32_mfma_apro_kernel(GemmArgs g, AproArgs pro) {
+    gemm_body<MT, NT, KW, BF, true>(g, blockIdx.x, blockIdx.y, pro);
 }
 
 // Several independent GEMMs in ONE launch (the step is launch/latency bound: a dW / dX pair, or the two heads that
@@ -480,6 +508,11 @@ static int fill_gemm_args(GemmArgs &g, const AirGemmDesc &d) {
     if (d.epilogue == AIR_EPI_BIAS || d.epilogue == AIR_EPI_BIAS_ELU) AIR_REQUIRE(d.bias, AIR_E_NULL);
     if (d.epilogue >= AIR_EPI_MUL_DELU) AIR_REQUIRE(d.aux && d.ldaux >= d.N, AIR_E_NULL);
     AIR_REQUIRE(!d.colsum || d.ta, AIR_E_UNSUPPORTED);
+    if (d.A2) {       // the A prologue: k-contiguous A, both slabs and the bias readable with the same 16-byte loads, K % 16 == 0
+        AIR_REQUIRE(!d.ta && d.a_bias && (d.K % 16 == 0) && (d.lda % 4 == 0), AIR_E_UNSUPPORTED);
+        AIR_REQUIRE(air_aligned16(d.A) && air_aligned16(d.A2) && air_aligned16(d.a_bias) && (!d.a_out || air_aligned16(d.a_out)),
+                    AIR_E_ALIGN);
+    }
     g.A = d.A; g.B = d.B; g.C = d.C; g.bias = d.bias; g.aux = d.aux; g.colsum = d.colsum; g.ws = nullptr;
     g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldaux = d.ldaux;
     g.ta = d.ta ? 1 : 0; g.tb = d.tb ? 1 : 0; g.epi = d.epilogue; g.beta = d.beta;
@@ -530,7 +563,13 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         if (bf) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT_, NT_, KW_, true>), dim3(tiles, 1), dim3(NTH_), 0, st, ga.g[0]);  \
         else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT_, NT_, KW_, false>), dim3(tiles, 1), dim3(NTH_), 0, st, ga.g[0]);    \
     } while (0)
-    if (count == 1) {
+    for (int i = 0; i < count; ++i) AIR_REQUIRE(!descs[i].A2 || count == 1, AIR_E_UNSUPPORTED);
+    if (count == 1 && descs[0].A2) {
+        AIR_REQUIRE(T_ == 16 && !long_k, AIR_E_UNSUPPORTED);       // latency-regime consumer of a K-split producer
+        const AproArgs pro = {descs[0].A2, descs[0].a_bias, descs[0].a_out, descs[0].a_elu};
+        if (bf) hipLaunchKernelGGL((gemm_f32_mfma_apro_kernel<1, 1, 4, true>), dim3(tiles, 1), dim3(256), 0, st, ga.g[0], pro);
+        else hipLaunchKernelGGL((gemm_f32_mfma_apro_kernel<1, 1, 4, false>), dim3(tiles, 1), dim3(256), 0, st, ga.g[0], pro);
+    } else if (count == 1) {
         if (long_k) AIR_SINGLE_LAUNCH(1, 1, 16, 1024);
         else if (T_ == 16) AIR_SINGLE_LAUNCH(1, 1, 4, 256);
         else AIR_SINGLE_LAUNCH(2, 2, 4, 256);

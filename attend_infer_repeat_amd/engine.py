@@ -15,6 +15,7 @@ torch supplies device memory, streams and (optionally) torch.distributed; all ar
 """
 import ctypes
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -338,9 +339,10 @@ class AIREngine:
         dp = lambda t: (t.data_ptr() if t is not None else None)
 
         def desc(ta, tb, Mm, Nn, Kk, Aa, lda, Bb, ldb, Cc, ldc, bias=None, epi=NONE, aux=None, ldaux=0, beta=0.0,
-                 colsum=None):
+                 colsum=None, A2=None, a_bias=None, a_elu=0, a_out=None):
             return _lib.AirGemmDesc(int(ta), int(tb), Mm, Nn, Kk, dp(Aa), lda, dp(Bb), ldb, dp(Cc), ldc, dp(bias), epi,
-                                    dp(aux), ldaux, float(beta), dp(colsum), prec)
+                                    dp(aux), ldaux, float(beta), dp(colsum), prec, dp(A2), dp(a_bias), int(a_elu),
+                                    dp(a_out))
 
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
@@ -446,22 +448,60 @@ class AIREngine:
 
         # cell.py:125 (hoisted out of the time loop) + the obs columns of the baseline's first layer (modules.py:131-143):
         # both contract over the P pixels of obs
-        lvl0 = [fwd_desc(self.enc, 0, self.obs, P)]
-        if cfg.use_reinforce:
-            n0 = self.bl.shapes[0][1]
-            lvl0.append(desc(0, 0, B, n0, P, self.obs, P, self.bl.w[0][:P], n0, self.bl_obs, n0, bias=self.bl.b[0],
-                             epi=BIAS))
-        if ((B + 15) // 16) * ((max(d.N for d in lvl0) + 15) // 16) <= 256:
-            launch(fwd, lvl0)                               # few tiles: one launch, 16 waves per tile share the long K
+        # The two products over the P pixels of obs have K = P (2500 / 10000) on B/16 x 16 tiles each: 128 workgroups, each
+        # pulling its whole K range through ONE CU -- ingest-bound at half of the chip.  In the latency regime K is split in two
+        # (4 problems, 256 workgroups, same launch) and the CONSUMERS add the halves where they read them: the next layer's
+        # A-operand prologue forms elu(slab0 + slab1 + bias) (and stores it for the backward); the baseline's second half is
+        # written straight into the buffer its second stage accumulates into (beta = 1) next to aux = first half.  No
+        # cross-workgroup hand-off, no extra launch, fixed summation order.
+        E0 = self.enc.shapes[0][1]
+        lvl0_tiles = ((B + 15) // 16) * ((E0 + 15) // 16)
+        split0 = (lvl0_tiles * (2 if cfg.use_reinforce else 1) <= 128 and P >= 2048 and P % 4 == 0 and E0 % 16 == 0
+                  and os.environ.get("AIR_SPLIT_K0", "1") == "1")
+        self._split0 = split0
+        if split0:
+            kh = (P // 2) // 16 * 16                       # both halves start 16-byte aligned (and on a chunk boundary)
+            s0, s1 = self._buf("enc_slab0", (B, E0)), self._buf("enc_slab1", (B, E0))
+            lvl0 = [desc(0, 0, B, E0, kh, self.obs, P, self.enc.w[0], E0, s0, E0),
+                    desc(0, 0, B, E0, P - kh, self.obs[:, kh:], P, self.enc.w[0][kh:], E0, s1, E0)]
+            if cfg.use_reinforce:
+                n0 = self.bl.shapes[0][1]
+                lvl0 += [desc(0, 0, B, n0, kh, self.obs, P, self.bl.w[0][:kh], n0, self.bl_obs, n0, bias=self.bl.b[0], epi=BIAS),
+                         desc(0, 0, B, n0, P - kh, self.obs[:, kh:], P, self.bl.w[0][kh:P], n0, self.bl.out[0], n0)]
+            launch(fwd, lvl0)
+            enc_pro = dict(A=s0, A2=s1, a_bias=self.enc.b[0], a_elu=1, a_out=self.enc.out[0])
         else:
-            for d in lvl0:
-                launch(fwd, [d], allow_splitk=True)
-        for i in range(1, self.enc.n):
+            lvl0 = [fwd_desc(self.enc, 0, self.obs, P)]
+            if cfg.use_reinforce:
+                n0 = self.bl.shapes[0][1]
+                lvl0.append(desc(0, 0, B, n0, P, self.obs, P, self.bl.w[0][:P], n0, self.bl_obs, n0, bias=self.bl.b[0],
+                                 epi=BIAS))
+            if ((B + 15) // 16) * ((max(d.N for d in lvl0) + 15) // 16) <= 256:
+                launch(fwd, lvl0)                               # few tiles: one launch, 16 waves per tile share the long K
+            else:
+                for d in lvl0:
+                    launch(fwd, [d], allow_splitk=True)
+            enc_pro = None
+
+        def after_enc0(k, n, Bmat, ldb, Cc, bias, epi):
+            """the product that consumes the first encoder layer's activation [B, E0]"""
+            if enc_pro is None:
+                return desc(0, 0, B, n, k, self.enc.out[0], E0, Bmat, ldb, Cc, n, bias=bias, epi=epi)
+            return desc(0, 0, B, n, k, enc_pro["A"], E0, Bmat, ldb, Cc, n, bias=bias, epi=epi, A2=enc_pro["A2"],
+                        a_bias=enc_pro["a_bias"], a_elu=enc_pro["a_elu"], a_out=enc_pro["a_out"])
+
+        if self.enc.n > 1:
+            k1, n1 = self.enc.shapes[1]
+            launch(fwd, [after_enc0(k1, n1, self.enc.w[1], n1, self.enc.out[1], self.enc.b[1], BELU)])
+        for i in range(2, self.enc.n):
             launch(fwd, [fwd_desc(self.enc, i, None, 0)])
         enc_out, E = self.enc.out[-1], self.enc.shapes[-1][1]
         wg, bg = self.params["lstm/w_gates"], self.params["lstm/b_gates"]
         w_x, w_h = wg[:E], wg[E:]
-        launch(fwd, [desc(0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)])
+        if self.enc.n == 1:
+            launch(fwd, [after_enc0(E, 4 * Hd, w_x, 4 * Hd, self.gx, bg, BIAS)])
+        else:
+            launch(fwd, [desc(0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)])
         # Recurrent product + gate math in ONE launch per step while the chain is latency bound (it is the only truly
         # sequential part of the step); at large batch the 32x32-tile GEMM + a pointwise pass re-reads less (measured:
         # B=1024 0.938 vs 0.954 ms/step), so the pair is kept there.
@@ -528,7 +568,7 @@ class AIREngine:
             n0 = self.bl.shapes[0][1]
             launch(fwd, [desc(0, 0, B, n0, KL, self.base_lat, KL, self.bl.w[0][P:], n0, self.bl.out[0], n0,
                               epi=ADDAUX_ELU if self.bl.n > 1 or not self.bl.last_linear else ADDAUX,
-                              aux=self.bl_obs, ldaux=n0),
+                              aux=self.bl_obs, ldaux=n0, beta=1.0 if split0 else 0.0),
                          fwd_desc(self.gd, 0, self.what, A)])                               # cell.py:158
             depth = max(self.gd.n, self.bl.n)
             for i in range(1, depth):

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 2
+#define AIR_ABI_VERSION 3
 
 enum {
     AIR_OK = 0,
@@ -136,6 +136,16 @@ typedef struct AirGemmDesc {
     float beta;
     float *colsum;
     int precision;           /* AIR_PREC_F32 (exact fp32 MFMA) or AIR_PREC_BF16 (operands rounded to bf16, fp32 accumulate) */
+    /* Consumer-side reduction of a K-split producer (all optional, NULL / 0 = off).  A long-K product on a handful of tiles is
+     * bound by what ONE CU can ingest; splitting K over more workgroups needs the partial results summed, and instead of a
+     * cross-workgroup hand-off inside the producer (agent-scope fences) the CONSUMER adds them where it reads them:
+     *   a[m,k] = act(A[m,k] + A2[m,k] + a_bias[k]),  act = ELU if a_elu  (ta == 0, K % 16 == 0, single-problem launch only);
+     *   a_out[M, lda] receives the reduced activation (written once, by the first column of tiles) for the backward pass.
+     * (A second aux slab needs no field: the partial product is written into C and picked up with beta = 1.)             */
+    const float *A2;
+    const float *a_bias;
+    int a_elu;
+    float *a_out;
 } AirGemmDesc;
 int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
 
