@@ -166,7 +166,8 @@ def gemm(A, B, ta=False, tb=False, bias=None, epilogue=EPI_NONE, aux=None, beta=
 
 def gemm_grouped(problems, precision=0):
     """Several independent GEMMs in one launch (air_gemm_grouped).  problems: dicts with A, B and optional ta, tb, bias,
-    epilogue, aux, beta, out, colsum (bool).  Returns [(C, colsum|None)]."""
+    epilogue, aux, beta, out, colsum (bool); a single problem may carry the K-split consumer prologue A2, a_bias, a_elu, a_out
+    (a = act(A + A2 + a_bias), see AirGemmDesc).  Returns [(C, colsum|None)]."""
     descs, outs, keep = [], [], []
     for pr in problems:
         A, B = pr["A"], pr["B"]
@@ -183,7 +184,10 @@ def gemm_grouped(problems, precision=0):
         d = _lib.AirGemmDesc(int(ta), int(tb), M, N, K, A.data_ptr(), ld(A), B.data_ptr(), ld(B), out.data_ptr(), ld(out),
                              bias.data_ptr() if bias is not None else None, int(pr.get("epilogue", EPI_NONE)),
                              aux.data_ptr() if aux is not None else None, ld(aux) if aux is not None else 0,
-                             float(pr.get("beta", 0.0)), cs.data_ptr() if cs is not None else None, int(precision))
+                             float(pr.get("beta", 0.0)), cs.data_ptr() if cs is not None else None, int(precision),
+                             pr["A2"].data_ptr() if pr.get("A2") is not None else None,
+                             pr["a_bias"].data_ptr() if pr.get("a_bias") is not None else None, int(bool(pr.get("a_elu", False))),
+                             pr["a_out"].data_ptr() if pr.get("a_out") is not None else None)
         descs.append(d); outs.append((out, cs)); keep.append((A, B, aux, bias))
     arr = (_lib.AirGemmDesc * len(descs))(*descs)
     _lib.check(lib().air_gemm_grouped(arr, len(descs), _stream()), "air_gemm_grouped")

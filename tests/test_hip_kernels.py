@@ -530,3 +530,30 @@ def test_hipgraph_capture_replay(hip):
     ref = torch.nn.functional.elu(x.double().cpu() @ w.double().cpu() + b.double().cpu())
     assert_close(y, ref, 2e-5, 2e-4, "graph replay")
     _lib.check(lib.air_graph_destroy(exe))
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_k_split_consumer_prologue(hip, prec):
+    """A long-K product split in two halves (two ordinary problems of one grouped launch) and reduced by its CONSUMER:
+    a = elu(slab0 + slab1 + bias) formed in the A-operand loader of the next product, which also stores the reduced activation;
+    a second consumer picks a partial product up with beta = 1.  Checked against the unsplit computation in float64."""
+    torch.manual_seed(7)
+    M, K, E, N = 64, 2500, 256, 320
+    x, w0, b0 = torch.rand(M, K).cuda(), (torch.randn(K, E) / 50).cuda(), (0.1 * torch.randn(E)).cuda()
+    w1, b1 = (torch.randn(E, N) / 16).cuda(), (0.1 * torch.randn(N)).cuda()
+    kh = (K // 2) // 16 * 16
+    (s0, _), (s1, _) = hip.gemm_grouped([dict(A=x[:, :kh], B=w0[:kh]), dict(A=x[:, kh:], B=w0[kh:])], precision=prec)
+    act = torch.empty(M, E, device="cuda")
+    (y, _), = hip.gemm_grouped([dict(A=s0, B=w1, bias=b1, epilogue=hip.EPI_BIAS_ELU, A2=s1, a_bias=b0, a_elu=True, a_out=act)],
+                               precision=prec)
+    r = lambda t: t.double() if prec == 0 else t.bfloat16().double()          # operand rounding of the bf16 mode
+    h_ref = torch.nn.functional.elu(r(x) @ r(w0) + b0.double())
+    y_ref = torch.nn.functional.elu(r(h_ref.float()) @ r(w1) + b1.double())
+    tol = 2e-5 if prec == 0 else 3e-3
+    assert ((act.double() - h_ref).abs().max() / h_ref.abs().max()).item() < tol
+    assert ((y.double() - y_ref).abs().max() / y_ref.abs().max()).item() < tol
+    # beta = 1 pick-up of a partial product written into C beforehand
+    c = s1.clone()
+    hip.gemm_grouped([dict(A=x[:, :kh], B=w0[:kh], out=c, beta=1.0, bias=b0, epilogue=hip.EPI_BIAS)], precision=prec)
+    full = r(x) @ r(w0) + b0.double()
+    assert ((c.double() - full).abs().max() / full.abs().max()).item() < tol
