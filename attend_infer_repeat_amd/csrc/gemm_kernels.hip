@@ -372,6 +372,194 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_f32_mfma_apro_ke
     gemm_body<MT, NT, KW, BF, true>(g, blockIdx.x, blockIdx.y, pro);
 }
 
+// ---- throughput regime (thousands of rows): "wide" wave tiles with every operand load 16 bytes per lane ---------------------
+// gemm_body feeds a k-strided operand (forward: W[K,N]; weight gradient: both operands) with dword loads -- 64-byte segments, 16
+// address cycles per wave instruction for 256 bytes: at batch 1024 the load path, not the MFMA pipe, bounds those products (the
+// texture-address unit is busier than the matrix cores: 640 against 512 cycles per 16-deep chunk of a 32x32 tile, 4 waves per CU).
+// Here a k-strided operand is read with ONE 16-byte load per lane ALONG ITS CONTIGUOUS DIMENSION, and the four values a lane gets
+// are handed to FOUR DIFFERENT 16-wide MFMA tiles: tile t of a 64-wide block owns the INTERLEAVED columns n0 + 4 i + t (i = 0..15)
+// instead of the contiguous columns n0 + 16 t + i.  MFMA does not care which column a lane's value belongs to, only that A and B
+// agree on k; the accumulator of lane (i, g) then holds C[row][n0 + 4 i + 0..3] across the four tiles: a 16-byte store.  A
+// k-contiguous operand keeps the block layout (one 16-byte load per lane per chunk along k).  Wave tile (16 MT) x 64: MT + 4
+// 16-byte loads per 16-deep chunk feed 4 MT (bf16) or 16 MT (fp32) MFMAs; KW waves split K and reduce through LDS in fixed order.
+template <int MT, int KW, bool BF, bool TA, bool TB>
+__device__ __forceinline__ void gemm_wide_body(const GemmArgs &g, const int block_tile) {
+    constexpr int NT = 4, TM = 16 * MT, TN = 64;
+    constexpr int NTH = 64 * KW;
+    constexpr int LDT = TN + 4;
+    static_assert(!TA || MT == 4, "an m-contiguous A operand is read 4 rows per lane: four interleaved row tiles");
+    __shared__ float s_tile[KW][TM * LDT];
+    __shared__ float s_col[KW][TN];
+
+    const gcf gA = (gcf)g.A, gB = (gcf)g.B, gBias = (gcf)g.bias, gAux = (gcf)g.aux;
+    const gf gC = (gf)g.C, gCol = (gf)g.colsum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tiles_n = (g.N + TN - 1) / TN;
+    const int tm = block_tile / tiles_n, tn = block_tile - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int total_chunks = (g.K + 15) >> 4;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[NT] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_colsum = TA && (g.colsum != nullptr) && (tm == 0);
+
+    // operand addressing.  Block layout: tile t row/col 16 t + li, one address per tile.  Interleaved: rows/cols 4 li + t, ONE
+    // address for all four tiles (clamped inside the matrix: lanes past the edge feed accumulators that are never stored; the
+    // dispatcher guarantees M % 4 == 0 / N % 4 == 0 for an interleaved operand, so a lane is entirely inside or entirely outside)
+    int offA[TA ? 1 : MT], offB[TB ? NT : 1];
+    if (TA) { int r = m0 + 4 * li; if (r > g.M - 4) r = g.M - 4; offA[0] = r; }
+    else {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) { int r = m0 + 16 * a + li; if (r > g.M - 1) r = g.M - 1; offA[a] = r * g.lda; }
+    }
+    if (!TB) { int c = n0 + 4 * li; if (c > g.N - 4) c = g.N - 4; offB[0] = c; }
+    else {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) { int c = n0 + 16 * b + li; if (c > g.N - 1) c = g.N - 1; offB[b] = c * g.ldb; }
+    }
+
+    // epilogue operands requested before the K loop (their round trip hides under the operand loads)
+    constexpr int EPT = (TM * TN) / NTH;
+    static_assert((TM * TN) % NTH == 0, "tile / threads");
+    float e_bias[EPT], e_aux[EPT], e_c[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + NTH * i;
+        const int r = e / TN, cidx = e - r * TN;
+        int m = m0 + r, n = n0 + cidx;
+        if (m > g.M - 1) m = g.M - 1;
+        if (n > g.N - 1) n = g.N - 1;
+        e_bias[i] = g.bias != nullptr ? gBias[n] : 0.f;
+        e_aux[i] = g.epi >= AIR_EPI_MUL_DELU ? gAux[(size_t)m * g.ldaux + n] : 0.f;
+        e_c[i] = g.beta != 0.f ? gC[(size_t)m * g.ldc + n] : 0.f;
+    }
+
+    constexpr int U = (MT == 4) ? 3 : 4;                   // chunks in flight per wave
+    const int full_end = g.K >> 4;
+    auto load_chunk = [&](int k, f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {       // k = first of the lane group's four k values
+        if (TA) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *(gcf4)(gA + (size_t)(k + j) * g.lda + offA[0]);
+#pragma unroll
+            for (int a = 0; a < MT; ++a) fa[a] = (f32x4){v[0][a], v[1][a], v[2][a], v[3][a]};
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) fa[a] = *(gcf4)(gA + offA[a] + k);
+        }
+        if (!TB) {
+            f32x4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = *(gcf4)(gB + (size_t)(k + j) * g.ldb + offB[0]);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[b] = (f32x4){w[0][b], w[1][b], w[2][b], w[3][b]};
+        } else {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[b] = *(gcf4)(gB + offB[b] + k);
+        }
+    };
+    int c = wave;
+#pragma nounroll
+    for (; c < full_end; c += U * KW) {
+        f32x4 fa[U][MT], fb[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cu = c + u * KW;
+            if (cu > full_end - 1) cu = full_end - 1;      // a short tail group re-reads the last chunk (never multiplied)
+            load_chunk((cu << 4) + 4 * lg, fa[u], fb[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW >= full_end) break;
+            mfma_chunk<MT, NT, BF>(acc, fa[u], fb[u]);
+            if (want_colsum) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) csum[b] += (fb[u][b].x + fb[u][b].y) + (fb[u][b].z + fb[u][b].w);
+            }
+        }
+    }
+    // the partial last chunk of K (K % 16 != 0; K % 4 == 0 is guaranteed): whole 4-deep lane groups are in or out
+    if ((g.K & 15) && (full_end % KW) == wave) {
+        const int k = (full_end << 4) + 4 * lg;
+        f32x4 fa[MT], fb[NT];
+        load_chunk(k < g.K ? k : 0, fa, fb);                                        // out-of-range lane groups read a valid address ...
+        if (k >= g.K) {                                                             // ... and contribute zeros
+#pragma unroll
+            for (int a = 0; a < MT; ++a) fa[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        mfma_chunk<MT, NT, BF>(acc, fa, fb);
+        if (want_colsum) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) csum[b] += (fb[b].x + fb[b].y) + (fb[b].z + fb[b].w);
+        }
+    }
+
+    // accumulators -> LDS tile in OUTPUT coordinates (C/D map of a 16x16 tile: column index li, row index 4 lg + r)
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = TA ? 4 * (4 * lg + r) + a : 16 * a + 4 * lg + r;
+            if (!TB) {
+                *(f32x4 *)&s_tile[wave][row * LDT + 4 * li] = (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+            } else {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) s_tile[wave][row * LDT + 16 * b + li] = acc[a][b][r];
+            }
+        }
+    if (want_colsum) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            float v = csum[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) s_col[wave][TB ? 16 * b + li : 4 * li + b] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + NTH * i;
+        const int r = e / TN, cidx = e - r * TN;
+        const int m = m0 + r, n = n0 + cidx;
+        const int off = r * LDT + cidx;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KW; q += 4) v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
+        if (g.beta != 0.f) v += g.beta * e_c[i];
+        switch (g.epi) {
+            case AIR_EPI_BIAS: v += e_bias[i]; break;
+            case AIR_EPI_BIAS_ELU: v = elu_acc(v + e_bias[i]); break;
+            case AIR_EPI_MUL_DELU: v *= (e_aux[i] > 0.f ? 1.f : e_aux[i] + 1.f); break;
+            case AIR_EPI_ADD_AUX: v += e_aux[i] + e_bias[i]; break;
+            case AIR_EPI_ADD_AUX_ELU: v = elu_acc(v + e_aux[i] + e_bias[i]); break;
+            default: break;
+        }
+        if (m < g.M && n < g.N) gC[(size_t)m * g.ldc + n] = v;
+    }
+    if (want_colsum && threadIdx.x < TN) {
+        const int n = n0 + threadIdx.x;
+        if (n < g.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < KW; q += 4)
+                v += (s_col[q][threadIdx.x] + s_col[q + 1][threadIdx.x]) + (s_col[q + 2][threadIdx.x] + s_col[q + 3][threadIdx.x]);
+            gCol[n] = v;
+        }
+    }
+}
+template <int MT, int KW, bool BF, bool TA, bool TB>
+__global__ __launch_bounds__(64 * KW) void gemm_wide_kernel(GemmArgs g) {
+    gemm_wide_body<MT, KW, BF, TA, TB>(g, blockIdx.x);
+}
+
 // Several independent GEMMs in ONE launch (the step is launch/latency bound: a dW / dX pair, or the two heads that
 // read the same hidden state, cost one dispatch instead of two).  Problem p owns blocks [tile_start[p], tile_start[p+1]).
 #define AIR_GEMM_GROUP_MAX 8
@@ -401,6 +589,25 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(G
         case 5: gemm_body<MT, NT, KW, BF>(ga.g[5], (int)blockIdx.x - ga.tile_start[5], blockIdx.y); break;
         case 6: gemm_body<MT, NT, KW, BF>(ga.g[6], (int)blockIdx.x - ga.tile_start[6], blockIdx.y); break;
         default: gemm_body<MT, NT, KW, BF>(ga.g[7], (int)blockIdx.x - ga.tile_start[7], blockIdx.y); break;
+    }
+}
+
+template <int MT, int KW, bool BF, bool TA, bool TB>
+__global__ __launch_bounds__(64 * KW) void gemm_grouped_wide_kernel(GroupArgs ga) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    switch (p) {       // constant descriptor index per copy, as in gemm_grouped_kernel
+        case 0: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[0], (int)blockIdx.x - ga.tile_start[0]); break;
+        case 1: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[1], (int)blockIdx.x - ga.tile_start[1]); break;
+        case 2: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[2], (int)blockIdx.x - ga.tile_start[2]); break;
+        case 3: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[3], (int)blockIdx.x - ga.tile_start[3]); break;
+        case 4: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[4], (int)blockIdx.x - ga.tile_start[4]); break;
+        case 5: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[5], (int)blockIdx.x - ga.tile_start[5]); break;
+        case 6: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[6], (int)blockIdx.x - ga.tile_start[6]); break;
+        default: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[7], (int)blockIdx.x - ga.tile_start[7]); break;
     }
 }
 
@@ -551,6 +758,53 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         AIR_REQUIRE((descs[i].precision == AIR_PREC_BF16) == bf, AIR_E_UNSUPPORTED);   // one precision per launch
     }
     hipStream_t st = air_stream(stream);
+    // throughput regime: the wide-tile kernels (every operand load 16 bytes per lane) when the whole group has one operand
+    // layout and every problem meets the alignment the interleaved loads need
+    {
+        static const long wide_min = getenv("AIR_GEMM_WIDE_MIN_TILES") ? atol(getenv("AIR_GEMM_WIDE_MIN_TILES")) : 1536;
+        static const long wide_tn_bf = getenv("AIR_GEMM_WIDE_TN_BF16") ? atol(getenv("AIR_GEMM_WIDE_TN_BF16")) : 48;
+        static const long wide_tn_f32 = getenv("AIR_GEMM_WIDE_TN_F32") ? atol(getenv("AIR_GEMM_WIDE_TN_F32")) : 48;
+        static const long wide_nt_k = getenv("AIR_GEMM_WIDE_NT_K") ? atol(getenv("AIR_GEMM_WIDE_NT_K")) : 512;
+        bool ok = tiles16 > wide_min;
+        const int ta = descs[0].ta ? 1 : 0, tb = descs[0].tb ? 1 : 0;
+        long tiles64 = 0;
+        int min_k = 1 << 30;
+        for (int i = 0; i < count && ok; ++i) {
+            const AirGemmDesc &d = descs[i];
+            ok = ok && (d.ta ? 1 : 0) == ta && (d.tb ? 1 : 0) == tb && !(ta && tb) && !d.A2;
+            ok = ok && air_aligned16(d.A) && air_aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.K % 4 == 0;
+            ok = ok && d.M >= 4 && d.N >= 4 && (!ta || d.M % 4 == 0) && (tb || d.N % 4 == 0);
+            tiles64 += (long)air_cdiv(d.M, 64) * air_cdiv(d.N, 64);
+            if (d.K < min_k) min_k = d.K;
+        }
+        if (ok && ta) ok = tiles64 >= (bf ? wide_tn_bf : wide_tn_f32);
+        if (ok && !ta && tb) ok = min_k >= wide_nt_k;
+        if (ok) {
+            const int TMw = ta ? 64 : 16;
+            int wt = 0;
+            for (int i = 0; i < count; ++i) {
+                ga.tile_start[i] = wt;
+                wt += air_cdiv(descs[i].M, TMw) * air_cdiv(descs[i].N, 64);
+            }
+            for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = wt;
+#define AIR_WIDE_LAUNCH(MT_, TA_, TB_)                                                                                     \
+            do {                                                                                                           \
+                if (count == 1) {                                                                                          \
+                    if (bf) hipLaunchKernelGGL((gemm_wide_kernel<MT_, 8, true, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga.g[0]);   \
+                    else hipLaunchKernelGGL((gemm_wide_kernel<MT_, 8, false, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga.g[0]);     \
+                } else {                                                                                                   \
+                    if (bf) hipLaunchKernelGGL((gemm_grouped_wide_kernel<MT_, 8, true, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga);   \
+                    else hipLaunchKernelGGL((gemm_grouped_wide_kernel<MT_, 8, false, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga);     \
+                }                                                                                                          \
+            } while (0)
+            if (ta) AIR_WIDE_LAUNCH(4, true, false);
+            else if (tb) AIR_WIDE_LAUNCH(1, false, true);
+            else AIR_WIDE_LAUNCH(1, false, false);
+#undef AIR_WIDE_LAUNCH
+            AIR_LAUNCH_CHECK();
+            return AIR_OK;
+        }
+    }
 #define AIR_GROUP_LAUNCH(MT_, NT_, KW_, NTH_)                                                                        \
     do {                                                                                                             \
         if (bf) hipLaunchKernelGGL((gemm_grouped_kernel<MT_, NT_, KW_, true>), dim3(tiles), dim3(NTH_), 0, st, ga);   \

@@ -344,8 +344,21 @@ class AIREngine:
                                     dp(aux), ldaux, float(beta), dp(colsum), prec, dp(A2), dp(a_bias), int(a_elu),
                                     dp(a_out))
 
+        # Throughput regime (thousands of rows): the weight gradients (K = rows, tiny outputs) leave the dX chain and are
+        # formed at the end of the backward in a few launches of their own -- nothing but the optimiser consumes them, and a
+        # launch that holds ALL of them has hundreds of 64x64 tiles: enough to fill the chip with the wide-tile kernel (16-byte
+        # operand loads, 8 waves split K inside the workgroup) instead of ~11 launches of 16x16 tiles with 16-way K splits.
+        defer_dw = M >= int(os.environ.get("AIR_DEFER_DW_MIN_ROWS", "1536"))
+        deferred_dw = []
+        self._defer_dw = defer_dw
+
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
+            if defer_dw and plan is bwd:
+                deferred_dw.extend(d for d in descs if d.ta and not d.tb)
+                descs = [d for d in descs if not (d.ta and not d.tb)]
+                if not descs:
+                    return
             tiles16 = sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in descs)
             if len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256:
                 d = descs[0]
@@ -505,7 +518,7 @@ class AIREngine:
         # Recurrent product + gate math in ONE launch per step while the chain is latency bound (it is the only truly
         # sequential part of the step); at large batch the 32x32-tile GEMM + a pointwise pass re-reads less (measured:
         # B=1024 0.938 vs 0.954 ms/step), so the pair is kept there.
-        fuse_lstm = ((B + 15) // 16) * ((Hd + 15) // 16) <= 512
+        fuse_lstm = ((B + 15) // 16) * ((Hd + 15) // 16) <= int(os.environ.get("AIR_FUSE_LSTM_TILES", "512"))
         if not fuse_lstm:
             self.gates = self._buf("gates", (T, B, 4 * Hd))
         for t in range(T):                                                                  # cell.py:126-127
@@ -529,7 +542,7 @@ class AIREngine:
         # "attend" fusion: output layers of the transform / steps MLPs + where sampling + presence / num-steps + the glimpse
         # read in ONE launch (three dependent launches otherwise).  Needs a 16-byte addressable image that fits the
         # register-prefetch staging, and (backward) one workgroup per glimpse.
-        fuse_attend = (P % 4 == 0) and (P // 4 <= 3 * 1024) and T <= 28 and M <= 2048
+        fuse_attend = (P % 4 == 0) and (P // 4 <= 3 * 1024) and T <= 28 and M <= int(os.environ.get("AIR_FUSE_ATTEND_M", str(1 << 30)))
         if fuse_attend:
             for i in range(max(self.tr.n, self.st.n) - 1):
                 launch(fwd, [fwd_desc(m, i, h_all, Hd) for m in (self.tr, self.st) if i < m.n - 1])
@@ -689,6 +702,20 @@ class AIREngine:
                            desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)]          # dc0
         mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail,
                       extra_last=lstm_dw)
+
+        if deferred_dw:
+            # wide-tile eligible problems (16-byte loads along M and N: both multiples of 4, aligned) together, longest K first
+            # so that the heaviest tiles start first; the rest (M = 50 / 677 / 1, N = 1) in a launch of the ordinary kernel
+            def wide_ok(d):
+                return (d.M % 4 == 0 and d.N % 4 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.K % 4 == 0
+                        and d.A % 16 == 0 and d.B % 16 == 0)
+            wide = sorted((d for d in deferred_dw if wide_ok(d)), key=lambda d: (-d.K, -d.M * d.N))
+            rest = [d for d in deferred_dw if not wide_ok(d)]
+            for grp in [wide[i:i + 8] for i in range(0, len(wide), 8)] + [rest[i:i + 8] for i in range(0, len(rest), 8)]:
+                arr = (_lib.AirGemmDesc * len(grp))(*grp)
+                self._keep.append(arr)
+                bwd.append((L.air_gemm_grouped, (arr, len(grp)), "air_gemm_grouped"))
+            marks = []                            # no gradient slice is final before the end of the backward
 
         # ---- optimiser: both centred-RMSProp updates + device counters in one launch ---------------------------------
         tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0

@@ -248,14 +248,26 @@ def test_bf16_graph_train_step_runs_and_learns(gpu_device):
     assert np.isfinite(last) and last < first - 50.0, (first, last)
 
 
-def test_large_batch_plan_matches_oracle(gpu_device):
-    """B = 704 (T*B = 2112 > 2048 glimpses, 44 x 16 LSTM tiles > 512): the plan switches to its throughput variants -- separate
-    heads / glimpse-read launches instead of the fused attend kernels, GEMM + pointwise LSTM steps, 32x32 GEMM tiles, long-K
-    weight gradients in their own launches.  Same parity bar as the latency-regime plan."""
+@pytest.mark.parametrize("variant", ["throughput", "unfused"])
+def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
+    """B = 704 (T*B = 2112 rows, 44 x 16 LSTM tiles > 512): the plan switches to its throughput variants -- GEMM + pointwise
+    LSTM steps, wide-tile GEMM kernels, and every weight gradient deferred to a few all-TN launches at the end of the backward.
+    "unfused" additionally forces the separate heads / glimpse-read launches (the path taken when the image is not 16-byte
+    addressable or too large for the attend kernels' staging) and the in-chain weight gradients.  Same parity bar as the
+    latency-regime plan."""
+    if variant == "unfused":
+        monkeypatch.setenv("AIR_FUSE_ATTEND_M", "0")
+        monkeypatch.setenv("AIR_DEFER_DW_MIN_ROWS", "100000000")
     ocfg, B = O.AIRConfig(), 704
     eng, params, obs, noise = make_pair(ocfg, B)
     names = [n for _, _, n in eng._plan_fwd_train + eng._plan_bwd]
-    assert "air_attend_fwd" not in names and "air_heads_fwd" in names and "air_lstm_pointwise_fwd" in names
+    assert "air_lstm_pointwise_fwd" in names
+    if variant == "unfused":
+        assert "air_attend_fwd" not in names and "air_heads_fwd" in names and not eng._defer_dw
+    else:
+        assert "air_attend_fwd" in names and eng._defer_dw
+        tail = [a[0] for _, a, n in eng._plan_bwd[-3:] if n == "air_gemm_grouped"]
+        assert tail and all(d.ta and not d.tb for arr in tail for d in arr)          # the deferred weight-gradient launches
     eng.forward(sample_noise=False)
     eng.backward()
     out = eng.outputs()

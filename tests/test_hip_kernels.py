@@ -557,3 +557,48 @@ def test_gemm_k_split_consumer_prologue(hip, prec):
     hip.gemm_grouped([dict(A=x[:, :kh], B=w0[:kh], out=c, beta=1.0, bias=b0, epilogue=hip.EPI_BIAS)], precision=prec)
     full = r(x) @ r(w0) + b0.double()
     assert ((c.double() - full).abs().max() / full.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("layout", ["NN", "NT", "TN"])
+def test_gemm_wide_tiles(hip, precision, layout):
+    """Throughput-regime groups with ONE operand layout take the wide-tile kernels (interleaved 16-byte loads, gemm_wide_body):
+    single and grouped launches, every epilogue, beta, colsum, ragged M / N (N % 64 != 0, M % 16 != 0), K with a 4-deep tail
+    (2500) and K < 16, row views with a leading dimension."""
+    gen = torch.Generator().manual_seed(11 + precision + len(layout) * ord(layout[0]))
+    r = (lambda t: t.cpu().to(torch.bfloat16).double()) if precision else (lambda t: t.cpu().double())
+    rn = lambda *s: torch.randn(*s, generator=gen).cuda()
+    atol = 2e-3
+    if layout == "NN":
+        x = rn(3000, 256); w = rn(256, 400) / 16; b = rn(400); aux = rn(3000, 400)
+        x2big = rn(1024, 2500 + 12); x2 = x2big[:, 8:8 + 2500]; w2 = rn(2500, 256) / 50; c0 = rn(1024, 256)
+        x3 = rn(2048, 12); w3 = rn(12, 100)
+        outs = hip.gemm_grouped([dict(A=x, B=w, bias=b, epilogue=hip.EPI_BIAS_ELU)], precision=precision)
+        assert_close(outs[0][0], torch.nn.functional.elu(r(x) @ r(w) + b.cpu().double()), 1e-5, atol, "single bias+elu")
+        outs = hip.gemm_grouped([
+            dict(A=x, B=w, bias=b, aux=aux, epilogue=hip.EPI_ADD_AUX_ELU),
+            dict(A=x2, B=w2, beta=1.0, out=c0.clone()),
+            dict(A=x3, B=w3),
+        ], precision=precision)
+        assert_close(outs[0][0], torch.nn.functional.elu(r(x) @ r(w) + b.cpu().double() + aux.cpu().double()), 1e-5, atol, "add aux elu")
+        assert_close(outs[1][0], r(x2) @ r(w2) + c0.cpu().double(), 1e-5, atol, "K tail + beta + view")
+        assert_close(outs[2][0], r(x3) @ r(w3), 1e-5, atol, "K < 16")
+    elif layout == "NT":
+        g = rn(3000, 400); w = rn(1024, 400) / 16; y = rn(3000, 1024)
+        g2 = rn(1024, 1024); w2 = rn(256, 1024) / 32; c0 = rn(1024, 256)
+        outs = hip.gemm_grouped([dict(A=g2, B=w2, tb=True, beta=1.0, out=c0.clone())], precision=precision)
+        assert_close(outs[0][0], r(g2) @ r(w2).t() + c0.cpu().double(), 1e-5, atol, "single beta")
+        outs = hip.gemm_grouped([dict(A=g, B=w, tb=True, epilogue=hip.EPI_MUL_DELU, aux=y),
+                                 dict(A=g2, B=w2, tb=True)], precision=precision)
+        d = torch.where(y.cpu() > 0, torch.ones_like(y.cpu()), y.cpu() + 1).double()
+        assert_close(outs[0][0], (r(g) @ r(w).t()) * d, 1e-5, atol, "mul delu")
+        assert_close(outs[1][0], r(g2) @ r(w2).t(), 1e-5, atol, "plain")
+    else:
+        x = rn(3072, 2500); g = rn(3072, 256); x2 = rn(1024, 260); g2 = rn(1024, 1024)
+        outs = hip.gemm_grouped([dict(A=x, B=g, ta=True, colsum=True)], precision=precision)
+        assert_close(outs[0][0], r(x).t() @ r(g), 1e-5, atol * 10, "single dW")
+        assert_close(outs[0][1], g.cpu().double().sum(0), 1e-5, 1e-3, "single db")
+        outs = hip.gemm_grouped([dict(A=x, B=g, ta=True, colsum=True), dict(A=x2, B=g2, ta=True, colsum=True)], precision=precision)
+        assert_close(outs[0][0], r(x).t() @ r(g), 1e-5, atol * 10, "dW")
+        assert_close(outs[1][0], r(x2).t() @ r(g2), 1e-5, atol * 10, "dW ragged M")
+        assert_close(outs[1][1], g2.cpu().double().sum(0), 1e-5, 1e-3, "db")

@@ -2,6 +2,8 @@
 """Summarise a rocprofv3 (ROCm 7 rocpd SQLite) kernel trace: per-kernel calls / total / avg / min / max / share.
 
 usage: python tools/rocpd_summary.py <results.db> [--steps N]  > profiles/<name>.txt
+       python tools/rocpd_summary.py <results.db> --by-position <last kernel of a step>   > profiles/<name>_positions.txt
+         per position inside the replayed step: mean duration and mean gap to the previous kernel's end (the boundary cost)
 """
 import re
 import sqlite3
@@ -14,8 +16,42 @@ def short(name):
     return name[:70]
 
 
+def by_position(db, last):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = sorted(cur.execute(f"select {name_col}, start, end from kernels").fetchall(), key=lambda r: r[1])
+    names = [short(r[0]) for r in rows]
+    ends = [i for i, n in enumerate(names) if n.startswith(last)]
+    # periods between consecutive occurrences of the step's last kernel; keep the most common length (the graph replays)
+    periods = [(a + 1, b + 1) for a, b in zip(ends[:-1], ends[1:])]
+    lens = {}
+    for a, b in periods:
+        lens[b - a] = lens.get(b - a, 0) + 1
+    P = max(lens, key=lens.get)
+    periods = [(a, b) for a, b in periods if b - a == P]
+    ref = names[periods[-1][0]:periods[-1][1]]
+    periods = [(a, b) for a, b in periods if names[a:b] == ref]
+    dur = [0.0] * P; gap = [0.0] * P; mx = [0.0] * P
+    for a, b in periods:
+        for k in range(P):
+            d = rows[a + k][2] - rows[a + k][1]
+            dur[k] += d; mx[k] = max(mx[k], d)
+            gap[k] += rows[a + k][1] - rows[a + k - 1][2]
+    n = len(periods)
+    span = sum(rows[b - 1][2] - rows[a - 1][2] for a, b in periods) / n
+    print(f"# {db}: {n} identical replays of a {P}-kernel step; mean step span {span / 1e3:.1f} us, "
+          f"kernel time {sum(dur) / n / 1e3:.1f} us, gaps {sum(gap) / n / 1e3:.1f} us")
+    print(f"{'pos':>3s} {'kernel':60s} {'avg_us':>8s} {'max_us':>8s} {'gap_us':>8s}")
+    for k in range(P):
+        print(f"{k:3d} {ref[k][:60]:60s} {dur[k] / n / 1e3:8.2f} {mx[k] / 1e3:8.2f} {gap[k] / n / 1e3:8.2f}")
+
+
 def main():
     db = sys.argv[1]
+    if "--by-position" in sys.argv:
+        return by_position(db, sys.argv[sys.argv.index("--by-position") + 1])
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     con = sqlite3.connect(db)
     cur = con.cursor()
