@@ -761,7 +761,7 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     // throughput regime: the wide-tile kernels (every operand load 16 bytes per lane) when the whole group has one operand
     // layout and every problem meets the alignment the interleaved loads need
     {
-        static const long wide_min = getenv("AIR_GEMM_WIDE_MIN_TILES") ? atol(getenv("AIR_GEMM_WIDE_MIN_TILES")) : 1536;
+        static const long wide_min = getenv("AIR_GEMM_WIDE_MIN_TILES") ? atol(getenv("AIR_GEMM_WIDE_MIN_TILES")) : 1000;
         static const long wide_tn_bf = getenv("AIR_GEMM_WIDE_TN_BF16") ? atol(getenv("AIR_GEMM_WIDE_TN_BF16")) : 48;
         static const long wide_tn_f32 = getenv("AIR_GEMM_WIDE_TN_F32") ? atol(getenv("AIR_GEMM_WIDE_TN_F32")) : 48;
         static const long wide_nt_k = getenv("AIR_GEMM_WIDE_NT_K") ? atol(getenv("AIR_GEMM_WIDE_NT_K")) : 512;

@@ -348,9 +348,10 @@ class AIREngine:
         # formed at the end of the backward in a few launches of their own -- nothing but the optimiser consumes them, and a
         # launch that holds ALL of them has hundreds of 64x64 tiles: enough to fill the chip with the wide-tile kernel (16-byte
         # operand loads, 8 waves split K inside the workgroup) instead of ~11 launches of 16x16 tiles with 16-way K splits.
-        defer_dw = M >= int(os.environ.get("AIR_DEFER_DW_MIN_ROWS", "1536"))
+        defer_dw = M >= int(os.environ.get("AIR_DEFER_DW_MIN_ROWS", "768"))
         deferred_dw = []
         self._defer_dw = defer_dw
+        throughput = defer_dw
 
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
@@ -360,7 +361,17 @@ class AIREngine:
                 if not descs:
                     return
             tiles16 = sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in descs)
-            if len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256:
+
+            def wide_ok(d):       # what air_gemm_grouped's wide-tile kernels need of a problem (gemm_kernels.hip)
+                return (not (d.ta and d.tb) and not d.A2 and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0
+                        and d.ldb % 4 == 0 and d.K % 4 == 0 and d.M >= 4 and d.N >= 4 and (not d.ta or d.M % 4 == 0)
+                        and (d.tb or d.N % 4 == 0))
+            if throughput and len(descs) > 1 and any(wide_ok(d) for d in descs) and not all(wide_ok(d) for d in descs):
+                # one odd problem (N = 1, K = 50 ...) would keep the whole group off the wide-tile kernels: it gets its own launch
+                launch(plan, [d for d in descs if wide_ok(d)])
+                launch(plan, [d for d in descs if not wide_ok(d)])
+                return
+            if len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256 and not (throughput and wide_ok(descs[0])):
                 d = descs[0]
                 plan.append((L.air_gemm_bf16 if prec else L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
                                           d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, wsp, wsb), "air_gemm"))
