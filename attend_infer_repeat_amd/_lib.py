@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 3  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 4  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -21,6 +21,13 @@ class AirGemmDesc(ctypes.Structure):
                 ("bias", c_void_p), ("epilogue", c_int), ("aux", c_void_p), ("ldaux", c_int), ("beta", c_float),
                 ("colsum", c_void_p), ("precision", c_int),
                 ("A2", c_void_p), ("a_bias", c_void_p), ("a_elu", c_int), ("a_out", c_void_p)]
+
+
+class AirRmspropSlice(ctypes.Structure):
+    """mirror of `struct AirRmspropSlice` (include/air_hip.h)"""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("ms", c_void_p), ("mg", c_void_p), ("mom", c_void_p),
+                ("lo", c_size_t), ("hi", c_size_t), ("n_model", c_size_t), ("lr_dev", c_void_p),
+                ("lr_mult_tail", c_float), ("decay", c_float), ("momentum", c_float), ("eps", c_float), ("grad_scale", c_float)]
 
 
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
@@ -67,6 +74,8 @@ SIGNATURES = {
                                            P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P]),
     "air_lstm_step_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "air_lstm_step_bwd_opt": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
+    "air_lstm_pointwise_bwd_opt": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_gauss_sample_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,

@@ -15,6 +15,7 @@
 // hidden sizes 5/7/11/13/17).
 #include "air_common.h"
 #include "prologue_device.h"
+#include "optimizer_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // explicit global address space: descriptors that travel through memory (grouped launch) would otherwise make every
@@ -777,7 +778,7 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
             tiles64 += (long)air_cdiv(d.M, 64) * air_cdiv(d.N, 64);
             if (d.K < min_k) min_k = d.K;
         }
-        if (ok && ta) ok = tiles64 >= (bf ? wide_tn_bf : wide_tn_f32);
+        if (ok && ta) ok = tiles64 >= (bf ? wide_tn_bf : wide_tn_f32) && min_k >= 256;     // (K = rows: short at small batch)
         if (ok && !ta && tb) ok = min_k >= wide_nt_k;
         if (ok) {
             const int TMw = ta ? 64 : 16;
@@ -953,12 +954,20 @@ struct LstmBwdArgs {
 // dh[m,u] = sum_k dgates_{t+1}[m,k] W_h[u,k]  (+ the direct dh terms of step t), then the pointwise backward of step t for
 // that (m,u): dgates_t (4 values), dc_{t-1}, and the running sum over time of dgates (what x.W_x receives) -- all
 // element-wise in (m,u), so the 16x16 output tile finishes everything it owns
+// (opt: an optimiser slice on the workgroups past the tiles -- a separate kernel argument, untouched by the tile workgroups)
 template <int KW, bool BF>
-__global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g) {
+__global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g, RmspropSlice opt) {
     constexpr int LDT = 20;
     __shared__ float s_tile[KW][16 * LDT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int tiles_n = (g.Hd + 15) >> 4;
+    {
+        const int tiles = ((g.M + 15) >> 4) * tiles_n;
+        if ((int)blockIdx.x >= tiles) {
+            rmsprop_slice_body(opt, (int)blockIdx.x - tiles, (int)gridDim.x - tiles);
+            return;
+        }
+    }
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int m0 = tm * 16, n0 = tn * 16;
     const int rowA = m0 + li, colB = n0 + li;
@@ -1070,11 +1079,14 @@ extern "C" int air_lstm_step_fwd_prologue(const float *h0, const float *c0, cons
 }
 
 template <bool BF>
-static int lstm_bwd_launch(const LstmBwdArgs &g, hipStream_t st) {
+static int lstm_bwd_launch(const LstmBwdArgs &g, const RmspropSlice &opt, size_t opt_nq, hipStream_t st) {
     const int tiles = air_cdiv(g.M, 16) * air_cdiv(g.Hd, 16);
     // few tiles (batch 64: 64 of them): 16 waves share the 4Hd-deep contraction of a tile; many tiles: 4 waves
-    if (tiles <= 512) hipLaunchKernelGGL((lstm_bwd_fused_kernel<16, BF>), dim3(tiles), dim3(1024), 0, st, g);
-    else hipLaunchKernelGGL((lstm_bwd_fused_kernel<4, BF>), dim3(tiles), dim3(256), 0, st, g);
+    const int nth = tiles <= 512 ? 1024 : 256;
+    size_t extra = (opt_nq + 2 * nth - 1) / (2 * nth);                     // about two float4 per thread of the riding slice
+    if (extra > 512) extra = 512;
+    if (tiles <= 512) hipLaunchKernelGGL((lstm_bwd_fused_kernel<16, BF>), dim3(tiles + (int)extra), dim3(1024), 0, st, g, opt);
+    else hipLaunchKernelGGL((lstm_bwd_fused_kernel<4, BF>), dim3(tiles + (int)extra), dim3(256), 0, st, g, opt);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -1082,6 +1094,15 @@ extern "C" int air_lstm_step_bwd(const float *dgates_next, const float *w_h, con
                                  const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                                  const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd,
                                  int precision, void *stream) {
+    return air_lstm_step_bwd_opt(dgates_next, w_h, dh_a, dh_b, dc_in, gate_act, c_prev, c, dgx_in, dgates, dc_prev, dgx_out, M,
+                                 Hd, precision, nullptr, stream);
+}
+extern "C" int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
+                                     const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
+                                     const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd,
+                                     int precision, const AirRmspropSlice *opt, void *stream) {
+    RmspropSlice os; size_t onq;
+    { int st_ = rmsprop_slice_from_abi(opt, os, &onq); if (st_) return st_; }
     AIR_REQUIRE(dgates_next && w_h && gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
     AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
@@ -1091,8 +1112,8 @@ extern "C" int air_lstm_step_bwd(const float *dgates_next, const float *w_h, con
     g.M = M; g.Hd = Hd;
     g.vecA = air_aligned16(dgates_next) ? 1 : 0;          // row stride 4*Hd floats is always a multiple of 16 bytes
     g.vecB = air_aligned16(w_h) ? 1 : 0;
-    return precision == AIR_PREC_BF16 ? lstm_bwd_launch<true>(g, air_stream(stream))
-                                      : lstm_bwd_launch<false>(g, air_stream(stream));
+    return precision == AIR_PREC_BF16 ? lstm_bwd_launch<true>(g, os, onq, air_stream(stream))
+                                      : lstm_bwd_launch<false>(g, os, onq, air_stream(stream));
 }
 
 // ---- linear layer wrappers (neural.py:56-60) ------------------------------------------------------------------

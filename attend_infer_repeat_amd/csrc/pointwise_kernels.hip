@@ -4,6 +4,7 @@
 #include <math.h>
 #include "air_common.h"
 
+#include "optimizer_device.h"
 #define PW_THREADS 256
 static inline int pw_blocks(size_t n) {
     size_t b = (n + PW_THREADS - 1) / PW_THREADS;
@@ -35,16 +36,13 @@ __global__ __launch_bounds__(PW_THREADS) void lstm_pw_fwd_kernel(const float *__
         }
     }
 }
-__global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__restrict__ gate_act,
-                                                                 const float *__restrict__ c_prev,
-                                                                 const float *__restrict__ c,
-                                                                 const float *__restrict__ dh,
-                                                                 const float *__restrict__ dh2,
-                                                                 const float *__restrict__ dc_in,
-                                                                 float *__restrict__ dgates,
-                                                                 float *__restrict__ dc_prev, int M, int Hd) {
+__device__ __forceinline__ void lstm_pw_bwd_body(const float *__restrict__ gate_act, const float *__restrict__ c_prev,
+                                                 const float *__restrict__ c, const float *__restrict__ dh,
+                                                 const float *__restrict__ dh2, const float *__restrict__ dc_in,
+                                                 float *__restrict__ dgates, float *__restrict__ dc_prev, int M, int Hd,
+                                                 int vblock, int vgrid) {
     const size_t n = (size_t)M * Hd;
-    PW_LOOP(e, n) {
+    for (size_t e = (size_t)vblock * PW_THREADS + threadIdx.x; e < n; e += (size_t)vgrid * PW_THREADS) {
         const size_t m = e / Hd, u = e - m * Hd;
         const float *ar = gate_act + m * 4 * (size_t)Hd;
         const float gi = ar[u], gj = ar[Hd + u], gf = ar[2 * (size_t)Hd + u], go = ar[3 * (size_t)Hd + u];
@@ -58,6 +56,32 @@ __global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__
         dr[3 * (size_t)Hd + u] = dhe * tc * go * (1.f - go);
         dc_prev[e] = dct * gf;
     }
+}
+__global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__restrict__ gate_act,
+                                                                 const float *__restrict__ c_prev,
+                                                                 const float *__restrict__ c,
+                                                                 const float *__restrict__ dh,
+                                                                 const float *__restrict__ dh2,
+                                                                 const float *__restrict__ dc_in,
+                                                                 float *__restrict__ dgates,
+                                                                 float *__restrict__ dc_prev, int M, int Hd) {
+    lstm_pw_bwd_body(gate_act, c_prev, c, dh, dh2, dc_in, dgates, dc_prev, M, Hd, blockIdx.x, gridDim.x);
+}
+// the same with an optimiser slice on workgroups [main_blocks, gridDim.x)
+__global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_opt_kernel(const float *__restrict__ gate_act,
+                                                                     const float *__restrict__ c_prev,
+                                                                     const float *__restrict__ c,
+                                                                     const float *__restrict__ dh,
+                                                                     const float *__restrict__ dh2,
+                                                                     const float *__restrict__ dc_in,
+                                                                     float *__restrict__ dgates,
+                                                                     float *__restrict__ dc_prev, int M, int Hd,
+                                                                     int main_blocks, RmspropSlice opt) {
+    if ((int)blockIdx.x >= main_blocks) {
+        rmsprop_slice_body(opt, (int)blockIdx.x - main_blocks, (int)gridDim.x - main_blocks);
+        return;
+    }
+    lstm_pw_bwd_body(gate_act, c_prev, c, dh, dh2, dc_in, dgates, dc_prev, M, Hd, blockIdx.x, main_blocks);
 }
 extern "C" int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, float *c, float *gate_act,
                                       int M, int Hd, float forget_bias, void *stream) {
@@ -76,6 +100,24 @@ extern "C" int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev
     AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
     hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(pw_blocks((size_t)M * Hd)), dim3(PW_THREADS), 0, air_stream(stream),
                        gate_act, c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const float *c, const float *dh,
+                                          const float *dh2, const float *dc, float *dgates, float *dc_prev, int M, int Hd,
+                                          const AirRmspropSlice *opt, void *stream) {
+    RmspropSlice s; size_t nq;
+    int st = rmsprop_slice_from_abi(opt, s, &nq);
+    if (st) return st;
+    if (nq == 0) return air_lstm_pointwise_bwd(gate_act, c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd, stream);
+    AIR_REQUIRE(gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
+    AIR_REQUIRE(dh || dc, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
+    const int main_blocks = pw_blocks((size_t)M * Hd);
+    size_t extra = (nq + 2 * PW_THREADS - 1) / (2 * PW_THREADS);           // about two float4 per thread
+    if (extra > 768) extra = 768;
+    hipLaunchKernelGGL(lstm_pw_bwd_opt_kernel, dim3(main_blocks + (int)extra), dim3(PW_THREADS), 0, air_stream(stream), gate_act,
+                       c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd, main_blocks, s);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -416,15 +458,6 @@ extern "C" int air_step_prologue(float *normal, size_t n_normal, float *uniform,
 
 // epilogue: both centred-RMSProp updates (model segment [0, n_model) at lr, baseline segment at lr * lr_mult_tail) in
 //           one pass over the flat buffers, then the device counters (global step, Philox offset) advance.
-__device__ __forceinline__ void rmsprop_elem(float &p, float gi_raw, float &ms, float &mg, float &mom, float lr, float decay,
-                                             float momentum, float eps, float gscale) {
-    const float gi = gi_raw * gscale;
-    const float msi = decay * ms + (1.f - decay) * gi * gi;
-    const float mgi = decay * mg + (1.f - decay) * gi;
-    const float mo = momentum * mom + lr * gi / sqrtf(msi - mgi * mgi + eps);
-    ms = msi; mg = mgi; mom = mo;
-    p -= mo;
-}
 // 16-byte accesses: the pass moves 9 x 4 B per parameter (94 MB at the 50x50 configuration) and is bound by memory-pipe
 // instructions, not arithmetic; the segment boundary n_model and every tensor start are multiples of 4 floats by construction
 // of the flat layout, so one learning rate applies to a whole float4.  VEC = false covers unaligned / odd-sized buffers.

@@ -681,22 +681,24 @@ class AIREngine:
         gw = self.grads["lstm/w_gates"]
         dc_in, dc_out = None, self.dc_a
         dgx = self.dgx if T > 1 else self.dgates[0]            # sum over time of dgates (what the hoisted x.W_x receives)
+        rider_hosts = []                    # (index in bwd, entry with an optimiser slice): see _plan_bwd_riders below
         for t in reversed(range(T)):
             if t == T - 1 or not fuse_lstm:
-                bwd.append((L.air_lstm_pointwise_bwd, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
-                                                       p(self.dH[t]), p(self.dH_b[t]),
-                                                       p(dc_in) if dc_in is not None else None,
-                                                       p(self.dgates[t]), p(dc_out), B, Hd), "air_lstm_pointwise_bwd"))
+                pw_args = (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]), p(self.dH[t]), p(self.dH_b[t]),
+                           p(dc_in) if dc_in is not None else None, p(self.dgates[t]), p(dc_out), B, Hd)
+                if fuse_lstm:
+                    rider_hosts.append((len(bwd), L.air_lstm_pointwise_bwd_opt, pw_args, "air_lstm_pointwise_bwd_opt"))
+                bwd.append((L.air_lstm_pointwise_bwd, pw_args, "air_lstm_pointwise_bwd"))
                 if not fuse_lstm and t > 0:    # dgates_t . W_h^T accumulates into dH[t-1] (beta = 1)
                     launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, self.dH[t - 1], Hd,
                                       beta=1.0)])
             else:
                 # one BPTT link per launch: dgates_{t+1}.W_h^T + direct dh terms -> gate backward of step t -> running dgx
-                bwd.append((L.air_lstm_step_bwd, (p(self.dgates[t + 1]), p(w_h), p(self.dH[t]), p(self.dH_b[t]), p(dc_in),
-                                                  p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
-                                                  p(self.dgates[T - 1]) if t == T - 2 else p(self.dgx),
-                                                  p(self.dgates[t]), p(dc_out), p(self.dgx), B, Hd, prec),
-                            "air_lstm_step_bwd"))
+                link_args = (p(self.dgates[t + 1]), p(w_h), p(self.dH[t]), p(self.dH_b[t]), p(dc_in), p(self.gate_act[t]),
+                             p(self.c_seq[t]), p(self.c_seq[t + 1]), p(self.dgates[T - 1]) if t == T - 2 else p(self.dgx),
+                             p(self.dgates[t]), p(dc_out), p(self.dgx), B, Hd, prec)
+                rider_hosts.append((len(bwd), L.air_lstm_step_bwd_opt, link_args, "air_lstm_step_bwd_opt"))
+                bwd.append((L.air_lstm_step_bwd, link_args, "air_lstm_step_bwd"))
             dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
         if not fuse_lstm and T > 1:
             bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
@@ -764,6 +766,31 @@ class AIREngine:
             self._grad_buckets.append((idx, lo, hi)); hi = lo
         self._grad_buckets.append((len(bwd), 0, hi))
         self._plan_opt = self._opt_calls_factory(1.0)
+        # Single-GPU train step in the latency regime: the centred-RMSProp update of everything whose gradient is final before
+        # the BPTT chain (all but the input encoder and the LSTM: half of the 94 MB the update streams) rides as extra
+        # workgroups of the BPTT launches -- 64 tiles each, three quarters of the chip idle -- and the closing launch only
+        # updates the head of the buffer.  backward() / data-parallel steps (update after the all-reduce) keep the plain plans.
+        self._plan_bwd_riders = self._plan_opt_rest = None
+        if rider_hosts and marks and not self._defer_dw and os.environ.get("AIR_OPT_RIDERS", "1") == "1":
+            r_lo, r_hi = self.param_offsets[marks[-1][1]], self.n_total
+            if r_lo % 4 == 0 and r_hi % 4 == 0 and self.n_model % 4 == 0 and r_lo > 0 and r_hi > r_lo:
+                nh = len(rider_hosts)
+                cuts = [r_lo + ((r_hi - r_lo) * i // nh) // 4 * 4 for i in range(nh)] + [r_hi]
+                riders = list(bwd)
+                self._rider_slices = []
+                for (idx, fn, args, name), lo, hi in zip(rider_hosts, cuts[:-1], cuts[1:]):
+                    sl = _lib.AirRmspropSlice(dp(self.flat_params), dp(self.flat_grads), dp(self.flat_ms), dp(self.flat_mg),
+                                              dp(self.flat_mom), lo, hi, self.n_model, dp(self.lr_dev), tail_mult,
+                                              cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0)
+                    self._rider_slices.append(sl)
+                    riders[idx] = (fn, args + (ctypes.byref(sl),), name)
+                self._plan_bwd_riders = riders
+                self._plan_opt_rest = [
+                    (L.air_step_epilogue, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
+                                           p(self.flat_mom), ctypes.c_size_t(min(self.n_model, r_lo)), ctypes.c_size_t(r_lo),
+                                           p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0,
+                                           p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
+                     "air_step_epilogue")]
 
     def _run(self, plan, stream_ptr):
         for fn, args, name in plan:
@@ -897,7 +924,10 @@ class AIREngine:
             self._graph = self._capture_plans(plans)
             self._graph_has_opt = True
             return
-        self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
+        if not split_optimizer and self._plan_bwd_riders is not None and self.world_size == 1:
+            self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest])
+        else:
+            self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
         self._graph_has_opt = not split_optimizer
         if split_optimizer:
             self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
@@ -929,6 +959,11 @@ class AIREngine:
                 _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
         else:
             self._run(self._plan_fwd_train, sp)
+            if allreduce is None and self.world_size == 1 and self._plan_bwd_riders is not None:
+                self._run(self._plan_bwd_riders, sp)
+                self._run(self._plan_opt_rest, sp)
+                self.global_step += 1
+                return
             self._run(self._plan_bwd, sp)
             if allreduce is not None:
                 with torch.cuda.stream(self.stream):

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 3
+#define AIR_ABI_VERSION 4
 
 enum {
     AIR_OK = 0,
@@ -190,6 +190,24 @@ int air_lstm_step_bwd(const float *dgates_next, const float *w_h, const float *d
                       const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                       const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
                       void *stream);
+/* A slice [lo, hi) of the flat parameter / gradient / optimiser-state buffers to be updated by centred RMSProp (exactly
+ * air_step_epilogue's arithmetic; elements >= n_model use lr * lr_mult_tail).  lo, hi, n_model multiples of 4, buffers 16-byte
+ * aligned.  The *_opt entries below run the update as EXTRA workgroups of a backward launch that leaves most of the chip idle:
+ * the caller guarantees that the slice's gradients are final and that no later launch of the backward reads its parameters.  */
+typedef struct AirRmspropSlice {
+    float *p; const float *g; float *ms, *mg, *mom;
+    size_t lo, hi, n_model;
+    const float *lr_dev;
+    float lr_mult_tail, decay, momentum, eps, grad_scale;
+} AirRmspropSlice;
+/* air_lstm_step_bwd / air_lstm_pointwise_bwd with an optimiser slice riding along (opt == NULL or lo == hi: none).          */
+int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
+                          const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
+                          const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
+                          const AirRmspropSlice *opt, void *stream);
+int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
+                               const float *dc, float *dgates, float *dc_prev, int M, int Hd, const AirRmspropSlice *opt,
+                               void *stream);
 
 /* ---- stochastic nodes ---------------------------------------------------------------------------------------*/
 

@@ -350,6 +350,29 @@ def test_graph_replay_equals_eager(gpu_device):
     assert torch.equal(eng_b.flat_params, eng_a.flat_params)
 
 
+@pytest.mark.parametrize("name", ["mnist_b8", "tiny"])
+def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
+    """Single-GPU latency-regime steps update every parameter whose gradient is final before the BPTT chain from extra
+    workgroups of the BPTT launches (air_lstm_pointwise_bwd_opt / air_lstm_step_bwd_opt) and only the head of the flat buffer
+    in the closing launch: bit-identical parameters and RMSProp slots to the single closing air_step_epilogue."""
+    ocfg, B = CONFIGS[name]
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_a._plan_bwd_riders is not None and any(n.endswith("_opt") for _, _, n in eng_a._plan_bwd_riders)
+    covered = sorted((s.lo, s.hi) for s in eng_a._rider_slices)
+    assert covered[-1][1] == eng_a.n_total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert eng_a._plan_opt_rest[0][1][6].value == covered[0][0]           # the closing launch ends where the riders start
+    monkeypatch.setenv("AIR_OPT_RIDERS", "0")
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_b._plan_bwd_riders is None
+    eng_a.capture(); eng_b.capture()
+    for _ in range(3):
+        eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
+
+
 def test_noise_changes_every_step_and_prior_anneals(gpu_device):
     ocfg, B = CONFIGS["tiny"]
     eng, *_ = make_pair(ocfg, B, gstep=0)
