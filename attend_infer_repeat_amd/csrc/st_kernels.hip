@@ -24,7 +24,9 @@
 // Developer tracing (tools/kbench/st_trace.cpp builds this file with -DAIR_TRACE): thread 0 of every workgroup stamps the
 // chip-wide 100 MHz counter at the marked phase boundaries.  Compiles to nothing in the product build.
 #ifdef AIR_TRACE
+#ifndef AIR_TRACE_BLOCKS
 #define AIR_TRACE_BLOCKS 512
+#endif
 #define AIR_TRACE_PHASES 8
 __device__ unsigned long long air_trace[AIR_TRACE_BLOCKS * AIR_TRACE_PHASES];
 // stamps go to LDS (a global store in front of a barrier would add its own latency to the phase being measured) and are
@@ -549,8 +551,11 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     // optional second role: the LAST workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
     // has to precede the baseline / logit backward that follow this launch)
     AIR_TR_INIT();
+    // the NVIL workgroup is the FIRST of the grid (a long float64 chain: at the end of a grid that fills the chip it would only
+    // start when the first glimpse workgroups retire)
     const int grid_st = nv.imp ? (int)gridDim.x - 1 : (int)gridDim.x;
-    if ((int)blockIdx.x >= grid_st) {
+    const int bid0 = nv.imp ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (bid0 < 0) {
         AIR_TR(5);
         nvil_body(nv);
         AIR_TR(6);
@@ -564,9 +569,9 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
     const float coef = loss_scale * mult / (std * std);
     const int n = T * B;
-    for (int k = blockIdx.x; k < n; k += grid_st) {
+    for (int k = bid0; k < n; k += grid_st) {
         const int b = k % B;
-        if (k != (int)blockIdx.x) __syncthreads();           // grid-stride reuse of the LDS carve
+        if (k != bid0) __syncthreads();                      // grid-stride reuse of the LDS carve
         // ---- every global load of the unit is requested first; the axis tables (which only need `where`, the oldest
         //      request) are built while the rest is still in flight, then the staged operands are written to LDS
         const int z0 = opaque_zero();                          // vector-path loads of the wave-uniform operands (see opaque_zero)
@@ -980,6 +985,7 @@ struct AttendFwdArgs {
     float *prob, *pres, *q, *kl_ps, *logp, *step_w;
     const float *img; float *glimpse;
     int T, B, H, W, h, w, bf16;
+    int img_major;      // role A: one workgroup per IMAGE runs its T glimpses (the image is staged once) instead of one per glimpse
     double stepx, stepy;
 };
 // operand of a dense product: as is, or rounded to bf16 (EngineConfig.mfma_dtype = "bf16": same arithmetic as the MFMA path)
@@ -990,20 +996,26 @@ __device__ __forceinline__ float opnd(float v, int bf16) { return bf16 ? (float)
 // prefetches its image into registers, wave 0 forms the 8 outputs of the transform layer for row t*B+b (one memory round trip,
 // wave_reduce8) and samples `where`, which reaches the other waves through LDS behind the ONE barrier of the kernel; the
 // glimpse pixels then compute their own axis entries (no table phase) and gather four taps from the LDS-staged image.
+// (5 waves per SIMD: with 4 -- 104 VGPRs -- a batch of 1024 fills every slot of the chip with role-A workgroups and the last
+//  few dozen only start when the first retire: two rounds instead of one)
 template <int MT, int NT, bool EXACT>
-__global__ __launch_bounds__(NT) void attend_fwd_kernel(AttendFwdArgs g) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 5 : 4))) void attend_fwd_kernel(AttendFwdArgs g) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    const int T = EXACT ? MT : g.T, B = g.B, n = T * B;     // EXACT: T is a compile-time constant, every t-loop unrolls flat
+    const int T = EXACT ? MT : g.T, B = g.B;                // EXACT: T is a compile-time constant, every t-loop unrolls flat
+    const int n = g.img_major ? B : T * B;                  // role-A workgroups
+    // role B owns the FIRST workgroups of the grid: it is the longer chain, and once role A alone fills the chip (batch 1024)
+    // workgroups at the end of the grid only start when the first ones retire (13.6 -> 8 us for the launch)
+    const int nb_ = (int)gridDim.x - n, bid = (int)blockIdx.x - nb_;
     AIR_TR_INIT();
-    if ((int)blockIdx.x >= n) {
+    if (bid < 0) {
         // ---- role B: steps-predictor output layer + presence / num-steps for 64 batch columns ----------------------
         // Four adjacent lanes per batch column: each sums a quarter of the K range of row (t, c) for every t with 16-byte
         // loads (the four lanes of a column cover one contiguous row segment), two cross-lane adds finish the dot product in
         // every lane, and the T logits stay in registers through the presence chain and the float64 posterior.  (The r01
         // form -- one lane per column, scalar loads -- walked 64 different cache lines per load instruction and read the
         // logits back from memory: 5.9 us for this role against 3.5 us for the glimpse role, traced.)
-        const int vb = (int)blockIdx.x - n, vgrid = (int)gridDim.x - n;
+        const int vb = (int)blockIdx.x, vgrid = nb_;
         AIR_TR(4);
         const int z0 = opaque_zero();                          // vector-path loads of wave-uniform operands (see opaque_zero)
         const float bias = g.st_b[z0];
@@ -1057,12 +1069,12 @@ __global__ __launch_bounds__(NT) void attend_fwd_kernel(AttendFwdArgs g) {
         return;
     }
     AIR_TR(0);
-    // ---- role A: glimpse (t, b) -----------------------------------------------------------------------------------
-    const int kk = blockIdx.x, b = kk % B;
-    const size_t m = (size_t)kk;                               // row t*B + b
+    // ---- role A: glimpse (t, b), or -- image-major, the throughput regime -- all T glimpses of image b ------------------
+    const int b = bid % B;
+    const int t0 = g.img_major ? 0 : bid / B, t1 = g.img_major ? T : t0 + 1;
     const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w, nq = HW >> 2;
     Carve c = carve_lds(smem, HW, 0, w, h);
-    float *s_where = c.scratch;                                // [4]
+    float *s_where = c.scratch;                                // [t1 - t0][4]
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
     const int q0 = tid < nq ? tid : nq - 1, q1 = tid + nt < nq ? tid + nt : nq - 1;
     const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
@@ -1070,38 +1082,42 @@ __global__ __launch_bounds__(NT) void attend_fwd_kernel(AttendFwdArgs g) {
     const float4 p0 = s4[q0], p1 = s4[q1], p2 = s4[q2];       // in flight while wave 0 forms `where`
     if (wave == 0) {
         const int o = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1), d = o & 3;
-        const float bias_o = g.tr_b[o], eps_d = g.eps[m * 4 + d];
-        const float *x = g.tr_h + m * g.tr_k;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float bias_o = g.tr_b[o];
+        for (int t = t0; t < t1; ++t) {
+            const size_t m = (size_t)t * B + b;                // row t*B + b
+            const float eps_d = g.eps[m * 4 + d];
+            const float *x = g.tr_h + m * g.tr_k;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int k = lane; k < g.tr_k; k += 64) {
-            const float xv = opnd(x[k], g.bf16);
-            float4 wa = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)k * 8);
-            float4 wb = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)k * 8 + 4);
-            if (g.bf16) {
-                wa.x = opnd(wa.x, 1); wa.y = opnd(wa.y, 1); wa.z = opnd(wa.z, 1); wa.w = opnd(wa.w, 1);
-                wb.x = opnd(wb.x, 1); wb.y = opnd(wb.y, 1); wb.z = opnd(wb.z, 1); wb.w = opnd(wb.w, 1);
+            for (int k = lane; k < g.tr_k; k += 64) {
+                const float xv = opnd(x[k], g.bf16);
+                float4 wa = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)k * 8);
+                float4 wb = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)k * 8 + 4);
+                if (g.bf16) {
+                    wa.x = opnd(wa.x, 1); wa.y = opnd(wa.y, 1); wa.z = opnd(wa.z, 1); wa.w = opnd(wa.w, 1);
+                    wb.x = opnd(wb.x, 1); wb.y = opnd(wb.y, 1); wb.z = opnd(wb.z, 1); wb.w = opnd(wb.w, 1);
+                }
+                acc[0] += xv * wa.x; acc[1] += xv * wa.y; acc[2] += xv * wa.z; acc[3] += xv * wa.w;
+                acc[4] += xv * wb.x; acc[5] += xv * wb.y; acc[6] += xv * wb.z; acc[7] += xv * wb.w;
             }
-            acc[0] += xv * wa.x; acc[1] += xv * wa.y; acc[2] += xv * wa.z; acc[3] += xv * wa.w;
-            acc[4] += xv * wb.x; acc[5] += xv * wb.y; acc[6] += xv * wb.z; acc[7] += xv * wb.w;
-        }
-        const float e_o = wave_reduce8(acc) + bias_o;          // lanes < 32: e_loc[d]; lanes >= 32: e_raw[d]
-        const float e_partner = __shfl_xor(e_o, 32, 64);
-        if (lane < 32) {
-            const float e_loc = e_o, e_raw = e_partner;
-            const float mu = (d & 1) ? tanhf(e_loc) : sigmoid_acc(e_loc);                    // modules.py:41-46
-            const float sc = softplus_acc(e_raw + g.raw_offset);
-            const float v = mu + sc * eps_d;                                                // cell.py:130-133
-            float kl = (d & 1) ? normal_kl(mu, sc, g.pl1, g.ps1) : normal_kl(mu, sc, g.pl0, g.ps0);
-            kl += __shfl_xor(kl, 8, 64);
-            kl += __shfl_xor(kl, 16, 64);
-            if ((lane & 7) == 0) {
-                g.pre[m * 8 + d] = e_loc;
-                g.pre[m * 8 + 4 + d] = e_raw;
-                const size_t oo = m * 4 + d;
-                g.loc[oo] = mu; g.scale[oo] = sc; g.where[oo] = v;
-                s_where[d] = v;
-                if (lane == 0) g.kl_row[m] = kl;
+            const float e_o = wave_reduce8(acc) + bias_o;      // lanes < 32: e_loc[d]; lanes >= 32: e_raw[d]
+            const float e_partner = __shfl_xor(e_o, 32, 64);
+            if (lane < 32) {
+                const float e_loc = e_o, e_raw = e_partner;
+                const float mu = (d & 1) ? tanhf(e_loc) : sigmoid_acc(e_loc);                    // modules.py:41-46
+                const float sc = softplus_acc(e_raw + g.raw_offset);
+                const float v = mu + sc * eps_d;                                                // cell.py:130-133
+                float kl = (d & 1) ? normal_kl(mu, sc, g.pl1, g.ps1) : normal_kl(mu, sc, g.pl0, g.ps0);
+                kl += __shfl_xor(kl, 8, 64);
+                kl += __shfl_xor(kl, 16, 64);
+                if ((lane & 7) == 0) {
+                    g.pre[m * 8 + d] = e_loc;
+                    g.pre[m * 8 + 4 + d] = e_raw;
+                    const size_t oo = m * 4 + d;
+                    g.loc[oo] = mu; g.scale[oo] = sc; g.where[oo] = v;
+                    s_where[4 * (t - t0) + d] = v;
+                    if (lane == 0) g.kl_row[m] = kl;
+                }
             }
         }
         AIR_TR(1);
@@ -1110,18 +1126,21 @@ __global__ __launch_bounds__(NT) void attend_fwd_kernel(AttendFwdArgs g) {
     if (tid < nq) d4[tid] = p0;
     if (tid + nt < nq) d4[tid + nt] = p1;
     if (tid + 2 * nt < nq) d4[tid + 2 * nt] = p2;
-    __syncthreads();                                           // image + `where` visible
+    __syncthreads();                                           // image + every `where` row of this workgroup visible
     AIR_TR(2);
-    const float sx = s_where[0], tx = s_where[1], sy = s_where[2], ty = s_where[3];
-    float *o = g.glimpse + m * hw;
-    for (int p = tid; p < hw; p += nt) {
-        const int i = p / w, j = p - i * w;
-        int fx, fy; float dx, dy;
-        axis_entry(grid_coord(sx, lin_m11(j, w, g.stepx), tx, cxs), W, &fx, &dx);
-        axis_entry(grid_coord(sy, lin_m11(i, h, g.stepy), ty, cys), H, &fy, &dy);
-        float v = 0.f;
-        if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps_sel(c.src, H, W, fy, fx), dx, dy);
-        o[p] = v;
+    for (int t = t0; t < t1; ++t) {
+        const float *sw = s_where + 4 * (t - t0);
+        const float sx = sw[0], tx = sw[1], sy = sw[2], ty = sw[3];
+        float *o = g.glimpse + ((size_t)t * B + b) * hw;
+        for (int p = tid; p < hw; p += nt) {
+            const int i = p / w, j = p - i * w;
+            int fx, fy; float dx, dy;
+            axis_entry(grid_coord(sx, lin_m11(j, w, g.stepx), tx, cxs), W, &fx, &dx);
+            axis_entry(grid_coord(sy, lin_m11(i, h, g.stepy), ty, cys), H, &fy, &dy);
+            float v = 0.f;
+            if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps_sel(c.src, H, W, fy, fx), dx, dy);
+            o[p] = v;
+        }
     }
     AIR_TR(3);
     AIR_TR_FLUSH();
@@ -1156,7 +1175,10 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
     g.kl_ps = kl_per_sample; g.logp = logp; g.step_w = step_weight; g.img = img; g.glimpse = glimpse;
     g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w; g.stepx = lin_step(w); g.stepy = lin_step(h);
     g.bf16 = precision == AIR_PREC_BF16 ? 1 : 0;
-    const int grid = T * B + air_cdiv(B, 64);
+    // one workgroup per glimpse while that is what fills the chip; beyond ~4 workgroups per CU one per image, which stages its
+    // image once for the T reads (measured at batch 1024: 20 -> see DESIGN.md)
+    g.img_major = ((long)T * B > 2048 && T > 1) ? 1 : 0;
+    const int grid = (g.img_major ? B : T * B) + air_cdiv(B, 64);
 #define AIR_ATTEND_FWD_LAUNCH(MT_, NT_, EX_)                                                                         \
     do {                                                                                                                \
         int st_ = st_allow_lds(attend_fwd_kernel<MT_, NT_, EX_>, lds);                                                 \
@@ -1196,25 +1218,28 @@ struct AttendBwdArgs {
     const float *tr_w, *tr_y; float *tr_dx; int tr_k, tr_ld;
     const float *st_w, *st_y; float *st_dx; int st_k, st_ld;
     int bf16;
+    int img_major;      // role A: one workgroup per IMAGE runs the backward of its T glimpses (image staged once)
 };
 
 template <int MT, int NT, bool EXACT>
-__global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 5 : 4))) void attend_bwd_kernel(AttendBwdArgs g) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    const int T = EXACT ? MT : g.T, B = g.B, n = T * B;
+    const int T = EXACT ? MT : g.T, B = g.B;
+    const int n = g.img_major ? B : T * B;                     // role-A workgroups
+    const int nb_ = (int)gridDim.x - n, bid = (int)blockIdx.x - nb_;       // role B first (see attend_fwd_kernel)
     AIR_TR_INIT();
-    if ((int)blockIdx.x >= n) {
+    if (bid < 0) {
         AIR_TR(4);
         if (g.st_dx == nullptr) {
-            numsteps_presence_bwd_body<MT>((int)blockIdx.x - n, (int)gridDim.x - n, g.prob, g.presence, g.prior, g.kl_scale,
+            numsteps_presence_bwd_body<MT>((int)blockIdx.x, nb_, g.prob, g.presence, g.prior, g.kl_scale,
                                            g.kl_a, g.kl_b, g.w_scale, g.dlogp, g.logit, g.step_bias, g.explore_eps, g.dlogit,
                                            T, B);
         } else {
             // 16 batch columns per workgroup: threads 0..15 run the float64 chain of their column, then all threads form
             // st_dx for the 16 x T rows (their input activations were requested before the chain started)
             __shared__ float s_dl[MT][16];
-            const int vb = (int)blockIdx.x - n, vgrid = (int)gridDim.x - n;
+            const int vb = (int)blockIdx.x, vgrid = nb_;
             for (int base = vb * 16; base < B; base += vgrid * 16) {
                 const int nout = 16 * T * g.st_k;
                 float yv[4], wv[4];
@@ -1257,10 +1282,13 @@ __global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
         return;
     }
     AIR_TR(0);
-    const int k = blockIdx.x, b = k % B;
+    const int b = bid % B;
+    const int t0 = g.img_major ? 0 : bid / B, t1 = g.img_major ? T : t0 + 1;
     const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w;
     Carve c = carve_lds(smem, HW, 0, w, h);
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+  for (int t = t0; t < t1; ++t) {                              // one glimpse, or (image-major) the T glimpses of image b
+    const int k = t * B + b;
     // every operand of this unit is requested before anything waits: the image, the `where` row, the incoming glimpse
     // gradient of this thread's (first four) pixels, and -- lanes 0..3 of wave 0 -- the operands of the where-sampling backward
     const int z0 = opaque_zero();                              // vector-path loads of the wave-uniform `where` row (see opaque_zero)
@@ -1289,8 +1317,8 @@ __global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
         s_raw = g.pre[(size_t)k * 8 + 4 + tid] + g.raw_offset;
         s_dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
     }
-    stage_to_lds(c.src, g.img + (size_t)b * HW, HW, g.vec4 != 0);
-    __syncthreads();
+    if (t == t0) stage_to_lds(c.src, g.img + (size_t)b * HW, HW, g.vec4 != 0);
+    __syncthreads();                                           // image staged / the previous glimpse's scratch consumers are done
     AIR_TR(1);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int p0 = tid; p0 < hw; p0 += 4 * nt) {
@@ -1367,13 +1395,15 @@ __global__ __launch_bounds__(NT) void attend_bwd_kernel(AttendBwdArgs g) {
             }
         }
     }
+  }
     AIR_TR(3);
     AIR_TR_FLUSH();
 }
 
 static int attend_bwd_launch(AttendBwdArgs &g, int T, int B, int H, int W, int h, int w, size_t lds, void *stream) {
     const int role_b = g.st_dx ? air_cdiv(B, 16) : air_cdiv(B, 64);
-    const int grid = T * B + role_b;
+    g.img_major = ((long)T * B > 2048 && T > 1) ? 1 : 0;       // as air_attend_fwd
+    const int grid = (g.img_major ? B : T * B) + role_b;
     const int hw_ = h * w;
 #define AIR_ATTEND_BWD_LAUNCH(MT_, NT_, EX_)                                                                         \
     do {                                                                                                                \
@@ -1389,7 +1419,9 @@ static int attend_bwd_launch(AttendBwdArgs &g, int T, int B, int H, int W, int h
         else AIR_ATTEND_BWD_LAUNCH(32, NT_, false);                                                                     \
     } while (0)
     // about one glimpse pixel per thread
-    if (hw_ <= 256) AIR_ATTEND_BWD_BY_T(256); else if (hw_ <= 512) AIR_ATTEND_BWD_BY_T(512); else AIR_ATTEND_BWD_BY_T(1024);
+    // (image-major: 256 threads, so that one workgroup per image -- B of them -- is resident at once: 5 per CU)
+    if (hw_ <= 256 || (g.img_major && hw_ <= 1024)) AIR_ATTEND_BWD_BY_T(256);
+    else if (hw_ <= 512) AIR_ATTEND_BWD_BY_T(512); else AIR_ATTEND_BWD_BY_T(1024);
 #undef AIR_ATTEND_BWD_BY_T
 #undef AIR_ATTEND_BWD_LAUNCH
     AIR_LAUNCH_CHECK();

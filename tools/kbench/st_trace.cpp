@@ -43,7 +43,14 @@ static void dump_trace(const char *name, int nblocks, int nphase) {
     for (int ph = 0; ph < nphase; ++ph) {
         double sum = 0; unsigned long long mx = 0; int cnt = 0;
         for (int b = 0; b < nblocks; ++b) { unsigned long long v = h[b * AIR_TRACE_PHASES + ph]; if (!v) continue; v -= t0; sum += v; mx = std::max(mx, v); ++cnt; }
-        if (cnt) printf("   phase %d: mean %7.2f us  max %7.2f us  (%d wgs)\n", ph, sum / cnt * 0.01, mx * 0.01, cnt);
+        if (cnt) {
+            // per quarter of the grid: when do later workgroups reach this phase?
+            double qs[4] = {0, 0, 0, 0}; int qc[4] = {0, 0, 0, 0};
+            for (int b = 0; b < nblocks; ++b) { unsigned long long v = h[b * AIR_TRACE_PHASES + ph]; if (!v) continue; const int q = (int)((long)b * 4 / nblocks); qs[q] += v - t0; ++qc[q]; }
+            printf("   phase %d: mean %7.2f us  max %7.2f us  (%d wgs)   by grid quarter:", ph, sum / cnt * 0.01, mx * 0.01, cnt);
+            for (int q = 0; q < 4; ++q) printf(" %6.2f", qc[q] ? qs[q] / qc[q] * 0.01 : 0.0);
+            printf("\n");
+        }
     }
     std::vector<unsigned long long> z(h.size(), 0);
     CK(hipMemcpyToSymbol(HIP_SYMBOL(air_trace), z.data(), z.size() * 8));
