@@ -28,5 +28,15 @@ $PY --config c4 --no-cpu-baseline --no-sweep --steps 1000 --warmup 100 > "$OUT/$
 $PY --config c5 --no-cpu-baseline --no-sweep --steps 300 --warmup 50 > "$OUT/${TAG}_bench_c5_b1024_bf16.json" 2>> "$OUT/bench.log"
 $PY --batch 1024 --no-cpu-baseline --no-sweep --steps 300 --warmup 50 > "$OUT/${TAG}_bench_c2_b1024_f32.json" 2>> "$OUT/bench.log"
 $PY --batch 512 --no-cpu-baseline --no-sweep --steps 500 --warmup 50 > "$OUT/${TAG}_bench_c2_b512_f32.json" 2>> "$OUT/bench.log"
+# the throughput regime: per-position picture of the replayed step at batch 1024 (bf16 operands = configs[4], and fp32)
+for V in "c5:--config c5" "b1024_f32:--batch 1024"; do
+  N=${V%%:*}; A=${V#*:}
+  rm -rf "$OUT/trace_$N"
+  rocprofv3 --kernel-trace -d "$OUT/trace_$N" -o b -- $PY $A --no-cpu-baseline --no-sweep --steps 200 --warmup 20 > /dev/null 2>> "$OUT/trace.log"
+  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace_$N" -name "*.db" | head -1) --by-position step_epilogue_kernel > "$OUT/${TAG}_positions_$N.txt"
+  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace_$N" -name "*.db" | head -1) > "$OUT/${TAG}_bench_${N}_kernel_stats.txt"
+  rm -rf "$OUT/trace_$N"
+done
+$PY --batch 256 --no-cpu-baseline --no-sweep --steps 500 --warmup 50 > "$OUT/${TAG}_bench_c2_b256_f32.json" 2>> "$OUT/bench.log"
 rm -rf "$OUT"/trace "$OUT"/pmc_*/   # the SQLite traces are large; the text summaries are what travels back
 ls -la "$OUT"
