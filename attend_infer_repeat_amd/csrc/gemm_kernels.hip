@@ -946,6 +946,117 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(LstmFwdArgs g, Prol
     }
 }
 
+// ---- throughput regime (more than 512 tiles of 16 x 16): the same fusion on the wide-tile scheme ---------------------------
+// Workgroup tile = 16 batch rows x 64 hidden units x the 4 gates: SIXTEEN 16-wide MFMA tiles per wave, tile (q, c) = gate q,
+// units u0 + 4 i + c (i = 0..15).  W_h[k, q*Hd + u] is k-strided; per k step a lane issues FOUR 16-byte loads (one per gate,
+// along the contiguous unit dimension) and every loaded value feeds a different tile -- no dword loads, no permuted copy of
+// w_gates.  8 waves split K (Hd = 256: two 16-deep chunks each, all loads of a wave in ONE round trip) and reduce through LDS in
+// a fixed order; the epilogue thread of (row, unit) then holds all four gates: `gates` never exists, one launch per step instead
+// of a product and a pointwise pass.
+template <bool BF>
+__global__ __launch_bounds__(512) void lstm_fwd_wide_kernel(LstmFwdArgs g, PrologueArgs pro) {
+    constexpr int KW = 8, LDT = 256 + 4;
+    __shared__ float s_tile[KW][16 * LDT];                  // local column = gate * 64 + unit
+    if ((int)blockIdx.x >= g.tiles) {
+        if (threadIdx.x < PW_THREADS) step_prologue_body(pro, (int)blockIdx.x - g.tiles, (int)gridDim.x - g.tiles);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_u = g.Hd >> 6;
+    const int tm = blockIdx.x / tiles_u, tu = blockIdx.x - tm * tiles_u;
+    const int m0 = tm * 16, u0 = tu * 64;
+    const gcf gA = (gcf)g.h_prev, gW = (gcf)g.w_h;
+    int rowA = m0 + li; if (rowA > g.M - 1) rowA = g.M - 1;
+    const size_t offA = (size_t)rowA * g.ldh;
+    const int colb = u0 + 4 * li;
+    // epilogue operands of this thread's two (row, unit) pairs, requested before the K loop
+    float e_gx[2][4], e_c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = threadIdx.x + 512 * i, r = e >> 6, u = e & 63;
+        int m = m0 + r; if (m > g.M - 1) m = g.M - 1;
+        const gcf gx = (gcf)g.gx + (size_t)m * g.ldgx + u0 + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_gx[i][q] = gx[(size_t)q * g.Hd];
+        e_c[i] = ((gcf)g.c_prev)[(size_t)m * g.ldc + u0 + u];
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 2;
+    const int nchunks = g.Hd >> 4;
+#pragma nounroll
+    for (int c = wave; c < nchunks; c += U * KW) {
+        f32x4 fa[U], fw[U][4][4];                           // fw[u][j][q] = W_h[k + j, q*Hd + colb .. colb+3]
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cu = c + u * KW; if (cu > nchunks - 1) cu = nchunks - 1;
+            const int k = (cu << 4) + 4 * lg;
+            fa[u] = *(gcf4)(gA + offA + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fw[u][j][q] = *(gcf4)(gW + (size_t)(k + j) * g.ldw + (size_t)q * g.Hd + colb);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW >= nchunks) break;
+            if (BF) {
+                const s16x4 ha = to_bf16x4(fa[u]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const s16x4 hb = to_bf16x4((f32x4){fw[u][0][q][cc], fw[u][1][q][cc], fw[u][2][q][cc], fw[u][3][q][cc]});
+                        acc[q * 4 + cc] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha, hb, acc[q * 4 + cc], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+                            acc[q * 4 + cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], fw[u][j][q][cc], acc[q * 4 + cc], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *(f32x4 *)&s_tile[wave][(4 * lg + r) * LDT + q * 64 + 4 * li] =
+                (f32x4){acc[q * 4 + 0][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = threadIdx.x + 512 * i, r = e >> 6, u = e & 63;
+        const int m = m0 + r;
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = r * LDT + q * 64 + u;
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < KW; w4 += 4)
+                v += (s_tile[w4][off] + s_tile[w4 + 1][off]) + (s_tile[w4 + 2][off] + s_tile[w4 + 3][off]);
+            pre[q] = v + e_gx[i][q];
+        }
+        if (m < g.M) {
+            const float gi = sigmoid_acc(pre[0]);
+            const float gj = tanhf(pre[1]);
+            const float gf = sigmoid_acc(pre[2] + g.fb);
+            const float go = sigmoid_acc(pre[3]);
+            const float cn = gf * e_c[i] + gi * gj;
+            const size_t eo = (size_t)m * g.Hd + u0 + u;
+            ((gf_t)g.c)[eo] = cn;
+            ((gf_t)g.h)[eo] = tanhf(cn) * go;
+            const gf_t ar = (gf_t)g.gate_act + (size_t)m * 4 * g.Hd + u0 + u;
+            ar[0] = gi; ar[g.Hd] = gj; ar[2 * (size_t)g.Hd] = gf; ar[3 * (size_t)g.Hd] = go;
+        }
+    }
+}
+
 struct LstmBwdArgs {
     const float *dgates_next, *w_h, *dh_a, *dh_b, *dc_in, *gate_act, *c_prev, *c, *dgx_in;
     float *dgates, *dc_prev, *dgx_out;
@@ -1027,7 +1138,16 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g, 
 
 template <bool BF>
 static int lstm_fwd_launch(const LstmFwdArgs &g, const PrologueArgs &pro, int extra_blocks, hipStream_t st) {
-    hipLaunchKernelGGL((lstm_fwd_fused_kernel<BF>), dim3(g.tiles + extra_blocks), dim3(256), 0, st, g, pro);
+    // more than 512 16x16 tiles of (batch, hidden): the wide-tile form (needs 16-byte addressable operands and Hd % 64 == 0)
+    const bool wide = air_cdiv(g.M, 16) * air_cdiv(g.Hd, 16) > 512 && g.Hd % 64 == 0 && g.ldw % 4 == 0 && g.ldh % 4 == 0 &&
+                      air_aligned16(g.w_h) && air_aligned16(g.h_prev);
+    if (wide) {
+        LstmFwdArgs gw = g;
+        gw.tiles = air_cdiv(g.M, 16) * (g.Hd / 64);
+        hipLaunchKernelGGL((lstm_fwd_wide_kernel<BF>), dim3(gw.tiles + extra_blocks), dim3(512), 0, st, gw, pro);
+    } else {
+        hipLaunchKernelGGL((lstm_fwd_fused_kernel<BF>), dim3(g.tiles + extra_blocks), dim3(256), 0, st, g, pro);
+    }
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -530,14 +530,19 @@ class AIREngine:
         # sequential part of the step); at large batch the 32x32-tile GEMM + a pointwise pass re-reads less (measured:
         # B=1024 0.938 vs 0.954 ms/step), so the pair is kept there.
         fuse_lstm = ((B + 15) // 16) * ((Hd + 15) // 16) <= int(os.environ.get("AIR_FUSE_LSTM_TILES", "512"))
-        if not fuse_lstm:
+        # forward: beyond 512 tiles the library's wide-tile form of the fused step (16 rows x 64 units x 4 gates per workgroup)
+        fuse_lstm_fwd = fuse_lstm or (Hd % 64 == 0 and E % 4 == 0 and os.environ.get("AIR_FUSE_LSTM_WIDE", "1") == "1")
+        if not fuse_lstm_fwd:
             self.gates = self._buf("gates", (T, B, 4 * Hd))
+        # (the step prologue rides in the first fused step only in the latency regime: the wide-tile form holds 133 KB of LDS
+        #  per workgroup, so riding prologue workgroups would wait for a free CU -- 14.4 us against 8.5 + 4.9 for two launches)
+        prologue_rides = fuse_lstm
         for t in range(T):                                                                  # cell.py:126-127
-            if fuse_lstm and t == 0:
+            if prologue_rides and t == 0:
                 fwd.append(None)        # placeholder: the first step carries the step prologue (filled in per plan below)
                 lstm0_index = len(fwd) - 1
                 continue
-            if fuse_lstm:
+            if fuse_lstm_fwd:
                 fwd.append((L.air_lstm_step_fwd, (p(self.h_seq[t]), p(self.c_seq[t]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,
                                                   p(self.h_seq[t + 1]), p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd,
                                                   1.0, prec), "air_lstm_step_fwd"))
@@ -742,7 +747,7 @@ class AIREngine:
         def fwd_plan(with_noise):
             """the forward list with its prologue: a launch of its own, or -- with the fused LSTM steps -- extra workgroups
             of the first LSTM step, which then reads h0 / c0 with a broadcast row stride"""
-            if not fuse_lstm:
+            if not prologue_rides:
                 return [prologue(with_noise)] + fwd
             lstm0 = (L.air_lstm_step_fwd_prologue,
                      (p(self.params["lstm/h0"]), p(self.params["lstm/c0"]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,

@@ -258,14 +258,17 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
     if variant == "unfused":
         monkeypatch.setenv("AIR_FUSE_ATTEND_M", "0")
         monkeypatch.setenv("AIR_DEFER_DW_MIN_ROWS", "100000000")
+        monkeypatch.setenv("AIR_FUSE_LSTM_WIDE", "0")
     ocfg, B = O.AIRConfig(), 704
     eng, params, obs, noise = make_pair(ocfg, B)
     names = [n for _, _, n in eng._plan_fwd_train + eng._plan_bwd]
-    assert "air_lstm_pointwise_fwd" in names
+    assert "air_lstm_pointwise_bwd" in names
     if variant == "unfused":
         assert "air_attend_fwd" not in names and "air_heads_fwd" in names and not eng._defer_dw
+        assert "air_lstm_pointwise_fwd" in names
     else:
         assert "air_attend_fwd" in names and eng._defer_dw
+        assert "air_lstm_step_fwd" in names and "air_lstm_pointwise_fwd" not in names       # wide-tile fused LSTM steps
         tail = [a[0] for _, a, n in eng._plan_bwd[-3:] if n == "air_gemm_grouped"]
         assert tail and all(d.ta and not d.tb for arr in tail for d in arr)          # the deferred weight-gradient launches
     eng.forward(sample_noise=False)

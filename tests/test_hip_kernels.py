@@ -284,7 +284,7 @@ def test_lstm_pointwise(hip):
     assert_close(dgates, gg, 1e-4, 1e-5, "dgates"); assert_close(dc_prev, gc, 1e-4, 1e-5, "dc_prev")
 
 
-@pytest.mark.parametrize("M,Hd", [(64, 256), (37, 50), (5, 7), (130, 40), (1024, 256)])
+@pytest.mark.parametrize("M,Hd", [(64, 256), (37, 50), (5, 7), (130, 40), (1024, 256), (2005, 64), (1024, 200)])
 def test_lstm_fused_step_matches_unfused_pair_and_fp64(hip, M, Hd):
     """air_lstm_step_fwd / _bwd = recurrent product + gate math in one launch; must equal GEMM + pointwise (bitwise: same
     K order, same reduction tree) and the fp64 formula."""
@@ -325,9 +325,9 @@ def test_lstm_fused_step_matches_unfused_pair_and_fp64(hip, M, Hd):
     assert_close(dcp2, dh0 * go * (1 - tc * tc) * gf, 1e-4, 2e-5, "dc_prev (no dh/dc terms)")
 
 
-def test_lstm_fused_step_bf16(hip):
+@pytest.mark.parametrize("M,Hd", [(48, 64), (1045, 128)])          # the second: wide-tile form (> 512 tiles), ragged rows
+def test_lstm_fused_step_bf16(hip, M, Hd):
     gen = torch.Generator().manual_seed(3)
-    M, Hd = 48, 64
     r16 = lambda t: t.to(torch.bfloat16).double()
     h0 = torch.randn(M, Hd, generator=gen); c0 = torch.randn(M, Hd, generator=gen)
     w = torch.randn(Hd, 4 * Hd, generator=gen) / 8; gx = torch.randn(M, 4 * Hd, generator=gen)
