@@ -1136,6 +1136,103 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g, 
     }
 }
 
+// One BPTT link in the throughput regime: dh = dgates_{t+1}[M, 4Hd] . W_h[Hd, 4Hd]^T on the wide-tile scheme (both operands
+// k-contiguous: 16 rows x 64 units per workgroup, 8 waves split the 4Hd-deep contraction), then -- exactly as
+// lstm_bwd_fused_kernel -- the pointwise backward of step t for the (row, unit) pairs the tile owns.
+template <bool BF>
+__global__ __launch_bounds__(512) void lstm_bwd_wide_kernel(LstmBwdArgs g, RmspropSlice opt) {
+    constexpr int KW = 8, NT = 4, LDT = 64 + 4;
+    __shared__ float s_tile[KW][16 * LDT];
+    const int tiles_n = g.Hd >> 6;
+    {
+        const int tiles = ((g.M + 15) >> 4) * tiles_n;
+        if ((int)blockIdx.x >= tiles) {
+            rmsprop_slice_body(opt, (int)blockIdx.x - tiles, (int)gridDim.x - tiles);
+            return;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 16, n0 = tn * 64;
+    const int K = 4 * g.Hd;
+    const gcf gA = (gcf)g.dgates_next, gB = (gcf)g.w_h;
+    int rowA = m0 + li; if (rowA > g.M - 1) rowA = g.M - 1;
+    const size_t offA = (size_t)rowA * K;
+    size_t offB[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) offB[b] = (size_t)(n0 + 16 * b + li) * K;
+    // epilogue operands of this thread's two (row, unit) pairs
+    float gi[2], gj[2], gff[2], go[2], cp[2], cc[2], dha[2], dhb[2], dci[2], sx[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e_ = threadIdx.x + 512 * i, r = e_ >> 6, u = n0 + (e_ & 63);
+        int m = m0 + r; if (m > g.M - 1) m = g.M - 1;
+        const size_t e = (size_t)m * g.Hd + u;
+        const gcf ar = (gcf)g.gate_act + (size_t)m * K + u;
+        gi[i] = ar[0]; gj[i] = ar[g.Hd]; gff[i] = ar[2 * (size_t)g.Hd]; go[i] = ar[3 * (size_t)g.Hd];
+        cp[i] = ((gcf)g.c_prev)[e];
+        cc[i] = ((gcf)g.c)[e];
+        dha[i] = g.dh_a ? ((gcf)g.dh_a)[e] : 0.f;
+        dhb[i] = g.dh_b ? ((gcf)g.dh_b)[e] : 0.f;
+        dci[i] = g.dc_in ? ((gcf)g.dc_in)[e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sx[i][q] = g.dgx_in ? ((gcf)g.dgx_in)[(size_t)m * K + u + (size_t)q * g.Hd] : 0.f;
+    }
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[0][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    const int nchunks = K >> 4;
+#pragma nounroll
+    for (int c = wave; c < nchunks; c += U * KW) {
+        f32x4 fa[U][1], fb[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cu = c + u * KW; if (cu > nchunks - 1) cu = nchunks - 1;
+            const int k = (cu << 4) + 4 * lg;
+            fa[u][0] = *(gcf4)(gA + offA + k);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[u][b] = *(gcf4)(gB + offB[b] + k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW >= nchunks) break;
+            mfma_chunk<1, NT, BF>(acc, fa[u], fb[u]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) s_tile[wave][(4 * lg + r) * LDT + 16 * b + li] = acc[0][b][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e_ = threadIdx.x + 512 * i, r = e_ >> 6, uc = e_ & 63, u = n0 + uc, m = m0 + r;
+        const int off = r * LDT + uc;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KW; q += 4) v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
+        if (m >= g.M) continue;
+        const float dh = (v + dha[i]) + dhb[i];                // same order as the unfused pair (beta = 1 accumulate, then + dh_b)
+        const float tc = tanhf(cc[i]);
+        const float dct = dci[i] + dh * go[i] * (1.f - tc * tc);
+        float d[4];
+        d[0] = dct * gj[i] * gi[i] * (1.f - gi[i]);
+        d[1] = dct * gi[i] * (1.f - gj[i] * gj[i]);
+        d[2] = dct * cp[i] * gff[i] * (1.f - gff[i]);
+        d[3] = dh * tc * go[i] * (1.f - go[i]);
+        const gf_t dr = (gf_t)g.dgates + (size_t)m * K + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dr[(size_t)q * g.Hd] = d[q];
+        ((gf_t)g.dc_prev)[(size_t)m * g.Hd + u] = dct * gff[i];
+        if (g.dgx_out) {
+            const gf_t so = (gf_t)g.dgx_out + (size_t)m * K + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) so[(size_t)q * g.Hd] = sx[i][q] + d[q];
+        }
+    }
+}
+
 template <bool BF>
 static int lstm_fwd_launch(const LstmFwdArgs &g, const PrologueArgs &pro, int extra_blocks, hipStream_t st) {
     // more than 512 16x16 tiles of (batch, hidden): the wide-tile form (needs 16-byte addressable operands and Hd % 64 == 0)
@@ -1202,10 +1299,12 @@ template <bool BF>
 static int lstm_bwd_launch(const LstmBwdArgs &g, const RmspropSlice &opt, size_t opt_nq, hipStream_t st) {
     const int tiles = air_cdiv(g.M, 16) * air_cdiv(g.Hd, 16);
     // few tiles (batch 64: 64 of them): 16 waves share the 4Hd-deep contraction of a tile; many tiles: 4 waves
-    const int nth = tiles <= 512 ? 1024 : 256;
+    const bool wide = tiles > 512 && g.Hd % 64 == 0 && g.vecA && g.vecB;
+    const int nth = tiles <= 512 ? 1024 : (wide ? 512 : 256);
     size_t extra = (opt_nq + 2 * nth - 1) / (2 * nth);                     // about two float4 per thread of the riding slice
     if (extra > 512) extra = 512;
-    if (tiles <= 512) hipLaunchKernelGGL((lstm_bwd_fused_kernel<16, BF>), dim3(tiles + (int)extra), dim3(1024), 0, st, g, opt);
+    if (wide) hipLaunchKernelGGL((lstm_bwd_wide_kernel<BF>), dim3(air_cdiv(g.M, 16) * (g.Hd / 64) + (int)extra), dim3(512), 0, st, g, opt);
+    else if (tiles <= 512) hipLaunchKernelGGL((lstm_bwd_fused_kernel<16, BF>), dim3(tiles + (int)extra), dim3(1024), 0, st, g, opt);
     else hipLaunchKernelGGL((lstm_bwd_fused_kernel<4, BF>), dim3(tiles + (int)extra), dim3(256), 0, st, g, opt);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

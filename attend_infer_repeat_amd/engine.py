@@ -687,14 +687,15 @@ class AIREngine:
         dc_in, dc_out = None, self.dc_a
         dgx = self.dgx if T > 1 else self.dgates[0]            # sum over time of dgates (what the hoisted x.W_x receives)
         rider_hosts = []                    # (index in bwd, entry with an optimiser slice): see _plan_bwd_riders below
+        fuse_lstm_bwd = fuse_lstm_fwd            # (the library picks the 16-wave or the wide-tile form of the link by size)
         for t in reversed(range(T)):
-            if t == T - 1 or not fuse_lstm:
+            if t == T - 1 or not fuse_lstm_bwd:
                 pw_args = (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]), p(self.dH[t]), p(self.dH_b[t]),
                            p(dc_in) if dc_in is not None else None, p(self.dgates[t]), p(dc_out), B, Hd)
                 if fuse_lstm:
                     rider_hosts.append((len(bwd), L.air_lstm_pointwise_bwd_opt, pw_args, "air_lstm_pointwise_bwd_opt"))
                 bwd.append((L.air_lstm_pointwise_bwd, pw_args, "air_lstm_pointwise_bwd"))
-                if not fuse_lstm and t > 0:    # dgates_t . W_h^T accumulates into dH[t-1] (beta = 1)
+                if not fuse_lstm_bwd and t > 0:    # dgates_t . W_h^T accumulates into dH[t-1] (beta = 1)
                     launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[t], 4 * Hd, w_h, 4 * Hd, self.dH[t - 1], Hd,
                                       beta=1.0)])
             else:
@@ -705,7 +706,7 @@ class AIREngine:
                 rider_hosts.append((len(bwd), L.air_lstm_step_bwd_opt, link_args, "air_lstm_step_bwd_opt"))
                 bwd.append((L.air_lstm_step_bwd, link_args, "air_lstm_step_bwd"))
             dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
-        if not fuse_lstm and T > 1:
+        if not fuse_lstm_bwd and T > 1:
             bwd.append((L.air_sum_leading, (p(self.dgates), p(self.dgx), T, ctypes.c_size_t(B * 4 * Hd)),
                         "air_sum_leading"))
         launch(bwd, [desc(0, 1, B, Hd, 4 * Hd, self.dgates[0], 4 * Hd, w_h, 4 * Hd, self.dh_init, Hd),   # d h_{-1}
