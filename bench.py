@@ -403,7 +403,7 @@ def main():
                              "north_star's kernel) launched on its own at the in-step shape; `achieved`/`frac` use the SURVEY 8(d) "
                              "algorithmic bytes, `frac_minimal_bytes` the bytes the launch must move (image once per image). At this "
                              "size it is latency bound; inside the train step the same read runs fused in attend_fwd_kernel "
-                             "(roofline_other_kernels.attend_fwd) whenever T*B <= 2048; the bandwidth regime is in "
+                             "(roofline_other_kernels.attend_fwd); the bandwidth regime is in "
                              "roofline_sweep_st_read_fwd"),
             "roofline_other_kernels": {k: v for k, v in roof.items() if k != "st_read_fwd"},
             "roofline_gemm": gemm_roofline(eng),
