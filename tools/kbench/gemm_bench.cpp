@@ -25,7 +25,7 @@ template <typename F> static double time_us(F fn, int reps) {
     std::sort(r.begin(), r.end());
     return r[r.size() / 2];
 }
-struct Shape { int ta, tb, M, N, K; const char *what; };
+struct Shape { int ta, tb, M, N, K; const char *what; int lda_over = 0; };
 
 template <int MT, int KW, bool BF, bool TA, bool TB> static void wide(const GemmArgs &g) {
     const int tiles = air_cdiv(g.M, 16 * MT) * air_cdiv(g.N, 64);
@@ -39,10 +39,11 @@ int main(int argc, char **argv) {
         {0, 0, 1024, 256, 2500, "input enc l0 fwd"}, {0, 0, 1024, 1024, 256, "LSTM recurrent fwd"}, {0, 0, 3072, 100, 256, "what head fwd"},
         {0, 1, 3072, 256, 256, "MLP dX"}, {0, 1, 3072, 256, 400, "decoder out dX"}, {0, 1, 1024, 256, 1024, "LSTM dh"},
         {1, 0, 256, 256, 3072, "MLP dW"}, {1, 0, 256, 1024, 3072, "LSTM dWx"}, {1, 0, 2500, 256, 1024, "input enc l0 dW"}, {1, 0, 400, 256, 3072, "glimpse enc l0 dW"},
+        {1, 0, 48, 256, 3072, "decoder l0 dW (48 of 50 rows, lda 50: unaligned 16-byte loads)", 50}, {1, 0, 676, 256, 1024, "baseline latent dW (676 of 677, lda 677)", 677},
     };
     for (const Shape &s : shapes) {
-        const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
-        float *A = devr((size_t)s.M * s.K), *B = devr((size_t)s.N * s.K), *bias = devr(s.N), *C0 = devz((size_t)s.M * s.N), *C1 = devz((size_t)s.M * s.N);
+        const int lda = s.lda_over ? s.lda_over : (s.ta ? s.M : s.K), ldb = s.tb ? s.K : s.N;
+        float *A = devr((size_t)(s.lda_over ? s.lda_over : s.M) * s.K + 64), *B = devr((size_t)s.N * s.K), *bias = devr(s.N), *C0 = devz((size_t)s.M * s.N), *C1 = devz((size_t)s.M * s.N);
         float *col0 = devz(s.N), *col1 = devz(s.N);
         AirGemmDesc d{};
         d.ta = s.ta; d.tb = s.tb; d.M = s.M; d.N = s.N; d.K = s.K; d.A = A; d.lda = lda; d.B = B; d.ldb = ldb; d.C = C0; d.ldc = s.N;
