@@ -484,16 +484,34 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs &g, const int bloc
             }
         }
     }
-    // the partial last chunk of K (K % 16 != 0; K % 4 == 0 is guaranteed): whole 4-deep lane groups are in or out
+    // the partial last chunk of K (K % 16 != 0).  A 4-deep lane group is entirely inside K, entirely outside (it reads a valid
+    // address and contributes zeros) or -- K % 4 != 0, k-contiguous A only -- straddles the end: that one group loads element by
+    // element (nothing is read past the end of a row, so the last row of a matrix never reads past its allocation)
     if ((g.K & 15) && (full_end % KW) == wave) {
         const int k = (full_end << 4) + 4 * lg;
         f32x4 fa[MT], fb[NT];
-        load_chunk(k < g.K ? k : 0, fa, fb);                                        // out-of-range lane groups read a valid address ...
-        if (k >= g.K) {                                                             // ... and contribute zeros
+        if (TA || k + 3 < g.K || k >= g.K) {
+            load_chunk(k < g.K ? k : 0, fa, fb);
+            if (k >= g.K) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) fa[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int a = 0; a < MT; ++a) fa[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < NT; ++b) fb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < NT; ++b) fb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) fa[a] = ld_kcontig(gA + offA[TA ? 0 : a], 0, 0, true, k, g.K, false);
+            if (!TB) {
+                f32x4 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = (k + j < g.K) ? *(gcf4)(gB + (size_t)(k + j) * g.ldb + offB[0]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < NT; ++b) fb[b] = (f32x4){w[0][b], w[1][b], w[2][b], w[3][b]};
+            } else {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) fb[b] = ld_kcontig(gB + offB[TB ? b : 0], 0, 0, true, k, g.K, false);
+            }
         }
         mfma_chunk<MT, NT, BF>(acc, fa, fb);
         if (want_colsum) {
@@ -782,8 +800,13 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         for (int i = 0; i < count && ok; ++i) {
             const AirGemmDesc &d = descs[i];
             ok = ok && (d.ta ? 1 : 0) == ta && (d.tb ? 1 : 0) == tb && !(ta && tb) && !d.A2;
-            ok = ok && air_aligned16(d.A) && air_aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.K % 4 == 0;
-            ok = ok && d.M >= 4 && d.N >= 4 && (!ta || d.M % 4 == 0) && (tb || d.N % 4 == 0);
+            // 16-byte operand loads need not be 16-byte aligned (any leading dimension of A; K of any length when A is
+            // k-contiguous); an interleaved operand must hold whole groups of 4 rows / columns; B as the weights are laid out
+            ok = ok && air_aligned16(d.B) && d.ldb % 4 == 0 && (!ta || d.K % 4 == 0) && (!tb || d.K % 4 == 0);
+            ok = ok && d.M >= 4 && d.N >= 4 && d.K >= 4 && (!ta || d.M % 4 == 0) && (tb || d.N % 4 == 0);
+            // (the unaligned / odd-K forms only where the launch is far into the throughput regime: around a thousand tiles
+            //  the 16x16-tile kernel is the better one for them -- K = 50 leaves half of the 8 K-splitting waves idle)
+            if (tiles16 <= 2048) ok = ok && air_aligned16(d.A) && d.lda % 4 == 0 && d.K % 4 == 0;
             tiles64 += (long)air_cdiv(d.M, 64) * air_cdiv(d.N, 64);
             if (d.K < min_k) min_k = d.K;
         }

@@ -363,9 +363,10 @@ class AIREngine:
             tiles16 = sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in descs)
 
             def wide_ok(d):       # what air_gemm_grouped's wide-tile kernels need of a problem (gemm_kernels.hip)
-                return (not (d.ta and d.tb) and not d.A2 and d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0
-                        and d.ldb % 4 == 0 and d.K % 4 == 0 and d.M >= 4 and d.N >= 4 and (not d.ta or d.M % 4 == 0)
-                        and (d.tb or d.N % 4 == 0))
+                strict = tiles16 > 2048 or (d.A % 16 == 0 and d.lda % 4 == 0 and d.K % 4 == 0)
+                return (strict and not (d.ta and d.tb) and not d.A2 and d.B % 16 == 0 and d.ldb % 4 == 0
+                        and (not (d.ta or d.tb) or d.K % 4 == 0) and d.M >= 4 and d.N >= 4 and d.K >= 4
+                        and (not d.ta or d.M % 4 == 0) and (d.tb or d.N % 4 == 0))
             if throughput and len(descs) > 1 and any(wide_ok(d) for d in descs) and not all(wide_ok(d) for d in descs):
                 # one odd problem (N = 1, K = 50 ...) would keep the whole group off the wide-tile kernels: it gets its own launch
                 launch(plan, [d for d in descs if wide_ok(d)])
@@ -726,10 +727,29 @@ class AIREngine:
             # wide-tile eligible problems (16-byte loads along M and N: both multiples of 4, aligned) together, longest K first
             # so that the heaviest tiles start first; the rest (M = 50 / 677 / 1, N = 1) in a launch of the ordinary kernel
             def wide_ok(d):
-                return (d.M % 4 == 0 and d.N % 4 == 0 and d.lda % 4 == 0 and d.ldb % 4 == 0 and d.K % 4 == 0
-                        and d.A % 16 == 0 and d.B % 16 == 0)
-            wide = sorted((d for d in deferred_dw if wide_ok(d)), key=lambda d: (-d.K, -d.M * d.N))
-            rest = [d for d in deferred_dw if not wide_ok(d)]
+                return d.M % 4 == 0 and d.M >= 4 and d.N % 4 == 0 and d.ldb % 4 == 0 and d.K % 4 == 0 and d.B % 16 == 0
+            # a row count that is not a multiple of 4 (50 latent / 677 baseline-input rows): the first M - M % 4 rows go wide,
+            # the remaining one to three rows are a problem of their own (the bias gradient stays with the first part)
+            parts = []
+            for d in deferred_dw:
+                m4 = d.M // 4 * 4
+                if d.M % 4 and m4 >= 16 and d.N % 4 == 0 and d.ldb % 4 == 0 and d.K % 4 == 0 and d.B % 16 == 0:
+                    parts.append(_lib.AirGemmDesc(d.ta, d.tb, m4, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
+                                                  d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, d.precision, None, None, 0, None))
+                    parts.append(_lib.AirGemmDesc(d.ta, d.tb, d.M - m4, d.N, d.K, d.A + 4 * m4, d.lda, d.B, d.ldb,
+                                                  d.C + 4 * m4 * d.ldc, d.ldc, d.bias, d.epilogue, d.aux, d.ldaux, d.beta, None,
+                                                  d.precision, None, None, 0, None))
+                else:
+                    parts.append(d)
+            wide = sorted((d for d in parts if wide_ok(d)), key=lambda d: (-d.K, -d.M * d.N))
+            rest = [d for d in parts if not wide_ok(d)]
+            # launches hold up to 8 problems: a few left-over wide problems would make a (latency-bound) launch of their own --
+            # the smallest ones join the launch of the odd-shaped rest instead
+            excess = len(wide) % 8
+            if 0 < excess <= 3 and len(wide) > 8 and len(rest) + excess <= 8:
+                small = sorted(wide, key=lambda d: d.M * d.N)[:excess]
+                wide = [d for d in wide if all(d is not s_ for s_ in small)]
+                rest = rest + small
             for grp in [wide[i:i + 8] for i in range(0, len(wide), 8)] + [rest[i:i + 8] for i in range(0, len(rest), 8)]:
                 arr = (_lib.AirGemmDesc * len(grp))(*grp)
                 self._keep.append(arr)

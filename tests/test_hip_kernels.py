@@ -583,6 +583,14 @@ def test_gemm_wide_tiles(hip, precision, layout):
         assert_close(outs[0][0], torch.nn.functional.elu(r(x) @ r(w) + b.cpu().double() + aux.cpu().double()), 1e-5, atol, "add aux elu")
         assert_close(outs[1][0], r(x2) @ r(w2) + c0.cpu().double(), 1e-5, atol, "K tail + beta + view")
         assert_close(outs[2][0], r(x3) @ r(w3), 1e-5, atol, "K < 16")
+        # K % 4 != 0 and leading dimensions that are not multiples of 4 (16-byte loads from 4-byte aligned addresses; the lane
+        # group that straddles the end of K loads element by element): the decoder's first layer (K = 50) and the baseline's
+        # latent columns (K = 677), the second through a row view that starts one float into its buffer
+        x4 = rn(3072, 50); w4 = rn(50, 256) / 7; b4 = rn(256)
+        x5big = rn(1024, 679); x5 = x5big[:, 1:678]; w5 = rn(677, 256) / 26
+        outs = hip.gemm_grouped([dict(A=x4, B=w4, bias=b4, epilogue=hip.EPI_BIAS_ELU), dict(A=x5, B=w5)], precision=precision)
+        assert_close(outs[0][0], torch.nn.functional.elu(r(x4) @ r(w4) + b4.cpu().double()), 1e-5, atol, "K = 50")
+        assert_close(outs[1][0], r(x5) @ r(w5), 1e-5, atol, "K = 677, unaligned rows")
     elif layout == "NT":
         g = rn(3000, 400); w = rn(1024, 400) / 16; y = rn(3000, 1024)
         g2 = rn(1024, 1024); w2 = rn(256, 1024) / 32; c0 = rn(1024, 256)
@@ -602,3 +610,8 @@ def test_gemm_wide_tiles(hip, precision, layout):
         assert_close(outs[0][0], r(x).t() @ r(g), 1e-5, atol * 10, "dW")
         assert_close(outs[1][0], r(x2).t() @ r(g2), 1e-5, atol * 10, "dW ragged M")
         assert_close(outs[1][1], g2.cpu().double().sum(0), 1e-5, 1e-3, "db")
+        # rows of A that are not 16-byte aligned (leading dimension 50): the first 48 of the 50 weight-gradient rows
+        x3 = rn(3072, 50); g3 = rn(3072, 256)
+        outs = hip.gemm_grouped([dict(A=x3[:, :48], B=g3, ta=True, colsum=True), dict(A=x2, B=g2, ta=True)], precision=precision)
+        assert_close(outs[0][0], r(x3[:, :48]).t() @ r(g3), 1e-5, atol * 10, "dW, lda = 50")
+        assert_close(outs[0][1], g3.cpu().double().sum(0), 1e-5, 1e-3, "db")
