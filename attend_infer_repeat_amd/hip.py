@@ -265,6 +265,40 @@ def lstm_step_bwd(dgates_next, w_h, dh_a, dh_b, dc_in, gate_act, c_prev, c, dgx_
     return dgates, dc_prev, dgx
 
 
+def rmsprop_slice(p, g, ms, mg, mom, lo, hi, n_model, lr_dev, lr_mult_tail=1.0, decay=0.9, momentum=0.9, eps=1e-10,
+                  grad_scale=1.0):
+    """AirRmspropSlice over the flat buffers: elements [lo, hi) are updated by the *_opt launch the slice is handed to."""
+    for t, nm in ((p, "p"), (g, "g"), (ms, "ms"), (mg, "mg"), (mom, "mom"), (lr_dev, "lr_dev")):
+        _f32(t, nm)
+    return _lib.AirRmspropSlice(p.data_ptr(), g.data_ptr(), ms.data_ptr(), mg.data_ptr(), mom.data_ptr(), int(lo), int(hi),
+                                int(n_model), lr_dev.data_ptr(), float(lr_mult_tail), float(decay), float(momentum), float(eps),
+                                float(grad_scale))
+
+
+def lstm_pointwise_bwd_opt(gate_act, c_prev, c, dh, dc, opt):
+    """air_lstm_pointwise_bwd with an optimiser slice (rmsprop_slice(...)) riding as extra workgroups of the launch"""
+    gate_act = _f32(gate_act, "gate_act", 2); c_prev = _f32(c_prev, "c_prev", 2); c = _f32(c, "c", 2)
+    dh = _f32(dh, "dh"); dc = _f32(dc, "dc")
+    M, Hd = c_prev.shape
+    dgates = torch.empty_like(gate_act); dc_prev = torch.empty_like(c_prev)
+    _lib.check(lib().air_lstm_pointwise_bwd_opt(_p(gate_act), _p(c_prev), _p(c), _p(dh), None, _p(dc), _p(dgates),
+                                                _p(dc_prev), M, Hd, ctypes.byref(opt) if opt is not None else None, _stream()),
+               "air_lstm_pointwise_bwd_opt")
+    return dgates, dc_prev
+
+
+def lstm_step_bwd_opt(dgates_next, w_h, dh_a, dh_b, dc_in, gate_act, c_prev, c, opt, precision=0):
+    """air_lstm_step_bwd with an optimiser slice riding along"""
+    dgates_next = _f32(dgates_next, "dgates_next", 2); w_h = _f32(w_h, "w_h", 2)
+    gate_act = _f32(gate_act, "gate_act", 2); c_prev = _f32(c_prev, "c_prev", 2); c = _f32(c, "c", 2)
+    M, Hd = c_prev.shape
+    dgates = torch.empty_like(gate_act); dc_prev = torch.empty_like(c_prev)
+    _lib.check(lib().air_lstm_step_bwd_opt(_p(dgates_next), _p(w_h), _p(dh_a), _p(dh_b), _p(dc_in), _p(gate_act), _p(c_prev),
+                                           _p(c), None, _p(dgates), _p(dc_prev), None, M, Hd, int(precision),
+                                           ctypes.byref(opt) if opt is not None else None, _stream()), "air_lstm_step_bwd_opt")
+    return dgates, dc_prev
+
+
 # ---- stochastic nodes ----------------------------------------------------------------------------------------------
 def gauss_sample_fwd(pre, eps, raw_offset, loc_mode, prior4, want_kl=True):
     """pre[M, >=2D] (row stride allowed), eps[M,D] or None -> loc, scale, sample|None, kl_row|None"""

@@ -479,6 +479,39 @@ def test_rmsprop_centered(hip):
     assert_close(pg, p["a/w"], 1e-6, 1e-7, "params"); assert_close(mom, slots["a/w"]["mom"], 1e-5, 1e-9, "mom")
 
 
+@pytest.mark.parametrize("M,Hd", [(64, 256), (1024, 256)])          # 16-wave link / wide-tile link
+def test_optimizer_slice_riding_on_bptt_launches(hip, M, Hd):
+    """air_lstm_pointwise_bwd_opt / air_lstm_step_bwd_opt: the launch's own result is unchanged and elements [lo, hi) of the
+    flat buffers -- and only those -- receive air_rmsprop_centered's update (two learning rates around n_model)."""
+    gen = torch.Generator().manual_seed(M + Hd)
+    rn = lambda *s_: torch.randn(*s_, generator=gen).cuda()
+    n, lo, hi, n_model = 40_000, 4_000, 29_996, 20_000
+    p0, g = rn(n), rn(n)
+    ms0, mg0, mom0 = torch.rand(n, generator=gen).cuda() + 1.0, rn(n) * 0.1, rn(n) * 0.01
+    lr = torch.tensor([1e-3]).cuda()
+    ref = [t.clone() for t in (p0, ms0, mg0, mom0)]
+    for a, b, mult in ((lo, n_model, 1.0), (n_model, hi, 10.0)):            # reference: the stand-alone update, segment by segment
+        hip.rmsprop_centered_(ref[0][a:b], g[a:b], ref[1][a:b], ref[2][a:b], ref[3][a:b], lr, lr_mult=mult)
+    act = torch.sigmoid(rn(M, 4 * Hd)); c0, c1, dh, dc = rn(M, Hd), rn(M, Hd), rn(M, Hd), rn(M, Hd)
+    w_h = rn(Hd, 4 * Hd) / 16; dgn = rn(M, 4 * Hd)
+    for which in ("pointwise", "link"):
+        bufs = [t.clone() for t in (p0, ms0, mg0, mom0)]
+        sl = hip.rmsprop_slice(bufs[0], g, bufs[1], bufs[2], bufs[3], lo, hi, n_model, lr, lr_mult_tail=10.0)
+        if which == "pointwise":
+            out = hip.lstm_pointwise_bwd_opt(act, c0, c1, dh, dc, sl)
+            plain = hip.lstm_pointwise_bwd(act, c0, c1, dh, dc)
+        else:
+            out = hip.lstm_step_bwd_opt(dgn, w_h, dh, None, dc, act, c0, c1, sl)
+            plain = hip.lstm_step_bwd(dgn, w_h, dh, None, dc, act, c0, c1)[:2]
+        torch.cuda.synchronize()
+        for o, q in zip(out, plain):
+            assert torch.equal(o, q), which
+        for b_, r_, o_, nm in zip(bufs, ref, (p0, ms0, mg0, mom0), ("p", "ms", "mg", "mom")):
+            assert torch.equal(b_[:lo], o_[:lo]) and torch.equal(b_[hi:], o_[hi:]), (which, nm, "outside the slice")
+            assert_close(b_[lo:hi], r_[lo:hi], 1e-6, 1e-7, which + " " + nm)     # (the stand-alone kernel contracts differently)
+            assert not torch.equal(b_[lo:hi], o_[lo:hi])
+
+
 def test_rng_statistics_and_advance(hip):
     state = torch.tensor([1234, 0], dtype=torch.int64).cuda()
     n = 1 << 20
