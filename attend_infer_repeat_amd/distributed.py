@@ -104,8 +104,9 @@ class DataParallelEngine(object):
     `engine` needs: flat_params, flat_grads, world_size, capture(...), train_step(obs, allreduce), synchronize() and
     (optionally) stream_context() / device -- the CPU tests drive this class with a stand-in engine over gloo."""
 
-    def __init__(self, engine, group=None, capture_graph=True, collective=None, overlap=None):
+    def __init__(self, engine, group=None, capture_graph=True, collective=None, overlap=None, steps_per_replay=1):
         self.engine = engine
+        self.steps_per_replay = 1
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -140,7 +141,11 @@ class DataParallelEngine(object):
             if capture_graph:
                 engine.capture(split_optimizer=True)
         elif capture_graph:
-            engine.capture()
+            if steps_per_replay > 1:        # single GPU only: several updates per graph replay (engine.capture)
+                engine.capture(steps_per_replay=steps_per_replay)
+                self.steps_per_replay = int(steps_per_replay)
+            else:
+                engine.capture()
 
     def _stream(self):
         ctx = getattr(self.engine, "stream_context", None)

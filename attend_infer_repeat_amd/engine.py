@@ -333,7 +333,7 @@ class AIREngine:
         if cfg.mfma_dtype not in ("f32", "bf16"):
             raise ValueError("mfma_dtype must be 'f32' or 'bf16', got %r" % (cfg.mfma_dtype,))
         prec = 1 if cfg.mfma_dtype == "bf16" else 0
-        self._keep = []
+        self._keep = getattr(self, "_keep", [])             # descriptor arrays of every plan ever built stay alive (graphs hold pointers)
         NONE, BIAS, BELU, MDELU, ADDAUX = H.EPI_NONE, H.EPI_BIAS, H.EPI_BIAS_ELU, H.EPI_MUL_DELU, H.EPI_ADD_AUX
         ADDAUX_ELU = H.EPI_ADD_AUX_ELU
         dp = lambda t: (t.data_ptr() if t is not None else None)
@@ -803,12 +803,14 @@ class AIREngine:
                 nh = len(rider_hosts)
                 cuts = [r_lo + ((r_hi - r_lo) * i // nh) // 4 * 4 for i in range(nh)] + [r_hi]
                 riders = list(bwd)
+                self._rider_slices_all = getattr(self, "_rider_slices_all", [])
                 self._rider_slices = []
                 for (idx, fn, args, name), lo, hi in zip(rider_hosts, cuts[:-1], cuts[1:]):
                     sl = _lib.AirRmspropSlice(dp(self.flat_params), dp(self.flat_grads), dp(self.flat_ms), dp(self.flat_mg),
                                               dp(self.flat_mom), lo, hi, self.n_model, dp(self.lr_dev), tail_mult,
                                               cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0)
                     self._rider_slices.append(sl)
+                    self._rider_slices_all.append(sl)
                     riders[idx] = (fn, args + (ctypes.byref(sl),), name)
                 self._plan_bwd_riders = riders
                 self._plan_opt_rest = [
@@ -900,7 +902,23 @@ class AIREngine:
                 raise _lib.AirHipError("air_allreduce_sum failed: %s" % (L.air_comm_last_error() or b"").decode())
         return call
 
-    def capture(self, split_optimizer: bool = False, comm=None, overlap: bool = False):
+    def _step_plans_for(self, obs):
+        """the single-GPU train-step plans [forward, backward, update] with `obs` as the observation buffer"""
+        saved = self.obs
+        self.obs = obs
+        try:
+            self._build_plans()
+            if self._plan_bwd_riders is not None:
+                return [self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest]
+            return [self._plan_fwd_train, self._plan_bwd, self._plan_opt]
+        finally:
+            self.obs = saved
+
+    def set_obs_slot(self, slot: int, obs: torch.Tensor):
+        """batch for step `slot` of a multi-step replay (capture(steps_per_replay=K)); slot 0 is the ordinary obs buffer"""
+        self._copy_in(self.obs if slot == 0 else self.obs_ring[slot - 1], obs)
+
+    def capture(self, split_optimizer: bool = False, comm=None, overlap: bool = False, steps_per_replay: int = 1):
         """Capture noise + forward + backward (+ gradient all-reduce) + both RMSProp updates into hipGraphs.
         comm=None, split_optimizer=False : single GPU, ONE graph.
         comm=<air_comm handle>           : data parallel, still ONE graph -- the RCCL all-reduce of the flat gradient buffer
@@ -950,6 +968,25 @@ class AIREngine:
             self._graph = self._capture_plans(plans)
             self._graph_has_opt = True
             return
+        self._steps_per_replay = 1
+        if steps_per_replay > 1:
+            # K consecutive updates per replay (a replay costs ~8 us on top of 1.7 us per node): step j reads its batch from
+            # slot j of an observation ring that the caller fills ahead of the replay (set_obs_slot) -- an input queue of depth K.
+            # Single GPU only: every step ends with its own update.
+            if split_optimizer or self.world_size != 1:
+                raise ValueError("steps_per_replay > 1 needs the single-GPU fused step")
+            K = int(steps_per_replay)
+            if getattr(self, "obs_ring", None) is None or self.obs_ring.shape[0] != K - 1:
+                self.obs_ring = torch.empty((K - 1,) + tuple(self.obs.shape), dtype=torch.float32, device=self.device)
+                self.obs_ring.copy_(self.obs.unsqueeze(0).expand_as(self.obs_ring))
+            plans = []
+            for j in range(K):
+                plans += self._step_plans_for(self.obs if j == 0 else self.obs_ring[j - 1])
+            self._step_plans_for(self.obs)                      # leave the engine's own plans on the ordinary buffer
+            self._graph = self._capture_plans(plans)
+            self._graph_has_opt = True
+            self._steps_per_replay = K
+            return
         if not split_optimizer and self._plan_bwd_riders is not None and self.world_size == 1:
             self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest])
         else:
@@ -978,6 +1015,9 @@ class AIREngine:
         sp = self._sp()
         if self._graph is not None:
             _lib.check(H.lib().air_graph_launch(self._graph, sp), "air_graph_launch")
+            if getattr(self, "_steps_per_replay", 1) > 1:
+                self.global_step += self._steps_per_replay
+                return
             if not self._graph_has_opt:
                 if allreduce is not None:
                     with torch.cuda.stream(self.stream):

@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--steps-per-replay", type=int, default=1,
+                    help="single GPU: consecutive updates captured per hipGraph replay (input queue of that depth; a replay "
+                         "costs ~8 us on top of its nodes).  --steps is rounded up to a multiple of it")
     ap.add_argument("--breakdown", action="store_true",
                     help="time every launch of the step plan in isolation (HIP events, back-to-back repeats) -> stderr")
     ap.add_argument("--mfma", default="f32", choices=["f32", "bf16"],
@@ -332,18 +335,25 @@ def main():
     eng.set_obs(torch.from_numpy(imgs).to(device))
     # replicated weights (broadcast from rank 0), one all-reduce (sum) of the flat gradient bucket per step,
     # RMSProp applies grad_scale = 1/world
-    dp = D.DataParallelEngine(eng, capture_graph=not args.no_graph)
+    dp = D.DataParallelEngine(eng, capture_graph=not args.no_graph, steps_per_replay=args.steps_per_replay)
+    spr = dp.steps_per_replay                                   # 1 unless --steps-per-replay K on a single GPU
+    if spr > 1:
+        for j in range(1, spr):                                 # a different synthetic batch in every slot of the input queue
+            eng.set_obs_slot(j, torch.from_numpy(synthetic_multi_mnist(B, cfg.img_size, max_objects=4 if args.config == "c4" else 2,
+                                                                      seed=rank + 100 * j)[0]).to(device))
+        args.steps = (args.steps + spr - 1) // spr * spr
+        args.warmup = (args.warmup + spr - 1) // spr * spr
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup // spr):
         dp.train_step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // spr):
         dp.train_step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -361,7 +371,7 @@ def main():
         # (the headline `value` stays "exactly K steps between two barriers", as the driver contract defines it)
         lib = H.lib()
         sp = eng._sp()
-        n_ev = min(args.steps, 400)
+        n_ev = min(args.steps // spr, 400)
         evs = [ctypes.c_void_p() for _ in range(n_ev + 1)]
         for e in evs:
             _lib.check(lib.air_event_create(ctypes.byref(e)))
@@ -378,7 +388,7 @@ def main():
         for e in evs:
             lib.air_event_destroy(e)
         per.sort()
-        median_ms = per[len(per) // 2]
+        median_ms = per[len(per) // 2] / spr                   # per update
         if args.breakdown:
             plan_breakdown(eng)
         roof = st_rooflines(eng)
@@ -397,7 +407,8 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "bf16 operands / f32 accumulate+storage", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
-                       "hipgraph": not args.no_graph, "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
+                       "hipgraph": not args.no_graph, "steps_per_graph_replay": spr,
+                       "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
                        "keep_canvas_steps": True, "collective": dp.collective, "params_finite_after_run": finite},
             "roofline": dict(roof["st_read_fwd"], kernel="st_read_fwd_pipe_kernel (the fused affine-grid + bilinear glimpse read, "
                              "north_star's kernel) launched on its own at the in-step shape; `achieved`/`frac` use the SURVEY 8(d) "

@@ -376,6 +376,33 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
 
 
+@pytest.mark.parametrize("name", ["mnist_b8", "t1_b5"])
+def test_multi_step_replay_equals_single_steps(gpu_device, name):
+    """capture(steps_per_replay=K): K consecutive updates in one graph replay, step j reading its batch from slot j of the
+    observation ring -- bit-identical to K single-step replays fed the same batches (device-side step counter, Philox offset and
+    annealed prior advance inside the graph)."""
+    ocfg, B = CONFIGS[name]
+    K = 3
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    batches = [O.synthetic_batch(ocfg, B, seed=20 + j)[0].cuda() for j in range(2 * K)]
+    eng_a.capture(); eng_b.capture(steps_per_replay=K)
+    for r in range(2):
+        for j in range(K):
+            eng_a.train_step(batches[r * K + j])
+            eng_b.set_obs_slot(j, batches[r * K + j])
+        eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    assert eng_a.global_step == eng_b.global_step == 2 * K and eng_b.step_dev.item() == 2 * K
+    for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads", "noise_normal"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    # the engine's own (single-step) plans still work on the ordinary buffer afterwards
+    eng_b.release_graphs(); eng_a.release_graphs()
+    eng_a.train_step(batches[0]); eng_b.train_step(batches[0])
+    eng_a.synchronize(); eng_b.synchronize()
+    assert torch.equal(eng_a.flat_params, eng_b.flat_params)
+
+
 def test_noise_changes_every_step_and_prior_anneals(gpu_device):
     ocfg, B = CONFIGS["tiny"]
     eng, *_ = make_pair(ocfg, B, gstep=0)

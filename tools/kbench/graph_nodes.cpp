@@ -6,15 +6,18 @@
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void k(float *p, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n) p[i] = p[i] * 1.0001f + 1.f; }
-int main() {
+struct Big { float *p; int n; int pad[250]; };       // ~1 KB of kernel arguments, like a grouped-GEMM launch
+__global__ void kbig(Big a) { int i = blockIdx.x * 256 + threadIdx.x; if (i < a.n) a.p[i] = a.p[i] * 1.0001f + 1.f + (float)a.pad[blockIdx.x & 127]; }
+int main(int argc, char **argv) {
+    const bool big = argc > 1;
     float *p; CK(hipMalloc(&p, 1 << 20)); CK(hipMemset(p, 0, 1 << 20));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     double prev = 0;
-    for (int N = 24; N <= 72; ++N) {
+    for (int N = 24; N <= 72; N += (big ? 2 : 1)) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
-        for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k, dim3(64), dim3(256), 0, st, p, 16384);
+        for (int i = 0; i < N; ++i) { if (big) { Big a{}; a.p = p; a.n = 16384; hipLaunchKernelGGL(kbig, dim3(64), dim3(256), 0, st, a); } else hipLaunchKernelGGL(k, dim3(64), dim3(256), 0, st, p, 16384); }
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge, st));
