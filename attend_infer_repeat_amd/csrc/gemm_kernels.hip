@@ -811,9 +811,12 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
             if (d.K < min_k) min_k = d.K;
         }
         if (ok && ta) ok = tiles64 >= (bf ? wide_tn_bf : wide_tn_f32) && min_k >= 256;     // (K = rows: short at small batch)
-        if (ok && !ta && tb) ok = min_k >= wide_nt_k;
+        // dX products (both operands k-contiguous): the 16x64 tile pays from K = 512; below that a 32x64 tile is 10-20 % faster than
+        // the 32x32-tile kernel with bf16 operands (L1 operand traffic) and no faster in fp32 (profiles/r02_j_kbench_gemm_*.txt)
+        const bool nt_short = !ta && tb && min_k < wide_nt_k;
+        if (ok && nt_short) ok = bf && tiles16 > 2048;
         if (ok) {
-            const int TMw = ta ? 64 : 16;
+            const int TMw = ta ? 64 : (nt_short ? 32 : 16);
             int wt = 0;
             for (int i = 0; i < count; ++i) {
                 ga.tile_start[i] = wt;
@@ -834,6 +837,7 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
                 }                                                                                                          \
             } while (0)
             if (ta) AIR_WIDE_LAUNCH(4, true, false);
+            else if (nt_short) AIR_WIDE_LAUNCH(2, false, true);
             else if (tb) AIR_WIDE_LAUNCH(1, false, true);
             else AIR_WIDE_LAUNCH(1, false, false);
 #undef AIR_WIDE_LAUNCH
