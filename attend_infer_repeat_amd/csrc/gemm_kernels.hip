@@ -638,6 +638,43 @@ __global__ __launch_bounds__(64 * KW) void gemm_grouped_wide_kernel(GroupArgs ga
     }
 }
 
+// All weight gradients of a step in ONE launch: up to 24 all-TN problems (a dynamic, wave-uniform descriptor index: scalar
+// loads from the kernel-argument segment).  With every long-K and short-K tile in the same grid -- long ones first -- the CUs
+// that finish early keep pulling short tiles instead of idling until the launch ends (two launches of 8: 72 + 69 us in fp32 at
+// batch 1024 with 184 and 408 tiles on 256 CUs).
+#define AIR_GEMM_BIG_GROUP_MAX 24
+struct BigGroupArgs {
+    GemmArgs g[AIR_GEMM_BIG_GROUP_MAX];
+    int tile_start[AIR_GEMM_BIG_GROUP_MAX + 1];
+    int count;
+    int xcd_map;
+};
+// the same within ONE problem's range of workgroup ids [s, e): the problem keeps its place in the dispatch order (long-K problems
+// first), and the workgroups of it that land on one XCD (ids congruent mod 8) get a contiguous run of its tiles
+__device__ __forceinline__ int xcd_contiguous_tile_in_range(int b, int s, int e) {
+    const int x = b & 7;
+    int start = 0, first_x = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const int f = s + ((y - s) & 7);                    // first id >= s on XCD y
+        const int cnt = f < e ? ((e - 1 - f) >> 3) + 1 : 0;
+        if (y < x) start += cnt;
+        if (y == x) first_x = f;
+    }
+    return s + start + ((b - first_x) >> 3);
+}
+template <int MT, int KW, bool BF>
+__global__ __launch_bounds__(64 * KW) void gemm_big_group_wide_tn_kernel(BigGroupArgs ga) {
+    const int b = (int)blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < ga.count; ++i)
+        if (b >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int s0 = ga.tile_start[p];
+    const int vb = ga.xcd_map ? xcd_contiguous_tile_in_range(b, s0, ga.tile_start[p + 1]) : b;
+    gemm_wide_body<MT, KW, BF, true, false>(ga.g[p], vb - s0);
+}
+
 // sums the S split-K slabs in fixed order and applies the epilogue
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
     const size_t total = (size_t)g.M * g.N;
@@ -756,8 +793,41 @@ static int fill_gemm_args(GemmArgs &g, const AirGemmDesc &d) {
     return AIR_OK;
 }
 
+// more than AIR_GEMM_GROUP_MAX problems: only the all-TN wide-tile form (the deferred weight gradients of a step)
+static int launch_big_tn_group(const AirGemmDesc *descs, int count, void *stream) {
+    AIR_REQUIRE(count <= AIR_GEMM_BIG_GROUP_MAX, AIR_E_SHAPE);
+    BigGroupArgs ga;
+    const bool bf = descs[0].precision == AIR_PREC_BF16;
+    int wt = 0, min_k = 1 << 30;
+    for (int i = 0; i < count; ++i) {
+        const AirGemmDesc &d = descs[i];
+        AIR_REQUIRE(d.precision == AIR_PREC_F32 || d.precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+        AIR_REQUIRE((d.precision == AIR_PREC_BF16) == bf, AIR_E_UNSUPPORTED);
+        AIR_REQUIRE(d.ta && !d.tb && !d.A2, AIR_E_UNSUPPORTED);
+        AIR_REQUIRE(air_aligned16(d.B) && d.ldb % 4 == 0 && d.K % 4 == 0 && d.M >= 4 && d.N >= 4 && d.M % 4 == 0 && d.N % 4 == 0,
+                    AIR_E_UNSUPPORTED);
+        int st = fill_gemm_args(ga.g[i], d);
+        if (st) return st;
+        ga.tile_start[i] = wt;
+        wt += air_cdiv(d.M, 64) * air_cdiv(d.N, 64);
+        if (d.K < min_k) min_k = d.K;
+    }
+    for (int i = count; i <= AIR_GEMM_BIG_GROUP_MAX; ++i) ga.tile_start[i] = wt;
+    for (int i = count; i < AIR_GEMM_BIG_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
+    ga.count = count;
+    // XCD-contiguous tiles WITHIN each problem (a map over the whole grid would hand every long-K problem to the first XCDs)
+    static const int big_xcd = getenv("AIR_GEMM_BIG_XCD") ? atoi(getenv("AIR_GEMM_BIG_XCD")) : 1;
+    ga.xcd_map = big_xcd && min_k >= 1024 ? 1 : 0;
+    hipStream_t st = air_stream(stream);
+    if (bf) hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, true>), dim3(wt), dim3(512), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, false>), dim3(wt), dim3(512), 0, st, ga);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
 extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream) {
     AIR_REQUIRE(descs, AIR_E_NULL);
+    if (count > AIR_GEMM_GROUP_MAX) return launch_big_tn_group(descs, count, stream);
     AIR_REQUIRE(count > 0 && count <= AIR_GEMM_GROUP_MAX, AIR_E_SHAPE);
     GroupArgs ga;
     // tile shape for the whole group: 16x16 tiles (more, shorter-lived workgroups) while the group is far from filling

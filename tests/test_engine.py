@@ -269,7 +269,7 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
     else:
         assert "air_attend_fwd" in names and eng._defer_dw
         assert "air_lstm_step_fwd" in names and "air_lstm_pointwise_fwd" not in names       # wide-tile fused LSTM steps
-        tail = [a[0] for _, a, n in eng._plan_bwd[-3:] if n == "air_gemm_grouped"]
+        tail = [a[0] for _, a, n in eng._plan_bwd[-2:] if n == "air_gemm_grouped"]
         assert tail and all(d.ta and not d.tb for arr in tail for d in arr)          # the deferred weight-gradient launches
     eng.forward(sample_noise=False)
     eng.backward()

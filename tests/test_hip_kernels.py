@@ -643,6 +643,15 @@ def test_gemm_wide_tiles(hip, precision, layout):
         assert_close(outs[0][0], r(x).t() @ r(g), 1e-5, atol * 10, "dW")
         assert_close(outs[1][0], r(x2).t() @ r(g2), 1e-5, atol * 10, "dW ragged M")
         assert_close(outs[1][1], g2.cpu().double().sum(0), 1e-5, 1e-3, "db")
+        # more than 8 problems: the whole-step form (dynamic descriptor index), long-K problems first
+        xs = [rn(1024 if i % 2 else 3072, 64 * (1 + i % 3)) for i in range(11)]
+        gs = [rn(x_.shape[0], 128 if i % 4 else 256) for i, x_ in enumerate(xs)]
+        order = sorted(range(11), key=lambda i: -xs[i].shape[0])
+        outs = hip.gemm_grouped([dict(A=xs[i], B=gs[i], ta=True, colsum=(i % 2 == 0)) for i in order], precision=precision)
+        for o, i in zip(outs, order):
+            assert_close(o[0], r(xs[i]).t() @ r(gs[i]), 1e-5, atol * 10, "big group dW %d" % i)
+            if i % 2 == 0:
+                assert_close(o[1], gs[i].cpu().double().sum(0), 1e-5, 1e-3, "big group db %d" % i)
         # rows of A that are not 16-byte aligned (leading dimension 50): the first 48 of the 50 weight-gradient rows
         x3 = rn(3072, 50); g3 = rn(3072, 256)
         outs = hip.gemm_grouped([dict(A=x3[:, :48], B=g3, ta=True, colsum=True), dict(A=x2, B=g2, ta=True)], precision=precision)

@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
         {0, 0, 3072, 256, 256, "MLP fwd"}, {0, 0, 3072, 256, 400, "glimpse enc l0 fwd"}, {0, 0, 3072, 400, 256, "decoder out fwd"},
         {0, 0, 1024, 256, 2500, "input enc l0 fwd"}, {0, 0, 1024, 1024, 256, "LSTM recurrent fwd"}, {0, 0, 3072, 100, 256, "what head fwd"},
         {0, 1, 3072, 256, 256, "MLP dX"}, {0, 1, 3072, 256, 400, "decoder out dX"}, {0, 1, 1024, 256, 1024, "LSTM dh"}, {0, 1, 3072, 400, 256, "glimpse enc l0 dX"}, {0, 1, 3072, 128, 64, "steps l1 dX"}, {0, 1, 3072, 256, 100, "what dX"},
-        {1, 0, 256, 256, 3072, "MLP dW"}, {1, 0, 256, 1024, 3072, "LSTM dWx"}, {1, 0, 2500, 256, 1024, "input enc l0 dW"}, {1, 0, 400, 256, 3072, "glimpse enc l0 dW"},
+        {1, 0, 256, 256, 3072, "MLP dW"}, {1, 0, 256, 1024, 3072, "LSTM dWx"}, {1, 0, 2500, 256, 1024, "input enc l0 dW"}, {1, 0, 400, 256, 3072, "glimpse enc l0 dW"}, {1, 0, 1024, 1024, 3072, "square dW (256 tiles: one per CU)"}, {1, 0, 2048, 1024, 3072, "512 tiles"}, {1, 0, 1024, 1024, 1024, "256 tiles, K = 1024"},
         {1, 0, 48, 256, 3072, "decoder l0 dW (48 of 50 rows, lda 50: unaligned 16-byte loads)", 50}, {1, 0, 676, 256, 1024, "baseline latent dW (676 of 677, lda 677)", 677},
     };
     for (const Shape &s : shapes) {
