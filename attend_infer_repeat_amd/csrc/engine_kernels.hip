@@ -4,6 +4,7 @@
 //             prior.py:62-151)                 -- both only read the transform / steps MLP outputs
 //   backward: d where-parameters (needs dwhere from both ST kernels)  ||  d steps-logit (num-steps KL, step weights, REINFORCE)
 #include "engine_device.h"
+#include "prologue_device.h"
 
 template <int MT>
 __global__ __launch_bounds__(PW_THREADS) void heads_fwd_kernel(
@@ -123,6 +124,51 @@ extern "C" int air_what_sample_pack(const float *pre, int ld_pre, const float *e
     hipLaunchKernelGGL(what_sample_pack_kernel, dim3(gb + pb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre, eps,
                        raw_offset, p_loc, p_scale, loc, scale, sample, kl_row, M, D, where, presence, state0, state1,
                        pack_out, T, B, S0, S1);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+
+// ---- HBM-resident batch feeder (reference: tensors_from_data -> np.random.choice(n, batch_size) behind tf.py_func, data.py:121-158:
+// a host round trip per step).  Here the dataset lives in HBM and the gather is a launch of the step itself: row b of the batch is
+// item idx_b of the dataset, idx_b drawn with replacement from Philox(seed, stream 1, counter step*B + b) -- or, sequential,
+// (step*B + b) mod n -- with `step` read from the DEVICE step counter, so a captured step (or several per graph replay) draws a
+// fresh batch every time it runs and a resumed run continues the sequence.  idx_out (optional) receives the indices (labels).
+__global__ __launch_bounds__(PW_THREADS) void batch_gather_kernel(const float *__restrict__ data, long long n_items, int item_floats,
+                                                                 const uint64_t *__restrict__ seed_dev,
+                                                                 const int64_t *__restrict__ step_dev, int shuffle,
+                                                                 float *__restrict__ out, int B, int64_t *__restrict__ idx_out,
+                                                                 int vec4) {
+    const long long step = step_dev[0];
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const unsigned long long ctr = (unsigned long long)step * (unsigned long long)B + (unsigned long long)b;
+        long long idx;
+        if (shuffle) {
+            uint32_t r[4];
+            philox4x32(ctr, 1, seed_dev[0], r);
+            const unsigned long long wide = ((unsigned long long)r[0] << 32) | r[1];
+            idx = (long long)(((unsigned __int128)wide * (unsigned __int128)n_items) >> 64);        // uniform in [0, n)
+        } else {
+            idx = (long long)(ctr % (unsigned long long)n_items);
+        }
+        if (threadIdx.x == 0 && idx_out) idx_out[b] = idx;
+        const float *src = data + (size_t)idx * item_floats;
+        float *dst = out + (size_t)b * item_floats;
+        if (vec4) {
+            for (int q = threadIdx.x; q < (item_floats >> 2); q += PW_THREADS)
+                reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(src)[q];
+        } else {
+            for (int q = threadIdx.x; q < item_floats; q += PW_THREADS) dst[q] = src[q];
+        }
+    }
+}
+extern "C" int air_batch_gather(const float *dataset, long long n_items, int item_floats, const uint64_t *seed_dev,
+                                const int64_t *step_dev, int shuffle, float *out, int B, int64_t *idx_out, void *stream) {
+    AIR_REQUIRE(dataset && seed_dev && step_dev && out, AIR_E_NULL);
+    AIR_REQUIRE(n_items > 0 && item_floats > 0 && B > 0, AIR_E_SHAPE);
+    const int vec4 = (item_floats % 4 == 0) && air_aligned16(dataset) && air_aligned16(out);
+    hipLaunchKernelGGL(batch_gather_kernel, dim3(B < 4096 ? B : 4096), dim3(PW_THREADS), 0, air_stream(stream), dataset, n_items,
+                       item_floats, seed_dev, step_dev, shuffle ? 1 : 0, out, B, idx_out, vec4);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

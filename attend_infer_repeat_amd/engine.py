@@ -793,6 +793,13 @@ class AIREngine:
         self._plan_fwd_noise = fwd_plan(True) + fwd_tail              # forward(): complete outputs
         self._plan_fwd = fwd_plan(False) + fwd_tail
         self._plan_fwd_train = fwd_plan(True)                         # train step: NVIL rides in the first backward launch
+        feeder = getattr(self, "_feeder", None)
+        if feeder is not None:
+            # the batch itself is drawn by the first launch of the train step (attach_dataset): no host work between updates
+            data, shuffle = feeder
+            self._plan_fwd_train = [(L.air_batch_gather, (p(data), ctypes.c_longlong(data.shape[0]), int(data.shape[1]),
+                                                          p(self.feeder_seed), p(self.step_dev), int(shuffle), p(self.obs), B,
+                                                          p(self.batch_idx)), "air_batch_gather")] + self._plan_fwd_train
         self._plan_bwd = bwd
         # data-parallel gradient buckets: (end index in the backward plan, [lo, hi) slice of the flat gradient buffer that
         # is final once the plan has run up to that index); contiguous, from the tail of the buffer to its head
@@ -923,6 +930,24 @@ class AIREngine:
             return [self._plan_fwd_train, self._plan_bwd, self._plan_opt]
         finally:
             self.obs = saved
+
+    def attach_dataset(self, data: torch.Tensor, shuffle: bool = True, seed: int = 0):
+        """HBM-resident input pipeline (the reference feeds every step through tf.py_func, data.py:121-158): `data` [N, H*W] (or
+        [N, H, W]) stays on the device and every train step starts by gathering its own batch -- indices drawn with replacement
+        from Philox(seed, device step counter) like np.random.choice, or walking the data in order -- as the first launch of the
+        step, inside the captured graph.  `batch_idx` holds the indices of the last batch (for labels).  data=None detaches.
+        Re-capture afterwards."""
+        self.release_graphs()
+        if data is None:
+            self._feeder = None
+        else:
+            d = data.reshape(data.shape[0], -1)
+            if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.shape[1] == self.obs.shape[1]):
+                raise ValueError("dataset must be a contiguous float32 device tensor of [N, %d] images" % self.obs.shape[1])
+            self._feeder = (d, bool(shuffle))
+            self.feeder_seed = torch.tensor([int(seed) & (2 ** 63 - 1)], dtype=torch.int64, device=self.device)
+            self.batch_idx = torch.zeros(self.B, dtype=torch.int64, device=self.device)
+        self._build_plans()
 
     def set_obs_slot(self, slot: int, obs: torch.Tensor):
         """batch for step `slot` of a multi-step replay (capture(steps_per_replay=K)); slot 0 is the ordinary obs buffer"""

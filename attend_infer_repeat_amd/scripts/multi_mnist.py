@@ -37,6 +37,9 @@ def main(argv=None):
     ap.add_argument("--eval-batches", type=int, default=10)
     ap.add_argument("--figures", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--device-feeder", action="store_true",
+                    help="draw every training batch inside the captured step from the HBM-resident training set (engine "
+                         "attach_dataset): no host work between updates")
     ap.add_argument("--resume", default=None,
                     help="checkpoint written by this script (model_<iter>.pt): restores parameters, the RMSProp slots, "
                          "the step counter, the learning rate, the Philox noise state and the feeders' positions")
@@ -80,6 +83,9 @@ def main(argv=None):
         if "train_feed" in ck:
             train_feed.load_state_dict(ck["train_feed"]); valid_feed.load_state_dict(ck["valid_feed"])
         global_step = air.global_step
+    if args.device_feeder:
+        air._engine.attach_dataset(train_feed.imgs.reshape(train_feed.n, -1), shuffle=True, seed=args.seed)
+        air._engine.capture()
     writer = open(osp.join(logdir, "log.jsonl"), "a")
     log = make_logger(air, train_feed, args.eval_batches, valid_feed, args.eval_batches, writer)
 
@@ -89,8 +95,11 @@ def main(argv=None):
         log(0)
     t0, last = time.time(), train_itr
     while train_itr < args.iters:
-        xb, yb = train_feed()
-        train_itr = int(train_step(xb, yb, refresh=False))
+        if args.device_feeder:
+            train_itr = int(train_step(None, None, refresh=False))
+        else:
+            xb, yb = train_feed()
+            train_itr = int(train_step(xb, yb, refresh=False))
         if train_itr % args.log_every == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0

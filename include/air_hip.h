@@ -393,6 +393,13 @@ int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom
                       const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
                       int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
 
+/* HBM-resident batch feeder (replaces tensors_from_data's per-step tf.py_func round trip, data.py:121-158): out[b, :] =
+ * dataset[idx_b, :] with idx_b drawn with replacement (shuffle != 0: Philox(seed_dev[0], stream 1, counter step*B + b), like
+ * np.random.choice(n, batch_size)) or idx_b = (step*B + b) mod n_items; step = *step_dev, the DEVICE step counter that
+ * air_step_epilogue advances, so the launch can be part of a captured step.  idx_out[B] (optional) receives the indices.     */
+int air_batch_gather(const float *dataset, long long n_items, int item_floats, const uint64_t *seed_dev,
+                     const int64_t *step_dev, int shuffle, float *out, int B, int64_t *idx_out, void *stream);
+
 /* ---- noise --------------------------------------------------------------------------------------------------
  * Philox4x32-10 counter RNG (replaces TF's sampler ops behind .sample(), cell.py:133,147,156).
  * normal[n_normal] ~ N(0,1), uniform[n_uniform] ~ U[0,1).  state_dev[2] = {seed, offset} DEVICE uint64; the

@@ -403,6 +403,41 @@ def test_multi_step_replay_equals_single_steps(gpu_device, name):
     assert torch.equal(eng_a.flat_params, eng_b.flat_params)
 
 
+def test_device_feeder_draws_the_batch_inside_the_step(gpu_device):
+    """attach_dataset: the first launch of the (captured) train step gathers the batch from an HBM-resident dataset, indices
+    from Philox(seed, device step counter) or sequential; the step then equals a step fed that batch by hand."""
+    ocfg, B = CONFIGS["mnist_b8"]
+    P = ocfg.img_size[0] * ocfg.img_size[1]
+    N = 37
+    data = torch.stack([O.synthetic_batch(ocfg, 1, seed=300 + i)[0][0] for i in range(N)]).reshape(N, P).cuda()
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    eng_a.attach_dataset(data, shuffle=True, seed=11)
+    assert eng_a._plan_fwd_train[0][2] == "air_batch_gather"
+    eng_a.capture(); eng_b.capture()
+    seen = []
+    for step in range(4):
+        eng_a.train_step(); eng_a.synchronize()
+        idx = eng_a.batch_idx.clone()
+        assert int(idx.min()) >= 0 and int(idx.max()) < N
+        assert torch.equal(eng_a.obs, data[idx])
+        seen.append(idx.cpu())
+        eng_b.train_step(data[idx]); eng_b.synchronize()
+        assert torch.equal(eng_a.flat_params, eng_b.flat_params), step
+    assert not torch.equal(seen[0], seen[1])                       # a new draw every step
+    eng_c, *_ = make_pair(ocfg, B, seed=3, gstep=0)                # same seed, same step counter -> same indices
+    eng_c.attach_dataset(data, shuffle=True, seed=11); eng_c.train_step(); eng_c.synchronize()
+    assert torch.equal(eng_c.batch_idx.cpu(), seen[0])
+    eng_c.attach_dataset(data, shuffle=False)                      # sequential: (step*B + b) mod N, step = 1 by now
+    eng_c.train_step(); eng_c.synchronize()
+    assert torch.equal(eng_c.batch_idx.cpu(), (torch.arange(B) + 1 * B) % N)
+    # several updates per replay: every step of the replay draws its own batch
+    eng_d, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    eng_d.attach_dataset(data, shuffle=True, seed=11); eng_d.capture(steps_per_replay=2)
+    eng_d.train_step(); eng_d.train_step(); eng_d.synchronize()
+    assert torch.equal(eng_d.flat_params, eng_a.flat_params)
+
+
 def test_noise_changes_every_step_and_prior_anneals(gpu_device):
     ocfg, B = CONFIGS["tiny"]
     eng, *_ = make_pair(ocfg, B, gstep=0)
