@@ -248,7 +248,7 @@ def test_bf16_graph_train_step_runs_and_learns(gpu_device):
     assert np.isfinite(last) and last < first - 50.0, (first, last)
 
 
-@pytest.mark.parametrize("variant", ["throughput", "unfused"])
+@pytest.mark.parametrize("variant", ["throughput", "unfused", "mid"])
 def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
     """B = 704 (T*B = 2112 rows, 44 x 16 LSTM tiles > 512): the plan switches to its throughput variants -- GEMM + pointwise
     LSTM steps, wide-tile GEMM kernels, and every weight gradient deferred to a few all-TN launches at the end of the backward.
@@ -259,11 +259,16 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
         monkeypatch.setenv("AIR_FUSE_ATTEND_M", "0")
         monkeypatch.setenv("AIR_DEFER_DW_MIN_ROWS", "100000000")
         monkeypatch.setenv("AIR_FUSE_LSTM_WIDE", "0")
-    ocfg, B = O.AIRConfig(), 704
+    # "mid": B = 272 (816 rows): throughput plan (deferred weight gradients, wide tiles where a launch is large enough) with the
+    # 16-wave fused LSTM steps and the prologue riding in the first of them
+    ocfg, B = O.AIRConfig(), (272 if variant == "mid" else 704)
     eng, params, obs, noise = make_pair(ocfg, B)
     names = [n for _, _, n in eng._plan_fwd_train + eng._plan_bwd]
     assert "air_lstm_pointwise_bwd" in names
-    if variant == "unfused":
+    if variant == "mid":
+        assert eng._defer_dw and "air_lstm_step_fwd_prologue" in names and "air_lstm_step_bwd" in names
+        assert eng._plan_bwd_riders is None
+    elif variant == "unfused":
         assert "air_attend_fwd" not in names and "air_heads_fwd" in names and not eng._defer_dw
         assert "air_lstm_pointwise_fwd" in names
     else:
