@@ -290,6 +290,43 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
     assert not bad, bad
 
 
+def test_throughput_plan_equals_latency_plan_per_sample_on_config4_shapes(gpu_device):
+    """BASELINE configs[3] shapes (100x100 canvas, 28x28 glimpse, T = 5) at batch 416 = 2080 glimpses: the throughput plan
+    (image-major attend kernels with the exact-T = 5 instantiation, wide-tile GEMMs and LSTM steps) against the SAME images run as
+    two batches of 208 on the latency-side kernels (one workgroup per glimpse, 16x16 tiles): every per-sample forward output must
+    agree (same arithmetic up to the summation order inside the dense products), and the backward must stay finite."""
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+    ocfg = O.AIRConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5)
+    B = 416
+    fields = {f.name for f in dataclasses.fields(EngineConfig)}
+    ecfg = EngineConfig(**{k: v for k, v in dataclasses.asdict(ocfg).items() if k in fields})
+    params = O.init_params(ocfg, seed=1, bias_std=0.1)
+    obs, _ = O.synthetic_batch(ocfg, B, seed=11)
+    noise = O.make_noise(ocfg, B, seed=21)
+
+    def run(sel):
+        eng = AIREngine(ecfg, len(sel), seed=1)
+        eng.load_parameters(params)
+        eng.set_obs(obs[sel].cuda())
+        eng.set_noise(noise["eps_where"][:, sel].cuda(), noise["eps_what"][:, sel].cuda(), noise["u_pres"][:, sel].cuda())
+        eng.set_global_step(20000)
+        eng.forward(sample_noise=False); eng.backward()
+        out = {k: v.clone() for k, v in eng.outputs().items() if torch.is_tensor(v)}
+        assert torch.isfinite(eng.flat_grads).all()
+        return eng, out
+    idx = torch.arange(B)
+    eng_big, big = run(idx)
+    assert eng_big._defer_dw and "air_attend_fwd" in [n for _, _, n in eng_big._plan_fwd_train]
+    halves = [run(idx[:208])[1], run(idx[208:])[1]]
+    assert torch.equal(big["presence"][:, :208], halves[0]["presence"]) and torch.equal(big["presence"][:, 208:], halves[1]["presence"])
+    for k, bdim in (("what", 1), ("where", 1), ("presence_prob", 1), ("final_canvas", 0), ("rec_loss_per_sample", 0),
+                    ("kl_what_per_sample", 0), ("glimpse", 1)):
+        if k not in big:
+            continue
+        ref = torch.cat([halves[0][k], halves[1][k]], dim=bdim)
+        assert rel_err(big[k], ref) < 2e-4, (k, rel_err(big[k], ref))
+
+
 @pytest.mark.parametrize("B,mfma", [(64, "f32"), (1024, "f32"), (1024, "bf16")])
 def test_batch_permutation_equivariance_at_full_size(gpu_device, B, mfma):
     """Size-independent property at BASELINE sizes (configs[1]: B=64; configs[4]: B=1024, where the oracle is too slow to be
