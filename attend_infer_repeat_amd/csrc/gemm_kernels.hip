@@ -647,7 +647,8 @@ struct BigGroupArgs {
     GemmArgs g[AIR_GEMM_BIG_GROUP_MAX];
     int tile_start[AIR_GEMM_BIG_GROUP_MAX + 1];
     int count;
-    int xcd_map;
+    int xcd_map;          // 0: none, 1: XCD-contiguous tiles within each problem, 2: over the whole grid
+    unsigned small_mask;  // bit p: problem p is not wide-tile eligible (one to three rows, one column ...): 16x16 tiles, gemm_body
 };
 // the same within ONE problem's range of workgroup ids [s, e): the problem keeps its place in the dispatch order (long-K problems
 // first), and the workgroups of it that land on one XCD (ids congruent mod 8) get a contiguous run of its tiles
@@ -663,15 +664,21 @@ __device__ __forceinline__ int xcd_contiguous_tile_in_range(int b, int s, int e)
     }
     return s + start + ((b - first_x) >> 3);
 }
+// (the odd-shaped rest of the weight gradients -- eight long-K reductions with one to three rows or a single column -- rides in
+//  the same grid on the 16x16-tile body with the same 8 K-splitting waves: a launch of their own cost 14.5 us at batch 1024)
 template <int MT, int KW, bool BF>
 __global__ __launch_bounds__(64 * KW) void gemm_big_group_wide_tn_kernel(BigGroupArgs ga) {
-    const int b = (int)blockIdx.x;
+    const int b = ga.xcd_map == 2 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     int p = 0;
     for (int i = 1; i < ga.count; ++i)
         if (b >= ga.tile_start[i]) p = i;
     p = __builtin_amdgcn_readfirstlane(p);
     const int s0 = ga.tile_start[p];
-    const int vb = ga.xcd_map ? xcd_contiguous_tile_in_range(b, s0, ga.tile_start[p + 1]) : b;
+    if ((ga.small_mask >> p) & 1u) {
+        gemm_body<1, 1, KW, BF>(ga.g[p], b - s0, 0);
+        return;
+    }
+    const int vb = ga.xcd_map == 1 ? xcd_contiguous_tile_in_range(b, s0, ga.tile_start[p + 1]) : b;
     gemm_wide_body<MT, KW, BF, true, false>(ga.g[p], vb - s0);
 }
 
@@ -798,26 +805,35 @@ static int launch_big_tn_group(const AirGemmDesc *descs, int count, void *stream
     AIR_REQUIRE(count <= AIR_GEMM_BIG_GROUP_MAX, AIR_E_SHAPE);
     BigGroupArgs ga;
     const bool bf = descs[0].precision == AIR_PREC_BF16;
-    int wt = 0, min_k = 1 << 30;
+    int wt = 0, min_k = 1 << 30, n_wide = 0;
+    ga.small_mask = 0u;
     for (int i = 0; i < count; ++i) {
         const AirGemmDesc &d = descs[i];
         AIR_REQUIRE(d.precision == AIR_PREC_F32 || d.precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
         AIR_REQUIRE((d.precision == AIR_PREC_BF16) == bf, AIR_E_UNSUPPORTED);
-        AIR_REQUIRE(d.ta && !d.tb && !d.A2, AIR_E_UNSUPPORTED);
-        AIR_REQUIRE(air_aligned16(d.B) && d.ldb % 4 == 0 && d.K % 4 == 0 && d.M >= 4 && d.N >= 4 && d.M % 4 == 0 && d.N % 4 == 0,
-                    AIR_E_UNSUPPORTED);
+        AIR_REQUIRE(!d.A2, AIR_E_UNSUPPORTED);
+        const bool wide = d.ta && !d.tb && air_aligned16(d.B) && d.ldb % 4 == 0 && d.K % 4 == 0 && d.M >= 4 && d.N >= 4 &&
+                          d.M % 4 == 0 && d.N % 4 == 0;
         int st = fill_gemm_args(ga.g[i], d);
         if (st) return st;
         ga.tile_start[i] = wt;
-        wt += air_cdiv(d.M, 64) * air_cdiv(d.N, 64);
-        if (d.K < min_k) min_k = d.K;
+        if (wide) {
+            wt += air_cdiv(d.M, 64) * air_cdiv(d.N, 64);
+            if (d.K < min_k) min_k = d.K;
+            ++n_wide;
+        } else {
+            ga.small_mask |= 1u << i;
+            wt += air_cdiv(d.M, 16) * air_cdiv(d.N, 16);
+        }
     }
+    AIR_REQUIRE(n_wide > 0, AIR_E_UNSUPPORTED);            // this form exists for the weight gradients of a step
     for (int i = count; i <= AIR_GEMM_BIG_GROUP_MAX; ++i) ga.tile_start[i] = wt;
     for (int i = count; i < AIR_GEMM_BIG_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
-    // XCD-contiguous tiles WITHIN each problem (a map over the whole grid would hand every long-K problem to the first XCDs)
+    // XCD-contiguous tiles: within each problem in fp32 (a map over the whole grid would hand every long-K problem -- they come
+    // first -- to the first XCDs); over the whole grid with bf16 operands (launches of equal-K problems, L2-traffic bound)
     static const int big_xcd = getenv("AIR_GEMM_BIG_XCD") ? atoi(getenv("AIR_GEMM_BIG_XCD")) : 1;
-    ga.xcd_map = big_xcd && min_k >= 1024 ? 1 : 0;
+    ga.xcd_map = (big_xcd && min_k >= 1024) ? (bf ? 2 : 1) : 0;
     hipStream_t st = air_stream(stream);
     if (bf) hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, true>), dim3(wt), dim3(512), 0, st, ga);
     else hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, false>), dim3(wt), dim3(512), 0, st, ga);

@@ -744,23 +744,24 @@ class AIREngine:
                     parts.append(d)
             wide = sorted((d for d in parts if wide_ok(d)), key=lambda d: (-d.K, -d.M * d.N))
             rest = [d for d in parts if not wide_ok(d)]
+            # The library takes up to 24 problems in one launch when at least one is wide-tile eligible: the odd-shaped rest (one to
+            # three rows, a single column: eight long-K reductions) rides in the same grid on 16x16 tiles instead of costing a
+            # 14.5 us launch of its own.
             if prec == 0:
-                # fp32 (MFMA-issue bound tiles): ONE launch for all wide-tile weight gradients (the library takes up to 24
-                # all-TN problems) -- long-K tiles first, the CUs that finish early keep pulling short-K tiles instead of idling
-                # until a launch of their own (batch 1024: 0.636 -> 0.607 ms)
-                per_launch = 24
+                # fp32 (MFMA-issue bound tiles): ONE launch for everything -- long-K tiles first, the CUs that finish early keep
+                # pulling short-K tiles instead of idling until a launch of their own (batch 1024: 0.636 -> 0.607 ms)
+                allp = wide + rest
+                groups = [allp[i:i + 24] for i in range(0, len(allp), 24)]
             else:
-                # bf16 operands (L2 / L1 traffic bound tiles): launches of up to 8 problems with the grid-wide XCD-contiguous
-                # tile map are the faster form (0.474 against 0.485 ms for the single launch); a few left-over wide problems
-                # would make a latency-bound launch of their own -- the smallest ones join the launch of the odd-shaped rest
-                per_launch = 8
-                excess = len(wide) % 8
-                if 0 < excess <= 3 and len(wide) > 8 and len(rest) + excess <= 8:
-                    small = sorted(wide, key=lambda d: d.M * d.N)[:excess]
-                    wide = [d for d in wide if all(d is not s_ for s_ in small)]
-                    rest = rest + small
-            for grp in ([wide[i:i + per_launch] for i in range(0, len(wide), per_launch)]
-                        + [rest[i:i + 8] for i in range(0, len(rest), 8)]):
+                # bf16 operands (L2 / L1 traffic bound tiles): the long-K problems in a launch of 8 with the grid-wide
+                # XCD-contiguous tile map, the others + the rest in a second one (0.474 against 0.485 ms for a single launch)
+                tail = wide[8:] + rest
+                groups = [wide[:8]] if wide[:8] else []
+                if len(tail) > 8:
+                    groups += [tail[i:i + 24] for i in range(0, len(tail), 24)]
+                else:
+                    groups += [g_ for g_ in (wide[8:], rest) if g_]
+            for grp in groups:
                 arr = (_lib.AirGemmDesc * len(grp))(*grp)
                 self._keep.append(arr)
                 bwd.append((L.air_gemm_grouped, (arr, len(grp)), "air_gemm_grouped"))

@@ -147,8 +147,9 @@ typedef struct AirGemmDesc {
     int a_elu;
     float *a_out;
 } AirGemmDesc;
-/* count <= 8; up to 24 when every problem is a weight-gradient form the wide-tile kernel takes (ta = 1, tb = 0, M, N, K and
- * ldb multiples of 4, B 16-byte aligned, no A2): the deferred weight gradients of a whole step in one launch.              */
+/* count <= 8; up to 24 for the deferred weight gradients of a whole step in one launch: problems the wide-tile kernel takes
+ * (ta = 1, tb = 0, M, N, K and ldb multiples of 4, B 16-byte aligned) on 64x64 tiles -- at least one --, any other problem
+ * (no A2) on 16x16 tiles in the same grid.                                                                                 */
 int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
 
 /* y = act(x.w + b), neural.py:56-60.  x[M,K], w[K,N] (Sonnet layout), b[N] (may be NULL), y[M,N].                 */
