@@ -1080,10 +1080,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
     const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
     const float4 *s4 = reinterpret_cast<const float4 *>(g.img + (size_t)b * HW);
     const float4 p0 = s4[q0], p1 = s4[q1], p2 = s4[q2];       // in flight while wave 0 forms `where`
-    if (wave == 0) {
+    // one wave per `where` row: wave 0 for a single glimpse; image-major, the T rows of the image go to different waves
+    // (serially on wave 0 they were the longest phase of the workgroup: 4.9 of 8.3 us at T = 3)
+    const int nwv = nt >> 6;
+    if (wave < t1 - t0) {
         const int o = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1), d = o & 3;
         const float bias_o = g.tr_b[o];
-        for (int t = t0; t < t1; ++t) {
+        for (int t = t0 + wave; t < t1; t += nwv) {
             const size_t m = (size_t)t * B + b;                // row t*B + b
             const float eps_d = g.eps[m * 4 + d];
             const float *x = g.tr_h + m * g.tr_k;
