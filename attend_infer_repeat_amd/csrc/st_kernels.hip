@@ -1290,6 +1290,89 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
     const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w;
     Carve c = carve_lds(smem, HW, 0, w, h);
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    // image-major with a few glimpses: three barriers for the whole image instead of three per glimpse -- the pixel passes of all T
+    // glimpses run back to back (per-glimpse partial sums side by side in the unused axis-table area of the carve), then wave
+    // t mod nw finishes glimpse t (final reduction + where-sampling backward: the T tails in parallel), then every thread takes
+    // its share of the T x tr_k outputs of the fused transform-layer dX
+    if (g.img_major && T * (nw * 8 + 8) <= 3 * w + 3 * h + 160) {
+        float *part = reinterpret_cast<float *>(c.fx);         // [T][nw * 8]
+        float *dps = part + T * nw * 8;                        // [T][8]
+        stage_to_lds(c.src, g.img + (size_t)b * HW, HW, g.vec4 != 0);
+        __syncthreads();
+        AIR_TR(1);
+        const int z0 = opaque_zero();
+        for (int t = 0; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            const float sx = g.where[4 * k + z0], tx = g.where[4 * k + 1 + z0];
+            const float sy = g.where[4 * k + 2 + z0], ty = g.where[4 * k + 3 + z0];
+            const float *go_p = g.dglimpse + k * hw;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int p = tid; p < hw; p += nt) {
+                const float go = go_p[p];
+                const int i = p / w, j = p - i * w;
+                const float X = lin_m11(j, w, g.stepx), Y = lin_m11(i, h, g.stepy);
+                int fx, fy; float dx, dy;
+                axis_entry(grid_coord(sx, X, tx, cxs), W, &fx, &dx);
+                axis_entry(grid_coord(sy, Y, ty, cys), H, &fy, &dy);
+                if (fx == ST_INVALID || fy == ST_INVALID) continue;
+                const Taps tp = load_taps_sel(c.src, H, W, fy, fx);
+                const float gx = dy * (tp.fc - tp.ff) + (1.f - dy) * (tp.cc - tp.cf);
+                const float gy = dx * (tp.cf - tp.ff) + (1.f - dx) * (tp.cc - tp.fc);
+                const float ax = go * gx * cxs, ay = go * gy * cys;
+                acc[0] += ax * X; acc[1] += ax;
+                acc[2] += ay * Y; acc[3] += ay;
+            }
+            const float r = wave_reduce8(acc);
+            if ((lane & 7) == 0) part[t * nw * 8 + wid * 8 + wave_reduce8_slot()] = r;
+        }
+        __syncthreads();
+        AIR_TR(2);
+        for (int t = wid; t < T; t += nw) {
+            const size_t k = (size_t)t * B + b;
+            float pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pr[q] = (lane < nw && q < 4) ? part[t * nw * 8 + lane * 8 + q] : 0.f;
+            const float tot = wave_reduce8(pr);
+            const float accd = __shfl(tot, 8 * (lane & 3), 64);
+            if (lane < 4) {
+                const int d_ = lane;
+                const size_t e = k * 4 + d_;
+                const float mu = g.loc[e], sc = g.scale[e], s_dw = g.dwhere_w[e], s_eps = g.eps[e];
+                const float s_raw = g.pre[k * 8 + 4 + d_] + g.raw_offset;
+                const float s_dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
+                g.dwhere_r[4 * k + d_] = accd;
+                const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
+                const float ds = s_dw + accd;
+                float dmu = ds + s_dk * (mu - pm) / (ps * ps);
+                const float dsc = ds * s_eps + s_dk * (sc / (ps * ps) - 1.f / sc);
+                dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
+                const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
+                g.dpre[k * 8 + d_] = dmu;
+                g.dpre[k * 8 + 4 + d_] = dsc * dsp;
+                dps[t * 8 + d_] = dmu; dps[t * 8 + 4 + d_] = dsc * dsp;
+            }
+        }
+        if (g.tr_dx) {
+            __syncthreads();
+            for (int e = tid; e < T * g.tr_k; e += nt) {
+                const int t = e / g.tr_k, nn = e - t * g.tr_k;
+                const size_t k = (size_t)t * B + b;
+                const float4 wa = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)nn * 8);
+                const float4 wb = *reinterpret_cast<const float4 *>(g.tr_w + (size_t)nn * 8 + 4);
+                const float *dpt = dps + t * 8;
+                float v = opnd(dpt[0], g.bf16) * opnd(wa.x, g.bf16);
+                v += opnd(dpt[1], g.bf16) * opnd(wa.y, g.bf16); v += opnd(dpt[2], g.bf16) * opnd(wa.z, g.bf16);
+                v += opnd(dpt[3], g.bf16) * opnd(wa.w, g.bf16); v += opnd(dpt[4], g.bf16) * opnd(wb.x, g.bf16);
+                v += opnd(dpt[5], g.bf16) * opnd(wb.y, g.bf16); v += opnd(dpt[6], g.bf16) * opnd(wb.z, g.bf16);
+                v += opnd(dpt[7], g.bf16) * opnd(wb.w, g.bf16);
+                if (g.tr_y) { const float y = g.tr_y[k * g.tr_ld + nn]; v *= (y > 0.f ? 1.f : y + 1.f); }
+                g.tr_dx[k * g.tr_ld + nn] = v;
+            }
+        }
+        AIR_TR(3);
+        AIR_TR_FLUSH();
+        return;
+    }
   for (int t = t0; t < t1; ++t) {                              // one glimpse, or (image-major) the T glimpses of image b
     const int k = t * B + b;
     // every operand of this unit is requested before anything waits: the image, the `where` row, the incoming glimpse
