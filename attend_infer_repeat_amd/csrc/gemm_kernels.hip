@@ -399,7 +399,6 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs &g, const int bloc
     const int tiles_n = (g.N + TN - 1) / TN;
     const int tm = block_tile / tiles_n, tn = block_tile - tm * tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
-    const int total_chunks = (g.K + 15) >> 4;
 
     f32x4 acc[MT][NT];
 #pragma unroll
