@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/kbench/graph_nodes.cpp -o tools/kbench/bin/graph_nodes
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -20,6 +21,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < N; ++i) { if (big) { Big a{}; a.p = p; a.n = 16384; hipLaunchKernelGGL(kbig, dim3(64), dim3(256), 0, st, a); } else hipLaunchKernelGGL(k, dim3(64), dim3(256), 0, st, p, 16384); }
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        if (getenv("GRAPH_UPLOAD")) CK(hipGraphUpload(ge, st));
         for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge, st));
         std::vector<double> r;
         for (int rep = 0; rep < 5; ++rep) {
