@@ -747,20 +747,27 @@ class AIREngine:
             # The library takes up to 24 problems in one launch when at least one is wide-tile eligible: the odd-shaped rest (one to
             # three rows, a single column: eight long-K reductions) rides in the same grid on 16x16 tiles instead of costing a
             # 14.5 us launch of its own.
+            def pack(problems, n_wide):
+                """launches of up to 24 problems while wide-tile members are among them (the library's mixed form needs at
+                least one), of up to 8 otherwise"""
+                out, i = [], 0
+                while i < len(problems):
+                    step = 24 if i < n_wide else 8
+                    chunk = problems[i:i + step]
+                    if len(chunk) <= 8 and i < n_wide < i + len(chunk):     # (8 or fewer go through the all-one-kind launches)
+                        out += [problems[i:n_wide], problems[n_wide:i + len(chunk)]]
+                    else:
+                        out.append(chunk)
+                    i += step
+                return out
             if prec == 0:
                 # fp32 (MFMA-issue bound tiles): ONE launch for everything -- long-K tiles first, the CUs that finish early keep
                 # pulling short-K tiles instead of idling until a launch of their own (batch 1024: 0.636 -> 0.607 ms)
-                allp = wide + rest
-                groups = [allp[i:i + 24] for i in range(0, len(allp), 24)]
+                groups = pack(wide + rest, len(wide))
             else:
                 # bf16 operands (L2 / L1 traffic bound tiles): the long-K problems in a launch of 8 with the grid-wide
                 # XCD-contiguous tile map, the others + the rest in a second one (0.474 against 0.485 ms for a single launch)
-                tail = wide[8:] + rest
-                groups = [wide[:8]] if wide[:8] else []
-                if len(tail) > 8:
-                    groups += [tail[i:i + 24] for i in range(0, len(tail), 24)]
-                else:
-                    groups += [g_ for g_ in (wide[8:], rest) if g_]
+                groups = ([wide[:8]] if wide[:8] else []) + pack(wide[8:] + rest, len(wide[8:]))
             for grp in groups:
                 arr = (_lib.AirGemmDesc * len(grp))(*grp)
                 self._keep.append(arr)
