@@ -290,6 +290,27 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
     assert not bad, bad
 
 
+def test_throughput_plan_with_odd_layer_sizes_matches_oracle(gpu_device):
+    """The throughput plan on a model none of whose layers fits the wide-tile forms (hidden sizes 48 / 33 / 21 / 30 / 24 / 16 / 8 / 20,
+    40 LSTM units, a 28x36 canvas with 9x12 glimpses, T = 5) at batch 300 = 1500 rows: every deferred weight gradient takes the
+    16x16-tile launches, the LSTM the 16-wave fused form, and the result still matches the oracle."""
+    ocfg, B = CONFIGS["rect_t5"][0], 300
+    eng, params, obs, noise = make_pair(ocfg, B)
+    assert eng._defer_dw
+    eng.forward(sample_noise=False)
+    eng.backward()
+    out = eng.outputs()
+    res, grads = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
+    assert torch.equal(out["presence"].cpu(), res["presence"])
+    for k in ["what", "where", "presence_prob", "final_canvas", "rec_loss_per_sample", "baseline"]:
+        assert rel_err(out[k].reshape(res[k].shape), res[k]) < 5e-4, (k, rel_err(out[k].reshape(res[k].shape), res[k]))
+    g = eng.named_grads()
+    bad = {k: rel_err(g[k], ref) for k, ref in grads.items() if not rel_err(g[k], ref) < 5e-3}
+    assert not bad, bad
+    eng.capture(); eng.train_step(); eng.synchronize()
+    assert torch.isfinite(eng.flat_params).all()
+
+
 def test_throughput_plan_equals_latency_plan_per_sample_on_config4_shapes(gpu_device):
     """BASELINE configs[3] shapes (100x100 canvas, 28x28 glimpse, T = 5) at batch 416 = 2080 glimpses: the throughput plan
     (image-major attend kernels with the exact-T = 5 instantiation, wide-tile GEMMs and LSTM steps) against the SAME images run as
