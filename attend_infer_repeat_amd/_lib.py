@@ -109,6 +109,7 @@ SIGNATURES = {
     "air_nvil": (c_int, [P, P, P, P, P, P, c_int, P]),
     "air_baseline_pack": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "air_rmsprop_centered": (c_int, [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, P]),
+    "air_rmsprop": (c_int, [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "air_rng_fill": (c_int, [P, c_size_t, P, c_size_t, P, P]),
     "air_rng_advance": (c_int, [P, c_uint64, P]),
     "air_fill": (c_int, [P, c_size_t, c_float, P]),
@@ -118,6 +119,8 @@ SIGNATURES = {
     "air_sum_leading": (c_int, [P, P, c_int, c_size_t, P]),
     "air_comm_unique_id": (c_int, [P]),
     "air_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, P]),
+    "air_comm_available": (c_int, []),
+    "air_comm_count": (c_int, [P, ctypes.POINTER(c_int)]),
     "air_comm_destroy": (c_int, [P]),
     "air_allreduce_sum": (c_int, [P, c_size_t, P, P]),
     "air_comm_last_error": (ctypes.c_char_p, []),

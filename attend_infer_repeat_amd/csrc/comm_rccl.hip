@@ -18,6 +18,7 @@ typedef struct { char internal[128]; } nccl_unique_id;      // ncclUniqueId (NCC
 typedef int (*fn_get_unique_id)(nccl_unique_id *);
 typedef int (*fn_comm_init_rank)(void **, int, nccl_unique_id, int);
 typedef int (*fn_comm_destroy)(void *);
+typedef int (*fn_comm_count)(void *, int *);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char *(*fn_error_string)(int);
 enum { NCCL_FLOAT32 = 7, NCCL_SUM = 0 };                      // ncclDataType_t / ncclRedOp_t values of rccl.h
@@ -27,10 +28,11 @@ struct RcclApi {
     fn_get_unique_id get_unique_id;
     fn_comm_init_rank comm_init_rank;
     fn_comm_destroy comm_destroy;
+    fn_comm_count comm_count;
     fn_all_reduce all_reduce;
     fn_error_string error_string;
 };
-RcclApi g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+RcclApi g_api = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 char g_last_error[256] = "";
 
 void set_error(const char *what, int code) {
@@ -50,9 +52,10 @@ int bind_rccl() {
     a.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
     a.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
     a.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    a.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
     a.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
     a.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
-    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_reduce) {
+    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.comm_count || !a.all_reduce) {
         snprintf(g_last_error, sizeof(g_last_error), "librccl.so lacks an expected symbol");
         return AIR_E_UNSUPPORTED;
     }
@@ -88,6 +91,19 @@ extern "C" int air_comm_init(void **comm_out, int world_size, int rank, const vo
     const int r = g_api.comm_init_rank(&comm, world_size, id, rank);
     if (r != 0) { set_error("ncclCommInitRank failed", r); return AIR_E_UNSUPPORTED; }
     *comm_out = comm;
+    return AIR_OK;
+}
+
+// 0 when the library can be bound in this process (dlopen + the symbols above); nothing collective happens here, so every
+// rank can call it and AGREE on the outcome before any of them enters the blocking air_comm_init
+extern "C" int air_comm_available(void) { return bind_rccl(); }
+
+// number of ranks the communicator spans, as RCCL itself reports it (ncclCommCount)
+extern "C" int air_comm_count(void *comm, int *count_out) {
+    AIR_REQUIRE(comm && count_out, AIR_E_NULL);
+    if (!g_api.handle) return AIR_E_UNSUPPORTED;
+    const int r = g_api.comm_count(comm, count_out);
+    if (r != 0) { set_error("ncclCommCount failed", r); return AIR_E_UNSUPPORTED; }
     return AIR_OK;
 }
 

@@ -944,7 +944,9 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     } while (0)
     for (int i = 0; i < count; ++i) AIR_REQUIRE(!descs[i].A2 || count == 1, AIR_E_UNSUPPORTED);
     if (count == 1 && descs[0].A2) {
-        AIR_REQUIRE(T_ == 16 && !long_k, AIR_E_UNSUPPORTED);       // latency-regime consumer of a K-split producer
+        // latency-regime consumer of a K-split producer; a long K (the first hidden layer >= 512 wide at a small batch) stays
+        // on the 4-wave prologue kernel: correct for any K, the 16-wave K split has no prologue form
+        AIR_REQUIRE(T_ == 16, AIR_E_UNSUPPORTED);
         const AproArgs pro = {descs[0].A2, descs[0].a_bias, descs[0].a_out, descs[0].a_elu};
         if (bf) hipLaunchKernelGGL((gemm_f32_mfma_apro_kernel<1, 1, 4, true>), dim3(tiles, 1), dim3(256), 0, st, ga.g[0], pro);
         else hipLaunchKernelGGL((gemm_f32_mfma_apro_kernel<1, 1, 4, false>), dim3(tiles, 1), dim3(256), 0, st, ga.g[0], pro);

@@ -356,7 +356,10 @@ extern "C" int air_baseline_pack(const float *img, const float *what, const floa
     return AIR_OK;
 }
 
-// ---- centred RMSProp with momentum (TF semantics; model.py:265,355-367) ----------------------------------------
+// ---- RMSProp with momentum, centred or not (TF semantics; model.py:265,355-367) ---------------------------------
+// The centred instantiation is the literal expression of rmsprop_elem (optimizer_device.h) -- the riders and the closing
+// update must agree with it bit for bit; the plain form keeps the mg slot up to date but never reads it
+template <bool CENTRED>
 __global__ __launch_bounds__(PW_THREADS) void rmsprop_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                              float *__restrict__ ms, float *__restrict__ mg,
                                                              float *__restrict__ mom, size_t n,
@@ -364,23 +367,38 @@ __global__ __launch_bounds__(PW_THREADS) void rmsprop_kernel(float *__restrict__
                                                              float decay, float momentum, float eps, float gscale) {
     const float lr = lr_dev[0] * lr_mult;
     PW_LOOP(i, n) {
-        const float gi = g[i] * gscale;
-        const float msi = decay * ms[i] + (1.f - decay) * gi * gi;
-        const float mgi = decay * mg[i] + (1.f - decay) * gi;
-        const float mo = momentum * mom[i] + lr * gi / sqrtf(msi - mgi * mgi + eps);
-        ms[i] = msi; mg[i] = mgi; mom[i] = mo;
-        p[i] -= mo;
+        if (CENTRED) {
+            float pv = p[i], a = ms[i], b = mg[i], c = mom[i];
+            rmsprop_elem(pv, g[i], a, b, c, lr, decay, momentum, eps, gscale);
+            ms[i] = a; mg[i] = b; mom[i] = c; p[i] = pv;
+        } else {
+            const float gi = g[i] * gscale;
+            const float msi = decay * ms[i] + (1.f - decay) * gi * gi;
+            const float mgi = decay * mg[i] + (1.f - decay) * gi;
+            const float mo = momentum * mom[i] + lr * gi / sqrtf(msi + eps);
+            ms[i] = msi; mg[i] = mgi; mom[i] = mo;
+            p[i] -= mo;
+        }
     }
+}
+extern "C" int air_rmsprop(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev,
+                           float lr_mult, float decay, float momentum, float eps, int centered, float grad_scale,
+                           void *stream) {
+    AIR_REQUIRE(p && g && ms && mg && mom && lr_dev, AIR_E_NULL);
+    AIR_REQUIRE(n > 0, AIR_E_SHAPE);
+    if (centered)
+        hipLaunchKernelGGL(rmsprop_kernel<true>, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), p, g, ms, mg, mom,
+                           n, lr_dev, lr_mult, decay, momentum, eps, grad_scale);
+    else
+        hipLaunchKernelGGL(rmsprop_kernel<false>, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), p, g, ms, mg, mom,
+                           n, lr_dev, lr_mult, decay, momentum, eps, grad_scale);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 extern "C" int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n,
                                     const float *lr_dev, float lr_mult, float decay, float momentum, float eps,
                                     float grad_scale, void *stream) {
-    AIR_REQUIRE(p && g && ms && mg && mom && lr_dev, AIR_E_NULL);
-    AIR_REQUIRE(n > 0, AIR_E_SHAPE);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), p, g, ms, mg, mom,
-                       n, lr_dev, lr_mult, decay, momentum, eps, grad_scale);
-    AIR_LAUNCH_CHECK();
-    return AIR_OK;
+    return air_rmsprop(p, g, ms, mg, mom, n, lr_dev, lr_mult, decay, momentum, eps, 1, grad_scale, stream);
 }
 
 // ---- Philox4x32-10 noise ----------------------------------------------------------------------------------------

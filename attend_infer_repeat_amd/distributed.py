@@ -7,14 +7,20 @@ own 64 images with its own Philox stream, the flat fp32 gradient bucket (model +
 1/world_size.  Nothing else is exchanged (no activations, no canvases).  Semantics: the averaged gradient equals the
 mean of `world_size` independent B=64 reference steps (the NVIL mean-baseline quirk stays per rank).
 
-Where the collective runs:
-  "rccl-captured" (default on GPUs, world > 1): the engine's own stream calls ncclAllReduce through the C ABI
-                  (air_allreduce_sum) INSIDE the captured step, so the step is still one hipGraph replay.  The
-                  communicator is created once from a unique id that rank 0 broadcasts through torch.distributed.
-  "torch-split"   (fallback; CPU / gloo tests): graph A (forward + backward) -> torch.distributed.all_reduce on the
-                  engine stream -> graph B (update).
-torch.distributed is plumbing here: rendezvous, the parameter broadcast and the fallback collective; backend "nccl" is
-RCCL on ROCm, "gloo" is used by the CPU tests.
+Where the collective runs (AIR_DP_COLLECTIVE / the `collective` argument):
+  "torch-split"   (default): graph A (forward + backward) -> torch.distributed.all_reduce on the engine stream (backend
+                  "nccl" = RCCL on ROCm; "gloo" in the CPU tests) -> graph B (update).  The plain, eager use of RCCL.
+  "rccl-split"    : the same two graphs, the all-reduce issued by the engine itself through the C ABI (air_allreduce_sum ->
+                  ncclAllReduce on the engine stream, eager) on a communicator of its own.
+  "rccl-captured" : the ncclAllReduce call is a NODE of the step's hipGraph, so the step stays one graph replay with no host
+                  round trip (+ AIR_DP_OVERLAP=1: the tail of the gradient buffer is reduced on a forked captured stream, on
+                  a second communicator, while the backward finishes).  Opt-in: bit-equal to the single-GPU graph with one
+                  rank on the GPU, but no multi-GPU node has been available to validate it on more than one.
+The own communicator is created once from a unique id that rank 0 broadcasts through torch.distributed, after every rank has
+AGREED that RCCL can be bound (a rank that failed early would otherwise leave the others blocked inside ncclCommInitRank); the
+first use is an eager all-reduce of a small known buffer checked against the analytic sum, and any failure -- on any rank --
+sends every rank to "torch-split" together.  torch.distributed is plumbing here: rendezvous, the parameter broadcast, the
+agreement flags and the default collective.
 """
 import contextlib
 import ctypes
@@ -72,30 +78,69 @@ def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None):
     return flat_params
 
 
+def _agree(ok: bool, device, group=None) -> bool:
+    """every rank contributes one int; the answer is the minimum (all ranks take the same branch afterwards)"""
+    backend = dist.get_backend(group)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
 def create_rccl_comm(device, group=None):
-    """One RCCL communicator for the engine's own collective calls (air_allreduce_sum): rank 0 draws the unique id, it
-    travels to the other ranks through torch.distributed (any backend), every rank joins with its GPU current."""
+    """One RCCL communicator for the engine's own collective calls (air_allreduce_sum).  Collective over `group`.
+    Protocol (no rank may block alone): (1) every rank binds the library -- not collective -- and the outcome is agreed on;
+    (2) rank 0 draws the unique id and broadcasts it (or the failure); (3) every rank joins with its GPU current
+    (ncclCommInitRank, blocking, all ranks are known to arrive); (4) the outcome and RCCL's own rank count are agreed on.
+    Returns the handle, or raises AirHipError ON EVERY RANK ALIKE."""
     from . import _lib
     from . import hip as H
     L = H.lib()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if not _agree(L.air_comm_available() == 0, device, group):
+        raise _lib.AirHipError("RCCL cannot be bound on every rank: %s" % (L.air_comm_last_error() or b"").decode())
     ident = [None]
     if rank == 0:
         buf = ctypes.create_string_buffer(128)
         st = L.air_comm_unique_id(buf)
-        if st != 0:
-            ident = [RuntimeError((L.air_comm_last_error() or b"").decode())]
-        else:
-            ident = [bytes(buf.raw)]
+        ident = [bytes(buf.raw) if st == 0 else RuntimeError((L.air_comm_last_error() or b"").decode())]
     dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    if not isinstance(ident[0], (bytes, bytearray)):
+    if not isinstance(ident[0], (bytes, bytearray)):                 # the same object on every rank: all raise together
         raise _lib.AirHipError("rank 0 could not create an RCCL unique id: %r" % (ident[0],))
     comm = ctypes.c_void_p()
     with torch.cuda.device(device):
         st = L.air_comm_init(ctypes.byref(comm), world, rank, ctypes.create_string_buffer(bytes(ident[0]), 128))
-    if st != 0:
-        raise _lib.AirHipError("air_comm_init failed: %s" % (L.air_comm_last_error() or b"").decode())
+    n = ctypes.c_int(0)
+    ok = st == 0 and L.air_comm_count(comm, ctypes.byref(n)) == 0 and n.value == world
+    if not _agree(ok, device, group):
+        if st == 0:
+            L.air_comm_destroy(comm)
+        raise _lib.AirHipError("air_comm_init failed on some rank: %s" % (L.air_comm_last_error() or b"").decode())
     return comm
+
+
+def comm_count(comm) -> int:
+    """ranks of an air_comm handle as RCCL reports them (ncclCommCount)"""
+    from . import hip as H
+    n = ctypes.c_int(0)
+    if H.lib().air_comm_count(comm, ctypes.byref(n)) != 0:
+        return -1
+    return int(n.value)
+
+
+def selftest_comm(comm, device, stream, group=None) -> bool:
+    """First use of a fresh communicator: an EAGER all-reduce of a small buffer whose sum is known in closed form
+    (rank r contributes r + 1 everywhere), checked on every rank and agreed on."""
+    from . import hip as H
+    L = H.lib()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok = True
+    with torch.cuda.device(device), torch.cuda.stream(stream):
+        probe = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=device)
+        st = L.air_allreduce_sum(ctypes.c_void_p(probe.data_ptr()), ctypes.c_size_t(probe.numel()), comm,
+                                 ctypes.c_void_p(stream.cuda_stream))
+        stream.synchronize()
+        ok = st == 0 and bool((probe == world * (world + 1) / 2.0).all().item())
+    return _agree(ok, device, group)
 
 
 class DataParallelEngine(object):
@@ -116,28 +161,42 @@ class DataParallelEngine(object):
         with self._stream():
             broadcast_parameters(engine.flat_params, 0, group)
         engine.synchronize()
-        want = collective or os.environ.get("AIR_DP_COLLECTIVE", "").strip().lower() or None
+        want = (collective or os.environ.get("AIR_DP_COLLECTIVE", "").strip().lower() or "torch-split")
+        want = {"captured": "rccl-captured", "split": "torch-split", "torch": "torch-split", "rccl": "rccl-split"}.get(want, want)
+        if want not in ("torch-split", "rccl-split", "rccl-captured"):
+            raise ValueError("AIR_DP_COLLECTIVE / collective must be torch-split, rccl-split or rccl-captured, got %r" % want)
         if overlap is None:
             overlap = os.environ.get("AIR_DP_OVERLAP", "0") == "1"
         on_gpu = getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
         self.collective = "none"
+        self.rccl_nranks = None
+        self._comm_side = None
         if self.world > 1:
             self.collective = "torch-split"
-            if capture_graph and on_gpu and want in (None, "captured", "rccl-captured"):
-                # ONE graph per step even with world > 1: the RCCL call is a captured node.  If the library cannot be bound,
-                # the communicator cannot be built or the capture is refused, fall back (on every rank alike: the outcome is
-                # agreed on with a tiny all-reduce so that no rank ends up in the other protocol).
-                ok = 1
+            if on_gpu and want in ("rccl-split", "rccl-captured"):
+                # Every step below is collective and ends in an agreement, so all ranks leave it in the same protocol.
                 try:
                     self.comm = create_rccl_comm(engine.device, group)
-                    engine.capture(comm=self.comm, overlap=bool(overlap))
-                except Exception as e:                              # noqa: BLE001 -- any failure means "use the fallback"
-                    ok, self._captured_error = 0, repr(e)
-                flag = torch.tensor([ok], dtype=torch.int32, device=engine.device if dist.get_backend(group) == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                if int(flag.item()) == 1:
-                    self.collective = "rccl-captured" + ("+overlap" if overlap else "")
-                    return
+                    if overlap and want == "rccl-captured":
+                        self._comm_side = create_rccl_comm(engine.device, group)     # the forked stream's own communicator
+                    good = selftest_comm(self.comm, engine.device, engine.stream, group)
+                    if good and self._comm_side is not None:
+                        good = selftest_comm(self._comm_side, engine.device, engine.stream, group)
+                except Exception as e:                              # noqa: BLE001 -- raised on every rank alike (see create_rccl_comm)
+                    good, self._captured_error = False, repr(e)
+                if good:
+                    self.rccl_nranks = comm_count(self.comm)
+                    if want == "rccl-captured" and capture_graph:
+                        ok = True
+                        try:
+                            engine.capture(comm=self.comm, overlap=bool(overlap), comm_side=self._comm_side)
+                        except Exception as e:                      # noqa: BLE001 -- a refused capture: agreed fallback below
+                            ok, self._captured_error = False, repr(e)
+                        if _agree(ok, engine.device, group):
+                            self.collective = "rccl-captured" + ("+overlap" if overlap else "")
+                            return
+                        want = "rccl-split"
+                    self.collective = "rccl-split"
             if capture_graph:
                 engine.capture(split_optimizer=True)
         elif capture_graph:
@@ -152,6 +211,14 @@ class DataParallelEngine(object):
         return ctx() if ctx is not None else contextlib.nullcontext()
 
     def _allreduce(self, grads):
+        if self.collective == "rccl-split":                 # the engine's own eager ncclAllReduce on its stream
+            from . import _lib
+            from . import hip as H
+            st = H.lib().air_allreduce_sum(ctypes.c_void_p(grads.data_ptr()), ctypes.c_size_t(grads.numel()), self.comm,
+                                           ctypes.c_void_p(self.engine.stream.cuda_stream))
+            if st != 0:
+                raise _lib.AirHipError("air_allreduce_sum failed: %s" % (H.lib().air_comm_last_error() or b"").decode())
+            return
         allreduce_gradients(grads, self.group, average=False)
 
     def train_step(self, obs=None):
@@ -163,5 +230,7 @@ class DataParallelEngine(object):
             from . import hip as H
             self.engine.synchronize()
             self.engine.release_graphs()
-            H.lib().air_comm_destroy(self.comm)
-            self.comm = None
+            for c in (self._comm_side, self.comm):
+                if c is not None:
+                    H.lib().air_comm_destroy(c)
+            self.comm = self._comm_side = None

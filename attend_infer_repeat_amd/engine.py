@@ -481,8 +481,11 @@ class AIREngine:
         # cross-workgroup hand-off, no extra launch, fixed summation order.
         E0 = self.enc.shapes[0][1]
         lvl0_tiles = ((B + 15) // 16) * ((E0 + 15) // 16)
+        # (the consumer -- the product over the E0 columns of the first hidden layer -- runs on the A-prologue kernel, which the
+        #  library only has on 16x16 tiles: its launch must stay below the 1536-tile switch to 32x32 tiles)
+        n_after = self.enc.shapes[1][1] if self.enc.n > 1 else 4 * Hd
         split0 = (lvl0_tiles * (2 if cfg.use_reinforce else 1) <= 128 and P >= 2048 and P % 4 == 0 and E0 % 16 == 0
-                  and os.environ.get("AIR_SPLIT_K0", "1") == "1")
+                  and ((B + 15) // 16) * ((n_after + 15) // 16) <= 1536 and os.environ.get("AIR_SPLIT_K0", "1") == "1")
         self._split0 = split0
         if split0:
             kh = (P // 2) // 16 * 16                       # both halves start 16-byte aligned (and on a chunk boundary)
@@ -620,6 +623,7 @@ class AIREngine:
         # is the consumer that adds the per-band shares of rec_loss_per_sample (and stores the sum in self.rec).
         nvil_args = (p(self.rec_parts), NB, p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out),
                      p(self.dlogp), p(self.dbase))
+        self._nvil_args = nvil_args
         rec_sum = (L.air_sum_leading, (p(self.rec_parts), p(self.rec), NB, ctypes.c_size_t(B)), "air_sum_leading")
         fwd_tail = [(L.air_nvil_parts, nvil_args + (B,), "air_nvil_parts")] if cfg.use_reinforce else [rec_sum]
 
@@ -844,12 +848,159 @@ class AIREngine:
                                            p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0,
                                            p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
                      "air_step_epilogue")]
+        # ... or, better, the two-lane form of the whole step (None where it does not apply)
+        self._plan_two_lane = self._build_two_lane_step()
 
     def _run(self, plan, stream_ptr):
-        for fn, args, name in plan:
-            st = fn(*args, stream_ptr)
+        """Issue a plan.  Entries: (fn, args, name) on the main stream; (fn, args, name, lane) with lane 1 = the engine's side
+        stream (two-lane plans: independent work next to the critical chain); ("record", event, lane) / ("wait", event, lane)
+        = hipEventRecord / hipStreamWaitEvent on that lane -- the edges between the lanes, captured as graph dependencies."""
+        side = None
+        for e in plan:
+            if e[0] == "record" or e[0] == "wait":
+                if side is None:
+                    side = ctypes.c_void_p(self._side_stream.cuda_stream)
+                sp = side if e[2] else stream_ptr
+                L = H.lib()
+                if e[0] == "record":
+                    _lib.check(L.air_event_record(e[1], sp), "air_event_record")
+                else:
+                    _lib.check(L.air_stream_wait_event(sp, e[1]), "air_stream_wait_event")
+                continue
+            fn, args, name = e[0], e[1], e[2]
+            sp = stream_ptr
+            if len(e) > 3 and e[3]:
+                if side is None:
+                    side = ctypes.c_void_p(self._side_stream.cuda_stream)
+                sp = side
+            st = fn(*args, sp)
             if st != 0:
                 _lib.check(st, name)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # two-lane train step (single GPU, latency regime)
+    # ------------------------------------------------------------------------------------------------------------
+    def _new_event(self):
+        ev = ctypes.c_void_p()
+        _lib.check(H.lib().air_event_create(ctypes.byref(ev)), "air_event_create")
+        self._lane_events.append(ev)
+        return ev
+
+    def _build_two_lane_step(self):
+        """The train step as TWO lanes of one captured graph (model.py:224-230,253-259: the baseline and every weight
+        gradient are off the ELBO's dX chain).  The step at batch 64 is one chain of ~35 dependent launches of 4.5-11 us on a
+        quarter of the chip; what is not on the chain's data path leaves it:
+          side lane : the baseline MLP forward (its obs product from the very start, the rest next to the decoder), NVIL, the
+                      baseline backward, EVERY weight-gradient product (each needs only the dX chain's g of its layer), and the
+                      RMSProp update of each parameter segment as soon as its gradients are final and the chain has read the
+                      weights for the last time;
+          main lane : the dX chain alone (single-problem launches: descriptor in kernarg SGPRs), joined by the side lane
+                      where it consumes its results -- d log q(z) from NVIL before the attend backward, everything before the
+                      closing update of the input encoder's segment.
+        Built by splitting the launches of the linear plans, so both forms run the same kernels on the same operands; every
+        side launch waits for the main launch that preceded it in the linear order (its inputs were complete there).
+        Reductions keep their fixed order: the result is bitwise the linear plan's."""
+        L = H.lib()
+        cfg = self.cfg
+        if (self._defer_dw or self.world_size != 1 or not cfg.use_reinforce
+                or os.environ.get("AIR_TWO_LANE", "1") != "1"):
+            return None
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        self._lane_events = getattr(self, "_lane_events", [])
+        g_lo, g_hi = self.flat_grads.data_ptr() + 4 * self.n_model, self.flat_grads.data_ptr() + 4 * self.n_total
+        side_c = {t.data_ptr() for t in list(self.bl.out) + list(self.bl.g) + [self.bl_obs]}
+
+        def is_side(d):
+            c = int(d.C)
+            return c in side_c or g_lo <= c < g_hi or bool(d.ta and not d.tb)
+
+        lstm_dw_c = {self.grads["lstm/w_gates"].data_ptr(), self.grads["lstm/w_gates"][self.enc.shapes[-1][1]:].data_ptr()}
+        out = []
+        n_main = [0]
+        last_wait = [-1]
+
+        def flush_side(entries):
+            """side entries whose inputs are complete once everything issued on the main lane so far has run"""
+            if not entries:
+                return
+            if last_wait[0] != n_main[0]:
+                ev = self._new_event()
+                out.append(("record", ev, 0)); out.append(("wait", ev, 1))
+                last_wait[0] = n_main[0]
+            out.extend(entries)
+
+        def regroup(descs):
+            arr = (_lib.AirGemmDesc * len(descs))(*descs)
+            self._keep.append(arr)
+            return (L.air_gemm_grouped, (arr, len(descs)), "air_gemm_grouped")
+
+        nvil_args = self._nvil_args
+        ev_nvil = None
+        plan = list(self._plan_fwd_train) + list(self._plan_bwd)
+        # the LSTM weight gradients sit in the LAST launch of the linear plan; here they are issued where their inputs are
+        # complete: next to the launch that closes the BPTT chain (d h_init / d enc_out)
+        hoisted = [d for e in plan if e[2] == "air_gemm_grouped" for d in e[1][0] if int(d.C) in lstm_dw_c]
+        dh_init_c = self.dh_init.data_ptr()
+        seg = self.param_offsets
+        for e in plan:
+            fn, args, name = e
+            if name == "air_gemm_grouped":
+                descs = list(args[0])
+                side_d = [d for d in descs if is_side(d) and int(d.C) not in lstm_dw_c]
+                main_d = [d for d in descs if not is_side(d)]
+                side_now = [regroup(side_d) + (1,)] if side_d else []
+                if any(int(d.C) == dh_init_c for d in descs):
+                    # BPTT done (dgates / dgx final) and the chain has read the transform / steps weights for the last time
+                    side_now = ([regroup(hoisted) + (1,)] if hoisted else []) + side_now
+                    side_now.append(self._opt_slice_entry(seg["transform/0/w"], seg["glimpse_encoder/0/w"], 1))
+                main_e = (regroup(main_d) if len(main_d) != len(descs) else e) if main_d else None
+                if n_main[0] == 0 and main_e is not None:        # (the side lane forks BEHIND the first node of the graph)
+                    out.append(main_e); n_main[0] += 1
+                    flush_side(side_now)
+                    continue
+                flush_side(side_now)
+                if main_e is not None:
+                    out.append(main_e); n_main[0] += 1
+                continue
+            if name == "air_canvas_unroll_bwd_nvil":
+                # NVIL leaves the canvas backward: it runs on the side lane behind the baseline's forward
+                flush_side([(L.air_nvil_parts, nvil_args + (self.B,), "air_nvil_parts", 1)])
+                ev_nvil = self._new_event()
+                out.append(("record", ev_nvil, 1))
+                out.append((L.air_canvas_unroll_bwd, args[:len(args) - len(nvil_args)], "air_canvas_unroll_bwd"))
+                n_main[0] += 1
+                continue
+            if name in ("air_attend_bwd_dx", "air_st_read_bwd"):
+                # glimpse encoder .. baseline: gradients final (side lane, in order), weights read for the last time
+                flush_side([self._opt_slice_entry(seg["glimpse_encoder/0/w"], self.n_total, 1)])
+            if name in ("air_attend_bwd_dx", "air_heads_bwd"):
+                out.append(("wait", ev_nvil, 0))                 # d log q(z) for REINFORCE comes from NVIL
+            out.append(e)
+            n_main[0] += 1
+        if ev_nvil is None:
+            return None
+        # the LSTM's weights are read by the chain until the launch that closes the BPTT (already issued); its gradients and
+        # the input encoder's were the side lane's last products
+        flush_side([self._opt_slice_entry(seg["lstm/w_gates"], seg["transform/0/w"], 1)])
+        ev_end = self._new_event()
+        out.append(("record", ev_end, 1)); out.append(("wait", ev_end, 0))
+        out.append(self._opt_slice_entry(0, seg["lstm/w_gates"], 0, counters=True))
+        return out
+
+    def _opt_slice_entry(self, lo, hi, lane, counters=False):
+        """centred RMSProp over elements [lo, hi) of the flat buffers (two learning rates around n_model) as one launch;
+        counters=True: the closing launch, which also advances the device step counter and the Philox offset"""
+        L, p, cfg = H.lib(), H._p, self.cfg
+        assert lo % 4 == 0 and hi % 4 == 0 and lo < hi
+        off = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * lo)
+        n_model = min(max(self.n_model - lo, 0), hi - lo)
+        tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
+        args = (off(self.flat_params), off(self.flat_grads), off(self.flat_ms), off(self.flat_mg), off(self.flat_mom),
+                ctypes.c_size_t(n_model), ctypes.c_size_t(hi - lo), p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum,
+                cfg.rms_eps, 1.0, p(self.step_dev) if counters else None, p(self.rng_state) if counters else None,
+                ctypes.c_uint64(self._rng_inc if counters else 0))
+        return (L.air_step_epilogue, args, "air_step_epilogue", lane)
 
     # ------------------------------------------------------------------------------------------------------------
     # public API
@@ -933,18 +1084,26 @@ class AIREngine:
         self.obs = obs
         try:
             self._build_plans()
-            if self._plan_bwd_riders is not None:
-                return [self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest]
-            return [self._plan_fwd_train, self._plan_bwd, self._plan_opt]
+            return self._single_gpu_step_plans()
         finally:
             self.obs = saved
 
-    def attach_dataset(self, data: torch.Tensor, shuffle: bool = True, seed: int = 0):
+    def _single_gpu_step_plans(self):
+        """the plans of one complete single-GPU update, best form first: two lanes, optimiser riders, plain"""
+        if self._plan_two_lane is not None:
+            return [self._plan_two_lane]
+        if self._plan_bwd_riders is not None:
+            return [self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest]
+        return [self._plan_fwd_train, self._plan_bwd, self._plan_opt]
+
+    def attach_dataset(self, data: torch.Tensor, shuffle: bool = True, seed: int = 0, rank: int = 0, world: int = 1):
         """HBM-resident input pipeline (the reference feeds every step through tf.py_func, data.py:121-158): `data` [N, H*W] (or
         [N, H, W]) stays on the device and every train step starts by gathering its own batch -- indices drawn with replacement
         from Philox(seed, device step counter) like np.random.choice, or walking the data in order -- as the first launch of the
         step, inside the captured graph.  `batch_idx` holds the indices of the last batch (for labels).  data=None detaches.
-        Re-capture afterwards."""
+        Data-parallel runs pass `rank` / `world`: every rank then draws from its own Philox stream (the seed is mixed with the
+        rank, like the per-rank noise seeds), so the global batch is world * B distinct draws, not B draws seen `world` times.
+        For an in-order walk (shuffle=False) under data parallelism, attach each rank's own shard.  Re-capture afterwards."""
         self.release_graphs()
         if data is None:
             self._feeder = None
@@ -953,6 +1112,9 @@ class AIREngine:
             if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.shape[1] == self.obs.shape[1]):
                 raise ValueError("dataset must be a contiguous float32 device tensor of [N, %d] images" % self.obs.shape[1])
             self._feeder = (d, bool(shuffle))
+            if world > 1:
+                from .distributed import rank_seed
+                seed = rank_seed(seed, rank)
             self.feeder_seed = torch.tensor([int(seed) & (2 ** 63 - 1)], dtype=torch.int64, device=self.device)
             self.batch_idx = torch.zeros(self.B, dtype=torch.int64, device=self.device)
         self._build_plans()
@@ -961,7 +1123,8 @@ class AIREngine:
         """batch for step `slot` of a multi-step replay (capture(steps_per_replay=K)); slot 0 is the ordinary obs buffer"""
         self._copy_in(self.obs if slot == 0 else self.obs_ring[slot - 1], obs)
 
-    def capture(self, split_optimizer: bool = False, comm=None, overlap: bool = False, steps_per_replay: int = 1):
+    def capture(self, split_optimizer: bool = False, comm=None, overlap: bool = False, steps_per_replay: int = 1,
+                comm_side=None):
         """Capture noise + forward + backward (+ gradient all-reduce) + both RMSProp updates into hipGraphs.
         comm=None, split_optimizer=False : single GPU, ONE graph.
         comm=<air_comm handle>           : data parallel, still ONE graph -- the RCCL all-reduce of the flat gradient buffer
@@ -974,6 +1137,7 @@ class AIREngine:
                                            (torch.distributed) can run between them (fallback when RCCL cannot be captured)."""
         self.release_graphs()
         self.stream.synchronize()
+        self._steps_per_replay = 1
         L = H.lib()
         if comm is not None:
             opt = self._opt_calls_factory(1.0 / self.world_size)
@@ -995,7 +1159,9 @@ class AIREngine:
                     self._side_events = ev
                 side = ctypes.c_void_p(self._side_stream.cuda_stream)
                 ev_fork, ev_join = self._side_events
-                tail_reduce = self._allreduce_call(comm, lo, self.n_total)
+                # (the forked stream reduces on a communicator of its own when one is given: two ncclAllReduce calls in
+                #  flight on ONE communicator from two streams is not something RCCL promises to order)
+                tail_reduce = self._allreduce_call(comm_side if comm_side is not None else comm, lo, self.n_total)
 
                 def fork(sp):
                     _lib.check(L.air_event_record(ev_fork, sp), "air_event_record")
@@ -1030,8 +1196,8 @@ class AIREngine:
             self._graph_has_opt = True
             self._steps_per_replay = K
             return
-        if not split_optimizer and self._plan_bwd_riders is not None and self.world_size == 1:
-            self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest])
+        if not split_optimizer and self.world_size == 1:
+            self._graph = self._capture_plans(self._single_gpu_step_plans())
         else:
             self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
         self._graph_has_opt = not split_optimizer
@@ -1067,12 +1233,12 @@ class AIREngine:
                         allreduce(self.flat_grads)
                 _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
         else:
-            self._run(self._plan_fwd_train, sp)
-            if allreduce is None and self.world_size == 1 and self._plan_bwd_riders is not None:
-                self._run(self._plan_bwd_riders, sp)
-                self._run(self._plan_opt_rest, sp)
+            if allreduce is None and self.world_size == 1:
+                for pl in self._single_gpu_step_plans():
+                    self._run(pl, sp)
                 self.global_step += 1
                 return
+            self._run(self._plan_fwd_train, sp)
             self._run(self._plan_bwd, sp)
             if allreduce is not None:
                 with torch.cuda.stream(self.stream):
@@ -1150,4 +1316,10 @@ class AIREngine:
         return dict(self.grads)
 
     def kernel_launch_count(self) -> Dict[str, int]:
-        return {"forward": len(self._plan_fwd_train), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}
+        """launches per train step of the linear plans; with the two-lane step also its split: launches on the main lane (the
+        dependent chain) and on the side lane"""
+        out = {"forward": len(self._plan_fwd_train), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}
+        if self._plan_two_lane is not None and self.world_size == 1:
+            k = [e for e in self._plan_two_lane if e[0] not in ("record", "wait")]
+            out = {"main_lane": sum(1 for e in k if not (len(e) > 3 and e[3])), "side_lane": sum(1 for e in k if len(e) > 3 and e[3])}
+        return out

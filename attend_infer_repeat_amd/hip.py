@@ -445,12 +445,15 @@ def baseline_pack(img, what, where, presence, state_parts):
 
 
 # ---- optimiser / noise / utils -------------------------------------------------------------------------------------
-def rmsprop_centered_(p, g, ms, mg, mom, lr_dev, lr_mult=1.0, decay=0.9, momentum=0.9, eps=1e-10, grad_scale=1.0):
+def rmsprop_centered_(p, g, ms, mg, mom, lr_dev, lr_mult=1.0, decay=0.9, momentum=0.9, eps=1e-10, grad_scale=1.0,
+                      centered=True):
+    """tf.train.RMSPropOptimizer's update (all of its keywords) in place; `centered=True, momentum=.9` is the reference's
+    choice (model.py:265)."""
     for t, nm in ((p, "p"), (g, "g"), (ms, "ms"), (mg, "mg"), (mom, "mom"), (lr_dev, "lr_dev")):
         _f32(t, nm)
-    _lib.check(lib().air_rmsprop_centered(_p(p), _p(g), _p(ms), _p(mg), _p(mom), ctypes.c_size_t(p.numel()),
-                                          _p(lr_dev), float(lr_mult), float(decay), float(momentum), float(eps),
-                                          float(grad_scale), _stream()), "air_rmsprop_centered")
+    _lib.check(lib().air_rmsprop(_p(p), _p(g), _p(ms), _p(mg), _p(mom), ctypes.c_size_t(p.numel()), _p(lr_dev),
+                                 float(lr_mult), float(decay), float(momentum), float(eps), int(bool(centered)),
+                                 float(grad_scale), _stream()), "air_rmsprop")
 
 
 def rng_fill(state_dev, normal=None, uniform=None, advance=True):

@@ -85,8 +85,8 @@ class AIRonMNIST(AIRModel):
         has = lambda p, *keys: p is not None and all(k in p for k in keys)
         if not (use_engine and self.discrete_steps and decay_rate is None and not l2_weight):
             return False
-        if getattr(self, "_custom_optimizer", None) is not None:
-            return False
+        if getattr(self, "_custom_optimizer", None) is not None or not getattr(self, "_default_rms", True):
+            return False       # (the engine's fused update is the script's RMSProp(momentum=.9, centered=True))
         if nsp is None or not getattr(nsp, 'analytic', True) or float(getattr(nsp, 'weight', 1.)) != 1.:
             return False
         if not (has(what_prior, 'loc', 'scale') and has(where_scale_prior, 'loc', 'scale')

@@ -252,11 +252,21 @@ class AIRModel(object):
         baseline, model.py:355-363): the default runs on the HIP centred-RMSProp kernel with TF's slot initialisation; any
         other choice is given as a torch.optim class (same calling convention: optimizer(params, lr, **opt_kwargs)) and
         steps the generic autograd path."""
-        custom_opt = optimizer is not None or (opt_kwargs is not None and dict(opt_kwargs) != dict(momentum=.9, centered=True))
-        if custom_opt and optimizer is None:
-            raise NotImplementedError("non-default opt_kwargs need an explicit torch.optim class in `optimizer` "
-                                      "(the built-in kernel is RMSProp(momentum=.9, centered=True))")
+        custom_opt = optimizer is not None
         self._custom_optimizer = (optimizer, dict(opt_kwargs or {})) if custom_opt else None
+        # the reference's default class with other keywords (model.py:265: RMSPropOptimizer(lr, **opt_kwargs), e.g. momentum=.5
+        # or centered=False): tf.train.RMSPropOptimizer's own defaults for what is not given, all of them plain scalars of
+        # the HIP update (air_rmsprop)
+        rms_kw = dict(decay=0.9, momentum=0.0, epsilon=1e-10, centered=False)
+        given = dict(momentum=.9, centered=True) if opt_kwargs is None else dict(opt_kwargs)
+        if not custom_opt:
+            unknown = set(given) - set(rms_kw) - {"use_locking", "name"}
+            if unknown:
+                raise TypeError("RMSPropOptimizer got unexpected keyword(s) %s" % sorted(unknown))
+            rms_kw.update({k: v for k, v in given.items() if k in rms_kw})
+        self._rms_kwargs = rms_kw
+        self._default_rms = (not custom_opt and float(rms_kw["decay"]) == 0.9 and float(rms_kw["momentum"]) == 0.9
+                             and float(rms_kw["epsilon"]) == 1e-10 and bool(rms_kw["centered"]))
         if num_steps_prior is not None and not hasattr(num_steps_prior, 'analytic'):
             num_steps_prior['analytic'] = True
         self.l2_weight = l2_weight
@@ -281,7 +291,8 @@ class AIRModel(object):
                 if p not in self._slots:
                     self._slots[p] = (torch.ones_like(p), torch.zeros_like(p), torch.zeros_like(p))
                 ms, mg, mom = self._slots[p]
-                H.rmsprop_centered_(p.data, p.grad, ms, mg, mom, lr_dev, lr_mult)
+                H.rmsprop_centered_(p.data, p.grad, ms, mg, mom, lr_dev, lr_mult, decay=rms_kw["decay"],
+                                    momentum=rms_kw["momentum"], eps=rms_kw["epsilon"], centered=rms_kw["centered"])
 
         def train_step_fn(obs=None, nums=None, noise=None):
             """One update (== sess.run(train_step)): fresh forward, both gradient sets, both RMSProp updates."""

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="time the CPU oracle on every host cpu as well (minutes on a 256-cpu host: ~100 s per step)")
     ap.add_argument("--steps-per-replay", type=int, default=1,
                     help="single GPU: consecutive updates captured per hipGraph replay (input queue of that depth; a replay "
                          "costs ~8 us on top of its nodes).  --steps is rounded up to a multiple of it")
@@ -229,12 +231,62 @@ def st_read_sweep(cfg, T, batches, device, share_image=True):
         nbytes = 4 * (HW + hw + 4) * n                      # the image charged once per glimpse
         minimal = 4 * (n_img * HW + n * (hw + 4))            # what the launch must move: each image once, each glimpse once
         gbs, gbs_min = nbytes / (ms * 1e-3) / 1e9, minimal / (ms * 1e-3) / 1e9
+        # (`frac` from the bytes the launch must move, so it cannot exceed 1; the SURVEY 8(d) figure -- image charged once per
+        #  glimpse -- is kept as a rate only: with T glimpses per staged image it over-counts the traffic by design)
         res.append({"batch": B, "glimpses": n, "images": n_img, "us_per_launch": round(ms * 1e3, 2),
                     "working_set_MiB": round((n_img * HW + n * hw) * 4 / 2 ** 20, 1),
                     "achieved_minimal_bytes": round(gbs_min, 1), "frac": round(gbs_min / HBM_PEAK_GBS, 4),
-                    "achieved_survey_8d": round(gbs, 1), "frac_survey_8d": round(gbs / HBM_PEAK_GBS, 4)})
+                    "achieved_survey_8d_bytes": round(gbs, 1)})
         del img, where, out
     return res
+
+
+def canvas_write_sweep(cfg, T, batches, device):
+    """The inverse canvas write (north_star names it next to the read) over a batch sweep, forward (T inverse warps + canvas
+    accumulation + reconstruction term, per-step canvases kept as the API path keeps them) and backward (dcanvas formed on the
+    fly -> dglimpse, dwhere).  Fractions from the bytes each launch must move once; SURVEY 8(d)'s per-(image, step) figures
+    (21,620 / 13,236 B at 50x50 / 20x20) next to them as rates."""
+    import torch
+    from attend_infer_repeat_amd import hip as H
+    lib = H.lib()
+    (Hh, Ww), (h, w) = cfg.img_size, cfg.crop_size
+    HW, hw = Hh * Ww, h * w
+    stream = torch.cuda.Stream(device=device)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    fwd, bwd = [], []
+    for B in batches:
+        n = T * B
+        g = torch.Generator(device=device).manual_seed(B)
+        glm = torch.randn(n, hw, device=device, generator=g)
+        where = torch.empty(n, 4, device=device)
+        where[:, 0] = 0.45 + 0.2 * torch.rand(n, device=device, generator=g); where[:, 2] = 0.45 + 0.2 * torch.rand(n, device=device, generator=g)
+        where[:, 1] = 0.6 * torch.rand(n, device=device, generator=g) - 0.3; where[:, 3] = 0.6 * torch.rand(n, device=device, generator=g) - 0.3
+        pres = (torch.rand(n, device=device, generator=g) < 0.7).float()
+        obs = torch.rand(B, HW, device=device, generator=g)
+        steps = torch.empty(T, B, HW, device=device)
+        final = torch.empty(B, HW, device=device)
+        nb = int(lib.air_canvas_unroll_bands(B, Hh))
+        parts = torch.empty(nb, B, device=device)
+        dgl = torch.empty(n, hw, device=device)
+        dwh = torch.empty(n, 4, device=device)
+        torch.cuda.synchronize()
+        p = H._p
+        f = lambda: lib.air_canvas_unroll_fwd_banded(p(glm), p(where), p(pres), p(obs), p(steps), p(final), p(parts), nb, T, B,
+                                                     Hh, Ww, h, w, cfg.output_multiplier, cfg.output_std, sp)
+        b = lambda: lib.air_canvas_unroll_bwd(p(glm), p(where), p(pres), p(obs), p(final), p(dgl), p(dwh), T, B, Hh, Ww, h, w,
+                                              cfg.output_multiplier, cfg.output_std, 1.0 / B, sp)
+        reps = 10 if B >= 16384 else 100
+        for name, fn, out, minimal, survey in (
+                ("fwd", f, fwd, 4 * (n * (hw + 5) + B * HW * (2 + T)), 4 * (hw + 2 * HW + 5) * n),
+                ("bwd", b, bwd, 4 * (2 * B * HW + n * (2 * hw + 9)), 4 * (HW + 2 * hw + 9) * n)):
+            ms = event_time_ms(lib, sp, fn, reps)
+            gmin = minimal / (ms * 1e-3) / 1e9
+            out.append({"batch": B, "glimpses": n, "us_per_launch": round(ms * 1e3, 2), "row_bands": nb,
+                        "working_set_MiB": round(minimal / 2 ** 20, 1), "minimal_bytes_per_launch": minimal,
+                        "achieved_minimal_bytes": round(gmin, 1), "frac": round(gmin / HBM_PEAK_GBS, 4),
+                        "achieved_survey_8d_bytes": round(survey / (ms * 1e-3) / 1e9, 1)})
+        del glm, where, pres, obs, steps, final, parts, dgl, dwh
+    return fwd, bwd
 
 
 def stream_reference(device, mib=1024):
@@ -259,7 +311,7 @@ def stream_reference(device, mib=1024):
             "frac_of_spec_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
 
-def cpu_baseline(cfg_kw, batch, seconds):
+def cpu_baseline(cfg_kw, batch, seconds, all_cores_flag=False):
     """The CPU oracle's full train step (reference-equivalent restatement) on this host's cores, bounded sample."""
     import torch
     from oracle import air_oracle as O
@@ -290,6 +342,20 @@ def cpu_baseline(cfg_kw, batch, seconds):
         O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=81 + n1), global_step=0)
         n1 += 1
     one_thread = batch * n1 / (time.perf_counter() - t0)
+    # ... and on ALL host cores (SURVEY 8d asks for it).  On these small ops more threads are SLOWER, dramatically so on a
+    # 256-cpu host: 0.6 images/s measured with 256 threads (profiles/r03_a_bench_c2_b64_all_cores.json: ~100 s per step), which
+    # would blow the few-minutes budget of a default run -- so the all-cores leg runs up to 64 threads by default and the
+    # full-host figure only with --cpu-all-cores
+    all_threads = avail if (all_cores_flag or avail <= 64) else 64
+    torch.set_num_threads(all_threads)
+    t0 = time.perf_counter()
+    O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=70), global_step=0)
+    first = time.perf_counter() - t0
+    na, t0 = 0, time.perf_counter()
+    while first < 5.0 and na < 10 and (na < 1 or time.perf_counter() - t0 < 3.0):
+        O.train_step(params, slots, ocfg, obs, O.make_noise(ocfg, batch, seed=71 + na), global_step=0)
+        na += 1
+    all_cores = batch * na / (time.perf_counter() - t0) if na else batch / first
     torch.set_num_threads(cores)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -299,21 +365,40 @@ def cpu_baseline(cfg_kw, batch, seconds):
         if el >= seconds or n >= 400:
             break
     return {"value": round(batch * n / el, 1), "unit": "images/sec", "cores": cores, "kind": "port",
-            "one_thread_value": round(one_thread, 1), "host_cpus": avail,
+            "one_thread_value": round(one_thread, 1), "all_cores_value": round(all_cores, 2),
+            "all_cores_threads": all_threads, "host_cpus": avail,
             "sample": f"{n} full train steps at batch {batch} ({el:.1f} s) of the torch-CPU fp32 oracle "
                       f"(oracle/air_oracle.py); threads={cores} chosen as the fastest of a sweep on this {avail}-cpu host"}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with one rank per GPU on this node
+    (exactly what the driver's own command line does), so that a plain invocation IS an N-rank run."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
     import torch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but this node exposes {torch.cuda.device_count()} GPU(s)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from attend_infer_repeat_amd import build as air_build
@@ -409,7 +494,13 @@ def main():
             "config": {"workload": workload, "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "steps_per_graph_replay": spr,
                        "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
-                       "keep_canvas_steps": True, "collective": dp.collective, "params_finite_after_run": finite},
+                       "kernel_launches_by_lane": eng.kernel_launch_count(),
+                       "keep_canvas_steps": True, "collective": dp.collective,
+                       # ranks as the communication layer itself reports them: ncclCommCount of the engine's own communicator
+                       # (rccl-split / rccl-captured), and the size of torch.distributed's process group (backend nccl = RCCL)
+                       "rccl_nranks": dp.rccl_nranks, "dist_world_size": (dist.get_world_size() if world > 1 else 1),
+                       "dist_backend": (dist.get_backend() if world > 1 else None),
+                       "params_finite_after_run": finite},
             "roofline": dict(roof["st_read_fwd"], kernel="st_read_fwd_pipe_kernel (the fused affine-grid + bilinear glimpse read, "
                              "north_star's kernel) launched on its own at the in-step shape; `achieved`/`frac` use the SURVEY 8(d) "
                              "algorithmic bytes, `frac_minimal_bytes` the bytes the launch must move (image once per image). At this "
@@ -425,10 +516,12 @@ def main():
             line["roofline_sweep_st_read_fwd"] = st_read_sweep(cfg, eng.T, [64, 512, 1024, 8192, 65536], device)
             line["roofline_sweep_st_read_fwd_one_image_per_glimpse"] = st_read_sweep(cfg, 1, [192, 3072, 24576, 196608],
                                                                                      device, share_image=False)
+            cw_f, cw_b = canvas_write_sweep(cfg, eng.T, [64, 1024, 8192, 65536], device)
+            line["roofline_sweep_canvas_write_fwd"], line["roofline_sweep_canvas_write_bwd"] = cw_f, cw_b
             line["stream_reference"] = stream_reference(device)
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize(device)
-            line["cpu_baseline"] = cpu_baseline(cfg_kw, B, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(cfg_kw, B, args.cpu_seconds, args.cpu_all_cores)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -381,6 +381,11 @@ int air_attend_bwd_dx(const float *img, const float *where, const float *dglimps
  * grad_scale multiplies g first (1/world_size after an all-reduce sum).                                            */
 int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev,
                          float lr_mult, float decay, float momentum, float eps, float grad_scale, void *stream);
+/* The reference instantiates its optimiser as optimizer(learning_rate, **opt_kwargs) (model.py:265,355-363), so the keyword
+ * set of tf.train.RMSPropOptimizer is part of the surface: decay, momentum, epsilon, centered.  centered = 0 drops the
+ * squared mean-gradient term from the denominator (the mg slot is still maintained, as scratch).                       */
+int air_rmsprop(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev, float lr_mult,
+                float decay, float momentum, float eps, int centered, float grad_scale, void *stream);
 
 /* Fused step prologue / epilogue for the launch-bound train step.
  *   prologue: air_rng_fill + air_steps_prior + tiling of the trainable LSTM initial state (h0,c0 [1,Hd] -> [B,Hd]).
@@ -429,6 +434,8 @@ int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream);
  * Failures return AIR_E_UNSUPPORTED; air_comm_last_error() has the RCCL message.                                      */
 int air_comm_unique_id(void *id_out_128_bytes);
 int air_comm_init(void **comm_out, int world_size, int rank, const void *id_128_bytes);
+int air_comm_available(void);                     /* 0 if RCCL can be bound here; not collective (agree on it BEFORE air_comm_init) */
+int air_comm_count(void *comm, int *count_out);   /* ncclCommCount: the number of ranks RCCL itself sees */
 int air_comm_destroy(void *comm);
 int air_allreduce_sum(float *buf, size_t n, void *comm, void *stream);
 const char *air_comm_last_error(void);

@@ -416,5 +416,19 @@ def test_custom_optimizer_runs_on_the_generic_path(amd):
     # Adam's first steps move every touched weight by ~lr (model) and ~10 lr (baseline, model.py:363)
     dm = (air.cell._input_encoder.mlp.layers[1].w - 0).abs().max()   # finite
     assert torch.isfinite(dm)
-    with pytest.raises(NotImplementedError):
-        _mnist_model(amd).train_step(1e-3, num_steps_prior=AD(anneal=None, init=0.5), opt_kwargs=dict(momentum=0.5))
+    # the DEFAULT class with other keywords (model.py:265 instantiates RMSPropOptimizer(lr, **opt_kwargs)): momentum=.5 alone means
+    # tf.train.RMSPropOptimizer's own defaults for the rest -- decay .9, epsilon 1e-10, NOT centred -- on the HIP update kernel
+    air2 = _mnist_model(amd)
+    ts2, gs2 = air2.train_step(1e-3, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.), AD(loc=0., scale=1.),
+                               AD(anneal=None, init=0.5), opt_kwargs=dict(momentum=0.5))
+    assert air2._engine is None and air2._custom_optimizer is None
+    w = air2.cell._input_encoder.mlp.layers[1].w
+    w0 = w.detach().clone()
+    ts2()
+    g = w.grad.double()
+    expect = w0.double() - 1e-3 * g / torch.sqrt(0.9 * 1.0 + 0.1 * g * g + 1e-10)        # slots start at ms = 1, mom = 0
+    assert torch.allclose(w.detach().double(), expect, rtol=0, atol=2e-7 * float(expect.abs().max()) + 1e-9)
+    ts2()
+    assert int(gs2) == 2 and torch.isfinite(w).all()
+    with pytest.raises(TypeError):
+        _mnist_model(amd).train_step(1e-3, num_steps_prior=AD(anneal=None, init=0.5), opt_kwargs=dict(beta1=0.5))

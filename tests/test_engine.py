@@ -153,20 +153,39 @@ def test_bf16_mfma_path_matches_bf16_emulating_oracle(gpu_device, name):
     assert 1e-4 < d32 < 5e-2, d32
 
 
+def _separate_borderline_draws(noise, res, margin=0.05):
+    """Bernoulli draws whose uniform variate sits within `margin` of the presence probability are moved away from it (same
+    outcome, but no longer within rounding noise of the threshold).  The presence probabilities depend on the image only
+    (cell.py:126-141: the LSTM sees the encoded image and its own state, never the samples), so the outcomes of the oracle
+    are unchanged and the bf16-operand engine -- whose probabilities differ by ~1e-3 -- then draws the same ones."""
+    u = noise["u_pres"].clone()
+    p = res["presence_prob"].reshape(u.shape).to(u.dtype)
+    near = (u - p).abs() < margin
+    u = torch.where(near & (u < p), (p - margin).clamp(min=0.0), u)
+    u = torch.where(near & (u >= p), (p + margin).clamp(max=1.0), u)
+    return dict(noise, u_pres=u), int(near.sum().item())
+
+
 def test_bf16_path_at_batch_1024_matches_bf16_emulating_oracle(gpu_device):
     """BASELINE configs[4] at its own size (batch 1024, 3072 glimpse rows: the throughput-regime plan) against the oracle that
-    emulates the bf16-operand arithmetic, evaluated in fp32 (0.6 s on the host)."""
+    emulates the bf16-operand arithmetic, evaluated in fp32 (0.6 s on the host).  Outputs AND gradients are compared on every
+    image, unconditionally: the (few) Bernoulli draws that sit within bf16 noise of their threshold are moved away from it
+    first, for both sides alike, so that no draw can flip."""
     ocfg, B = O.AIRConfig(), 1024
     eng, params, obs, noise = make_pair(ocfg, B, mfma_dtype="bf16")
+    with O.matmul_mode("bf16"):
+        res0, _ = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
+    noise, moved = _separate_borderline_draws(noise, res0)
+    assert moved < 0.15 * noise["u_pres"].numel(), moved
+    eng.set_noise(noise["eps_where"].cuda(), noise["eps_what"].cuda(), noise["u_pres"].cuda())
     eng.forward(sample_noise=False)
     eng.backward()
     out = eng.outputs()
     with O.matmul_mode("bf16"):
         res, grads = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
-    # a Bernoulli draw whose probability sits within bf16 noise of its uniform variate may flip; such images are excluded
-    # from the per-sample comparison (there must be almost none) and the batch-summed gradients are compared regardless
-    same = (out["presence"].cpu().reshape(ocfg.max_steps, B) == res["presence"].reshape(ocfg.max_steps, B)).all(0)
-    assert same.float().mean().item() > 0.995, same.float().mean().item()
+    assert torch.equal(res["presence"], res0["presence"])             # moving the variates changed no outcome
+    assert torch.equal(out["presence"].cpu().reshape(ocfg.max_steps, B), res["presence"].reshape(ocfg.max_steps, B))
+
     def close(k, a, r):
         """bf16 mode at 3072 rows: an operand that sits within fp32 noise of a bf16 rounding boundary flips one bf16 ulp on
         that element, and through `where` that moves a glimpse by a fraction of a pixel -- a handful of canvas pixels next to
@@ -180,26 +199,24 @@ def test_bf16_path_at_batch_1024_matches_bf16_emulating_oracle(gpu_device):
         record_margin("bf16_b1024", "c5", "out_l2", k, l2_err(a, r))
         assert l2_err(a, r) < 2e-3 and p999 < 2e-3 and err.max().item() < 0.1, (k, l2_err(a, r), p999, err.max().item())
 
-    for k in ["what", "where", "presence_prob"]:                                                     # [T, B, ...]
-        close(k, out[k].cpu().reshape(ocfg.max_steps, B, -1)[:, same], res[k].reshape(ocfg.max_steps, B, -1)[:, same])
-    for k in ["final_canvas", "rec_loss_per_sample", "kl_what_per_sample", "kl_where_per_sample", "baseline"]:   # [B, ...]
-        close(k, out[k].cpu().reshape(B, -1)[same], res[k].reshape(B, -1)[same])
-    if bool(same.all()):
-        for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
-            assert abs(out[k].item() - res[k].item()) <= 2e-3 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
-        # Gradients.  Several tensors (input encoder, LSTM, transform MLP: everything that only sees the loss through `where`
-        # and the step logits) are batch sums with heavy cancellation: rounding the operands to bf16 moves them by 40-140 % of
-        # their norm (bf16-emulating oracle vs the exact-fp32 oracle), so "1 % of the tensor" is not a meaningful bar for
-        # them.  The bar that is: the engine must agree with the EMULATION of its arithmetic far better than that arithmetic
-        # differs from fp32 -- relative L2 error <= max(5e-3, a quarter of the bf16-vs-fp32 distance); measured 1-14 % of it.
-        _, grads32 = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
-        g = eng.named_grads()
-        for k, ref in grads.items():
-            spread = l2_err(ref, grads32[k])
-            e2, e = l2_err(g[k], ref), rel_err(g[k], ref)
-            record_margin("bf16_b1024", "c5", "grad_l2_over_spread", k, e2 / (spread + 1e-30))
-            record_margin("bf16_b1024", "c5", "grad_l2", k, e2)
-            assert e2 < max(5e-3, 0.25 * spread) and e < 3 * max(5e-3, 0.25 * spread), (k, e, e2, spread)
+    for k in ["what", "where", "presence_prob", "final_canvas", "rec_loss_per_sample", "kl_what_per_sample",
+              "kl_where_per_sample", "baseline"]:
+        close(k, out[k].cpu(), res[k])
+    for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
+        assert abs(out[k].item() - res[k].item()) <= 2e-3 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
+    # Gradients.  Several tensors (input encoder, LSTM, transform MLP: everything that only sees the loss through `where`
+    # and the step logits) are batch sums with heavy cancellation: rounding the operands to bf16 moves them by 40-140 % of
+    # their norm (bf16-emulating oracle vs the exact-fp32 oracle), so "1 % of the tensor" is not a meaningful bar for
+    # them.  The bar that is: the engine must agree with the EMULATION of its arithmetic far better than that arithmetic
+    # differs from fp32 -- relative L2 error <= max(5e-3, a quarter of the bf16-vs-fp32 distance); measured 1-14 % of it.
+    _, grads32 = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
+    g = eng.named_grads()
+    for k, ref in grads.items():
+        spread = l2_err(ref, grads32[k])
+        e2, e = l2_err(g[k], ref), rel_err(g[k], ref)
+        record_margin("bf16_b1024", "c5", "grad_l2_over_spread", k, e2 / (spread + 1e-30))
+        record_margin("bf16_b1024", "c5", "grad_l2", k, e2)
+        assert e2 < max(5e-3, 0.25 * spread) and e < 3 * max(5e-3, 0.25 * spread), (k, e, e2, spread)
 
 
 def test_graph_captured_train_steps_at_batch_64_match_oracle(gpu_device):
@@ -276,18 +293,49 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
         assert "air_lstm_step_fwd" in names and "air_lstm_pointwise_fwd" not in names       # wide-tile fused LSTM steps
         last = eng._plan_bwd[-1]                                     # ONE launch holds every deferred weight gradient (fp32)
         assert last[2] == "air_gemm_grouped" and last[1][1] > 8 and all(d.ta and not d.tb for d in last[1][0])
+    _check_against_f64_oracle("large_batch", variant, eng, ocfg, params, obs, noise)
+
+
+def _check_against_f64_oracle(test, name, eng, ocfg, params, obs, noise, gstep=20000, out_tol=3e-4):
+    """forward + backward of `eng` against the float64 oracle at the latency-regime bar (OUT_L2 / GRAD_TOL / GRAD_L2 above).
+    The worst-ELEMENT bound of the outputs is 3e-4 here instead of 1e-4: it is a maximum over 10-100x more elements than at
+    batch 64 (2 M canvas pixels at batch 272: measured 1.1e-4 on one edge pixel of one canvas, where a 1e-7 difference in
+    `where` moves a bilinear tap weight across a stroke edge), while the relative L2 error -- 5e-6 there -- keeps its bound."""
     eng.forward(sample_noise=False)
     eng.backward()
     out = eng.outputs()
-    res, grads = O.forward_backward(params, ocfg, obs, noise, global_step=20000)        # fp32 oracle: 704 images in fp64 is slow
-    assert torch.equal(out["presence"].cpu(), res["presence"])
-    for k in ["what", "where", "presence_prob", "final_canvas", "rec_loss_per_sample", "kl_what_per_sample", "baseline"]:
-        assert rel_err(out[k].reshape(res[k].shape), res[k]) < 5e-4, (k, rel_err(out[k].reshape(res[k].shape), res[k]))
-    for k in ["rec_loss", "kl_what", "kl_where", "loss", "opt_loss", "baseline_loss"]:
-        assert abs(out[k].item() - res[k].item()) <= 5e-4 * (abs(res[k].item()) + 1.0), (k, out[k].item(), res[k].item())
+    res, grads = O.forward_backward(f64(params), ocfg, obs.double(), f64(noise), global_step=gstep)
+    assert torch.equal(out["presence"].cpu().double(), res["presence"])
+    for k in ["what", "what_loc", "what_scale", "where", "where_loc", "where_scale", "presence_prob", "canvas", "final_canvas",
+              "glimpse", "rec_loss_per_sample", "kl_num_steps_per_sample", "kl_what_per_sample", "kl_where_per_sample",
+              "num_steps_posterior", "prior_step_weight", "num_steps_log_prob", "baseline"]:
+        check_tensor(test, name, "out", k, out[k].reshape(res[k].shape), res[k], out_tol, OUT_L2)
+    for k in ["rec_loss", "kl_num_steps", "kl_what", "kl_where", "loss", "reinforce_loss", "baseline_loss", "opt_loss"]:
+        err = abs(out[k].item() - res[k].item()) / (abs(res[k].item()) + 1.0)
+        record_margin(test, name, "scalar", k, err)
+        assert err <= 2e-5, (k, out[k].item(), res[k].item())
     g = eng.named_grads()
-    bad = {k: rel_err(g[k], ref) for k, ref in grads.items() if not rel_err(g[k], ref) < 5e-3}
-    assert not bad, bad
+    for k, ref in grads.items():
+        check_tensor(test, name, "grad", k, g[k], ref, GRAD_TOL, GRAD_L2)
+
+
+def test_throughput_plan_at_batch_1024_fp32_matches_f64_oracle(gpu_device):
+    """BASELINE configs[4]'s batch (1024 images, 3072 glimpse rows) in exact fp32: the throughput plan against the float64
+    oracle on every output and every gradient element, same bar as batch 64 (the oracle takes ~6 s on 8 host cores)."""
+    ocfg, B = O.AIRConfig(), 1024
+    eng, params, obs, noise = make_pair(ocfg, B)
+    assert eng._defer_dw
+    _check_against_f64_oracle("throughput_b1024", "c2_b1024_f32", eng, ocfg, params, obs, noise)
+
+
+def test_config4_throughput_plan_matches_f64_oracle(gpu_device):
+    """BASELINE configs[3] shapes (100x100 canvas, 28x28 glimpse, T = 5) at batch 416 = 2080 glimpses: the image-major attend
+    kernels (exact-T = 5 instantiation), wide-tile GEMMs / LSTM steps and deferred weight gradients against the float64 oracle
+    (~11 s on 8 host cores), outputs and all gradients."""
+    ocfg, B = O.AIRConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5), 416
+    eng, params, obs, noise = make_pair(ocfg, B)
+    assert eng._defer_dw and "air_attend_fwd" in [n for _, _, n in eng._plan_fwd_train]
+    _check_against_f64_oracle("throughput_c4", "c4_b416", eng, ocfg, params, obs, noise)
 
 
 def test_throughput_plan_with_odd_layer_sizes_matches_oracle(gpu_device):
@@ -297,16 +345,7 @@ def test_throughput_plan_with_odd_layer_sizes_matches_oracle(gpu_device):
     ocfg, B = CONFIGS["rect_t5"][0], 300
     eng, params, obs, noise = make_pair(ocfg, B)
     assert eng._defer_dw
-    eng.forward(sample_noise=False)
-    eng.backward()
-    out = eng.outputs()
-    res, grads = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
-    assert torch.equal(out["presence"].cpu(), res["presence"])
-    for k in ["what", "where", "presence_prob", "final_canvas", "rec_loss_per_sample", "baseline"]:
-        assert rel_err(out[k].reshape(res[k].shape), res[k]) < 5e-4, (k, rel_err(out[k].reshape(res[k].shape), res[k]))
-    g = eng.named_grads()
-    bad = {k: rel_err(g[k], ref) for k, ref in grads.items() if not rel_err(g[k], ref) < 5e-3}
-    assert not bad, bad
+    _check_against_f64_oracle("throughput_odd", "rect_t5_b300", eng, ocfg, params, obs, noise)
     eng.capture(); eng.train_step(); eng.synchronize()
     assert torch.isfinite(eng.flat_params).all()
 
@@ -422,7 +461,9 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     workgroups of the BPTT launches (air_lstm_pointwise_bwd_opt / air_lstm_step_bwd_opt) and only the head of the flat buffer
     in the closing launch: bit-identical parameters and RMSProp slots to the single closing air_step_epilogue."""
     ocfg, B = CONFIGS[name]
+    monkeypatch.setenv("AIR_TWO_LANE", "0")              # (the two-lane step supersedes the riders where it applies)
     eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_a._plan_two_lane is None
     assert eng_a._plan_bwd_riders is not None and any(n.endswith("_opt") for _, _, n in eng_a._plan_bwd_riders)
     covered = sorted((s.lo, s.hi) for s in eng_a._rider_slices)
     assert covered[-1][1] == eng_a.n_total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
@@ -437,6 +478,36 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads"):
         assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
     assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
+
+
+@pytest.mark.parametrize("name", ["mnist_b8", "tiny", "t1_b5", "rect_t5", "mnist_b64"])
+@pytest.mark.parametrize("captured", [True, False])
+def test_two_lane_step_equals_linear_plan(gpu_device, monkeypatch, name, captured):
+    """The single-GPU latency-regime step runs as two lanes of one graph -- the dX chain on the main lane; the baseline MLP, NVIL,
+    every weight gradient and the RMSProp update of each finished segment on a side lane -- built by splitting the launches of
+    the linear plan.  Same kernels, same operands, fixed-order reductions: parameters, RMSProp slots, gradients and the noise
+    stream after three updates are BITWISE those of the linear plan (one closing update), replayed from a graph or issued
+    eagerly on two streams."""
+    ocfg, B = CONFIGS[name]
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_a._plan_two_lane is not None
+    lanes = eng_a.kernel_launch_count()
+    assert lanes["side_lane"] >= 8 and lanes["main_lane"] < len(eng_a._plan_fwd_train) + len(eng_a._plan_bwd) + 1
+    names_main = [e[2] for e in eng_a._plan_two_lane if e[0] not in ("record", "wait") and not (len(e) > 3 and e[3])]
+    assert "air_canvas_unroll_bwd" in names_main and "air_canvas_unroll_bwd_nvil" not in names_main
+    monkeypatch.setenv("AIR_TWO_LANE", "0"); monkeypatch.setenv("AIR_OPT_RIDERS", "0")
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_b._plan_two_lane is None and eng_b._plan_bwd_riders is None
+    if captured:
+        eng_a.capture()
+    eng_b.capture()
+    for _ in range(3):
+        eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    for k in ("flat_grads", "flat_params", "flat_ms", "flat_mg", "flat_mom", "noise_normal", "nvil_out", "rec"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
+    assert torch.equal(eng_a.rng_state, eng_b.rng_state)
 
 
 @pytest.mark.parametrize("name", ["mnist_b8", "t1_b5"])
@@ -552,12 +623,15 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
         for _ in range(3):
             eng_a.train_step()
         eng_a.synchronize()
-        # --- captured RCCL collective (the default of DataParallelEngine for world > 1) ---------------------------------
+        # --- captured RCCL collective (opt-in protocol of DataParallelEngine: AIR_DP_COLLECTIVE=rccl-captured) ----------
         comm = D.create_rccl_comm(torch.device("cuda", 0))
+        comm_side = D.create_rccl_comm(torch.device("cuda", 0))          # the forked stream reduces on a communicator of its own
+        assert D.comm_count(comm) == 1 and D.comm_count(comm_side) == 1   # ncclCommCount through the C ABI
+        assert D.selftest_comm(comm, torch.device("cuda", 0), eng_a.stream)
         for overlap in (False, True):
             eng_c, *_ = make_pair(ocfg, B, seed=3, gstep=0)
             eng_c.world_size = 1
-            eng_c.capture(comm=comm, overlap=overlap)
+            eng_c.capture(comm=comm, overlap=overlap, comm_side=comm_side if overlap else None)
             assert eng_c._graph is not None and eng_c._graph_opt is None and eng_c._graph_has_opt      # ONE graph
             for _ in range(3):
                 eng_c.train_step()
@@ -570,7 +644,7 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
         st = H.lib().air_allreduce_sum(H._p(g), ctypes.c_size_t(g.numel()), comm, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert st == 0 and torch.equal(g, torch.arange(1000, dtype=torch.float32, device="cuda"))
-        assert H.lib().air_comm_destroy(comm) == 0
+        assert H.lib().air_comm_destroy(comm_side) == 0 and H.lib().air_comm_destroy(comm) == 0
         # --- the wrapper: world 1 -> plain single graph, collective "none" ---------------------------------------------
         eng_d, *_ = make_pair(ocfg, B, seed=3, gstep=0)
         dp = D.DataParallelEngine(eng_d)
@@ -599,6 +673,57 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
         assert all(buckets[i][1] == buckets[i + 1][2] for i in range(len(buckets) - 1))
     finally:
         dist.destroy_process_group()
+
+
+def _dp_rank_main(rank, world, port, out_dir, collective):
+    """one rank of test_data_parallel_two_ranks_on_two_gpus (spawned: one process per GPU)"""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    from attend_infer_repeat_amd import distributed as D
+    D.init_from_env(backend="nccl")
+    ocfg, B = CONFIGS["mnist_b8"]
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+    fields = {f.name for f in dataclasses.fields(EngineConfig)}
+    eng = AIREngine(EngineConfig(**{k: v for k, v in dataclasses.asdict(ocfg).items() if k in fields}), B,
+                    device=torch.device("cuda", rank), seed=D.rank_seed(3, rank))
+    eng.load_parameters(O.init_params(ocfg, seed=3 + rank, bias_std=0.1))     # deliberately different before the broadcast
+    obs, _ = O.synthetic_batch(ocfg, B, seed=40 + rank)
+    eng.set_obs(obs.cuda())
+    dp = D.DataParallelEngine(eng, collective=collective)
+    start = eng.flat_params.cpu().clone()
+    # one step with the gradient read back before the update: split protocols expose it between the two graphs
+    for _ in range(3):
+        dp.train_step()
+    eng.synchronize()
+    torch.save(dict(start=start, params=eng.flat_params.cpu(), grads=eng.flat_grads.cpu(), collective=dp.collective,
+                    nranks=dp.rccl_nranks, noise=eng.eps_what.cpu()), os.path.join(out_dir, f"{collective}_{rank}.pt"))
+    dp.close()
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("collective", ["torch-split", "rccl-split", "rccl-captured"])
+def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
+    """The real thing where the box has it: min(device_count, 2) = 2 ranks, one process per GPU, each protocol of
+    DataParallelEngine.  After three steps both replicas must hold IDENTICAL parameters (they started from rank 0's, every
+    update used the same all-reduced gradient, scaled by 1/2), their summed gradient buffers must be identical, their noise
+    must differ, and RCCL itself must report two ranks.  Skips on a single-GPU box (the driver's 1-GPU tier)."""
+    import socket
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_rank_main, args=(2, port, str(tmp_path), collective), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(2)]
+    assert r[0]["collective"] == r[1]["collective"] == collective
+    if collective != "torch-split":
+        assert r[0]["nranks"] == r[1]["nranks"] == 2
+    assert torch.equal(r[0]["start"], r[1]["start"])
+    assert torch.equal(r[0]["grads"], r[1]["grads"]) and r[0]["grads"].abs().max() > 0
+    assert torch.equal(r[0]["params"], r[1]["params"]) and not torch.equal(r[0]["params"], r[0]["start"])
+    assert not torch.equal(r[0]["noise"], r[1]["noise"])
 
 
 def test_data_parallel_semantics_two_virtual_ranks(gpu_device):

@@ -479,6 +479,29 @@ def test_rmsprop_centered(hip):
     assert_close(pg, p["a/w"], 1e-6, 1e-7, "params"); assert_close(mom, slots["a/w"]["mom"], 1e-5, 1e-9, "mom")
 
 
+@pytest.mark.parametrize("kw", [dict(momentum=0.5), dict(decay=0.8, epsilon=1e-6, centered=True), dict()])
+def test_rmsprop_keyword_set_of_tf_rmsprop(hip, kw):
+    """air_rmsprop: every keyword of tf.train.RMSPropOptimizer (model.py:265 passes **opt_kwargs through) against the update
+    written out in float64 -- TF's defaults for what is not given: decay .9, momentum 0, epsilon 1e-10, centered False."""
+    full = dict(decay=0.9, momentum=0.0, epsilon=1e-10, centered=False); full.update(kw)
+    gen = torch.Generator().manual_seed(9)
+    n = 4099
+    p, ms, mg, mom = torch.randn(n, generator=gen).double(), torch.ones(n).double(), torch.zeros(n).double(), torch.zeros(n).double()
+    pg, msg, mgg, momg = p.float().cuda(), ms.float().cuda(), mg.float().cuda(), mom.float().cuda()
+    lr = torch.tensor([3e-3]).cuda()
+    for it in range(3):
+        g = torch.randn(n, generator=gen)
+        gd = g.double()
+        ms = full["decay"] * ms + (1 - full["decay"]) * gd * gd
+        mg = full["decay"] * mg + (1 - full["decay"]) * gd
+        denom = ms - mg * mg if full["centered"] else ms
+        mom = full["momentum"] * mom + 3e-3 * gd / torch.sqrt(denom + full["epsilon"])
+        p = p - mom
+        hip.rmsprop_centered_(pg, g.cuda(), msg, mgg, momg, lr, decay=full["decay"], momentum=full["momentum"],
+                              eps=full["epsilon"], centered=full["centered"])
+    assert_close(pg, p.float(), 1e-6, 1e-6, "params"); assert_close(momg, mom.float(), 1e-5, 1e-8, "mom")
+
+
 @pytest.mark.parametrize("M,Hd", [(64, 256), (1024, 256)])          # 16-wave link / wide-tile link
 def test_optimizer_slice_riding_on_bptt_launches(hip, M, Hd):
     """air_lstm_pointwise_bwd_opt / air_lstm_step_bwd_opt: the launch's own result is unchanged and elements [lo, hi) of the
