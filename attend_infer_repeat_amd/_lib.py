@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 4  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 5  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -20,7 +20,8 @@ class AirGemmDesc(ctypes.Structure):
                 ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
                 ("bias", c_void_p), ("epilogue", c_int), ("aux", c_void_p), ("ldaux", c_int), ("beta", c_float),
                 ("colsum", c_void_p), ("precision", c_int),
-                ("A2", c_void_p), ("a_bias", c_void_p), ("a_elu", c_int), ("a_out", c_void_p)]
+                ("A2", c_void_p), ("a_bias", c_void_p), ("a_elu", c_int), ("a_out", c_void_p),
+                ("A16", c_void_p), ("B16", c_void_p), ("C16", c_void_p)]
 
 
 class AirRmspropSlice(ctypes.Structure):
@@ -103,6 +104,9 @@ SIGNATURES = {
     "air_batch_gather": (c_int, [P, ctypes.c_longlong, c_int, P, P, c_int, P, c_int, P, P]),
     "air_step_epilogue": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
                                   P, P, c_uint64, P]),
+    "air_step_epilogue_shadow": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
+                                         P, P, c_uint64, P, P]),
+    "air_f32_to_bf16": (c_int, [P, P, c_size_t, P]),
     "air_steps_prior": (c_int, [P, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_double, P, c_int, P]),
     "air_counter_add": (c_int, [P, ctypes.c_int64, P]),

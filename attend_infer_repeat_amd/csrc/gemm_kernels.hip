@@ -28,6 +28,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1))) *gcu4;
+typedef const u32x2 __attribute__((address_space(1))) *gcu2;
+typedef const unsigned short __attribute__((address_space(1))) *gch;
+typedef unsigned short __attribute__((address_space(1))) *gh_t;
+struct Gemm16Ptrs { const void *A16, *B16; void *C16; };
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    const bf16x2 v = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 // bf16 operand mode (BASELINE config 5, "bf16 MFMA MLP path"): storage stays fp32; the four k-values a lane holds for a
 // 16-deep chunk are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers and ONE v_mfma_f32_16x16x16_bf16 replaces the
@@ -149,7 +162,9 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
 template <int MT, int NT, int KW, bool BF, bool APRO = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split, const AproArgs pro = AproArgs()) {
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split, const AproArgs pro = AproArgs(),
+                                          void *c16 = nullptr) {
+    const gh_t hC = (gh_t)c16;             // bf16 mirror of C (bf16 data path: the next product reads it instead of the fp32 value)
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
     constexpr int NWV = (KW == 1) ? 4 : KW;               // waves per workgroup
@@ -334,6 +349,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                     default: break;
                 }
                 gC[(size_t)m * g.ldc + n] = v;
+                if (BF && hC) hC[(size_t)m * g.ldc + n] = bf16_bits(v);
             }
         }
         if (want_colsum && threadIdx.x < TN) {
@@ -354,7 +370,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
             if (m >= g.M || n >= g.N) continue;
             const float v = s_tile[wave][r * LDT + cidx];
             if (g.S > 1) gWs[((size_t)split * g.M + m) * g.N + n] = v;
-            else gC[(size_t)m * g.ldc + n] = apply_epilogue(v, m, n, g);
+            else {
+                const float o = apply_epilogue(v, m, n, g);
+                gC[(size_t)m * g.ldc + n] = o;
+                if (BF && hC) hC[(size_t)m * g.ldc + n] = bf16_bits(o);
+            }
         }
         if (want_colsum && lane < TN) {
             const int n = n0 + lane;
@@ -366,6 +386,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 template <int MT, int NT, int KW, bool BF>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_f32_mfma_kernel(GemmArgs g) {
     gemm_body<MT, NT, KW, BF>(g, blockIdx.x, blockIdx.y);
+}
+// bf16 data path, small tiles: fp32 operand fetch (rounded in registers) + the bf16 mirror of C
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_bf16_c16_kernel(GemmArgs g, void *c16) {
+    gemm_body<MT, NT, KW, true>(g, blockIdx.x, blockIdx.y, AproArgs(), c16);
 }
 // the same body with the A-operand prologue (consumer-side reduction of a K-split producer) compiled in
 template <int MT, int NT, int KW, bool BF>
@@ -578,6 +603,286 @@ __global__ __launch_bounds__(64 * KW) void gemm_wide_kernel(GemmArgs g) {
     gemm_wide_body<MT, KW, BF, TA, TB>(g, blockIdx.x);
 }
 
+// ---- the bf16 DATA path (BASELINE configs[4]) --------------------------------------------------------------------------------------
+// gemm_wide_body<BF = true> only ROUNDS to bf16: every operand is still fetched as fp32 and fed to the CDNA3-form 16-deep MFMA.
+// Here the operands may live in memory as bf16 -- a bf16 shadow of the flat parameter buffer (rewritten by the optimiser launch)
+// and bf16 mirrors of the activations / gradients that GEMM epilogues produce (written by the producing epilogue next to the fp32
+// value the non-GEMM consumers keep using) -- so an operand costs half the bytes, and the product runs on the gfx950 instruction
+// v_mfma_f32_16x16x32_bf16: 32 k-slots per instruction, lane (i, lg) supplies slots 8 lg .. 8 lg + 7.  MFMA only needs A and B to
+// agree on which k sits in a slot, so every loader below -- k-contiguous or interleaved along the contiguous dimension, fp32 or
+// bf16 in memory -- produces "k = 32 c + 8 lg + j in slot 8 lg + j" and any combination of operand kinds multiplies correctly:
+//   k-contiguous bf16 : ONE 16-byte load per lane per 32-deep chunk (8 consecutive k);
+//   k-contiguous fp32 : two 16-byte loads, v_cvt_pk_bf16_f32 x4 (an operand without a mirror: LSTM state, sampled latents ...);
+//   interleaved bf16  : eight 8-byte loads (row k + j, the lane's 4 columns) and a 16-bit transpose with v_perm_b32: the four
+//                       values of a load go to four different MFMA tiles, exactly as in gemm_wide_body;
+//   interleaved fp32  : eight 16-byte loads, converted pairwise.
+// Same wave tile (16 MT x 64), same fixed-order K split over KW waves through LDS, same fused epilogues; the epilogue also writes
+// the bf16 mirror of C when the descriptor names one.  fp32 accumulate, fp32 master copy of everything.
+__device__ __forceinline__ float bf16_to_f32(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ u32x4 pk8(f32x4 lo, f32x4 hi) {
+    return (u32x4){pk_bf16(lo.x, lo.y), pk_bf16(lo.z, lo.w), pk_bf16(hi.x, hi.y), pk_bf16(hi.z, hi.w)};
+}
+// tile t (0..3) of eight 4-wide bf16 rows w[0..7] (row j = k + j; w[j].x = columns 0,1, w[j].y = columns 2,3)
+template <int T_>
+__device__ __forceinline__ u32x4 tr16(const u32x2 (&w)[8]) {
+    constexpr unsigned sel = (T_ & 1) ? 0x07060302u : 0x05040100u;     // v_perm_b32: {hi half | lo half} of (S0, S1)
+    u32x4 r;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned lo = (T_ < 2) ? w[2 * d].x : w[2 * d].y, hi = (T_ < 2) ? w[2 * d + 1].x : w[2 * d + 1].y;
+        r[d] = __builtin_amdgcn_perm(hi, lo, sel);
+    }
+    return r;
+}
+template <int T_>
+__device__ __forceinline__ u32x4 tr32(const f32x4 (&w)[8]) {
+    return (u32x4){pk_bf16(w[0][T_], w[1][T_]), pk_bf16(w[2][T_], w[3][T_]), pk_bf16(w[4][T_], w[5][T_]), pk_bf16(w[6][T_], w[7][T_])};
+}
+
+template <int MT, int KW>
+struct Wide16Lds {                       // declared once per KERNEL and handed to the body: a kernel that holds several
+    float tile[KW][16 * MT * (64 + 4)];  // instantiations of the body (per-problem operand kinds) must not hold several copies
+    float col[KW][64];
+};
+template <int MT, int KW, bool TA, bool TB, bool A16, bool B16>
+__device__ __forceinline__ void gemm_wide16_body(const GemmArgs &g, const Gemm16Ptrs &h, const int block_tile, Wide16Lds<MT, KW> &lds) {
+    constexpr int NT = 4, TM = 16 * MT, TN = 64;
+    constexpr int NTH = 64 * KW;
+    constexpr int LDT = TN + 4;
+    static_assert(!TA || MT == 4, "an m-contiguous A operand is read 4 rows per lane: four interleaved row tiles");
+    float (&s_tile)[KW][TM * LDT] = lds.tile;
+    float (&s_col)[KW][TN] = lds.col;
+
+    const gcf gA = (gcf)g.A, gB = (gcf)g.B, gBias = (gcf)g.bias, gAux = (gcf)g.aux;
+    const gch hA = (gch)h.A16, hB = (gch)h.B16;
+    const gf gC = (gf)g.C, gCol = (gf)g.colsum;
+    const gh_t hC = (gh_t)h.C16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tiles_n = (g.N + TN - 1) / TN;
+    const int tm = block_tile / tiles_n, tn = block_tile - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[NT] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_colsum = TA && (g.colsum != nullptr) && (tm == 0);
+
+    int offA[TA ? 1 : MT], offB[TB ? NT : 1];
+    if (TA) { int r = m0 + 4 * li; if (r > g.M - 4) r = g.M - 4; offA[0] = r; }
+    else {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) { int r = m0 + 16 * a + li; if (r > g.M - 1) r = g.M - 1; offA[a] = r * g.lda; }
+    }
+    if (!TB) { int c = n0 + 4 * li; if (c > g.N - 4) c = g.N - 4; offB[0] = c; }
+    else {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) { int c = n0 + 16 * b + li; if (c > g.N - 1) c = g.N - 1; offB[b] = c * g.ldb; }
+    }
+
+    constexpr int EPT = (TM * TN) / NTH;
+    static_assert((TM * TN) % NTH == 0, "tile / threads");
+    float e_bias[EPT], e_aux[EPT], e_c[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + NTH * i;
+        const int r = e / TN, cidx = e - r * TN;
+        int m = m0 + r, n = n0 + cidx;
+        if (m > g.M - 1) m = g.M - 1;
+        if (n > g.N - 1) n = g.N - 1;
+        e_bias[i] = g.bias != nullptr ? gBias[n] : 0.f;
+        e_aux[i] = g.epi >= AIR_EPI_MUL_DELU ? gAux[(size_t)m * g.ldaux + n] : 0.f;
+        e_c[i] = g.beta != 0.f ? gC[(size_t)m * g.ldc + n] : 0.f;
+    }
+
+    // one 32-deep chunk: k = first of the lane group's eight k values, kn = number of them inside K (8 in the main loop)
+    auto load_chunk = [&](int k, int kn, u32x4 (&fa)[MT], u32x4 (&fb)[NT], bool full) {
+        if (TA) {
+            if (A16) {
+                u32x2 w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kj = (full || j < kn) ? k + j : k;
+                    w[j] = *(gcu2)(hA + (size_t)kj * g.lda + offA[0]);
+                    if (!full && j >= kn) w[j] = (u32x2){0u, 0u};
+                }
+                fa[0] = tr16<0>(w); fa[1] = tr16<1>(w); fa[2] = tr16<2>(w); fa[3] = tr16<3>(w);
+            } else {
+                f32x4 w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kj = (full || j < kn) ? k + j : k;
+                    w[j] = *(gcf4)(gA + (size_t)kj * g.lda + offA[0]);
+                    if (!full && j >= kn) w[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                fa[0] = tr32<0>(w); fa[1] = tr32<1>(w); fa[2] = tr32<2>(w); fa[3] = tr32<3>(w);
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                if (full) {
+                    if (A16) fa[a] = *(gcu4)(hA + offA[a] + k);
+                    else fa[a] = pk8(*(gcf4)(gA + offA[a] + k), *(gcf4)(gA + offA[a] + k + 4));
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = j < kn ? (A16 ? bf16_to_f32(hA[offA[a] + k + j]) : gA[offA[a] + k + j]) : 0.f;
+                    fa[a] = (u32x4){pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                }
+            }
+        }
+        if (!TB) {
+            if (B16) {
+                u32x2 w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kj = (full || j < kn) ? k + j : k;
+                    w[j] = *(gcu2)(hB + (size_t)kj * g.ldb + offB[0]);
+                    if (!full && j >= kn) w[j] = (u32x2){0u, 0u};
+                }
+                fb[0] = tr16<0>(w); fb[1] = tr16<1>(w); fb[2] = tr16<2>(w); fb[3] = tr16<3>(w);
+                if (want_colsum) {       // the bias gradient sums the UNROUNDED gradient: the first row of tiles also reads the fp32 rows
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (full || j < kn) {
+                            const f32x4 r = *(gcf4)(gB + (size_t)(k + j) * g.ldb + offB[0]);
+                            csum[0] += r.x; csum[1] += r.y; csum[2] += r.z; csum[3] += r.w;
+                        }
+                    }
+                }
+            } else {
+                f32x4 w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kj = (full || j < kn) ? k + j : k;
+                    w[j] = *(gcf4)(gB + (size_t)kj * g.ldb + offB[0]);
+                    if (!full && j >= kn) w[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                fb[0] = tr32<0>(w); fb[1] = tr32<1>(w); fb[2] = tr32<2>(w); fb[3] = tr32<3>(w);
+                if (want_colsum) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { csum[0] += w[j].x; csum[1] += w[j].y; csum[2] += w[j].z; csum[3] += w[j].w; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                if (full) {
+                    if (B16) fb[b] = *(gcu4)(hB + offB[b] + k);
+                    else fb[b] = pk8(*(gcf4)(gB + offB[b] + k), *(gcf4)(gB + offB[b] + k + 4));
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = j < kn ? (B16 ? bf16_to_f32(hB[offB[b] + k + j]) : gB[offB[b] + k + j]) : 0.f;
+                    fb[b] = (u32x4){pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                }
+            }
+        }
+    };
+    auto mma = [&](const u32x4 (&fa)[MT], const u32x4 (&fb)[NT]) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]),
+                                                                   acc[a][b], 0, 0, 0);
+    };
+
+    constexpr int U = (MT == 4) ? ((A16 && B16) ? 2 : 1) : 2;          // 32-deep chunks in flight per wave
+    const int full_end = g.K >> 5;
+    int c = wave;
+#pragma nounroll
+    for (; c < full_end; c += U * KW) {
+        u32x4 fa[U][MT], fb[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cu = c + u * KW;
+            if (cu > full_end - 1) cu = full_end - 1;      // a short tail group re-reads the last chunk (never multiplied)
+            load_chunk((cu << 5) + 8 * lg, 8, fa[u], fb[u], true);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW >= full_end) break;
+            mma(fa[u], fb[u]);
+        }
+    }
+    // the partial last chunk (K % 32 != 0), element-masked, by the wave whose turn it is
+    if ((g.K & 31) && (full_end % KW) == wave) {
+        const int k = (full_end << 5) + 8 * lg;
+        int kn = g.K - k;
+        kn = kn < 0 ? 0 : (kn > 8 ? 8 : kn);
+        u32x4 fa[MT], fb[NT];
+        load_chunk(kn > 0 ? k : 0, kn, fa, fb, false);
+        mma(fa, fb);
+    }
+
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = TA ? 4 * (4 * lg + r) + a : 16 * a + 4 * lg + r;
+            if (!TB) {
+                *(f32x4 *)&s_tile[wave][row * LDT + 4 * li] = (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+            } else {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) s_tile[wave][row * LDT + 16 * b + li] = acc[a][b][r];
+            }
+        }
+    if (want_colsum) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            float v = csum[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) s_col[wave][TB ? 16 * b + li : 4 * li + b] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + NTH * i;
+        const int r = e / TN, cidx = e - r * TN;
+        const int m = m0 + r, n = n0 + cidx;
+        const int off = r * LDT + cidx;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KW; q += 4) v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
+        if (g.beta != 0.f) v += g.beta * e_c[i];
+        switch (g.epi) {
+            case AIR_EPI_BIAS: v += e_bias[i]; break;
+            case AIR_EPI_BIAS_ELU: v = elu_acc(v + e_bias[i]); break;
+            case AIR_EPI_MUL_DELU: v *= (e_aux[i] > 0.f ? 1.f : e_aux[i] + 1.f); break;
+            case AIR_EPI_ADD_AUX: v += e_aux[i] + e_bias[i]; break;
+            case AIR_EPI_ADD_AUX_ELU: v = elu_acc(v + e_aux[i] + e_bias[i]); break;
+            default: break;
+        }
+        if (m < g.M && n < g.N) {
+            gC[(size_t)m * g.ldc + n] = v;
+            if (hC) hC[(size_t)m * g.ldc + n] = bf16_bits(v);
+        }
+    }
+    if (want_colsum && threadIdx.x < TN) {
+        const int n = n0 + threadIdx.x;
+        if (n < g.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < KW; q += 4)
+                v += (s_col[q][threadIdx.x] + s_col[q + 1][threadIdx.x]) + (s_col[q + 2][threadIdx.x] + s_col[q + 3][threadIdx.x]);
+            gCol[n] = v;
+        }
+    }
+}
+template <int MT, int KW, bool TA, bool TB, bool A16, bool B16>
+__global__ __launch_bounds__(64 * KW) void gemm_wide16_kernel(GemmArgs g, Gemm16Ptrs h) {
+    __shared__ Wide16Lds<MT, KW> lds;
+    gemm_wide16_body<MT, KW, TA, TB, A16, B16>(g, h, blockIdx.x, lds);
+}
+
 // Several independent GEMMs in ONE launch (the step is launch/latency bound: a dW / dX pair, or the two heads that
 // read the same hidden state, cost one dispatch instead of two).  Problem p owns blocks [tile_start[p], tile_start[p+1]).
 #define AIR_GEMM_GROUP_MAX 8
@@ -611,6 +916,26 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(G
     }
 }
 
+struct C16Ptrs { void *p[AIR_GEMM_GROUP_MAX]; };
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_c16_kernel(GroupArgs ga, C16Ptrs c16) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    switch (p) {
+        case 0: gemm_body<MT, NT, KW, true>(ga.g[0], (int)blockIdx.x - ga.tile_start[0], blockIdx.y, AproArgs(), c16.p[0]); break;
+        case 1: gemm_body<MT, NT, KW, true>(ga.g[1], (int)blockIdx.x - ga.tile_start[1], blockIdx.y, AproArgs(), c16.p[1]); break;
+        case 2: gemm_body<MT, NT, KW, true>(ga.g[2], (int)blockIdx.x - ga.tile_start[2], blockIdx.y, AproArgs(), c16.p[2]); break;
+        case 3: gemm_body<MT, NT, KW, true>(ga.g[3], (int)blockIdx.x - ga.tile_start[3], blockIdx.y, AproArgs(), c16.p[3]); break;
+        case 4: gemm_body<MT, NT, KW, true>(ga.g[4], (int)blockIdx.x - ga.tile_start[4], blockIdx.y, AproArgs(), c16.p[4]); break;
+        case 5: gemm_body<MT, NT, KW, true>(ga.g[5], (int)blockIdx.x - ga.tile_start[5], blockIdx.y, AproArgs(), c16.p[5]); break;
+        case 6: gemm_body<MT, NT, KW, true>(ga.g[6], (int)blockIdx.x - ga.tile_start[6], blockIdx.y, AproArgs(), c16.p[6]); break;
+        default: gemm_body<MT, NT, KW, true>(ga.g[7], (int)blockIdx.x - ga.tile_start[7], blockIdx.y, AproArgs(), c16.p[7]); break;
+    }
+}
+
 // consecutive workgroup ids go to different XCDs (each with its own L2): give every XCD a CONTIGUOUS range of tiles -- same
 // problem, same row slab, neighbouring column slabs -- so that an operand slab is pulled into one L2, not into all eight
 __device__ __forceinline__ int xcd_contiguous_tile(int b, int G) {
@@ -634,6 +959,34 @@ __global__ __launch_bounds__(64 * KW) void gemm_grouped_wide_kernel(GroupArgs ga
         case 5: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[5], vb - ga.tile_start[5]); break;
         case 6: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[6], vb - ga.tile_start[6]); break;
         default: gemm_wide_body<MT, KW, BF, TA, TB>(ga.g[7], vb - ga.tile_start[7]); break;
+    }
+}
+
+struct GroupArgs16 {
+    GemmArgs g[AIR_GEMM_GROUP_MAX];
+    Gemm16Ptrs h[AIR_GEMM_GROUP_MAX];
+    int tile_start[AIR_GEMM_GROUP_MAX + 1];
+    int count;
+    int xcd_map;
+};
+template <int MT, int KW, bool TA, bool TB, bool A16, bool B16>
+__global__ __launch_bounds__(64 * KW) void gemm_grouped_wide16_kernel(GroupArgs16 ga) {
+    __shared__ Wide16Lds<MT, KW> lds;
+    const int vb = ga.xcd_map ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && vb >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    switch (p) {       // constant descriptor index per copy, as in gemm_grouped_kernel
+        case 0: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[0], ga.h[0], vb - ga.tile_start[0], lds); break;
+        case 1: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[1], ga.h[1], vb - ga.tile_start[1], lds); break;
+        case 2: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[2], ga.h[2], vb - ga.tile_start[2], lds); break;
+        case 3: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[3], ga.h[3], vb - ga.tile_start[3], lds); break;
+        case 4: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[4], ga.h[4], vb - ga.tile_start[4], lds); break;
+        case 5: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[5], ga.h[5], vb - ga.tile_start[5], lds); break;
+        case 6: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[6], ga.h[6], vb - ga.tile_start[6], lds); break;
+        default: gemm_wide16_body<MT, KW, TA, TB, A16, B16>(ga.g[7], ga.h[7], vb - ga.tile_start[7], lds); break;
     }
 }
 
@@ -679,6 +1032,39 @@ __global__ __launch_bounds__(64 * KW) void gemm_big_group_wide_tn_kernel(BigGrou
     }
     const int vb = ga.xcd_map == 1 ? xcd_contiguous_tile_in_range(b, s0, ga.tile_start[p + 1]) : b;
     gemm_wide_body<MT, KW, BF, true, false>(ga.g[p], vb - s0);
+}
+
+// bf16 data path: the same launch with the operands' bf16 mirrors (weight gradients: A = an activation, B = a gradient, both
+// interleaved reads); the odd-shaped members keep the fp32-fetch small-tile body
+struct BigGroupArgs16 {
+    GemmArgs g[AIR_GEMM_BIG_GROUP_MAX];
+    Gemm16Ptrs h[AIR_GEMM_BIG_GROUP_MAX];
+    int tile_start[AIR_GEMM_BIG_GROUP_MAX + 1];
+    int count;
+    int xcd_map;
+    unsigned small_mask;
+};
+// (the operand kinds are per PROBLEM here -- a weight-gradient launch mixes activations with and without a mirror -- chosen by a
+//  wave-uniform branch between the four instantiations of the body)
+template <int MT, int KW>
+__global__ __launch_bounds__(64 * KW) void gemm_big_group_wide16_tn_kernel(BigGroupArgs16 ga) {
+    __shared__ Wide16Lds<MT, KW> lds;
+    const int b = ga.xcd_map == 2 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < ga.count; ++i)
+        if (b >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int s0 = ga.tile_start[p];
+    if ((ga.small_mask >> p) & 1u) {
+        gemm_body<1, 1, KW, true>(ga.g[p], b - s0, 0);
+        return;
+    }
+    const int vb = ga.xcd_map == 1 ? xcd_contiguous_tile_in_range(b, s0, ga.tile_start[p + 1]) : b;
+    const bool a16 = ga.h[p].A16 != nullptr, b16 = ga.h[p].B16 != nullptr;
+    if (a16 && b16) gemm_wide16_body<MT, KW, true, false, true, true>(ga.g[p], ga.h[p], vb - s0, lds);
+    else if (a16) gemm_wide16_body<MT, KW, true, false, true, false>(ga.g[p], ga.h[p], vb - s0, lds);
+    else if (b16) gemm_wide16_body<MT, KW, true, false, false, true>(ga.g[p], ga.h[p], vb - s0, lds);
+    else gemm_wide16_body<MT, KW, true, false, false, false>(ga.g[p], ga.h[p], vb - s0, lds);
 }
 
 // sums the S split-K slabs in fixed order and applies the epilogue
@@ -834,8 +1220,21 @@ static int launch_big_tn_group(const AirGemmDesc *descs, int count, void *stream
     static const int big_xcd = getenv("AIR_GEMM_BIG_XCD") ? atoi(getenv("AIR_GEMM_BIG_XCD")) : 1;
     ga.xcd_map = (big_xcd && min_k >= 1024) ? (bf ? 2 : 1) : 0;
     hipStream_t st = air_stream(stream);
-    if (bf) hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, true>), dim3(wt), dim3(512), 0, st, ga);
-    else hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, false>), dim3(wt), dim3(512), 0, st, ga);
+    if (bf) {
+        static const int use16 = getenv("AIR_GEMM_BF16_STORAGE") ? atoi(getenv("AIR_GEMM_BF16_STORAGE")) : 1;
+        BigGroupArgs16 g16;
+        for (int i = 0; i < AIR_GEMM_BIG_GROUP_MAX; ++i) {
+            const int j = i < count ? i : 0;
+            const AirGemmDesc &d = descs[j];
+            g16.g[i] = ga.g[j];
+            g16.h[i].A16 = (use16 && d.A16 && d.lda % 2 == 0 && ((uintptr_t)d.A16 % 4 == 0)) ? d.A16 : nullptr;
+            g16.h[i].B16 = (use16 && d.B16 && d.ldb % 2 == 0 && ((uintptr_t)d.B16 % 4 == 0)) ? d.B16 : nullptr;
+            g16.h[i].C16 = nullptr;
+        }
+        for (int i = 0; i <= AIR_GEMM_BIG_GROUP_MAX; ++i) g16.tile_start[i] = ga.tile_start[i];
+        g16.count = count; g16.xcd_map = ga.xcd_map; g16.small_mask = ga.small_mask;
+        hipLaunchKernelGGL((gemm_big_group_wide16_tn_kernel<4, 8>), dim3(wt), dim3(512), 0, st, g16);
+    } else hipLaunchKernelGGL((gemm_big_group_wide_tn_kernel<4, 8, false>), dim3(wt), dim3(512), 0, st, ga);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -911,15 +1310,50 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
             // long-K weight-gradient groups (1.5 MB of operands per tile): measured +1.3 % on the batch-1024 step with bf16
             // operands, nothing in fp32 (MFMA issue bound), -1.5 % at batch 256 (K = 768)
             ga.xcd_map = (ta && min_k >= 1024) ? 1 : 0;
+            if (bf) {
+                // the bf16 data path: operands from their bf16 mirrors where EVERY problem of the launch has one (4-byte
+                // aligned rows), from the fp32 buffers otherwise; mirrors of C written by the epilogue
+                static const int use16 = getenv("AIR_GEMM_BF16_STORAGE") ? atoi(getenv("AIR_GEMM_BF16_STORAGE")) : 1;
+                bool a16 = use16 != 0, b16 = use16 != 0;
+                for (int i = 0; i < count; ++i) {
+                    a16 = a16 && descs[i].A16 && descs[i].lda % 2 == 0 && ((uintptr_t)descs[i].A16 % 4 == 0);
+                    b16 = b16 && descs[i].B16 && descs[i].ldb % 2 == 0 && ((uintptr_t)descs[i].B16 % 4 == 0);
+                }
+                GroupArgs16 g16;
+                for (int i = 0; i < AIR_GEMM_GROUP_MAX; ++i) {
+                    const int j = i < count ? i : 0;
+                    g16.g[i] = ga.g[j];
+                    g16.h[i].A16 = a16 ? descs[j].A16 : nullptr;
+                    g16.h[i].B16 = b16 ? descs[j].B16 : nullptr;
+                    g16.h[i].C16 = descs[j].C16;
+                }
+                for (int i = 0; i <= AIR_GEMM_GROUP_MAX; ++i) g16.tile_start[i] = ga.tile_start[i];
+                g16.count = count; g16.xcd_map = ga.xcd_map;
+#define AIR_WIDE16_LAUNCH2(MT_, TA_, TB_, A16_, B16_)                                                                              \
+                do {                                                                                                       \
+                    if (count == 1) hipLaunchKernelGGL((gemm_wide16_kernel<MT_, 8, TA_, TB_, A16_, B16_>), dim3(wt), dim3(512), 0, st, g16.g[0], g16.h[0]); \
+                    else hipLaunchKernelGGL((gemm_grouped_wide16_kernel<MT_, 8, TA_, TB_, A16_, B16_>), dim3(wt), dim3(512), 0, st, g16);                   \
+                } while (0)
+#define AIR_WIDE16_LAUNCH(MT_, TA_, TB_)                                                                                   \
+                do {                                                                                                       \
+                    if (a16 && b16) AIR_WIDE16_LAUNCH2(MT_, TA_, TB_, true, true);                                         \
+                    else if (a16) AIR_WIDE16_LAUNCH2(MT_, TA_, TB_, true, false);                                          \
+                    else if (b16) AIR_WIDE16_LAUNCH2(MT_, TA_, TB_, false, true);                                          \
+                    else AIR_WIDE16_LAUNCH2(MT_, TA_, TB_, false, false);                                                  \
+                } while (0)
+                if (ta) AIR_WIDE16_LAUNCH(4, true, false);
+                else if (nt_short) AIR_WIDE16_LAUNCH(2, false, true);
+                else if (tb) AIR_WIDE16_LAUNCH(1, false, true);
+                else AIR_WIDE16_LAUNCH(1, false, false);
+#undef AIR_WIDE16_LAUNCH
+#undef AIR_WIDE16_LAUNCH2
+                AIR_LAUNCH_CHECK();
+                return AIR_OK;
+            }
 #define AIR_WIDE_LAUNCH(MT_, TA_, TB_)                                                                                     \
             do {                                                                                                           \
-                if (count == 1) {                                                                                          \
-                    if (bf) hipLaunchKernelGGL((gemm_wide_kernel<MT_, 8, true, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga.g[0]);   \
-                    else hipLaunchKernelGGL((gemm_wide_kernel<MT_, 8, false, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga.g[0]);     \
-                } else {                                                                                                   \
-                    if (bf) hipLaunchKernelGGL((gemm_grouped_wide_kernel<MT_, 8, true, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga);   \
-                    else hipLaunchKernelGGL((gemm_grouped_wide_kernel<MT_, 8, false, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga);     \
-                }                                                                                                          \
+                if (count == 1) hipLaunchKernelGGL((gemm_wide_kernel<MT_, 8, false, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga.g[0]);     \
+                else hipLaunchKernelGGL((gemm_grouped_wide_kernel<MT_, 8, false, TA_, TB_>), dim3(wt), dim3(512), 0, st, ga);             \
             } while (0)
             if (ta) AIR_WIDE_LAUNCH(4, true, false);
             else if (nt_short) AIR_WIDE_LAUNCH(2, false, true);
@@ -943,6 +1377,25 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MT_, NT_, KW_, false>), dim3(tiles, 1), dim3(NTH_), 0, st, ga.g[0]);    \
     } while (0)
     for (int i = 0; i < count; ++i) AIR_REQUIRE(!descs[i].A2 || count == 1, AIR_E_UNSUPPORTED);
+    bool any_c16 = false;
+    for (int i = 0; i < count; ++i) any_c16 = any_c16 || (descs[i].C16 != nullptr);
+    if (any_c16) {
+        // bf16 data path on small tiles: fp32 operand fetch, rounded in registers; the epilogue also writes the bf16 mirror of C
+        AIR_REQUIRE(bf && !descs[0].A2, AIR_E_UNSUPPORTED);
+        C16Ptrs c16;
+        for (int i = 0; i < AIR_GEMM_GROUP_MAX; ++i) c16.p[i] = i < count ? descs[i].C16 : nullptr;
+#define AIR_C16_LAUNCH(MT_, NT_, KW_, NTH_)                                                                          \
+        do {                                                                                                         \
+            if (count == 1) hipLaunchKernelGGL((gemm_bf16_c16_kernel<MT_, NT_, KW_>), dim3(tiles, 1), dim3(NTH_), 0, st, ga.g[0], c16.p[0]);  \
+            else hipLaunchKernelGGL((gemm_grouped_c16_kernel<MT_, NT_, KW_>), dim3(tiles), dim3(NTH_), 0, st, ga, c16);                     \
+        } while (0)
+        if (long_k) AIR_C16_LAUNCH(1, 1, 16, 1024);
+        else if (T_ == 16) AIR_C16_LAUNCH(1, 1, 4, 256);
+        else AIR_C16_LAUNCH(2, 2, 4, 256);
+#undef AIR_C16_LAUNCH
+        AIR_LAUNCH_CHECK();
+        return AIR_OK;
+    }
     if (count == 1 && descs[0].A2) {
         // latency-regime consumer of a K-split producer; a long K (the first hidden layer >= 512 wide at a small batch) stays
         // on the 4-wave prologue kernel: correct for any K, the 16-wave K split has no prologue form

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(PW_THREADS) void step_epilogue_kernel(float *__rest
                                                                    const float *__restrict__ lr_dev, float lr_mult_tail,
                                                                    float decay, float momentum, float eps, float gscale,
                                                                    int64_t *__restrict__ gstep, uint64_t *__restrict__ rng_state,
-                                                                   uint64_t rng_inc) {
+                                                                   uint64_t rng_inc, unsigned short *__restrict__ p16) {
     const float lr0 = lr_dev[0];
     if (VEC) {
         float4 *p4 = reinterpret_cast<float4 *>(p), *ms4 = reinterpret_cast<float4 *>(ms), *mg4 = reinterpret_cast<float4 *>(mg),
@@ -500,6 +500,11 @@ __global__ __launch_bounds__(PW_THREADS) void step_epilogue_kernel(float *__rest
             rmsprop_elem(pv.z, gv.z, a.z, b.z, c.z, lr, decay, momentum, eps, gscale);
             rmsprop_elem(pv.w, gv.w, a.w, b.w, c.w, lr, decay, momentum, eps, gscale);
             ms4[q] = a; mg4[q] = b; mom4[q] = c; p4[q] = pv;
+            if (p16) {       // bf16 shadow of the weights (bf16 data path): the next step's products read it, the fp32 copy stays the master
+                const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)pv.x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)pv.y) << 16);
+                const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)pv.z) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)pv.w) << 16);
+                reinterpret_cast<uint2 *>(p16)[q] = make_uint2(lo, hi);
+            }
         }
     } else {
         PW_LOOP(i, n_total) {
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(PW_THREADS) void step_epilogue_kernel(float *__rest
             float pv = p[i], a = ms[i], b = mg[i], c = mom[i];
             rmsprop_elem(pv, g[i], a, b, c, lr, decay, momentum, eps, gscale);
             ms[i] = a; mg[i] = b; mom[i] = c; p[i] = pv;
+            if (p16) p16[i] = __builtin_bit_cast(unsigned short, (__bf16)pv);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -514,22 +520,61 @@ __global__ __launch_bounds__(PW_THREADS) void step_epilogue_kernel(float *__rest
         if (rng_state) rng_state[1] += rng_inc;
     }
 }
+extern "C" int air_step_epilogue_shadow(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model,
+                                        size_t n_total, const float *lr_dev, float lr_mult_tail, float decay, float momentum,
+                                        float eps, float grad_scale, int64_t *global_step_dev, uint64_t *rng_state_dev,
+                                        uint64_t rng_increment, void *p_bf16, void *stream);
 extern "C" int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model,
                                  size_t n_total, const float *lr_dev, float lr_mult_tail, float decay, float momentum,
                                  float eps, float grad_scale, int64_t *global_step_dev, uint64_t *rng_state_dev,
                                  uint64_t rng_increment, void *stream) {
+    return air_step_epilogue_shadow(p, g, ms, mg, mom, n_model, n_total, lr_dev, lr_mult_tail, decay, momentum, eps, grad_scale,
+                                    global_step_dev, rng_state_dev, rng_increment, nullptr, stream);
+}
+extern "C" int air_step_epilogue_shadow(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model,
+                                        size_t n_total, const float *lr_dev, float lr_mult_tail, float decay, float momentum,
+                                        float eps, float grad_scale, int64_t *global_step_dev, uint64_t *rng_state_dev,
+                                        uint64_t rng_increment, void *p_bf16, void *stream) {
     AIR_REQUIRE(p && g && ms && mg && mom && lr_dev, AIR_E_NULL);
     AIR_REQUIRE(n_total > 0 && n_model <= n_total, AIR_E_SHAPE);
+    unsigned short *p16 = (unsigned short *)p_bf16;
+    AIR_REQUIRE(!p16 || ((uintptr_t)p16 % 8 == 0), AIR_E_ALIGN);
     const bool vec = (n_total % 4 == 0) && (n_model % 4 == 0) && air_aligned16(p) && air_aligned16(g) && air_aligned16(ms) &&
                      air_aligned16(mg) && air_aligned16(mom);
     if (vec)
         hipLaunchKernelGGL(step_epilogue_kernel<true>, dim3(pw_blocks(n_total >> 2)), dim3(PW_THREADS), 0, air_stream(stream), p,
                            g, ms, mg, mom, n_model, n_total, lr_dev, lr_mult_tail, decay, momentum, eps, grad_scale,
-                           global_step_dev, rng_state_dev, rng_increment);
+                           global_step_dev, rng_state_dev, rng_increment, p16);
     else
         hipLaunchKernelGGL(step_epilogue_kernel<false>, dim3(pw_blocks(n_total)), dim3(PW_THREADS), 0, air_stream(stream), p,
                            g, ms, mg, mom, n_model, n_total, lr_dev, lr_mult_tail, decay, momentum, eps, grad_scale,
-                           global_step_dev, rng_state_dev, rng_increment);
+                           global_step_dev, rng_state_dev, rng_increment, p16);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// out16[i] = bf16(x[i]) (round to nearest even): the bf16 mirror of a buffer no kernel of this library produces -- the observation
+// batch at the start of a step, the parameters after a load
+__global__ __launch_bounds__(PW_THREADS) void f32_to_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ out, size_t n) {
+    PW_LOOP(i, n) out[i] = __builtin_bit_cast(unsigned short, (__bf16)x[i]);
+}
+__global__ __launch_bounds__(PW_THREADS) void f32_to_bf16_vec_kernel(const float4 *__restrict__ x, uint2 *__restrict__ out, size_t nq) {
+    PW_LOOP(q, nq) {
+        const float4 v = x[q];
+        const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.y) << 16);
+        const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.z) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.w) << 16);
+        out[q] = make_uint2(lo, hi);
+    }
+}
+extern "C" int air_f32_to_bf16(const float *x, void *out_bf16, size_t n, void *stream) {
+    AIR_REQUIRE(x && out_bf16, AIR_E_NULL);
+    AIR_REQUIRE(n > 0, AIR_E_SHAPE);
+    if (n % 4 == 0 && air_aligned16(x) && ((uintptr_t)out_bf16 % 8 == 0))
+        hipLaunchKernelGGL(f32_to_bf16_vec_kernel, dim3(pw_blocks(n >> 2)), dim3(PW_THREADS), 0, air_stream(stream),
+                           reinterpret_cast<const float4 *>(x), reinterpret_cast<uint2 *>(out_bf16), n >> 2);
+    else
+        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), x,
+                           (unsigned short *)out_bf16, n);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

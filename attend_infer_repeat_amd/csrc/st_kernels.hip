@@ -456,28 +456,33 @@ __global__ __launch_bounds__(1024) void st_write_fwd_kernel(
 //   T1[I,j] = sum_J g[I,J] * wx[J,j]   over the contiguous J-range that touches glimpse column j
 //   dG[i,j] = sum_I wy[I,i] * T1[I,j]  over the contiguous I-range that touches glimpse row i
 struct CarveBwd {
-    float *src, *g, *t1, *X, *Y, *scratch;
+    float *src, *g, *t1, *X, *Y, *scratch, *pres;
     float2 *xe, *ye;
     int2 *jr, *ir;               // exact [lo, hi] canvas column / row range that touches glimpse column j / row i
+    int hwp;
 };
-__device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, int w) {
+// n_src = 1: the unit's own glimpse and axis tables; n_src = T (recompute form): those of all T steps of the unit's image,
+// step-major (src + t*hwp, xe + t*W, ye + t*H)
+__device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, int w, int n_src) {
     CarveBwd c;
     float *p = smem;
-    c.src = p; p += (h * w + 3) & ~3;
+    c.hwp = (h * w + 3) & ~3;
+    c.src = p; p += n_src * c.hwp;
     c.g = p; p += (H * W + 3) & ~3;
     c.t1 = p; p += (H * w + 3) & ~3;
-    c.xe = reinterpret_cast<float2 *>(p); p += 2 * W;
-    c.ye = reinterpret_cast<float2 *>(p); p += 2 * H;
+    c.xe = reinterpret_cast<float2 *>(p); p += 2 * W * n_src;
+    c.ye = reinterpret_cast<float2 *>(p); p += 2 * H * n_src;
     c.jr = reinterpret_cast<int2 *>(p); p += 2 * w;
     c.ir = reinterpret_cast<int2 *>(p); p += 2 * h;
     c.X = p; p += W;
     c.Y = p; p += H;
+    c.pres = p; p += (n_src + 3) & ~3;
     c.scratch = p;
     return c;
 }
-static inline size_t carve_bwd_bytes(int H, int W, int h, int w) {
-    return sizeof(float) * (size_t)(((h * w + 3) & ~3) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 3 * W + 3 * H + 2 * w +
-                                    2 * h + 128 + 16);
+static inline size_t carve_bwd_bytes(int H, int W, int h, int w, int n_src) {
+    return sizeof(float) * (size_t)(n_src * ((h * w + 3) & ~3) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + W + H +
+                                    2 * n_src * (W + H) + 2 * w + 2 * h + ((n_src + 3) & ~3) + 128 + 16);
 }
 // Canvas indices J (of n) whose source coordinate x(J) = cs*((a*X_J + b) + 1), X_J = -1 + 2J/(n-1), can land in [x0, x1].
 // The map is affine in J, so the set is an interval; it is obtained from the inverse map with a margin of one index on each
@@ -541,6 +546,11 @@ __device__ __forceinline__ int2 valid_span(const float2 *tab, int n) {
 // found with two ballots over the tables); exact per-column / per-row source ranges from the inverse affine map, re-checked
 // against the tables, computed by the idlest wave during the pixel pass; 4-wide predicated contraction loops (one LDS round
 // trip); and multi-value wave reductions.
+// RC ("recompute") form: no final canvas is read.  The unit stages ALL T glimpses, `where` rows and presences of its image,
+// re-forms the canvas on its own footprint exactly as st_write_fwd_kernel does (same table entries, same taps, t in order:
+// bit-identical values) and derives dcanvas from it and the observation.  The backward then no longer depends on the canvas
+// forward launch: in the two-lane step the forward (needed for the outputs and the NVIL loss value) leaves the dX chain.
+template <bool RC>
 __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
@@ -564,13 +574,17 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     }
     AIR_TR(0);
     const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    CarveBwd c = carve_bwd(smem, H, W, h, w);
+    CarveBwd c = carve_bwd(smem, H, W, h, w, RC ? T : 1);
+    float *const src_all = c.src;
+    float2 *const xe_all = c.xe, *const ye_all = c.ye;
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
     const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
     const float coef = loss_scale * mult / (std * std);
     const int n = T * B;
     for (int k = bid0; k < n; k += grid_st) {
         const int b = k % B;
+        const int t_own = k / B;
+        if (RC) { c.src = src_all + (size_t)t_own * c.hwp; c.xe = xe_all + t_own * W; c.ye = ye_all + t_own * H; }
         if (k != bid0) __syncthreads();                      // grid-stride reuse of the LDS carve
         // ---- every global load of the unit is requested first; the axis tables (which only need `where`, the oldest
         //      request) are built while the rest is still in flight, then the staged operands are written to LDS
@@ -587,45 +601,79 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
         // dword requests cost four times the load and LDS-store instructions)
         const bool v4 = vec4_canvas != 0;
         const int nQ = HW >> 2;
-        const float *pa = dcp ? dcp : fcp, *pb = dcp ? dcp : obp;
+        const float *pa = RC ? obp : (dcp ? dcp : fcp), *pb = RC ? obp : (dcp ? dcp : obp);
         float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
         if (v4) {
             const int q = tid < nQ ? tid : nQ - 1;
-            qa = reinterpret_cast<const float4 *>(pa)[q];
+            if (!RC) qa = reinterpret_cast<const float4 *>(pa)[q];
             qb = reinterpret_cast<const float4 *>(pb)[q];
+            if (RC) qa = qb;
         }
         const int nq = hw >> 2;
+        const int n_gq = RC ? T * nq : nq;                     // recompute form: the T glimpses of image b, step-major in LDS
         float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec4_glimpse && tid < nq) gq = reinterpret_cast<const float4 *>(gsrc)[tid];
+        if (vec4_glimpse && tid < n_gq) {
+            if (RC) { const int tt = tid / nq; gq = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[tid - tt * nq]; }
+            else gq = reinterpret_cast<const float4 *>(gsrc)[tid];
+        }
         const float ax = 1.0f / sx, bx = -tx / sx;
         const float ay = 1.0f / sy, by = -ty / sy;
-        {   // axis tables: columns by the first ceil(W/64) waves, rows by the next ceil(H/64) (no divergence inside a wave)
+        {   // axis tables: columns by the first ceil(W/64) waves, rows by the next ceil(H/64) (no divergence inside a wave);
+            // recompute form: one such block per step, each from that step's `where` row
             const int Wp = (W + 63) & ~63, Hp = (H + 63) & ~63;
-            for (int a = tid; a < Wp + Hp; a += nt) {
+            const int n_tab = RC ? T : 1;
+            for (int a0 = tid; a0 < n_tab * (Wp + Hp); a0 += nt) {
+                const int tt = RC ? a0 / (Wp + Hp) : 0, a = a0 - tt * (Wp + Hp);
+                float axt = ax, bxt = bx, ayt = ay, byt = by;
+                if (RC) {
+                    const float *wk = where + 4 * ((size_t)tt * B + b);
+                    if (a < Wp) { const float s_ = wk[0], t_ = wk[1]; axt = 1.0f / s_; bxt = -t_ / s_; }
+                    else { const float s_ = wk[2], t_ = wk[3]; ayt = 1.0f / s_; byt = -t_ / s_; }
+                }
+                float2 *xe_t = RC ? xe_all + tt * W : c.xe, *ye_t = RC ? ye_all + tt * H : c.ye;
                 if (a < Wp) {
                     if (a < W) {
                         const float X = lin_m11(a, W, stepX);
-                        c.X[a] = X;
-                        c.xe[a] = axis_entry2(grid_coord(ax, X, bx, cxs), w);
+                        if (!RC || tt == 0) c.X[a] = X;
+                        xe_t[a] = axis_entry2(grid_coord(axt, X, bxt, cxs), w);
                     }
                 } else {
                     const int i = a - Wp;
                     if (i < H) {
                         const float Y = lin_m11(i, H, stepY);
-                        c.Y[i] = Y;
-                        c.ye[i] = axis_entry2(grid_coord(ay, Y, by, cys), h);
+                        if (!RC || tt == 0) c.Y[i] = Y;
+                        ye_t[i] = axis_entry2(grid_coord(ayt, Y, byt, cys), h);
                     }
                 }
             }
+            if (RC && tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
         }
         AIR_TR(7);
-        if (vec4_glimpse) {
+        if (RC) {
+            if (vec4_glimpse) {
+                if (tid < n_gq) { const int tt = tid / nq; reinterpret_cast<float4 *>(src_all + (size_t)tt * c.hwp)[tid - tt * nq] = gq; }
+                for (int q = tid + nt; q < n_gq; q += nt) {
+                    const int tt = q / nq;
+                    reinterpret_cast<float4 *>(src_all + (size_t)tt * c.hwp)[q - tt * nq] =
+                        reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[q - tt * nq];
+                }
+            } else {
+                for (int q = tid; q < T * hw; q += nt) { const int tt = q / hw; src_all[(size_t)tt * c.hwp + (q - tt * hw)] = glimpse[((size_t)tt * B + b) * hw + (q - tt * hw)]; }
+            }
+        } else if (vec4_glimpse) {
             if (tid < nq) reinterpret_cast<float4 *>(c.src)[tid] = gq;
             for (int q = tid + nt; q < nq; q += nt) reinterpret_cast<float4 *>(c.src)[q] = reinterpret_cast<const float4 *>(gsrc)[q];
         } else {
             for (int q = tid; q < hw; q += nt) c.src[q] = gsrc[q];
         }
-        if (v4) {
+        if (RC) {                                              // c.g holds the OBSERVATION until the pixel pass replaces it
+            if (v4) {
+                if (tid < nQ) reinterpret_cast<float4 *>(c.g)[tid] = qb;
+                for (int q = tid + nt; q < nQ; q += nt) reinterpret_cast<float4 *>(c.g)[q] = reinterpret_cast<const float4 *>(obp)[q];
+            } else {
+                for (int p = tid; p < HW; p += nt) c.g[p] = obp[p];
+            }
+        } else if (v4) {
             if (tid < nQ) {
                 float4 gv = qa;
                 if (!dcp) { gv.x = coef * (mult * qa.x - qb.x); gv.y = coef * (mult * qa.y - qb.y);
@@ -655,10 +703,26 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
             const int Ir = idx / fw, I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
             const float2 ex = c.xe[J], ey = c.ye[I];
             const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);       // valid by construction of the footprint
-            const float dc = c.g[p];
             const float dx = ex.y, dy = ey.y;
             const Taps t = load_taps_sel(c.src, h, w, fy, fx);
             const float v = bilerp(t, dx, dy);
+            float dc = c.g[p];
+            if (RC) {
+                // the canvas at this pixel, accumulated as the forward does: ((0 + p0*v0) + p1*v1) + ... over ALL steps
+                float cv = 0.f;
+                for (int tt = 0; tt < T; ++tt) {
+                    float vt = v;
+                    if (tt != t_own) {
+                        const float2 ext = xe_all[tt * W + J], eyt = ye_all[tt * H + I];
+                        const int fxt = __float_as_int(ext.x), fyt = __float_as_int(eyt.x);
+                        vt = 0.f;
+                        if (fxt != ST_INVALID && fyt != ST_INVALID)
+                            vt = bilerp(load_taps_sel(src_all + (size_t)tt * c.hwp, h, w, fyt, fxt), ext.y, eyt.y);
+                    }
+                    cv = cv + c.pres[tt] * vt;
+                }
+                dc = coef * (mult * cv - dc);                  // (dc held the observation)
+            }
             const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
             const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
             const float go = pres * dc;
@@ -907,19 +971,25 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
                             const float *final_canvas, const float *obs, float *dglimpse, float *dwhere,
                             float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
                             float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
-    const size_t lds = carve_bwd_bytes(H, W, h, w);
+    const bool rc = !dcanvas && !final_canvas;                // recompute form: the canvas is re-formed on the unit's footprint
+    const size_t lds = carve_bwd_bytes(H, W, h, w, rc ? T : 1);
     NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
     if (nvil) nv = *nvil;
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
-    const int vec4c = ((H * W) % 4 == 0) && (dcanvas ? air_aligned16(dcanvas) : (air_aligned16(final_canvas) && air_aligned16(obs)));
-    { int st_ = st_allow_lds(st_write_bwd_kernel, lds); if (st_) return st_; }
+    const int vec4c = ((H * W) % 4 == 0) && (dcanvas ? air_aligned16(dcanvas) : ((rc || air_aligned16(final_canvas)) && air_aligned16(obs)));
+    { int st_ = rc ? st_allow_lds(st_write_bwd_kernel<true>, lds) : st_allow_lds(st_write_bwd_kernel<false>, lds); if (st_) return st_; }
     // 512 threads (about one per footprint pixel) while the launch does not fill the chip: 7.5 us at 192 units against 8.2 with
     // 1024; beyond that 256-thread workgroups, 8 per CU, hide each other's barriers (29 vs 74 us at 3072 units, 11 vs 21 at 768)
     const int wr_threads = (long)B * T <= 512 ? 512 : ST_THREADS;
-    hipLaunchKernelGGL(st_write_bwd_kernel, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
-                       air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
-                       dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
+    if (rc)
+        hipLaunchKernelGGL(st_write_bwd_kernel<true>, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
+                           air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
+                           dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
+    else
+        hipLaunchKernelGGL(st_write_bwd_kernel<false>, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
+                           air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
+                           dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -938,7 +1008,7 @@ extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, c
                                      const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
                                      int T, int B, int H, int W, int h, int w, float mult, float std,
                                      float loss_scale, void *stream) {
-    AIR_REQUIRE(glimpse && where && obs && final_canvas && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
     AIR_REQUIRE(T > 0, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
@@ -952,7 +1022,7 @@ extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *whe
                                           float loss_scale, const float *imp_parts, int n_parts, float *imp_sum,
                                           const float *baseline, const float *logp, float *nvil_out, float *dlogp,
                                           float *dbaseline, void *stream) {
-    AIR_REQUIRE(glimpse && where && obs && final_canvas && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
     AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
     AIR_REQUIRE(T > 0 && n_parts > 0, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);

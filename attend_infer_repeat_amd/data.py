@@ -166,6 +166,58 @@ def create_multi_mnist(templates, labels=None, canvas_size=(50, 50), obj_size=(2
     return dict(imgs=imgs, labels=lab, nums=nums)
 
 
+# ---- procedural digit templates (no network, no MNIST files in the container) ----------------------------------------------
+# Seven-segment skeletons of the ten digits, drawn as anti-aliased poly-lines with per-sample slant, aspect, stroke width, corner
+# rounding and endpoint jitter into the 20x20 box MNIST size-normalises its digits to, centred in a 28x28 field (so the tight
+# boxes create_multi_mnist crops -- data.py:81-92 -- have MNIST-like statistics: ~20 pixels tall, 5-18 wide, ~10-20 % ink).
+_SEGMENTS = {  # unit-square coordinates (x right, y down): a top, b upper right, c lower right, d bottom, e lower left, f upper left, g middle
+    "a": ((0, 0), (1, 0)), "b": ((1, 0), (1, .5)), "c": ((1, .5), (1, 1)), "d": ((0, 1), (1, 1)),
+    "e": ((0, .5), (0, 1)), "f": ((0, 0), (0, .5)), "g": ((0, .5), (1, .5))}
+_DIGIT_SEGMENTS = ["abcdef", "bc", "abged", "abgcd", "fgbc", "afgcd", "afgedc", "abc", "abcdefg", "abfgcd"]
+
+
+def procedural_digit_templates(n, seed=0, size=28):
+    """n digit-like glyphs: uint8 [n, size, size] (0 background, up to 255 ink) and their labels uint8 [n]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((n, size, size), np.uint8)
+    labels = rng.integers(0, 10, size=n).astype(np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    for i in range(n):
+        d = int(labels[i])
+        h = rng.uniform(14.0, 17.5)
+        w = h * (rng.uniform(0.18, 0.3) if d == 1 else rng.uniform(0.45, 0.8))
+        slant = rng.uniform(-0.25, 0.25)
+        thick = rng.uniform(1.1, 2.0)
+        cx, cy = size / 2 + rng.uniform(-1, 1), size / 2 + rng.uniform(-1, 1)
+        img = np.zeros((size, size), np.float32)
+        for sname in _DIGIT_SEGMENTS[d]:
+            (ax, ay), (bx, by) = _SEGMENTS[sname]
+            pts = []
+            for (ux, uy) in ((ax, ay), (bx, by)):
+                ux, uy = ux + rng.normal(0, 0.04), uy + rng.normal(0, 0.03)
+                y = cy + (uy - 0.5) * h
+                x = cx + (ux - 0.5) * w + slant * (0.5 - uy) * h
+                pts.append((x, y))
+            (x0, y0), (x1, y1) = pts
+            # a bowed stroke: three-point poly-line through a displaced midpoint
+            mx, my = (x0 + x1) / 2 + rng.normal(0, 0.6), (y0 + y1) / 2 + rng.normal(0, 0.6)
+            for (px0, py0), (px1, py1) in (((x0, y0), (mx, my)), ((mx, my), (x1, y1))):
+                dxs, dys = px1 - px0, py1 - py0
+                tt = np.clip(((xx - px0) * dxs + (yy - py0) * dys) / (dxs * dxs + dys * dys + 1e-9), 0, 1)
+                dist = np.sqrt((xx - px0 - tt * dxs) ** 2 + (yy - py0 - tt * dys) ** 2)
+                img = np.maximum(img, np.clip(thick + 0.5 - dist, 0, 1))
+        out[i] = np.clip(np.round(img * 255.0), 0, 255).astype(np.uint8)
+    return out, labels
+
+
+def procedural_multi_mnist(n_samples, canvas_size=(50, 50), n_objects=(0, 2), seed=0, n_templates=4000):
+    """A multi-MNIST-shaped dataset in the reference's format (dict(imgs uint8, labels, nums) of create_multi_mnist, i.e. of
+    data.py:35-107) from procedural digit templates: the reference's generator end to end, with only the MNIST download replaced."""
+    templates, labels = procedural_digit_templates(n_templates, seed=seed)
+    return create_multi_mnist(templates, labels, canvas_size=canvas_size, n_objects=n_objects, n_samples=n_samples,
+                              seed=seed + 1)
+
+
 def load_mnist_idx(directory, partition="train"):
     """MNIST digits from the standard idx-ubyte files (train-images-idx3-ubyte[.gz], ...), for create_multi_mnist.
     (The reference downloads them through tensorflow.examples.tutorials.mnist, data.py:38; there is no network here.)"""

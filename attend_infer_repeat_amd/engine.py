@@ -224,6 +224,8 @@ class AIREngine:
                 self._copy_in(self.params[k], w * (1.0 / math.sqrt(shape[0])))
             else:
                 self._fill_in(self.params[k], 0.0)
+        if getattr(self, "flat_params16", None) is not None:
+            self._sync_param_shadow()
 
     # ---- stream discipline ------------------------------------------------------------------------------------------
     # The engine runs on its own stream.  Everything that enters its buffers from outside (a batch gathered on the default
@@ -255,6 +257,7 @@ class AIREngine:
     def load_parameters(self, named: Dict[str, torch.Tensor]):
         for k, v in named.items():
             self._copy_in(self.params[k], torch.as_tensor(v).to(torch.float32))
+        self._sync_param_shadow()
 
     def reset_optimizer(self):
         self._fill_in(self.flat_ms, 1.0); self._fill_in(self.flat_mg, 0.0); self._fill_in(self.flat_mom, 0.0)
@@ -352,6 +355,11 @@ class AIREngine:
         deferred_dw = []
         self._defer_dw = defer_dw
         throughput = defer_dw
+        # bf16 DATA path (throughput regime of mfma_dtype="bf16"): the dense products read bf16 mirrors of their operands -- a
+        # shadow of the flat parameter buffer kept by the optimiser launch, mirrors of the activations / gradients that GEMM
+        # epilogues produce, the observation batch converted at the start of the step -- see _apply_bf16_mirrors
+        use16 = prec == 1 and throughput and os.environ.get("AIR_BF16_STORAGE", "1") == "1"
+        self._use16 = use16
 
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
@@ -372,7 +380,8 @@ class AIREngine:
                 launch(plan, [d for d in descs if wide_ok(d)])
                 launch(plan, [d for d in descs if not wide_ok(d)])
                 return
-            if len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256 and not (throughput and wide_ok(descs[0])):
+            if (len(descs) == 1 and allow_splitk and descs[0].K >= 1024 and tiles16 > 256 and not use16
+                    and not (throughput and wide_ok(descs[0]))):
                 d = descs[0]
                 plan.append((L.air_gemm_bf16 if prec else L.air_gemm, (d.ta, d.tb, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.bias,
                                           d.epilogue, d.aux, d.ldaux, d.beta, d.colsum, wsp, wsb), "air_gemm"))
@@ -780,12 +789,23 @@ class AIREngine:
 
         # ---- optimiser: both centred-RMSProp updates + device counters in one launch ---------------------------------
         tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
-        self._opt_calls_factory = lambda gscale: [
-            (L.air_step_epilogue, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
-                                   p(self.flat_mom), ctypes.c_size_t(self.n_model), ctypes.c_size_t(self.n_total),
-                                   p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale,
-                                   p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
-             "air_step_epilogue")]
+        pre_fwd = []
+        if use16:
+            pre_fwd = self._apply_bf16_mirrors([fwd, bwd])
+            shadow = p(self.flat_params16)
+            self._opt_calls_factory = lambda gscale: [
+                (L.air_step_epilogue_shadow, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
+                                              p(self.flat_mom), ctypes.c_size_t(self.n_model), ctypes.c_size_t(self.n_total),
+                                              p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale,
+                                              p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc), shadow),
+                 "air_step_epilogue_shadow")]
+        else:
+            self._opt_calls_factory = lambda gscale: [
+                (L.air_step_epilogue, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
+                                       p(self.flat_mom), ctypes.c_size_t(self.n_model), ctypes.c_size_t(self.n_total),
+                                       p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale,
+                                       p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
+                 "air_step_epilogue")]
         self._plan_rng = rng
         def fwd_plan(with_noise):
             """the forward list with its prologue: a launch of its own, or -- with the fused LSTM steps -- extra workgroups
@@ -802,9 +822,9 @@ class AIREngine:
                      "air_lstm_step_fwd_prologue")
             return fwd[:lstm0_index] + [lstm0] + fwd[lstm0_index + 1:]
 
-        self._plan_fwd_noise = fwd_plan(True) + fwd_tail              # forward(): complete outputs
-        self._plan_fwd = fwd_plan(False) + fwd_tail
-        self._plan_fwd_train = fwd_plan(True)                         # train step: NVIL rides in the first backward launch
+        self._plan_fwd_noise = pre_fwd + fwd_plan(True) + fwd_tail    # forward(): complete outputs
+        self._plan_fwd = pre_fwd + fwd_plan(False) + fwd_tail
+        self._plan_fwd_train = pre_fwd + fwd_plan(True)               # train step: NVIL rides in the first backward launch
         feeder = getattr(self, "_feeder", None)
         if feeder is not None:
             # the batch itself is drawn by the first launch of the train step (attach_dataset): no host work between updates
@@ -850,6 +870,66 @@ class AIREngine:
                      "air_step_epilogue")]
         # ... or, better, the two-lane form of the whole step (None where it does not apply)
         self._plan_two_lane = self._build_two_lane_step()
+
+    def _apply_bf16_mirrors(self, plans):
+        """bf16 data path: give every GEMM descriptor of `plans` the bf16 mirrors of its operands and of its output.
+
+        Mirrored buffers (same shape, bf16): the flat parameter buffer (`flat_params16`: refreshed by every writer of the
+        parameters -- the optimiser launch, load_parameters / init / load_state_dict), the observation batch (`obs16`: a convert
+        launch at the start of every forward), and the activations / gradients whose ONLY writers are GEMM epilogues -- each
+        MLP's layer outputs and the hidden-layer gradients of the chains that GEMMs produce end to end (the library writes the
+        mirror of C on every bf16 code path when the descriptor names one).  Whatever a non-GEMM kernel writes (LSTM state,
+        sampled latents, glimpses, the gradients the loss kernels hand to the chains) has no mirror: those operands are
+        fetched as fp32 and rounded in registers, as before.  The values a product sees are identical either way (the mirror
+        holds bf16(x), the register path computes bf16(x)); only the bytes moved change.
+        Returns the launches that must precede a forward (the conversion of obs)."""
+        L, p = H.lib(), H._p
+        dev = self.device
+        if getattr(self, "flat_params16", None) is None:
+            self.flat_params16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
+            self.obs16 = torch.zeros(self.obs.shape, dtype=torch.bfloat16, device=dev)
+            self._mirror_of = {}
+        trusted = [(self.flat_params, self.flat_params16), (self.obs, self.obs16)]
+        mlps = [self.enc, self.tr, self.st, self.ge, self.gd, self.bl]
+        gemm_made = []
+        for m in mlps:
+            gemm_made += list(m.out)
+        for m in (self.enc, self.ge, self.gd, self.bl):      # (transform / steps: attend_bwd writes part of their gradient chain)
+            gemm_made += list(m.g[:-1])
+        gemm_made += [self.ge.g[-1], self.enc.g[-1]]
+        for t in gemm_made:
+            if t.data_ptr() not in self._mirror_of:
+                self._mirror_of[t.data_ptr()] = torch.zeros(t.shape, dtype=torch.bfloat16, device=dev)
+            trusted.append((t, self._mirror_of[t.data_ptr()]))
+        spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel(), m16.data_ptr()) for t, m16 in trusted]
+
+        def mirror(ptr):
+            if not ptr:
+                return None
+            for lo, hi, base16 in spans:
+                if lo <= ptr < hi:
+                    return base16 + (ptr - lo) // 2
+            return None
+
+        out_spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel()) for t in gemm_made]
+        for plan in plans:
+            for e in plan:
+                if e is None or e[2] != "air_gemm_grouped":
+                    continue
+                for d in e[1][0]:
+                    d.A16, d.B16 = mirror(d.A), mirror(d.B)
+                    c = int(d.C) if d.C else 0
+                    d.C16 = mirror(c) if any(lo <= c < hi for lo, hi in out_spans) else None
+        self._sync_param_shadow()
+        return [(L.air_f32_to_bf16, (p(self.obs), ctypes.c_void_p(self.obs16.data_ptr()), ctypes.c_size_t(self.obs.numel())),
+                 "air_f32_to_bf16")]
+
+    def _sync_param_shadow(self):
+        """bf16 shadow of the parameters after anything but the optimiser launch wrote them"""
+        if getattr(self, "flat_params16", None) is not None:
+            st = H.lib().air_f32_to_bf16(H._p(self.flat_params), ctypes.c_void_p(self.flat_params16.data_ptr()),
+                                         ctypes.c_size_t(self.n_total), self._sp())
+            _lib.check(st, "air_f32_to_bf16")
 
     def _run(self, plan, stream_ptr):
         """Issue a plan.  Entries: (fn, args, name) on the main stream; (fn, args, name, lane) with lane 1 = the engine's side
@@ -937,6 +1017,7 @@ class AIREngine:
 
         nvil_args = self._nvil_args
         ev_nvil = None
+        recompute = os.environ.get("AIR_CANVAS_RECOMPUTE", "1") == "1"
         plan = list(self._plan_fwd_train) + list(self._plan_bwd)
         # the LSTM weight gradients sit in the LAST launch of the linear plan; here they are issued where their inputs are
         # complete: next to the launch that closes the BPTT chain (d h_init / d enc_out)
@@ -963,12 +1044,20 @@ class AIREngine:
                 if main_e is not None:
                     out.append(main_e); n_main[0] += 1
                 continue
+            if name == "air_canvas_unroll_fwd_banded" and recompute:
+                # the canvas forward (per-step canvases, final canvas, reconstruction shares for NVIL) is not on the dX chain
+                # any more: the backward re-forms the canvas on each glimpse's footprint itself
+                flush_side([e + (1,)])
+                continue
             if name == "air_canvas_unroll_bwd_nvil":
                 # NVIL leaves the canvas backward: it runs on the side lane behind the baseline's forward
                 flush_side([(L.air_nvil_parts, nvil_args + (self.B,), "air_nvil_parts", 1)])
                 ev_nvil = self._new_event()
                 out.append(("record", ev_nvil, 1))
-                out.append((L.air_canvas_unroll_bwd, args[:len(args) - len(nvil_args)], "air_canvas_unroll_bwd"))
+                cu = list(args[:len(args) - len(nvil_args)])
+                if recompute:
+                    cu[4] = None                                 # final_canvas = NULL: the recompute form
+                out.append((L.air_canvas_unroll_bwd, tuple(cu), "air_canvas_unroll_bwd"))
                 n_main[0] += 1
                 continue
             if name in ("air_attend_bwd_dx", "air_st_read_bwd"):
@@ -1138,6 +1227,8 @@ class AIREngine:
         self.release_graphs()
         self.stream.synchronize()
         self._steps_per_replay = 1
+        self._capture_kwargs = dict(split_optimizer=split_optimizer, comm=comm, overlap=overlap,
+                                    steps_per_replay=steps_per_replay, comm_side=comm_side)
         L = H.lib()
         if comm is not None:
             opt = self._opt_calls_factory(1.0 / self.world_size)
@@ -1204,6 +1295,32 @@ class AIREngine:
         if split_optimizer:
             self._graph_opt = self._capture_plans([self._opt_calls_factory(1.0 / self.world_size)])
 
+    # ---- the reference's non-trainable variables (model.py:58,71,307-308, mnist_model.py:24-26) ----------------------------
+    KNOBS = ("use_prior", "explore_eps", "step_bias", "transform_var_bias", "output_multiplier")
+
+    def update_config(self, **changes):
+        """Change run-time switches the reference holds in non-trainable tf.Variables -- use_prior (toggle_prior), explore_eps,
+        step_bias, transform_var_bias, output_multiplier -- on a built engine.  They are launch arguments of the step's kernels,
+        so the plans are rebuilt and a captured graph is re-captured with the arguments it was captured with (milliseconds;
+        these switches change a handful of times per run, the step itself stays free of extra loads).  Returns True if
+        anything changed."""
+        import dataclasses
+        bad = set(changes) - set(self.KNOBS)
+        if bad:
+            raise ValueError("not run-time switches of the engine: %s" % sorted(bad))
+        norm = lambda k, v: (bool(v) if k == "use_prior" else (None if v is None else float(v)))
+        new = {k: norm(k, v) for k, v in changes.items() if norm(k, v) != norm(k, getattr(self.cfg, k))}
+        if not new:
+            return False
+        self.synchronize()
+        recapture = getattr(self, "_capture_kwargs", None) if self._graph is not None else None
+        self.release_graphs()
+        self.cfg = dataclasses.replace(self.cfg, **new)
+        self._build_plans()
+        if recapture is not None:
+            self.capture(**recapture)
+        return True
+
     def release_graphs(self):
         L = H.lib()
         for g in (self._graph_opt, self._graph):
@@ -1268,6 +1385,7 @@ class AIREngine:
             self._copy_in(dst, sd[key])
         self.set_learning_rate(float(sd["learning_rate"]))
         self.set_global_step(int(sd["global_step"]))
+        self._sync_param_shadow()
         self.synchronize()
 
     # ---- read-outs (plumbing; not part of the timed step) ---------------------------------------------------------

@@ -6,54 +6,95 @@ import json
 import time
 
 
-def rect_stn(ax, width, height, stn_params, c=None, line_width=3):
-    """Draw the attention box of [sx, tx, sy, ty] (evaluation.py:23-28: the in-tree statement of the ST convention)."""
-    from matplotlib.patches import Rectangle
+def attention_box(stn_params, width, height):
+    """Pixel rectangle (left, top, box_width, box_height) that the glimpse of [sx, tx, sy, ty] covers on a width x height
+    canvas.  This is the only in-tree statement of the reference's spatial-transformer convention (evaluation.py:23-28): the
+    glimpse spans sx (sy) of the canvas extent and its centre sits tx (ty) half-extents away from the canvas centre."""
     sx, tx, sy, ty = (float(v) for v in stn_params)
-    x = width * (1. - sx + tx) / 2
-    y = height * (1. - sy + ty) / 2
-    r = Rectangle((x - .5, y - .5), width * sx, height * sy, linewidth=line_width, edgecolor=c, facecolor='none')
-    ax.add_patch(r)
-    return r
+    return width * (1. - sx + tx) / 2, height * (1. - sy + ty) / 2, width * sx, height * sy
+
+
+def rect_stn(ax, width, height, stn_params, c=None, line_width=3):
+    """Draw the attention box of one glimpse on `ax` (pixel centres at integer coordinates, hence the half-pixel shift)."""
+    from matplotlib.patches import Rectangle
+    left, top, bw, bh = attention_box(stn_params, width, height)
+    patch = Rectangle((left - .5, top - .5), bw, bh, linewidth=line_width, edgecolor=c, facecolor='none')
+    ax.add_patch(patch)
+    return patch
+
+
+def _figure_tensors(air):
+    """what the progress figure shows, as host arrays"""
+    host = lambda t: t.detach().cpu().numpy()
+    step_probs = None
+    if hasattr(air, "num_steps_distrib"):
+        step_probs = host(air.num_steps_distrib.prob()[..., 1:])          # [B, T]: p(n = t + 1)
+    return dict(obs=host(air.obs), canvas=host(air.canvas), glimpse=host(air.glimpse), presence=host(air.presence)[..., 0],
+                where=host(air.where), step_probs=step_probs)
 
 
 def make_fig(air, checkpoint_dir=None, global_step=None, n_samples=10):
-    """Progress figure (evaluation.py:31-65): inputs, per-step canvases with attention boxes, per-step glimpses."""
+    """Progress figure with the content of the reference's (evaluation.py:31-65): one column per sample; the first row shows the
+    input, the next max_steps rows the canvas after each step with the attention box of every step that is present, the last
+    max_steps rows the glimpse each step reconstructed, titled with the sampled presence and the posterior probability of that
+    step count.  Saved as progress_fig_<global_step>.png when a directory is given."""
     import os.path as osp
     import matplotlib
     matplotlib.use('Agg')
     import matplotlib.pyplot as plt
-    import numpy as np
-    n_steps = air.max_steps
-    xx = air.obs.detach().cpu().numpy()
-    pred_canvas = air.canvas.detach().cpu().numpy()
-    pred_crop = air.glimpse.detach().cpu().numpy()
-    prob = air.num_steps_distrib.prob()[..., 1:].detach().cpu().numpy() if hasattr(air, "num_steps_distrib") else None
-    pres = air.presence.detach().cpu().numpy()
-    w = air.where.detach().cpu().numpy()
-    height, width = xx.shape[1:]
-    bs = min(n_samples, air.batch_size)
-    scale = 1.5
-    fig, axes = plt.subplots(2 * n_steps + 1, bs, figsize=scale * np.asarray((bs, 2 * n_steps + 1)))
-    for i, ax in enumerate(axes[0]):
-        ax.imshow(xx[i], cmap='gray', vmin=0, vmax=1)
-    for i, ax_row in enumerate(axes[1:1 + n_steps]):
-        for j, ax in enumerate(ax_row):
-            ax.imshow(pred_canvas[i, j], cmap='gray', vmin=0, vmax=1)
-            if pres[i, j, 0] > .5:
-                rect_stn(ax, width, height, w[i, j], 'r')
-    for i, ax_row in enumerate(axes[1 + n_steps:]):
-        for j, ax in enumerate(ax_row):
-            ax.imshow(pred_crop[i, j], cmap='gray')
-            if prob is not None:
-                ax.set_title('{:d} with p({:d}) = {:.02f}'.format(int(pres[i, j, 0]), i + 1, float(prob[j, i])),
-                             fontsize=4 * scale)
-    for ax in axes.flatten():
-        ax.xaxis.set_visible(False); ax.yaxis.set_visible(False)
+    d = _figure_tensors(air)
+    T = air.max_steps
+    cols = min(n_samples, air.batch_size)
+    img_h, img_w = d["obs"].shape[1:]
+    inch = 1.5
+    fig, axes = plt.subplots(2 * T + 1, cols, figsize=(inch * cols, inch * (2 * T + 1)), squeeze=False)
+    for col in range(cols):
+        axes[0][col].imshow(d["obs"][col], cmap='gray', vmin=0, vmax=1)
+        for t in range(T):
+            canvas_ax, glimpse_ax = axes[1 + t][col], axes[1 + T + t][col]
+            canvas_ax.imshow(d["canvas"][t, col], cmap='gray', vmin=0, vmax=1)
+            if d["presence"][t, col] > .5:
+                rect_stn(canvas_ax, img_w, img_h, d["where"][t, col], 'r')
+            glimpse_ax.imshow(d["glimpse"][t, col], cmap='gray')
+            if d["step_probs"] is not None:
+                glimpse_ax.set_title('{:d} with p({:d}) = {:.02f}'.format(int(d["presence"][t, col]), t + 1,
+                                                                         float(d["step_probs"][col, t])), fontsize=4 * inch)
+    for ax in axes.ravel():
+        ax.set_axis_off()
     if checkpoint_dir is not None:
         fig.savefig(osp.join(checkpoint_dir, 'progress_fig_{}.png'.format(global_step)), dpi=300)
-        plt.close('all')
+        plt.close(fig)
     return fig
+
+
+def gradient_summaries(named_grads, named_vars, norm=True, ratio=True):
+    """The scalar part of evaluation.py:221-248: the global norm of the gradient and, per variable, mean(|g| / (|v| + 1e-8))
+    (log_ratio, evaluation.py:169-180).  `named_grads` / `named_vars`: name -> tensor (AIREngine.named_grads() / .params; on the
+    engine the gradients are those of the last update and the variables the ones it produced).  Histograms are TensorBoard
+    artefacts and are not produced.  Returns {'grad_norm': ..., 'grad_ratio/<name>': ...} of Python floats."""
+    import torch
+    out = {}
+    if norm:
+        out['grad_norm'] = float(torch.sqrt(sum((g.double() ** 2).sum() for g in named_grads.values())))
+    if ratio:
+        for k, g in named_grads.items():
+            out['grad_ratio/' + k] = float((g.abs() / (named_vars[k].abs() + 1e-8)).mean())
+    return out
+
+
+def step_summaries(air):
+    """The scalars the reference registers with tf.summary.scalar and writes every 1000 iterations (multi_mnist.py:138-140;
+    model.py:152,185,213,244-257,323-371), read from the engine after a train step: the objective's terms on the batch just
+    trained on + the gradient summaries of that update."""
+    eng = air._engine
+    o = eng.outputs()
+    pick = ["rec_loss", "kl_num_steps", "kl_what", "kl_where", "prior_loss", "loss", "opt_loss"]
+    if eng.cfg.use_reinforce:
+        pick += ["imp_weight_mean", "imp_weight_var", "reinforce_loss", "baseline_loss"]
+    out = {('rec' if k == 'rec_loss' else 'prior' if k == 'prior_loss' else k): _scalar(o[k]) for k in pick}
+    out['num_step'] = _scalar(o["num_step_per_sample"].mean())
+    out.update(gradient_summaries(eng.named_grads(), eng.params))
+    return out
 
 
 def _scalar(v):

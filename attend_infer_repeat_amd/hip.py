@@ -123,8 +123,11 @@ def canvas_unroll_fwd(glimpse, where, presence, img_size, obs=None, mult=1.0, st
 
 
 def canvas_unroll_bwd(glimpse, where, presence, obs, final_canvas, mult, std, loss_scale):
+    """final_canvas=None: the recompute form (every (t, b) unit re-forms the canvas on its own footprint from the T glimpses of
+    its image, bit-identically to the forward) -- the backward then does not depend on the forward launch."""
     glimpse = _f32(glimpse, "glimpse", 4); where = _f32(where, "where", 3); presence = _f32(presence, "presence")
-    obs = _f32(obs, "obs", 3); final_canvas = _f32(final_canvas, "final_canvas", 3)
+    obs = _f32(obs, "obs", 3)
+    final_canvas = _f32(final_canvas, "final_canvas", 3) if final_canvas is not None else None
     T, B, h, w = glimpse.shape
     H, W = obs.shape[1:]
     dg = torch.empty_like(glimpse)
@@ -167,7 +170,8 @@ def gemm(A, B, ta=False, tb=False, bias=None, epilogue=EPI_NONE, aux=None, beta=
 def gemm_grouped(problems, precision=0):
     """Several independent GEMMs in one launch (air_gemm_grouped).  problems: dicts with A, B and optional ta, tb, bias,
     epilogue, aux, beta, out, colsum (bool); a single problem may carry the K-split consumer prologue A2, a_bias, a_elu, a_out
-    (a = act(A + A2 + a_bias), see AirGemmDesc).  Returns [(C, colsum|None)]."""
+    (a = act(A + A2 + a_bias), see AirGemmDesc).  bf16 data path (precision=1): A16 / B16 = bf16 mirrors of A / B (same shape
+    and strides in elements), C16 = bf16 tensor that receives bf16(C).  Returns [(C, colsum|None)]."""
     descs, outs, keep = [], [], []
     for pr in problems:
         A, B = pr["A"], pr["B"]
@@ -188,7 +192,13 @@ def gemm_grouped(problems, precision=0):
                              pr["A2"].data_ptr() if pr.get("A2") is not None else None,
                              pr["a_bias"].data_ptr() if pr.get("a_bias") is not None else None, int(bool(pr.get("a_elu", False))),
                              pr["a_out"].data_ptr() if pr.get("a_out") is not None else None)
-        descs.append(d); outs.append((out, cs)); keep.append((A, B, aux, bias))
+        for fld in ("A16", "B16", "C16"):
+            t = pr.get(fld)
+            if t is not None:
+                if t.dtype != torch.bfloat16 or not t.is_cuda:
+                    raise _lib.AirHipError(f"gemm_grouped: {fld} must be a bfloat16 CUDA tensor")
+                setattr(d, fld, t.data_ptr())
+        descs.append(d); outs.append((out, cs)); keep.append((A, B, aux, bias, pr.get("A16"), pr.get("B16"), pr.get("C16")))
     arr = (_lib.AirGemmDesc * len(descs))(*descs)
     _lib.check(lib().air_gemm_grouped(arr, len(descs), _stream()), "air_gemm_grouped")
     return outs

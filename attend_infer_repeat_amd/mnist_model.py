@@ -153,6 +153,7 @@ class AIRonMNIST(AIRModel):
             lr = float(self.learning_rate)
             if lr != state["lr"]:
                 eng.set_learning_rate(lr); state["lr"] = lr
+            self._sync_engine_switches()
             eng.train_step(obs)
             self.global_step += 1
             if refresh:
@@ -161,6 +162,17 @@ class AIRonMNIST(AIRModel):
 
         self._train_step = train_step_fn
         return self._train_step, self.global_step
+
+    def _sync_engine_switches(self):
+        """The reference's non-trainable variables (use_prior / toggle_prior, explore_eps, step_bias, transform_var_bias,
+        output_multiplier: model.py:58,71,307-308, mnist_model.py:24-26) are plain attributes here; whatever they hold NOW is
+        what the next engine launch uses (AIREngine.update_config re-captures when one of them changed)."""
+        eng = self._engine
+        if eng is not None:
+            eng.update_config(use_prior=bool(self.use_prior),
+                              explore_eps=None if self.explore_eps is None else float(self.explore_eps),
+                              step_bias=float(self.step_bias), transform_var_bias=float(self.transform_var_bias),
+                              output_multiplier=float(self.output_multiplier))
 
     def forward(self, obs=None, nums=None, noise=None):
         """Generic cell-by-cell unroll (model.py:66-104).  Once the engine owns the parameters the module tree aliases its
@@ -182,6 +194,7 @@ class AIRonMNIST(AIRModel):
             self.obs = obs
         if nums is not None:
             self.nums = nums
+        self._sync_engine_switches()
         self._engine.forward(self.obs, sample_noise=True)
         self._refresh_from_engine()
         return self

@@ -33,6 +33,20 @@ class _OutputDistrib(object):
 class AIRModel(object):
     """Generic AIR model"""
 
+    @property
+    def explore_eps(self):
+        """model.py:70-71: a non-trainable variable SHARED with the cell (cell.py:47,140-141) -- assigning it here changes
+        what the next unroll clips the step probability with, on the generic path and (through
+        AIRonMNIST._sync_engine_switches) on the engine."""
+        return self._explore_eps
+
+    @explore_eps.setter
+    def explore_eps(self, value):
+        self._explore_eps = value
+        cell = getattr(self, "cell", None)
+        if cell is not None:
+            cell._explore_eps = value
+
     def __init__(self, obs, nums, max_steps, glimpse_size,
                  n_appearance, transition, input_encoder, glimpse_encoder, glimpse_decoder, transform_estimator,
                  steps_predictor,

@@ -19,8 +19,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-from attend_infer_repeat_amd.data import DeviceFeeder, load_data, synthetic_dataset  # noqa: E402
-from attend_infer_repeat_amd.evaluation import make_fig, make_logger  # noqa: E402
+from attend_infer_repeat_amd.data import DeviceFeeder, load_data, procedural_multi_mnist, synthetic_dataset  # noqa: E402
+from attend_infer_repeat_amd.evaluation import make_fig, make_logger, step_summaries  # noqa: E402
 from attend_infer_repeat_amd.mnist_model import AIRonMNIST  # noqa: E402
 from attend_infer_repeat_amd.utils import AttrDict  # noqa: E402
 
@@ -36,6 +36,11 @@ def main(argv=None):
     ap.add_argument("--synthetic-samples", type=int, default=60000)
     ap.add_argument("--eval-batches", type=int, default=10)
     ap.add_argument("--figures", action="store_true")
+    ap.add_argument("--summary-every", type=int, default=1000)        # multi_mnist.py:138-140
+    ap.add_argument("--glyphs", action="store_true",
+                    help="no multi-MNIST pickles: synthesise the dataset with the reference's generator (data.create_multi_mnist) "
+                         "from procedural digit templates instead of stroke blobs")
+    ap.add_argument("--learning-rate", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device-feeder", action="store_true",
                     help="draw every training batch inside the captured step from the HBM-resident training set (engine "
@@ -45,7 +50,7 @@ def main(argv=None):
                          "the step counter, the learning rate, the Philox noise state and the feeders' positions")
     args = ap.parse_args(argv)
 
-    learning_rate, n_steps, batch_size = 1e-4, 3, 64                  # multi_mnist.py:24-25,37
+    learning_rate, n_steps, batch_size = args.learning_rate, 3, 64    # multi_mnist.py:24-25,37
     num_steps_prior = AttrDict(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3)
     appearance_prior = AttrDict(loc=0., scale=1.)
     where_scale_prior = AttrDict(loc=0., scale=1.)
@@ -59,6 +64,11 @@ def main(argv=None):
     tr, va = osp.join(args.data_dir, "mnist_train.pickle"), osp.join(args.data_dir, "mnist_validation.pickle")
     if osp.exists(tr) and osp.exists(va):
         train_data, valid_data = load_data(tr), load_data(va)
+    elif args.glyphs:
+        print("no multi-MNIST pickles under {!r}: procedural digit templates through the reference's generator".format(args.data_dir))
+        as_float = lambda d: dict(imgs=d["imgs"].astype("float32") / 255.0, nums=d["nums"].astype("float32"))
+        train_data = as_float(procedural_multi_mnist(args.synthetic_samples, seed=args.seed))
+        valid_data = as_float(procedural_multi_mnist(max(args.synthetic_samples // 6, batch_size), seed=args.seed + 1000))
     else:
         print("no multi-MNIST pickles under {!r}: using a synthetic dataset".format(args.data_dir))
         train_data = synthetic_dataset(args.synthetic_samples, seed=args.seed)
@@ -100,6 +110,9 @@ def main(argv=None):
         else:
             xb, yb = train_feed()
             train_itr = int(train_step(xb, yb, refresh=False))
+        if args.summary_every and train_itr % args.summary_every == 0:
+            # the reference's `all_summaries` (model.py's tf.summary scalars + evaluation.gradient_summaries), every 1000 iterations
+            writer.write(json.dumps(dict(step=train_itr, data="summary", **step_summaries(air))) + "\n")
         if train_itr % args.log_every == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0

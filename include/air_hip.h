@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 4
+#define AIR_ABI_VERSION 5
 
 enum {
     AIR_OK = 0,
@@ -146,6 +146,14 @@ typedef struct AirGemmDesc {
     const float *a_bias;
     int a_elu;
     float *a_out;
+    /* bf16 DATA path (precision == AIR_PREC_BF16; all optional, NULL = off).  A16 / B16: bf16 mirrors of A / B -- the same
+     * values rounded to bf16 (RNE), same shape and leading dimension in ELEMENTS -- which the throughput-regime kernels read
+     * instead of the fp32 buffers (half the operand bytes, v_mfma_f32_16x16x32_bf16) when every problem of the launch names
+     * one for that operand; C16: the epilogue also stores bf16(C) there, the mirror a later product reads.  The fp32 buffers
+     * stay authoritative: whatever is not a dense product (ELU', the losses, the optimiser) keeps reading them.              */
+    const void *A16;
+    const void *B16;
+    void *C16;
 } AirGemmDesc;
 /* count <= 8; up to 24 for the deferred weight gradients of a whole step in one launch: problems the wide-tile kernel takes
  * (ta = 1, tb = 0, M, N, K and ldb multiples of 4, B 16-byte aligned) on 64x64 tiles -- at least one --, any other problem
@@ -398,6 +406,14 @@ int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_u
 int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                       const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
                       int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
+/* air_step_epilogue + the bf16 shadow of the parameters (bf16 data path): p_bf16[i] = bf16(p[i]) for every updated element, so
+ * the next step's dense products read half the weight bytes; NULL = no shadow.  air_f32_to_bf16: the same rounding as a launch of
+ * its own, for buffers no kernel of this library produces (the observation batch, parameters after a load).               */
+int air_step_epilogue_shadow(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+                             const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
+                             int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *p_bf16,
+                             void *stream);
+int air_f32_to_bf16(const float *x, void *out_bf16, size_t n, void *stream);
 
 /* HBM-resident batch feeder (replaces tensors_from_data's per-step tf.py_func round trip, data.py:121-158): out[b, :] =
  * dataset[idx_b, :] with idx_b drawn with replacement (shuffle != 0: Philox(seed_dev[0], stream 1, counter step*B + b), like

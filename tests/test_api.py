@@ -192,6 +192,66 @@ def test_aironmnist_engine_backed_training(amd):
     assert rel(air.where, eo["where"]) < 1e-4 and rel(air.final_canvas, eo["final_canvas"]) < 1e-4
 
 
+def test_runtime_switches_reach_the_captured_engine(amd):
+    """model.py:58,71,307-308 / mnist_model.py:24-26: use_prior (toggle_prior), explore_eps, step_bias, transform_var_bias and
+    output_multiplier are non-trainable VARIABLES of the reference, assignable between steps.  On the engine path they are
+    launch arguments of a captured graph; after toggling / assigning them mid-run the next fused step must be the step the
+    oracle takes with the new values (same weights, the engine's own noise), not the step of the stale graph."""
+    import dataclasses
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    AD = amd.utils.AttrDict
+    B = 8
+    imgs, nums = synthetic_multi_mnist(B, (50, 50), 2, seed=0)
+    x, y = torch.from_numpy(imgs).cuda(), torch.from_numpy(nums).cuda()
+    n_hiddens = [256, 256]
+    air = amd.mnist_model.AIRonMNIST(x, y, max_steps=3, explore_eps=1e-3, inpt_encoder_hidden=n_hiddens,
+                                     glimpse_encoder_hidden=n_hiddens, glimpse_decoder_hidden=n_hiddens,
+                                     transform_estimator_hidden=n_hiddens, steps_pred_hidden=[128, 64],
+                                     baseline_hidden=[256, 128], transform_var_bias=.5, step_bias=.75,
+                                     output_multiplier=.5)
+    nsp = AD(anneal='exp', init=1. - 1e-15, final=1e-7, steps_div=1e4, steps=1e5, hold_init=1e3)
+    train_step, _ = air.train_step(1e-4, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.), AD(loc=0., scale=1.), nsp)
+    eng = air._engine
+    assert eng is not None and eng._graph is not None
+    train_step()
+    graph_before = eng._graph.value
+
+    def oracle_step_matches(ocfg):
+        """the update the engine just made == O.train_step from the parameters before it, with the noise the graph drew"""
+        p_before = {k: v.detach().cpu().double().clone() for k, v in eng.params.items()}
+        slots = {k: dict(ms=eng.flat_ms[eng.param_offsets[k]:eng.param_offsets[k] + eng.param_sizes[k]].view(eng.param_shapes[k]).cpu().double().clone(),
+                         mg=eng.flat_mg[eng.param_offsets[k]:eng.param_offsets[k] + eng.param_sizes[k]].view(eng.param_shapes[k]).cpu().double().clone(),
+                         mom=eng.flat_mom[eng.param_offsets[k]:eng.param_offsets[k] + eng.param_sizes[k]].view(eng.param_shapes[k]).cpu().double().clone())
+                 for k in eng.params}
+        gs = int(eng.step_dev.item())
+        train_step()
+        eng.synchronize()
+        noise = dict(eps_where=eng.eps_where.cpu().double(), eps_what=eng.eps_what.cpu().double(),
+                     u_pres=eng.u_pres.cpu().double().reshape(3, B, 1))
+        ref = {k: v.clone() for k, v in p_before.items()}
+        O.train_step(ref, slots, ocfg, x.cpu().double(), noise, global_step=gs)
+        worst = max(rel(eng.params[k].cpu().double() - p_before[k], ref[k] - p_before[k]) for k in ref)
+        return worst
+
+    base = O.AIRConfig()
+    assert oracle_step_matches(base) < 5e-4                      # the unmodified step agrees (sanity of the harness)
+    # toggle the prior off (model.py:308) and move every other switch
+    assert air.toggle_prior() is False
+    air.explore_eps = 0.05
+    air.step_bias.fill_(0.25)
+    air.transform_var_bias.fill_(-0.5)
+    air.output_multiplier.fill_(0.75)
+    changed = dataclasses.replace(base, use_prior=False, explore_eps=0.05, step_bias=0.25, transform_var_bias=-0.5,
+                                  output_multiplier=0.75)
+    assert oracle_step_matches(changed) < 5e-4
+    assert eng.cfg.use_prior is False and eng._graph is not None and eng._graph.value != graph_before     # re-captured
+    assert oracle_step_matches(base) > 5e-3                      # ... and the stale configuration would NOT have matched
+    # the generic cell-by-cell path sees the same switches (shared variables)
+    assert air.cell._explore_eps == 0.05
+    air.toggle_prior()
+    assert oracle_step_matches(dataclasses.replace(changed, use_prior=True)) < 5e-4
+
+
 def test_aironmnist_bf16_mfma_option(amd):
     """BASELINE configs[4] through the reference's surface: train_step(..., mfma_dtype="bf16") runs the engine with
     bf16-rounded operands; a few updates stay finite and close to the fp32 run from the same weights and noise stream."""

@@ -111,3 +111,38 @@ def test_create_dataset_script_writes_loadable_pickles(tmp_path):
     assert d["imgs"].dtype == np.float32 and d["imgs"].shape == (64, 50, 50) and 0.0 <= d["imgs"].min() and d["imgs"].max() <= 1.0
     assert d["nums"].shape == (3, 64, 1) and d["nums"].dtype == np.float32
     assert (tmp_path / "mnist_validation.pickle").exists()
+
+
+def test_procedural_digit_templates_have_mnist_like_boxes():
+    """The stand-in for the MNIST download (data.py:38): ten glyph classes whose tight boxes -- what create_multi_mnist crops and
+    pastes (data.py:81-92) -- look like MNIST's: about 20 pixels tall inside the 28 x 28 field, ones narrow, 8-25 % ink."""
+    from attend_infer_repeat_amd import data as D
+    t, labels = D.procedural_digit_templates(300, seed=4)
+    assert t.shape == (300, 28, 28) and t.dtype == np.uint8 and set(np.unique(labels)) == set(range(10))
+    boxes = [D._tight_box(x)[1] for x in t]
+    hs, ws = np.array([b[0] for b in boxes]), np.array([b[1] for b in boxes])
+    assert 15 <= hs.mean() <= 22 and hs.max() <= 26 and ws.max() <= 26
+    assert ws[labels == 1].mean() < 0.6 * ws[labels == 8].mean()
+    ink = (t > 0).mean()
+    assert 0.08 < ink < 0.25
+    assert np.array_equal(t, D.procedural_digit_templates(300, seed=4)[0])          # deterministic in the seed
+    d = D.procedural_multi_mnist(64, seed=1, n_templates=100)
+    assert d["imgs"].shape == (64, 50, 50) and d["nums"].shape == (3, 64, 1)
+    counts = d["nums"].sum(0).reshape(-1)
+    assert set(np.unique(counts)) <= {0, 1, 2} and (d["imgs"][counts == 0] == 0).all()
+
+
+def test_gradient_summaries_and_attention_box():
+    """evaluation.py:169-180,221-248 (global gradient norm, mean |g| / (|v| + 1e-8) per variable) and the box convention of
+    evaluation.py:23-28 on hand-computable inputs."""
+    import torch
+    from attend_infer_repeat_amd.evaluation import attention_box, gradient_summaries
+    g = {"a/w": torch.tensor([[3.0, 0.0], [0.0, 4.0]]), "b": torch.tensor([12.0])}
+    v = {"a/w": torch.tensor([[1.0, 2.0], [4.0, 8.0]]), "b": torch.tensor([-3.0])}
+    out = gradient_summaries(g, v)
+    assert abs(out["grad_norm"] - 13.0) < 1e-9                                      # sqrt(9 + 16 + 144)
+    assert abs(out["grad_ratio/a/w"] - (3.0 / 1.0 + 0 + 0 + 4.0 / 8.0) / 4) < 1e-6 and abs(out["grad_ratio/b"] - 4.0) < 1e-6
+    # identity transform covers the canvas; half-size glimpse shifted right by half an extent sits in the right half
+    assert attention_box([1.0, 0.0, 1.0, 0.0], 50, 40) == (0.0, 0.0, 50.0, 40.0)
+    left, top, w, h = attention_box([0.5, 0.5, 0.5, 0.0], 50, 40)
+    assert (left, top, w, h) == (25.0, 10.0, 25.0, 20.0)

@@ -164,6 +164,27 @@ def test_canvas_unroll_fwd_bwd(hip):
     assert_close(dg, gg, 2e-4, 1e-4 * gg.abs().max().item(), "dglimpse")
     scale = gw.abs().amax(-1, keepdim=True).numpy() + 1.0
     assert_close(dwhere.cpu().numpy() / scale, gw.numpy() / scale, 5e-4, 5e-5, "dwhere")
+    # the recompute form (no final canvas: each unit re-forms the canvas on its footprint) is BITWISE the same backward
+    dg2, dwhere2 = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), None, mult, std, 1.0 / B)
+    assert torch.equal(dg, dg2) and torch.equal(dwhere, dwhere2)
+
+
+@pytest.mark.parametrize("T,B,H,W,h,w", [(5, 3, 100, 100, 28, 28), (1, 4, 17, 13, 5, 7), (4, 70, 28, 36, 9, 12), (3, 1100, 50, 50, 20, 20)])
+def test_canvas_unroll_bwd_recompute_equals_stored_canvas(hip, T, B, H, W, h, w):
+    """air_canvas_unroll_bwd(final_canvas=NULL) against the form that reads the stored final canvas, bit for bit, on the
+    BASELINE configs[3] shapes, odd sizes (scalar staging paths), negative / degenerate scales and a grid-strided batch."""
+    rng = np.random.default_rng(T * 1000 + B)
+    glm = rng.standard_normal((T, B, h, w)).astype(np.float32)
+    where = rand_where(T * B, rng).reshape(T, B, 4)
+    where[0, 0] = [-0.7, 0.2, 0.9, -0.1]                                   # mirrored glimpse
+    if B > 2:
+        where[-1, 2] = [3.0, 0.0, 3.0, 0.0]                                # glimpse larger than the canvas
+    pres = np.cumprod(rng.integers(0, 2, (T, B)), 0).astype(np.float32); pres[:, 0] = 1.0
+    obs = rng.random((B, H, W)).astype(np.float32)
+    _, final, _ = hip.canvas_unroll_fwd(g(glm), g(where), g(pres), (H, W), obs=g(obs), mult=0.5, std=0.3, keep_steps=False)
+    dg, dwhere = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, 0.5, 0.3, 1.0 / B)
+    dg2, dwhere2 = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), None, 0.5, 0.3, 1.0 / B)
+    assert torch.equal(dg, dg2) and torch.equal(dwhere, dwhere2)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -613,6 +634,133 @@ def test_gemm_k_split_consumer_prologue(hip, prec):
     hip.gemm_grouped([dict(A=x[:, :kh], B=w0[:kh], out=c, beta=1.0, bias=b0, epilogue=hip.EPI_BIAS)], precision=prec)
     full = r(x) @ r(w0) + b0.double()
     assert ((c.double() - full).abs().max() / full.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize("mirrors", ["ab", "a", "b", "none"])
+@pytest.mark.parametrize("layout", ["NN", "NT", "TN"])
+def test_gemm_bf16_data_path(hip, layout, mirrors):
+    """BASELINE configs[4], the bf16 DATA path: operands read from bf16 mirrors (A16 / B16: any combination -- an operand
+    without a mirror is fetched as fp32 and rounded in registers), products on v_mfma_f32_16x16x32_bf16, the epilogue writing
+    the bf16 mirror of C.  Against float64 products of the bf16-rounded operands: K with 32-, 8- and sub-8 tails (2500, 400,
+    50, 100, 12), ragged M / N, every epilogue, beta, bias gradients (summed from the UNROUNDED fp32 gradient), single, grouped
+    and whole-step (more than 8 problems, per-problem operand kinds) launches; the mirror of C must be exactly bf16(C)."""
+    gen = torch.Generator().manual_seed(31 + len(layout) * ord(layout[1]) + len(mirrors))
+    rn = lambda *s_: torch.randn(*s_, generator=gen).cuda()
+    r = lambda t: t.cpu().to(torch.bfloat16).double()
+    h16 = lambda t: t.to(torch.bfloat16)
+    ua, ub = "a" in mirrors, "b" in mirrors
+    atol = 2e-3
+
+    def prob(A, B, **kw):
+        d = dict(A=A, B=B, **kw)
+        if ua:
+            d["A16"] = h16(A)
+        if ub:
+            d["B16"] = h16(B)
+        return d
+
+    def check_c16(out, c16, what):
+        assert torch.equal(c16, out.to(torch.bfloat16)), what
+
+    if layout == "NN":
+        x = rn(3000, 256); w = rn(256, 400) / 16; b = rn(400); aux = rn(3000, 400)
+        x2 = rn(1024, 2500); w2 = rn(2500, 256) / 50; c0 = rn(1024, 256)
+        x3 = rn(2048, 12); w3 = rn(12, 100)
+        c16 = torch.zeros(3000, 400, dtype=torch.bfloat16, device="cuda")
+        outs = hip.gemm_grouped([prob(x, w, bias=b, epilogue=hip.EPI_BIAS_ELU, C16=c16)], precision=1)
+        assert_close(outs[0][0], torch.nn.functional.elu(r(x) @ r(w) + b.cpu().double()), 1e-5, atol, "single bias+elu")
+        check_c16(outs[0][0], c16, "mirror of C, single")
+        c16b = torch.zeros(1024, 256, dtype=torch.bfloat16, device="cuda")
+        outs = hip.gemm_grouped([prob(x, w, bias=b, aux=aux, epilogue=hip.EPI_ADD_AUX_ELU),
+                                 prob(x2, w2, beta=1.0, out=c0.clone(), C16=c16b), prob(x3, w3)], precision=1)
+        assert_close(outs[0][0], torch.nn.functional.elu(r(x) @ r(w) + b.cpu().double() + aux.cpu().double()), 1e-5, atol, "add aux elu")
+        assert_close(outs[1][0], r(x2) @ r(w2) + c0.cpu().double(), 1e-5, atol, "K = 2500 (tail of 4) + beta")
+        check_c16(outs[1][0], c16b, "mirror of C, grouped")
+        assert_close(outs[2][0], r(x3) @ r(w3), 1e-5, atol, "K = 12")
+        x4 = rn(3072, 50); w4 = rn(50, 256) / 7; b4 = rn(256)
+        x5 = rn(3072, 100); w5 = rn(100, 256) / 10
+        outs = hip.gemm_grouped([prob(x4, w4, bias=b4, epilogue=hip.EPI_BIAS_ELU), prob(x5, w5)], precision=1)
+        assert_close(outs[0][0], torch.nn.functional.elu(r(x4) @ r(w4) + b4.cpu().double()), 1e-5, atol, "K = 50")
+        assert_close(outs[1][0], r(x5) @ r(w5), 1e-5, atol, "K = 100")
+    elif layout == "NT":
+        g = rn(3000, 400); w = rn(1024, 400) / 16; y = rn(3000, 1024)
+        g2 = rn(1024, 1024); w2 = rn(256, 1024) / 32; c0 = rn(1024, 256)
+        c16 = torch.zeros(1024, 256, dtype=torch.bfloat16, device="cuda")
+        outs = hip.gemm_grouped([prob(g2, w2, tb=True, beta=1.0, out=c0.clone(), C16=c16)], precision=1)
+        assert_close(outs[0][0], r(g2) @ r(w2).t() + c0.cpu().double(), 1e-5, atol, "single beta")
+        check_c16(outs[0][0], c16, "mirror of C")
+        c16b = torch.zeros(3000, 1024, dtype=torch.bfloat16, device="cuda")
+        outs = hip.gemm_grouped([prob(g, w, tb=True, epilogue=hip.EPI_MUL_DELU, aux=y, C16=c16b), prob(g2, w2, tb=True)], precision=1)
+        d = torch.where(y.cpu() > 0, torch.ones_like(y.cpu()), y.cpu() + 1).double()
+        assert_close(outs[0][0], (r(g) @ r(w).t()) * d, 1e-5, atol, "mul delu, K = 400 (tail of 16)")
+        check_c16(outs[0][0], c16b, "mirror of C, grouped")
+        assert_close(outs[1][0], r(g2) @ r(w2).t(), 1e-5, atol, "plain")
+        # short K on the 32x64 tiles (dX of a 50-wide layer) and a 100-deep one
+        g3 = rn(3072, 256); w3 = rn(50, 256) / 16
+        g4 = rn(3072, 100); w4 = rn(256, 100) / 10
+        outs = hip.gemm_grouped([prob(g3, w3, tb=True)], precision=1)
+        assert_close(outs[0][0], r(g3) @ r(w3).t(), 1e-5, atol, "N = 50")
+        outs = hip.gemm_grouped([prob(g4, w4, tb=True)], precision=1)
+        assert_close(outs[0][0], r(g4) @ r(w4).t(), 1e-5, atol, "K = 100")
+    else:
+        x = rn(3072, 2500); g = rn(3072, 256); x2 = rn(1024, 260); g2 = rn(1024, 1024)
+        outs = hip.gemm_grouped([prob(x, g, ta=True, colsum=True)], precision=1)
+        assert_close(outs[0][0], r(x).t() @ r(g), 1e-5, atol * 10, "single dW")
+        assert_close(outs[0][1], g.cpu().double().sum(0), 1e-5, 1e-3, "single db (from the fp32 gradient)")
+        outs = hip.gemm_grouped([prob(x, g, ta=True, colsum=True), prob(x2, g2, ta=True, colsum=True)], precision=1)
+        assert_close(outs[0][0], r(x).t() @ r(g), 1e-5, atol * 10, "dW")
+        assert_close(outs[1][0], r(x2).t() @ r(g2), 1e-5, atol * 10, "dW ragged M")
+        assert_close(outs[1][1], g2.cpu().double().sum(0), 1e-5, 1e-3, "db")
+        # more than 8 problems: per-problem operand kinds (every other problem has no A mirror, every third no B mirror)
+        xs = [rn(1024 if i % 2 else 3072, 64 * (1 + i % 3)) for i in range(11)]
+        gs = [rn(x_.shape[0], 128 if i % 4 else 256) for i, x_ in enumerate(xs)]
+        order = sorted(range(11), key=lambda i: -xs[i].shape[0])
+        probs = []
+        for i in order:
+            d = dict(A=xs[i], B=gs[i], ta=True, colsum=(i % 2 == 0))
+            if ua and i % 2 == 0:
+                d["A16"] = h16(xs[i])
+            if ub and i % 3 != 0:
+                d["B16"] = h16(gs[i])
+            probs.append(d)
+        outs = hip.gemm_grouped(probs, precision=1)
+        for o, i in zip(outs, order):
+            assert_close(o[0], r(xs[i]).t() @ r(gs[i]), 1e-5, atol * 10, "big group dW %d" % i)
+            if i % 2 == 0:
+                assert_close(o[1], gs[i].cpu().double().sum(0), 1e-5, 1e-3, "big group db %d" % i)
+
+
+def test_step_epilogue_shadow_and_f32_to_bf16(hip):
+    """bf16 shadow of the parameters: air_step_epilogue_shadow == air_step_epilogue on the fp32 state and additionally leaves
+    bf16(p) in the shadow; air_f32_to_bf16 rounds like torch (RNE), vector and scalar paths."""
+    import ctypes
+    from attend_infer_repeat_amd import hip as H
+    L = H.lib()
+    gen = torch.Generator().manual_seed(2)
+    n, n_model = 40_004, 30_000
+    mk = lambda: [torch.randn(n, generator=gen).cuda(), torch.randn(n, generator=gen).cuda(), (torch.rand(n, generator=gen) + 1).cuda(),
+                  (torch.randn(n, generator=gen) * 0.1).cuda(), (torch.randn(n, generator=gen) * 0.01).cuda()]
+    a = mk(); b = [t.clone() for t in a]
+    lr = torch.tensor([1e-3]).cuda()
+    step = torch.zeros(1, dtype=torch.int64).cuda(); rng = torch.zeros(2, dtype=torch.int64).cuda()
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = H._p
+    common = lambda t: (P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), ctypes.c_size_t(n_model), ctypes.c_size_t(n), P(lr), 10.0, 0.9, 0.9,
+                        1e-10, 1.0)
+    assert L.air_step_epilogue(*common(a), P(step), P(rng), ctypes.c_uint64(7), sp) == 0
+    shadow = torch.zeros(n, dtype=torch.bfloat16).cuda()
+    assert L.air_step_epilogue_shadow(*common(b), None, None, ctypes.c_uint64(0), ctypes.c_void_p(shadow.data_ptr()), sp) == 0
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(shadow, b[0].to(torch.bfloat16))
+    assert step.item() == 1 and rng[1].item() == 7
+    for m in (4096, 4099):
+        src = torch.randn(m + 1, generator=gen).cuda()[1:] if m == 4099 else torch.randn(m, generator=gen).cuda()
+        dst = torch.zeros(m, dtype=torch.bfloat16).cuda()
+        assert L.air_f32_to_bf16(P(src), ctypes.c_void_p(dst.data_ptr()), ctypes.c_size_t(m), sp) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("precision", [0, 1])
