@@ -983,7 +983,7 @@ class AIREngine:
         L = H.lib()
         cfg = self.cfg
         if (self._defer_dw or self.world_size != 1 or not cfg.use_reinforce
-                or os.environ.get("AIR_TWO_LANE", "1") != "1"):
+                or os.environ.get("AIR_TWO_LANE", "0") != "1"):
             return None
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)

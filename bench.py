@@ -85,6 +85,10 @@ def st_rooflines(eng, reps=200):
     HW, hw = Hh * Ww, h * w
     p, sp = H._p, eng._sp()
     dec, dgl = eng.gd.out[-1], eng.gd.g[-1]
+    # the canvas backward in the form the step runs it: the two-lane step re-forms the canvas on each glimpse's footprint
+    # (final_canvas = NULL) instead of reading the stored final canvas
+    rc = any(e[0] not in ("record", "wait") and e[2] == "air_canvas_unroll_bwd" and e[1][4] is None
+             for e in (getattr(eng, "_plan_two_lane", None) or []))
     calls = {
         "st_read_fwd": (lambda: lib.air_st_read_fwd(p(eng.obs), p(eng.where), p(eng.glimpse_in), M, B, Hh, Ww, h, w, sp),
                         4 * (HW + hw + 4) * M),
@@ -96,7 +100,7 @@ def st_rooflines(eng, reps=200):
                                                                         cfg.output_multiplier, cfg.output_std, sp),
                               4 * (hw + 2 * HW + 4 + 1) * M),
         "canvas_unroll_bwd": (lambda: lib.air_canvas_unroll_bwd(p(dec), p(eng.where), p(eng.presence), p(eng.obs),
-                                                                 p(eng.final_canvas), p(dgl), p(eng.dwhere_w), T, B, Hh,
+                                                                 None if rc else p(eng.final_canvas), p(dgl), p(eng.dwhere_w), T, B, Hh,
                                                                  Ww, h, w, cfg.output_multiplier, cfg.output_std,
                                                                  1.0 / B, sp), 4 * (HW + 2 * hw + 4 + 4 + 1) * M),
     }
@@ -112,7 +116,9 @@ def st_rooflines(eng, reps=200):
         "st_read_fwd": 4 * (B * HW + M * (hw + 4)), "attend_fwd": 4 * (B * HW + M * (hw + 4)),
         "st_read_bwd": 4 * (B * HW + M * (hw + 4 + 4)), "attend_bwd": 4 * (B * HW + M * (hw + 4 + 4)),
         "canvas_unroll_fwd": 4 * (M * (hw + 5) + B * HW * (2 + (T if eng.canvas_steps is not None else 0))),
-        "canvas_unroll_bwd": 4 * (2 * B * HW + M * (2 * hw + 9)),
+        # stored-canvas form: final canvas + obs once per image; recompute form: obs + the image's T glimpses per (t, b) unit
+        # are re-read from L2, the bytes that MUST move are obs, glimpse, dglimpse, where, dwhere, presence
+        "canvas_unroll_bwd": 4 * ((1 if rc else 2) * B * HW + M * (2 * hw + 9)),
     }
     pmc, pmc_note = pmc_traffic(lib, (Hh, Ww, h, w, T, B))
     out = {}
@@ -126,6 +132,7 @@ def st_rooflines(eng, reps=200):
                      "frac_minimal_bytes": round(minimal[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         if pmc_note:
             out[name]["traffic_note"] = pmc_note
+    out["canvas_unroll_bwd"]["form"] = "recompute (no final-canvas read)" if rc else "stored final canvas"
     return out
 
 

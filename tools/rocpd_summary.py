@@ -2,8 +2,11 @@
 """Summarise a rocprofv3 (ROCm 7 rocpd SQLite) kernel trace: per-kernel calls / total / avg / min / max / share.
 
 usage: python tools/rocpd_summary.py <results.db> [--steps N]  > profiles/<name>.txt
-       python tools/rocpd_summary.py <results.db> --by-position <last kernel of a step>   > profiles/<name>_positions.txt
-         per position inside the replayed step: mean duration and mean gap to the previous kernel's end (the boundary cost)
+       python tools/rocpd_summary.py <results.db> --by-position <last kernel of a step> [--every K]  > profiles/<name>_positions.txt
+         per position (by start time) inside the replayed step: mean duration and mean gap to the previous kernel's end (the
+         boundary cost; NEGATIVE = the kernel started while the previous one was still running: two-lane graphs, marked '*').
+         --every K: the step's last kernel occurs K times per step (the two-lane step runs its optimiser slices through the
+         same kernel): every K-th occurrence closes a step.
 """
 import re
 import sqlite3
@@ -16,7 +19,7 @@ def short(name):
     return name[:70]
 
 
-def by_position(db, last):
+def by_position(db, last, every=1):
     con = sqlite3.connect(db)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -24,6 +27,11 @@ def by_position(db, last):
     rows = sorted(cur.execute(f"select {name_col}, start, end from kernels").fetchall(), key=lambda r: r[1])
     names = [short(r[0]) for r in rows]
     ends = [i for i, n in enumerate(names) if n.startswith(last)]
+    if every > 1:
+        # the occurrence that closes a step is the one followed by the longest pause (the host's replay gap): align on it
+        gaps_after = [(rows[i + 1][1] - rows[i][2]) if i + 1 < len(rows) else 0 for i in ends]
+        best = max(range(every), key=lambda r: sum(gaps_after[r::every]) / max(1, len(gaps_after[r::every])))
+        ends = ends[best::every]
     # periods between consecutive occurrences of the step's last kernel; keep the most common length (the graph replays)
     periods = [(a + 1, b + 1) for a, b in zip(ends[:-1], ends[1:])]
     lens = {}
@@ -45,13 +53,15 @@ def by_position(db, last):
           f"kernel time {sum(dur) / n / 1e3:.1f} us, gaps {sum(gap) / n / 1e3:.1f} us")
     print(f"{'pos':>3s} {'kernel':60s} {'avg_us':>8s} {'max_us':>8s} {'gap_us':>8s}")
     for k in range(P):
-        print(f"{k:3d} {ref[k][:60]:60s} {dur[k] / n / 1e3:8.2f} {mx[k] / 1e3:8.2f} {gap[k] / n / 1e3:8.2f}")
+        mark = "*" if gap[k] / n < -50.0 else " "          # started >50 ns before the previous kernel ended: overlapped
+        print(f"{k:3d} {ref[k][:60]:60s} {dur[k] / n / 1e3:8.2f} {mx[k] / 1e3:8.2f} {gap[k] / n / 1e3:8.2f} {mark}")
 
 
 def main():
     db = sys.argv[1]
     if "--by-position" in sys.argv:
-        return by_position(db, sys.argv[sys.argv.index("--by-position") + 1])
+        every = int(sys.argv[sys.argv.index("--every") + 1]) if "--every" in sys.argv else 1
+        return by_position(db, sys.argv[sys.argv.index("--by-position") + 1], every)
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     con = sqlite3.connect(db)
     cur = con.cursor()
