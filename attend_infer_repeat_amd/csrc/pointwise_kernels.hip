@@ -124,6 +124,7 @@ extern "C" int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_
 
 // ---- reparameterised Gaussian + KL (cell.py:130-133,154-156; modules.py:17-24,41-46,58-63; model.py:174-209) ----
 #include "engine_device.h"
+#include "nvil_device.h"
 __global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, float raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
@@ -144,6 +145,41 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__re
                                                                float *__restrict__ dpre, int ld_dpre, int M, int D) {
     gauss_bwd_body(blockIdx.x, gridDim.x, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
                    dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
+}
+// the same launch with ONE extra workgroup (the first of the grid) that evaluates the NVIL objective (nvil_body): the two are
+// independent, and in the step whose canvas forward + backward are one launch (air_canvas_unroll_fwd_bwd) this is the first
+// launch behind the reconstruction shares NVIL needs that has room for a rider
+__global__ __launch_bounds__(PW_THREADS) void gauss_bwd_nvil_kernel(const float *__restrict__ pre, int ld_pre,
+                                                                    const float *__restrict__ eps, float raw_offset,
+                                                                    int loc_mode, float pl0, float ps0, float pl1, float ps1,
+                                                                    const float *__restrict__ loc,
+                                                                    const float *__restrict__ scale,
+                                                                    const float *__restrict__ dsample,
+                                                                    const float *__restrict__ dsample2,
+                                                                    const float *__restrict__ dkl_row, float dkl_scale,
+                                                                    float *__restrict__ dpre, int ld_dpre, int M, int D, NvilArgs nv) {
+    if (blockIdx.x == 0) { nvil_body(nv); return; }
+    gauss_bwd_body(blockIdx.x - 1, gridDim.x - 1, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
+                   dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
+}
+extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                                         float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
+                                         const float *loc, const float *scale, const float *dsample,
+                                         const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
+                                         int ld_dpre, int M, int D, const float *imp_parts, int n_parts, float *imp_sum,
+                                         const float *baseline, const float *logp, float *nvil_out, float *dlogp,
+                                         float *dbaseline, int B, void *stream) {
+    AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
+    AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
+    AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
+    AIR_REQUIRE(B > 0 && n_parts > 0, AIR_E_SHAPE);
+    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
+    hipLaunchKernelGGL(gauss_bwd_nvil_kernel, dim3(pw_blocks((size_t)M * D) + 1), dim3(PW_THREADS), 0, air_stream(stream), pre,
+                       ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
+                       dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, nv);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 extern "C" int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                                     float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,

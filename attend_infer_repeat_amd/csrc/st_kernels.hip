@@ -346,20 +346,30 @@ static inline size_t carve_wr_bytes(int T, int RB, int W, int h, int w) {
 // ((0 + p0*v0) + p1*v1) + ...).  rec_parts[q*B + b] receives the band's share of the reconstruction term; with NB = 1 that
 // IS rec[b], with NB > 1 the consumer (air_nvil_parts / air_canvas_unroll_bwd_nvil / air_sum_leading) adds the NB shares
 // in band order (no float atomics: bitwise reproducible).
-__global__ __launch_bounds__(1024) void st_write_fwd_kernel(
-    const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
-    const float *__restrict__ canvas_in, const float *__restrict__ obs,
-    float *__restrict__ canvas_steps, float *__restrict__ final_canvas, float *__restrict__ rec_parts,
-    int T, int B, int NB, int RB, int H, int W, int h, int w, double stepX, double stepY, float mult, float std,
-    int vec4_glimpse) {
-    extern __shared__ __align__(16) float smem[];
+struct WriteFwdArgs {
+    const float *glimpse, *where, *presence, *canvas_in, *obs;
+    float *canvas_steps, *final_canvas, *rec_parts;
+    int T, B, NB, RB, H, W, h, w;
+    double stepX, stepY;
+    float mult, std;
+    int vec4_glimpse;
+};
+// (vblock of vgrid: the workgroup's index among the workgroups that run this role -- the whole grid of st_write_fwd_kernel, the
+//  first part of the grid of canvas_fused_kernel)
+__device__ __forceinline__ void st_write_fwd_body(const WriteFwdArgs &a, float *smem, const int vblock, const int vgrid) {
+    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
+    const float *__restrict__ canvas_in = a.canvas_in, *__restrict__ obs = a.obs;
+    float *__restrict__ canvas_steps = a.canvas_steps, *__restrict__ final_canvas = a.final_canvas, *__restrict__ rec_parts = a.rec_parts;
+    const int T = a.T, B = a.B, NB = a.NB, RB = a.RB, H = a.H, W = a.W, h = a.h, w = a.w, vec4_glimpse = a.vec4_glimpse;
+    const double stepX = a.stepX, stepY = a.stepY;
+    const float mult = a.mult, std = a.std;
     AIR_TR_INIT();
     const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
     CarveWr c = carve_wr(smem, T, RB, W, h, w);
     const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
     const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
     const int n_units = B * NB;
-    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    for (int unit = vblock; unit < n_units; unit += vgrid) {
         const int b = unit % B, band = unit / B;
         const int r0 = band * RB, r1 = (r0 + RB < H) ? r0 + RB : H, npx = (r1 - r0) * W, pbase = r0 * W;
         AIR_TR(0);
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(1024) void st_write_fwd_kernel(
             const int p = tid + u * nt;
             xo[u] = ob[p < ob_last ? p : ob_last];
         }
-        if (unit != (int)blockIdx.x) __syncthreads();          // grid-stride reuse of the carve
+        if (unit != vblock) __syncthreads();                   // grid-stride reuse of the carve
         if (vec4_glimpse) {
             const int nq = hw >> 2;
             for (int e = tid; e < T * nq; e += nt) {
@@ -446,6 +456,10 @@ __global__ __launch_bounds__(1024) void st_write_fwd_kernel(
         AIR_TR(4);
     }
     AIR_TR_FLUSH();
+}
+__global__ __launch_bounds__(1024) void st_write_fwd_kernel(WriteFwdArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    st_write_fwd_body(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Backward of the write for every (t, b): dglimpse, dwhere, optional dpresence.
@@ -550,21 +564,29 @@ __device__ __forceinline__ int2 valid_span(const float2 *tab, int n) {
 // re-forms the canvas on its own footprint exactly as st_write_fwd_kernel does (same table entries, same taps, t in order:
 // bit-identical values) and derives dcanvas from it and the observation.  The backward then no longer depends on the canvas
 // forward launch: in the two-lane step the forward (needed for the outputs and the NVIL loss value) leaves the dX chain.
+struct WriteBwdArgs {
+    const float *glimpse, *where, *presence, *dcanvas, *final_canvas, *obs;
+    float *dglimpse, *dwhere, *dpresence;
+    int T, B, H, W, h, w;
+    double stepX, stepY;
+    float mult, std, loss_scale;
+    int vec4_glimpse, vec4_canvas;
+};
 template <bool RC>
-__global__ __launch_bounds__(1024) void st_write_bwd_kernel(
-    const float *__restrict__ glimpse, const float *__restrict__ where, const float *__restrict__ presence,
-    const float *__restrict__ dcanvas, const float *__restrict__ final_canvas, const float *__restrict__ obs,
-    float *__restrict__ dglimpse, float *__restrict__ dwhere, float *__restrict__ dpresence,
-    int T, int B, int H, int W, int h, int w, double stepX, double stepY, float mult, float std, float loss_scale,
-    int vec4_glimpse, int vec4_canvas, NvilArgs nv) {
-    extern __shared__ __align__(16) float smem[];
-    // optional second role: the LAST workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
+__device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const NvilArgs &nv, float *smem, const int vblock, const int vgrid) {
+    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
+    const float *__restrict__ dcanvas = a.dcanvas, *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
+    float *__restrict__ dglimpse = a.dglimpse, *__restrict__ dwhere = a.dwhere, *__restrict__ dpresence = a.dpresence;
+    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w, vec4_glimpse = a.vec4_glimpse, vec4_canvas = a.vec4_canvas;
+    const double stepX = a.stepX, stepY = a.stepY;
+    const float mult = a.mult, std = a.std, loss_scale = a.loss_scale;
+    // optional second role: one workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
     // has to precede the baseline / logit backward that follow this launch)
     AIR_TR_INIT();
-    // the NVIL workgroup is the FIRST of the grid (a long float64 chain: at the end of a grid that fills the chip it would only
-    // start when the first glimpse workgroups retire)
-    const int grid_st = nv.imp ? (int)gridDim.x - 1 : (int)gridDim.x;
-    const int bid0 = nv.imp ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    // the NVIL workgroup is the FIRST of the role's workgroups (a long float64 chain: at the end of a grid that fills the chip it
+    // would only start when the first glimpse workgroups retire)
+    const int grid_st = nv.imp ? vgrid - 1 : vgrid;
+    const int bid0 = nv.imp ? vblock - 1 : vblock;
     if (bid0 < 0) {
         AIR_TR(5);
         nvil_body(nv);
@@ -813,6 +835,24 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(
     }
     AIR_TR_FLUSH();
 }
+template <bool RC>
+__global__ __launch_bounds__(1024) void st_write_bwd_kernel(WriteBwdArgs a, NvilArgs nv) {
+    extern __shared__ __align__(16) float smem[];
+    st_write_bwd_body<RC>(a, nv, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+// Canvas forward and backward of a train step in ONE launch (latency regime).  The recompute form of the backward reads nothing
+// the forward writes, so the two are independent roles of one grid: workgroups [0, n_fwd) run st_write_fwd_body (image x row
+// band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_body<true> (one per glimpse).  One
+// dependent launch less on the step's chain; NVIL -- which needs the forward's reconstruction shares -- rides on a later launch
+// (air_gauss_sample_bwd_nvil).
+__global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, WriteBwdArgs b, int n_fwd) {
+    extern __shared__ __align__(16) float smem[];
+    if ((int)blockIdx.x < n_fwd) st_write_fwd_body(f, smem, (int)blockIdx.x, n_fwd);
+    else {
+        const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
+        st_write_bwd_body<true>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
+    }
+}
 
 // ============================================================================================================
 // host side
@@ -911,9 +951,9 @@ static int launch_write_fwd(const float *glimpse, const float *where, const floa
         wr_threads = px >= 1024 ? 1024 : ((px + 63) / 64) * 64;
         if (wr_threads < 64) wr_threads = 64;
     }
-    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid((int)units)), dim3(wr_threads), lds, air_stream(stream), glimpse,
-                       where, presence, canvas_in, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
-                       lin_step(W), lin_step(H), mult, std, vec4g);
+    const WriteFwdArgs a = {glimpse, where, presence, canvas_in, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, vec4g};
+    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid((int)units)), dim3(wr_threads), lds, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -982,14 +1022,14 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     // 512 threads (about one per footprint pixel) while the launch does not fill the chip: 7.5 us at 192 units against 8.2 with
     // 1024; beyond that 256-thread workgroups, 8 per CU, hide each other's barriers (29 vs 74 us at 3072 units, 11 vs 21 at 768)
     const int wr_threads = (long)B * T <= 512 ? 512 : ST_THREADS;
+    const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c};
     if (rc)
         hipLaunchKernelGGL(st_write_bwd_kernel<true>, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
-                           air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
-                           dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
+                           air_stream(stream), a, nv);
     else
         hipLaunchKernelGGL(st_write_bwd_kernel<false>, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
-                           air_stream(stream), glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere,
-                           dpresence, T, B, H, W, h, w, lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, nv);
+                           air_stream(stream), a, nv);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -1030,6 +1070,36 @@ extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *whe
     const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
     return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
                             h, w, mult, std, loss_scale, stream, &nv);
+}
+
+// forward (banded, as air_canvas_unroll_fwd_banded) + backward (recompute form of air_canvas_unroll_bwd) as ONE launch
+extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+                                         float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
+                                         float *dglimpse, float *dwhere, int T, int B, int H, int W, int h, int w, float mult,
+                                         float std, float loss_scale, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && (final_canvas || canvas_steps) && rec_parts && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n_bands > 0, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    int NB, RB;
+    wr_bands(H, n_bands, &NB, &RB);
+    AIR_REQUIRE(NB == n_bands, AIR_E_SHAPE);
+    const size_t lds_f = carve_wr_bytes(T, RB, W, h, w), lds_b = carve_bwd_bytes(H, W, h, w, T);
+    const size_t lds = lds_f > lds_b ? lds_f : lds_b;
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    // one launch only pays while both roles fit the chip side by side (the latency regime); beyond that the two launches
+    AIR_REQUIRE((long)B * NB <= 2048 && (long)B * T <= 2048, AIR_E_UNSUPPORTED);
+    const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
+    { int st_ = st_allow_lds(canvas_fused_kernel, lds); if (st_) return st_; }
+    const WriteFwdArgs f = {glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, vec4g};
+    const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c};
+    const int n_fwd = B * NB;
+    hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B), dim3(512), lds, air_stream(stream), f, b, n_fwd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 // ============================================================================================================

@@ -641,27 +641,57 @@ class AIREngine:
         inv_b = 1.0 / B
         cu_args = (p(decoded), p(self.where), p(self.presence), p(self.obs), p(self.final_canvas), p(self.gd.g[-1]),
                    p(self.dwhere_w), T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std, inv_b)
-        if cfg.use_reinforce:
+        # Latency regime with REINFORCE: the canvas forward and the (recompute-form) backward are ONE launch -- the backward
+        # re-forms the canvas on each glimpse's footprint, so it reads nothing the forward writes (air_canvas_unroll_fwd_bwd) -- the
+        # train step's forward list then ends before the canvas; NVIL, which needs the forward's reconstruction shares, rides on
+        # the next pointwise launch (air_gauss_sample_bwd_nvil) and the baseline's backward, which needs NVIL, rides with the
+        # three launches after that (what / glimpse-encoder backward) instead of the decoder's.  35 -> 34 dependent launches.
+        fuse_canvas = (cfg.use_reinforce and not throughput and B * NB <= 2048 and M <= 2048
+                       and os.environ.get("AIR_FUSE_CANVAS", "1") == "1" and os.environ.get("AIR_TWO_LANE", "0") != "1")
+        bl_chain = dict(m=self.bl, g_last=self.dbase,
+                        x_parts=[(self.obs, P, 0, P), (self.base_lat, cfg.baseline_in - P, P, cfg.baseline_in - P)])
+        bl_levels = [[], [], []]
+        if fuse_canvas:
+            tmp = []
+            mlp_bwd_multi(tmp, [bl_chain])                 # the baseline's backward, launch by launch, to ride later launches
+            lv = [list(e[1][0]) for e in tmp]
+            # one level per launch, in order: the `what` backward, the glimpse encoder's first level, its last level
+            slots = 1 + min(self.ge.n, 2)
+            if len(lv) > slots or any(e[2] != "air_gemm_grouped" for e in tmp):
+                fuse_canvas = False                          # (a deeper baseline than there are launches to ride: the plain plan)
+            else:
+                lv = lv + [[]] * (3 - len(lv))
+                bl_levels = [lv[0], lv[1], lv[2]] if self.ge.n >= 2 else [lv[0], lv[1], []]
+        self._fuse_canvas = fuse_canvas
+        if fuse_canvas:
+            bwd.append((L.air_canvas_unroll_fwd_bwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
+                                                      p(self.canvas_steps), p(self.final_canvas), p(self.rec_parts), NB,
+                                                      p(self.gd.g[-1]), p(self.dwhere_w), T, B, Hi, Wi, hc, wc,
+                                                      cfg.output_multiplier, cfg.output_std, inv_b),
+                        "air_canvas_unroll_fwd_bwd"))
+        elif cfg.use_reinforce:
             bwd.append((L.air_canvas_unroll_bwd_nvil, cu_args + nvil_args, "air_canvas_unroll_bwd_nvil"))
         else:
             bwd.append(rec_sum)          # nobody consumes rec in the step itself; keeps outputs() complete after train_step
             bwd.append((L.air_canvas_unroll_bwd, cu_args, "air_canvas_unroll_bwd"))
         chains = [dict(m=self.gd, x=self.what, ldx=A, g_last=self.gd.g[-1], dx_out=self.d_what)]
-        if cfg.use_reinforce:                                                               # model.py:253-259, 362-367
-            chains.append(dict(m=self.bl, g_last=self.dbase,
-                               x_parts=[(self.obs, P, 0, P), (self.base_lat, cfg.baseline_in - P, P, cfg.baseline_in - P)]))
+        if cfg.use_reinforce and not fuse_canvas:                                           # model.py:253-259, 362-367
+            chains.append(bl_chain)
         mlp_bwd_multi(bwd, chains)
-        marks = [(len(bwd), "glimpse_decoder/0/w")]      # gradients of [glimpse_decoder .. baseline] are final here
-        bwd.append((L.air_gauss_sample_bwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
-                                             wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale),
-                                             p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M,
-                                             A), "air_gauss_sample_bwd"))
+        marks = [] if fuse_canvas else [(len(bwd), "glimpse_decoder/0/w")]   # gradients of [glimpse_decoder .. baseline] are final here
+        gb_args = (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0], wp[1], wp[0], wp[1], p(self.what_loc),
+                   p(self.what_scale), p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M, A)
+        if fuse_canvas:
+            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B,), "air_gauss_sample_bwd_nvil"))
+        else:
+            bwd.append((L.air_gauss_sample_bwd, gb_args, "air_gauss_sample_bwd"))
         launch(bwd, [desc(1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
                           colsum=self.grads["what/b"]),
                      desc(0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
-                          aux=ge_out, ldaux=G)])
-        mlp_bwd_multi(bwd, [dict(m=self.ge, x=self.glimpse_in, ldx=hw, g_last=self.ge.g[-1], dx_out=self.d_glimpse_in)])
-        marks.append((len(bwd), "glimpse_encoder/0/w"))        # + [glimpse_encoder, what]
+                          aux=ge_out, ldaux=G)] + bl_levels[0])
+        mlp_bwd_multi(bwd, [dict(m=self.ge, x=self.glimpse_in, ldx=hw, g_last=self.ge.g[-1], dx_out=self.d_glimpse_in)],
+                      extra_first=bl_levels[1], extra_last=bl_levels[2])
+        marks.append((len(bwd), "glimpse_encoder/0/w"))        # + [glimpse_encoder, what] (+ decoder, baseline when fused)
         dlogp_p = p(self.dlogp) if cfg.use_reinforce else None
         if fuse_attend:
             # ... including the dX of the two MLP output layers (K = 8 and 1): their launch disappears from the chain, their
@@ -825,6 +855,9 @@ class AIREngine:
         self._plan_fwd_noise = pre_fwd + fwd_plan(True) + fwd_tail    # forward(): complete outputs
         self._plan_fwd = pre_fwd + fwd_plan(False) + fwd_tail
         self._plan_fwd_train = pre_fwd + fwd_plan(True)               # train step: NVIL rides in the first backward launch
+        if fuse_canvas:                                               # ... and the canvas forward IS the first backward launch
+            assert self._plan_fwd_train[-1][2] == "air_canvas_unroll_fwd_banded"
+            self._plan_fwd_train = self._plan_fwd_train[:-1]
         feeder = getattr(self, "_feeder", None)
         if feeder is not None:
             # the batch itself is drawn by the first launch of the train step (attach_dataset): no host work between updates

@@ -104,6 +104,14 @@ int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const f
                                int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                                const float *imp_parts, int n_parts, float *imp_sum, const float *baseline,
                                const float *logp, float *nvil_out, float *dlogp, float *dbaseline, void *stream);
+/* Canvas forward (banded, as air_canvas_unroll_fwd_banded) and backward (as air_canvas_unroll_bwd with final_canvas = NULL: every
+ * (t, b) unit re-forms the canvas on its own footprint, bit-identically to the forward, so it reads nothing the forward writes) as
+ * the two roles of ONE launch: one dependent launch less on the train step's chain at small batch.  The NVIL objective, which
+ * needs the forward's reconstruction shares, then rides on air_gauss_sample_bwd_nvil.  B * n_bands and B * T at most 2048.       */
+int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+                              float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands, float *dglimpse,
+                              float *dwhere, int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
+                              void *stream);
 /* ---- dense layers -------------------------------------------------------------------------------------------
  * Replaces the TF MatMul/BiasAdd/Elu nodes under snt.Linear (neural.py:42-60) and snt.LSTM (mnist_model.py:35).   */
 
@@ -238,6 +246,13 @@ int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float r
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          const float *loc, const float *scale, const float *dsample, const float *dsample2,
                          const float *dkl_row, float dkl_scale, float *dpre, int ld_dpre, int M, int D, void *stream);
+/* air_gauss_sample_bwd with air_nvil_parts riding as one extra workgroup (arguments of both, in that order; B = batch).  */
+int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+                              float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc,
+                              const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
+                              float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *imp_parts, int n_parts,
+                              float *imp_sum, const float *baseline, const float *logp, float *nvil_out, float *dlogp,
+                              float *dbaseline, int B, void *stream);
 
 /* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
  * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
