@@ -108,6 +108,9 @@ SIGNATURES = {
     "air_batch_gather": (c_int, [P, ctypes.c_longlong, c_int, P, P, c_int, P, c_int, P, P]),
     "air_step_epilogue": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
                                   P, P, c_uint64, P]),
+    "air_lstm_step_fwd_bf16": (c_int, [P, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_float, P]),
+    "air_lstm_step_bwd_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "air_lstm_pointwise_bwd_bf16": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_step_epilogue_shadow": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
                                          P, P, c_uint64, P, P]),
     "air_f32_to_bf16": (c_int, [P, P, c_size_t, P]),

@@ -1299,6 +1299,7 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
         // the 32x32-tile kernel with bf16 operands (L1 operand traffic) and no faster in fp32 (profiles/r02_j_kbench_gemm_*.txt)
         const bool nt_short = !ta && tb && min_k < wide_nt_k;
         if (ok && nt_short) ok = bf && tiles16 > 2048;
+        if (ok && bf && ta) return launch_big_tn_group(descs, count, stream);   // per-problem operand kinds (mirrors) in one launch
         if (ok) {
             const int TMw = ta ? 64 : (nt_short ? 32 : 16);
             int wt = 0;
@@ -1810,6 +1811,229 @@ __global__ __launch_bounds__(512) void lstm_bwd_wide_kernel(LstmBwdArgs g, Rmspr
             for (int q = 0; q < 4; ++q) so[(size_t)q * g.Hd] = sx[i][q] + d[q];
         }
     }
+}
+
+// ---- the LSTM recurrence on the bf16 data path (throughput regime) -----------------------------------------------------------
+// lstm_fwd_wide_kernel / lstm_bwd_wide_kernel with the operands in memory as bf16: W_h from the bf16 shadow of the parameters
+// (half the bytes of the larger operand), h_prev / dgates_{t+1} from their mirrors where one exists (the previous step's launch
+// wrote it; the first step reads the fp32 tiled initial state), products on v_mfma_f32_16x16x32_bf16, and the epilogue writes
+// the mirrors of h / dgates / running dgx next to the fp32 values.  Same tiles, same fixed-order K split over 8 waves.
+struct Lstm16 { const void *w16, *a16; void *out16, *out16_b; };
+__global__ __launch_bounds__(512) void lstm_fwd_wide16_kernel(LstmFwdArgs g, Lstm16 x) {
+    constexpr int KW = 8, LDT = 256 + 4;
+    __shared__ float s_tile[KW][16 * LDT];                  // local column = gate * 64 + unit
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_u = g.Hd >> 6;
+    const int tm = blockIdx.x / tiles_u, tu = blockIdx.x - tm * tiles_u;
+    const int m0 = tm * 16, u0 = tu * 64;
+    const gcf gA = (gcf)g.h_prev;
+    const gch hA = (gch)x.a16, hW = (gch)x.w16;
+    int rowA = m0 + li; if (rowA > g.M - 1) rowA = g.M - 1;
+    const size_t offA = (size_t)rowA * g.ldh;
+    const int colb = u0 + 4 * li;
+    float e_gx[2][4], e_c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = threadIdx.x + 512 * i, r = e >> 6, u = e & 63;
+        int m = m0 + r; if (m > g.M - 1) m = g.M - 1;
+        const gcf gx = (gcf)g.gx + (size_t)m * g.ldgx + u0 + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_gx[i][q] = gx[(size_t)q * g.Hd];
+        e_c[i] = ((gcf)g.c_prev)[(size_t)m * g.ldc + u0 + u];
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunks = g.Hd >> 5;                          // 32-deep chunks
+#pragma nounroll
+    for (int c = wave; c < nchunks; c += KW) {
+        const int k = (c << 5) + 8 * lg;
+        u32x4 fa;
+        if (hA) fa = *(gcu4)(hA + offA + k);
+        else fa = pk8(*(gcf4)(gA + offA + k), *(gcf4)(gA + offA + k + 4));
+        u32x2 w[4][8];                                      // w[q][j] = W_h16[k + j, q*Hd + colb .. colb+3]
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q][j] = *(gcu2)(hW + (size_t)(k + j) * g.ldw + (size_t)q * g.Hd + colb);
+        const bf16x8 ha = __builtin_bit_cast(bf16x8, fa);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[q * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, __builtin_bit_cast(bf16x8, tr16<0>(w[q])), acc[q * 4 + 0], 0, 0, 0);
+            acc[q * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, __builtin_bit_cast(bf16x8, tr16<1>(w[q])), acc[q * 4 + 1], 0, 0, 0);
+            acc[q * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, __builtin_bit_cast(bf16x8, tr16<2>(w[q])), acc[q * 4 + 2], 0, 0, 0);
+            acc[q * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, __builtin_bit_cast(bf16x8, tr16<3>(w[q])), acc[q * 4 + 3], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *(f32x4 *)&s_tile[wave][(4 * lg + r) * LDT + q * 64 + 4 * li] =
+                (f32x4){acc[q * 4 + 0][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+    __syncthreads();
+    const gh_t h16 = (gh_t)x.out16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = threadIdx.x + 512 * i, r = e >> 6, u = e & 63;
+        const int m = m0 + r;
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = r * LDT + q * 64 + u;
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < KW; w4 += 4)
+                v += (s_tile[w4][off] + s_tile[w4 + 1][off]) + (s_tile[w4 + 2][off] + s_tile[w4 + 3][off]);
+            pre[q] = v + e_gx[i][q];
+        }
+        if (m < g.M) {
+            const float gi = sigmoid_acc(pre[0]);
+            const float gj = tanhf(pre[1]);
+            const float gf = sigmoid_acc(pre[2] + g.fb);
+            const float go = sigmoid_acc(pre[3]);
+            const float cn = gf * e_c[i] + gi * gj;
+            const size_t eo = (size_t)m * g.Hd + u0 + u;
+            const float hn = tanhf(cn) * go;
+            ((gf_t)g.c)[eo] = cn;
+            ((gf_t)g.h)[eo] = hn;
+            if (h16) h16[eo] = bf16_bits(hn);
+            const gf_t ar = (gf_t)g.gate_act + (size_t)m * 4 * g.Hd + u0 + u;
+            ar[0] = gi; ar[g.Hd] = gj; ar[2 * (size_t)g.Hd] = gf; ar[3 * (size_t)g.Hd] = go;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_wide16_kernel(LstmBwdArgs g, Lstm16 x) {
+    constexpr int KW = 8, NT = 4, LDT = 64 + 4;
+    __shared__ float s_tile[KW][16 * LDT];
+    const int tiles_n = g.Hd >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 16, n0 = tn * 64;
+    const int K = 4 * g.Hd;
+    const gcf gA = (gcf)g.dgates_next;
+    const gch hA = (gch)x.a16, hB = (gch)x.w16;
+    int rowA = m0 + li; if (rowA > g.M - 1) rowA = g.M - 1;
+    const size_t offA = (size_t)rowA * K;
+    size_t offB[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) offB[b] = (size_t)(n0 + 16 * b + li) * K;
+    float gi[2], gj[2], gff[2], go[2], cp[2], cc[2], dha[2], dhb[2], dci[2], sx[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e_ = threadIdx.x + 512 * i, r = e_ >> 6, u = n0 + (e_ & 63);
+        int m = m0 + r; if (m > g.M - 1) m = g.M - 1;
+        const size_t e = (size_t)m * g.Hd + u;
+        const gcf ar = (gcf)g.gate_act + (size_t)m * K + u;
+        gi[i] = ar[0]; gj[i] = ar[g.Hd]; gff[i] = ar[2 * (size_t)g.Hd]; go[i] = ar[3 * (size_t)g.Hd];
+        cp[i] = ((gcf)g.c_prev)[e];
+        cc[i] = ((gcf)g.c)[e];
+        dha[i] = g.dh_a ? ((gcf)g.dh_a)[e] : 0.f;
+        dhb[i] = g.dh_b ? ((gcf)g.dh_b)[e] : 0.f;
+        dci[i] = g.dc_in ? ((gcf)g.dc_in)[e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sx[i][q] = g.dgx_in ? ((gcf)g.dgx_in)[(size_t)m * K + u + (size_t)q * g.Hd] : 0.f;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    const int nchunks = K >> 5;
+#pragma nounroll
+    for (int c = wave; c < nchunks; c += U * KW) {
+        u32x4 fa[U], fb[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cu = c + u * KW; if (cu > nchunks - 1) cu = nchunks - 1;
+            const int k = (cu << 5) + 8 * lg;
+            if (hA) fa[u] = *(gcu4)(hA + offA + k);
+            else fa[u] = pk8(*(gcf4)(gA + offA + k), *(gcf4)(gA + offA + k + 4));
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[u][b] = *(gcu4)(hB + offB[b] + k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW >= nchunks) break;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u]), __builtin_bit_cast(bf16x8, fb[u][b]),
+                                                                acc[b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) s_tile[wave][(4 * lg + r) * LDT + 16 * b + li] = acc[b][r];
+    __syncthreads();
+    const gh_t d16 = (gh_t)x.out16, s16 = (gh_t)x.out16_b;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e_ = threadIdx.x + 512 * i, r = e_ >> 6, uc = e_ & 63, u = n0 + uc, m = m0 + r;
+        const int off = r * LDT + uc;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KW; q += 4) v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
+        if (m >= g.M) continue;
+        const float dh = (v + dha[i]) + dhb[i];
+        const float tc = tanhf(cc[i]);
+        const float dct = dci[i] + dh * go[i] * (1.f - tc * tc);
+        float d[4];
+        d[0] = dct * gj[i] * gi[i] * (1.f - gi[i]);
+        d[1] = dct * gi[i] * (1.f - gj[i] * gj[i]);
+        d[2] = dct * cp[i] * gff[i] * (1.f - gff[i]);
+        d[3] = dh * tc * go[i] * (1.f - go[i]);
+        const gf_t dr = (gf_t)g.dgates + (size_t)m * K + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dr[(size_t)q * g.Hd] = d[q];
+            if (d16) d16[(size_t)m * K + u + (size_t)q * g.Hd] = bf16_bits(d[q]);
+        }
+        ((gf_t)g.dc_prev)[(size_t)m * g.Hd + u] = dct * gff[i];
+        if (g.dgx_out) {
+            const gf_t so = (gf_t)g.dgx_out + (size_t)m * K + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float sv = sx[i][q] + d[q];
+                so[(size_t)q * g.Hd] = sv;
+                if (s16) s16[(size_t)m * K + u + (size_t)q * g.Hd] = bf16_bits(sv);
+            }
+        }
+    }
+}
+
+extern "C" int air_lstm_step_fwd_bf16(const float *h_prev, const void *h_prev_bf16, const float *c_prev, const void *w_h_bf16,
+                                      int ldw, const float *gx, int ldgx, float *h, void *h_bf16, float *c, float *gate_act,
+                                      int M, int Hd, float forget_bias, void *stream) {
+    AIR_REQUIRE(h_prev && c_prev && w_h_bf16 && gx && h && c && gate_act, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0 && Hd % 64 == 0 && ldw >= 4 * Hd && ldw % 4 == 0 && ldgx >= 4 * Hd, AIR_E_SHAPE);
+    AIR_REQUIRE(air_aligned16(h_prev) && ((uintptr_t)w_h_bf16 % 8 == 0) && (!h_prev_bf16 || (uintptr_t)h_prev_bf16 % 16 == 0), AIR_E_ALIGN);
+    LstmFwdArgs g;
+    g.h_prev = h_prev; g.w_h = nullptr; g.gx = gx; g.c_prev = c_prev; g.h = h; g.c = c; g.gate_act = gate_act;
+    g.M = M; g.Hd = Hd; g.ldw = ldw; g.ldgx = ldgx; g.vecA = 1; g.ldh = Hd; g.ldc = Hd; g.fb = forget_bias;
+    g.tiles = air_cdiv(M, 16) * (Hd / 64);
+    const Lstm16 x = {w_h_bf16, h_prev_bf16, h_bf16, nullptr};
+    hipLaunchKernelGGL(lstm_fwd_wide16_kernel, dim3(g.tiles), dim3(512), 0, air_stream(stream), g, x);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_lstm_step_bwd_bf16(const float *dgates_next, const void *dgates_next_bf16, const void *w_h_bf16,
+                                      const float *dh_a, const float *dh_b, const float *dc_in, const float *gate_act,
+                                      const float *c_prev, const float *c, const float *dgx_in, float *dgates,
+                                      void *dgates_bf16, float *dc_prev, float *dgx_out, void *dgx_bf16, int M, int Hd,
+                                      void *stream) {
+    AIR_REQUIRE(dgates_next && w_h_bf16 && gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0 && Hd % 64 == 0, AIR_E_SHAPE);
+    AIR_REQUIRE(air_aligned16(dgates_next) && ((uintptr_t)w_h_bf16 % 16 == 0) &&
+                    (!dgates_next_bf16 || (uintptr_t)dgates_next_bf16 % 16 == 0), AIR_E_ALIGN);
+    LstmBwdArgs g;
+    g.dgates_next = dgates_next; g.w_h = nullptr; g.dh_a = dh_a; g.dh_b = dh_b; g.dc_in = dc_in; g.gate_act = gate_act;
+    g.c_prev = c_prev; g.c = c; g.dgx_in = dgx_in; g.dgates = dgates; g.dc_prev = dc_prev; g.dgx_out = dgx_out;
+    g.M = M; g.Hd = Hd; g.vecA = 1; g.vecB = 1;
+    const Lstm16 x = {w_h_bf16, dgates_next_bf16, dgates_bf16, dgx_bf16};
+    hipLaunchKernelGGL(lstm_bwd_wide16_kernel, dim3(air_cdiv(M, 16) * (Hd / 64)), dim3(512), 0, air_stream(stream), g, x);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 template <bool BF>

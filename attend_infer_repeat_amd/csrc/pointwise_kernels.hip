@@ -40,7 +40,7 @@ __device__ __forceinline__ void lstm_pw_bwd_body(const float *__restrict__ gate_
                                                  const float *__restrict__ c, const float *__restrict__ dh,
                                                  const float *__restrict__ dh2, const float *__restrict__ dc_in,
                                                  float *__restrict__ dgates, float *__restrict__ dc_prev, int M, int Hd,
-                                                 int vblock, int vgrid) {
+                                                 int vblock, int vgrid, unsigned short *__restrict__ dgates16 = nullptr) {
     const size_t n = (size_t)M * Hd;
     for (size_t e = (size_t)vblock * PW_THREADS + threadIdx.x; e < n; e += (size_t)vgrid * PW_THREADS) {
         const size_t m = e / Hd, u = e - m * Hd;
@@ -55,7 +55,25 @@ __device__ __forceinline__ void lstm_pw_bwd_body(const float *__restrict__ gate_
         dr[2 * (size_t)Hd + u] = dct * c_prev[e] * gf * (1.f - gf);
         dr[3 * (size_t)Hd + u] = dhe * tc * go * (1.f - go);
         dc_prev[e] = dct * gf;
+        if (dgates16) {                                       // bf16 mirror of dgates (bf16 data path: the weight gradient and the
+            unsigned short *d16 = dgates16 + m * 4 * (size_t)Hd;                        // next BPTT link read it)
+            d16[u] = __builtin_bit_cast(unsigned short, (__bf16)dr[u]);
+            d16[Hd + u] = __builtin_bit_cast(unsigned short, (__bf16)dr[Hd + u]);
+            d16[2 * (size_t)Hd + u] = __builtin_bit_cast(unsigned short, (__bf16)dr[2 * (size_t)Hd + u]);
+            d16[3 * (size_t)Hd + u] = __builtin_bit_cast(unsigned short, (__bf16)dr[3 * (size_t)Hd + u]);
+        }
     }
+}
+__global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_mirror_kernel(const float *__restrict__ gate_act,
+                                                                        const float *__restrict__ c_prev,
+                                                                        const float *__restrict__ c,
+                                                                        const float *__restrict__ dh,
+                                                                        const float *__restrict__ dh2,
+                                                                        const float *__restrict__ dc_in,
+                                                                        float *__restrict__ dgates,
+                                                                        float *__restrict__ dc_prev, int M, int Hd,
+                                                                        unsigned short *__restrict__ dgates16) {
+    lstm_pw_bwd_body(gate_act, c_prev, c, dh, dh2, dc_in, dgates, dc_prev, M, Hd, blockIdx.x, gridDim.x, dgates16);
 }
 __global__ __launch_bounds__(PW_THREADS) void lstm_pw_bwd_kernel(const float *__restrict__ gate_act,
                                                                  const float *__restrict__ c_prev,
@@ -100,6 +118,17 @@ extern "C" int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev
     AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
     hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(pw_blocks((size_t)M * Hd)), dim3(PW_THREADS), 0, air_stream(stream),
                        gate_act, c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_lstm_pointwise_bwd_bf16(const float *gate_act, const float *c_prev, const float *c, const float *dh,
+                                           const float *dh2, const float *dc, float *dgates, void *dgates_bf16, float *dc_prev,
+                                           int M, int Hd, void *stream) {
+    AIR_REQUIRE(gate_act && c_prev && c && dgates && dc_prev && dgates_bf16, AIR_E_NULL);
+    AIR_REQUIRE(dh || dc, AIR_E_NULL);
+    AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(lstm_pw_bwd_mirror_kernel, dim3(pw_blocks((size_t)M * Hd)), dim3(PW_THREADS), 0, air_stream(stream),
+                       gate_act, c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd, (unsigned short *)dgates_bf16);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

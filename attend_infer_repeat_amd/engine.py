@@ -360,6 +360,9 @@ class AIREngine:
         # epilogues produce, the observation batch converted at the start of the step -- see _apply_bf16_mirrors
         use16 = prec == 1 and throughput and os.environ.get("AIR_BF16_STORAGE", "1") == "1"
         self._use16 = use16
+        if use16:
+            self._alloc_bf16_mirrors()
+        m16 = self._mirror_ptr if use16 else (lambda t: None)
 
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
@@ -556,6 +559,13 @@ class AIREngine:
                 fwd.append(None)        # placeholder: the first step carries the step prologue (filled in per plan below)
                 lstm0_index = len(fwd) - 1
                 continue
+            if fuse_lstm_fwd and use16 and not fuse_lstm and self._lstm16_ok():
+                # bf16 data path: W_h from the shadow, h_t from its mirror (h_0 = the tiled initial state has none)
+                fwd.append((L.air_lstm_step_fwd_bf16, (p(self.h_seq[t]), m16(self.h_seq[t]), p(self.c_seq[t]), m16(w_h), 4 * Hd,
+                                                       p(self.gx), 4 * Hd, p(self.h_seq[t + 1]), m16(self.h_seq[t + 1]),
+                                                       p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd, 1.0),
+                            "air_lstm_step_fwd_bf16"))
+                continue
             if fuse_lstm_fwd:
                 fwd.append((L.air_lstm_step_fwd, (p(self.h_seq[t]), p(self.c_seq[t]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,
                                                   p(self.h_seq[t + 1]), p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd,
@@ -733,7 +743,24 @@ class AIREngine:
         dgx = self.dgx if T > 1 else self.dgates[0]            # sum over time of dgates (what the hoisted x.W_x receives)
         rider_hosts = []                    # (index in bwd, entry with an optimiser slice): see _plan_bwd_riders below
         fuse_lstm_bwd = fuse_lstm_fwd            # (the library picks the 16-wave or the wide-tile form of the link by size)
+        lstm16 = use16 and fuse_lstm_bwd and not fuse_lstm and self._lstm16_ok()
         for t in reversed(range(T)):
+            if lstm16 and t == T - 1:
+                bwd.append((L.air_lstm_pointwise_bwd_bf16, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
+                                                            p(self.dH[t]), p(self.dH_b[t]), None, p(self.dgates[t]),
+                                                            m16(self.dgates[t]), p(dc_out), B, Hd),
+                            "air_lstm_pointwise_bwd_bf16"))
+                dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
+                continue
+            if lstm16:
+                bwd.append((L.air_lstm_step_bwd_bf16, (p(self.dgates[t + 1]), m16(self.dgates[t + 1]), m16(w_h), p(self.dH[t]),
+                                                       p(self.dH_b[t]), p(dc_in), p(self.gate_act[t]), p(self.c_seq[t]),
+                                                       p(self.c_seq[t + 1]),
+                                                       p(self.dgates[T - 1]) if t == T - 2 else p(self.dgx),
+                                                       p(self.dgates[t]), m16(self.dgates[t]), p(dc_out), p(self.dgx),
+                                                       m16(self.dgx), B, Hd), "air_lstm_step_bwd_bf16"))
+                dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
+                continue
             if t == T - 1 or not fuse_lstm_bwd:
                 pw_args = (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]), p(self.dH[t]), p(self.dH_b[t]),
                            p(dc_in) if dc_in is not None else None, p(self.dgates[t]), p(dc_out), B, Hd)
@@ -904,47 +931,72 @@ class AIREngine:
         # ... or, better, the two-lane form of the whole step (None where it does not apply)
         self._plan_two_lane = self._build_two_lane_step()
 
-    def _apply_bf16_mirrors(self, plans):
-        """bf16 data path: give every GEMM descriptor of `plans` the bf16 mirrors of its operands and of its output.
-
-        Mirrored buffers (same shape, bf16): the flat parameter buffer (`flat_params16`: refreshed by every writer of the
-        parameters -- the optimiser launch, load_parameters / init / load_state_dict), the observation batch (`obs16`: a convert
-        launch at the start of every forward), and the activations / gradients whose ONLY writers are GEMM epilogues -- each
-        MLP's layer outputs and the hidden-layer gradients of the chains that GEMMs produce end to end (the library writes the
-        mirror of C on every bf16 code path when the descriptor names one).  Whatever a non-GEMM kernel writes (LSTM state,
-        sampled latents, glimpses, the gradients the loss kernels hand to the chains) has no mirror: those operands are
-        fetched as fp32 and rounded in registers, as before.  The values a product sees are identical either way (the mirror
-        holds bf16(x), the register path computes bf16(x)); only the bytes moved change.
-        Returns the launches that must precede a forward (the conversion of obs)."""
-        L, p = H.lib(), H._p
-        dev = self.device
-        if getattr(self, "flat_params16", None) is None:
-            self.flat_params16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
-            self.obs16 = torch.zeros(self.obs.shape, dtype=torch.bfloat16, device=dev)
-            self._mirror_of = {}
+    def _alloc_bf16_mirrors(self):
+        """bf16 mirrors (same shape) of every buffer ALL of whose writers keep the mirror up to date -- see _apply_bf16_mirrors"""
+        if getattr(self, "_mirror_spans", None) is not None:
+            return
+        dev, bf = self.device, torch.bfloat16
+        self.flat_params16 = torch.zeros(self.n_total, dtype=bf, device=dev)
+        self.obs16 = torch.zeros(self.obs.shape, dtype=bf, device=dev)
+        self.h_seq16 = torch.zeros(self.h_seq.shape, dtype=bf, device=dev)
+        self.dgates16 = torch.zeros(self.dgates.shape, dtype=bf, device=dev)
+        self.dgx16 = torch.zeros(self.dgx.shape, dtype=bf, device=dev)
+        self._mirror_of = {}
         trusted = [(self.flat_params, self.flat_params16), (self.obs, self.obs16)]
-        mlps = [self.enc, self.tr, self.st, self.ge, self.gd, self.bl]
+        # the LSTM's products: h_1..h_T (h_0 is the tiled initial state, written by the prologue: no mirror), dgates, running dgx
+        lstm16 = self._lstm16_ok()
+        if lstm16:
+            trusted += [(self.h_seq[1:], self.h_seq16[1:]), (self.dgates, self.dgates16)]
+            if self.T > 1:
+                trusted.append((self.dgx, self.dgx16))
         gemm_made = []
-        for m in mlps:
+        for m in (self.enc, self.tr, self.st, self.ge, self.gd, self.bl):
             gemm_made += list(m.out)
         for m in (self.enc, self.ge, self.gd, self.bl):      # (transform / steps: attend_bwd writes part of their gradient chain)
             gemm_made += list(m.g[:-1])
         gemm_made += [self.ge.g[-1], self.enc.g[-1]]
         for t in gemm_made:
-            if t.data_ptr() not in self._mirror_of:
-                self._mirror_of[t.data_ptr()] = torch.zeros(t.shape, dtype=torch.bfloat16, device=dev)
+            self._mirror_of[t.data_ptr()] = torch.zeros(t.shape, dtype=bf, device=dev)
             trusted.append((t, self._mirror_of[t.data_ptr()]))
-        spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel(), m16.data_ptr()) for t, m16 in trusted]
+        self._gemm_made = gemm_made
+        self._mirror_spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel(), m16.data_ptr()) for t, m16 in trusted]
+
+    def _lstm16_ok(self):
+        """the shapes air_lstm_step_*_bf16 take (the library's wide-tile LSTM form)"""
+        Hd, E = self.cfg.n_hidden, int(self.cfg.inpt_encoder_hidden[-1])
+        return (((self.B + 15) // 16) * ((Hd + 15) // 16) > 512 and Hd % 64 == 0 and E % 4 == 0
+                and os.environ.get("AIR_FUSE_LSTM_WIDE", "1") == "1" and os.environ.get("AIR_BF16_LSTM", "1") == "1")
+
+    def _mirror_ptr(self, t):
+        """address of the bf16 mirror of tensor / address `t` (None if it has none)"""
+        ptr = t.data_ptr() if torch.is_tensor(t) else (int(t) if t else 0)
+        if not ptr:
+            return None
+        for lo, hi, base16 in self._mirror_spans:
+            if lo <= ptr < hi:
+                return ctypes.c_void_p(base16 + (ptr - lo) // 2)
+        return None
+
+    def _apply_bf16_mirrors(self, plans):
+        """bf16 data path: give every GEMM descriptor of `plans` the bf16 mirrors of its operands and of its output.
+
+        Mirrored buffers (same shape, bf16): the flat parameter buffer (`flat_params16`: refreshed by every writer of the
+        parameters -- the optimiser launch, load_parameters / init / load_state_dict), the observation batch (`obs16`: a convert
+        launch at the start of every forward), the activations / gradients whose ONLY writers are GEMM epilogues -- each
+        MLP's layer outputs and the hidden-layer gradients of the chains that GEMMs produce end to end (the library writes the
+        mirror of C on every bf16 code path when the descriptor names one) -- and the LSTM's h_1..h_T, dgates and running dgx
+        (air_lstm_step_*_bf16 write them).  Whatever another kernel writes (sampled latents, glimpses, the gradients the loss
+        kernels hand to the chains, the tiled initial state) has no mirror: those operands are fetched as fp32 and rounded in
+        registers, as before.  The values a product sees are identical either way (the mirror
+        holds bf16(x), the register path computes bf16(x)); only the bytes moved change.
+        Returns the launches that must precede a forward (the conversion of obs)."""
+        L, p = H.lib(), H._p
+        out_spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel()) for t in self._gemm_made]
 
         def mirror(ptr):
-            if not ptr:
-                return None
-            for lo, hi, base16 in spans:
-                if lo <= ptr < hi:
-                    return base16 + (ptr - lo) // 2
-            return None
+            m = self._mirror_ptr(ptr)
+            return m.value if m is not None else None
 
-        out_spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel()) for t in gemm_made]
         for plan in plans:
             for e in plan:
                 if e is None or e[2] != "air_gemm_grouped":

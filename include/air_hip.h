@@ -224,6 +224,19 @@ int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const floa
                           const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                           const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
                           const AirRmspropSlice *opt, void *stream);
+/* The recurrence on the bf16 DATA path (throughput regime: more than 512 16x16 tiles of (batch, hidden), Hd % 64 == 0): W_h is
+ * read from the bf16 shadow of the parameters (w_h_bf16: same layout as w_h), h_prev / dgates_next from their bf16 mirrors when
+ * given (NULL: the fp32 buffer, rounded in registers), products on v_mfma_f32_16x16x32_bf16; h_bf16 / dgates_bf16 / dgx_bf16
+ * (optional) receive the mirrors of the outputs.  Otherwise exactly air_lstm_step_fwd / air_lstm_step_bwd / air_lstm_pointwise_bwd. */
+int air_lstm_step_fwd_bf16(const float *h_prev, const void *h_prev_bf16, const float *c_prev, const void *w_h_bf16, int ldw,
+                           const float *gx, int ldgx, float *h, void *h_bf16, float *c, float *gate_act, int M, int Hd,
+                           float forget_bias, void *stream);
+int air_lstm_step_bwd_bf16(const float *dgates_next, const void *dgates_next_bf16, const void *w_h_bf16, const float *dh_a,
+                           const float *dh_b, const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
+                           const float *dgx_in, float *dgates, void *dgates_bf16, float *dc_prev, float *dgx_out,
+                           void *dgx_bf16, int M, int Hd, void *stream);
+int air_lstm_pointwise_bwd_bf16(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
+                                const float *dc, float *dgates, void *dgates_bf16, float *dc_prev, int M, int Hd, void *stream);
 int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
                                const float *dc, float *dgates, float *dc_prev, int M, int Hd, const AirRmspropSlice *opt,
                                void *stream);

@@ -514,8 +514,10 @@ def test_two_lane_step_equals_linear_plan(gpu_device, monkeypatch, name, capture
     p0 = eng_a.flat_params.clone()
     eng_a.train_step(); eng_b.train_step()
     eng_a.synchronize(); eng_b.synchronize()
-    for k in ("noise_normal", "u_pres", "presence", "rec", "final_canvas"):          # the forward is the same launches
+    for k in ("noise_normal", "u_pres", "presence"):                                  # same noise stream, same discrete draws
         assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    for k in ("rec", "final_canvas", "what", "where"):                               # (a product that left a grouped launch may
+        assert rel_err(getattr(eng_a, k), getattr(eng_b, k)) < 1e-5, k               #  reduce in another order)
     ga, gb = eng_a.named_grads(), eng_b.named_grads()
     for k in ga:
         assert rel_err(ga[k], gb[k]) < 1e-5, (k, rel_err(ga[k], gb[k]))

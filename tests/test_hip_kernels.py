@@ -828,3 +828,53 @@ def test_gemm_wide_tiles(hip, precision, layout):
         outs = hip.gemm_grouped([dict(A=x3[:, :48], B=g3, ta=True, colsum=True), dict(A=x2, B=g2, ta=True)], precision=precision)
         assert_close(outs[0][0], r(x3[:, :48]).t() @ r(g3), 1e-5, atol * 10, "dW, lda = 50")
         assert_close(outs[0][1], g3.cpu().double().sum(0), 1e-5, 1e-3, "db")
+
+
+@pytest.mark.parametrize("mirror_in", [False, True])
+def test_lstm_steps_on_the_bf16_data_path(hip, mirror_in):
+    """air_lstm_step_fwd_bf16 / air_lstm_step_bwd_bf16 / air_lstm_pointwise_bwd_bf16 (W_h from the bf16 shadow, h_prev / dgates_next
+    from mirrors or from fp32, v_mfma_f32_16x16x32_bf16) against the entries that fetch fp32 and round in registers
+    (precision = bf16): the operands a product sees are identical, so the results agree to summation order, and every mirror the
+    kernels write is exactly bf16 of the fp32 output next to it."""
+    import ctypes
+    from attend_infer_repeat_amd import hip as H
+    L, P = H.lib(), H._p
+    gen = torch.Generator().manual_seed(17)
+    rn = lambda *s_: torch.randn(*s_, generator=gen).cuda()
+    M, Hd = 1024, 256
+    h_prev, c_prev, gx = rn(M, Hd) * 0.5, rn(M, Hd), rn(M, 4 * Hd)
+    w_h = rn(Hd, 4 * Hd) / 16
+    w16, h16_in = w_h.to(torch.bfloat16), h_prev.to(torch.bfloat16)
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    v = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    h_ref, c_ref, act_ref = hip.lstm_step_fwd(h_prev, c_prev, w_h, gx, precision=1)
+    h, c, act = torch.empty_like(c_prev), torch.empty_like(c_prev), torch.empty_like(gx)
+    h16 = torch.zeros(M, Hd, dtype=torch.bfloat16, device="cuda")
+    st = L.air_lstm_step_fwd_bf16(P(h_prev), v(h16_in if mirror_in else None), P(c_prev), v(w16), 4 * Hd, P(gx), 4 * Hd, P(h), v(h16),
+                                  P(c), P(act), M, Hd, 1.0, sp)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert_close(h, h_ref, 1e-4, 1e-5, "h"); assert_close(c, c_ref, 1e-4, 1e-5, "c"); assert_close(act, act_ref, 1e-4, 1e-5, "gate_act")
+    assert torch.equal(h16, h.to(torch.bfloat16))
+    # one BPTT link
+    dg_next, dh_a, dh_b, dc_in, dgx_in = rn(M, 4 * Hd), rn(M, Hd), rn(M, Hd), rn(M, Hd), rn(M, 4 * Hd)
+    dg_ref, dcp_ref, dgx_ref = hip.lstm_step_bwd(dg_next, w_h, dh_a, dh_b, dc_in, act_ref, c_prev, c_ref, dgx_in=dgx_in, want_dgx=True,
+                                                 precision=1)
+    dg, dcp, dgx = torch.empty_like(gx), torch.empty_like(c_prev), torch.empty_like(gx)
+    dg16 = torch.zeros(M, 4 * Hd, dtype=torch.bfloat16, device="cuda"); dgx16 = torch.zeros_like(dg16)
+    dgn16 = dg_next.to(torch.bfloat16)
+    st = L.air_lstm_step_bwd_bf16(P(dg_next), v(dgn16 if mirror_in else None), v(w16), P(dh_a), P(dh_b), P(dc_in), P(act_ref), P(c_prev),
+                                  P(c_ref), P(dgx_in), P(dg), v(dg16), P(dcp), P(dgx), v(dgx16), M, Hd, sp)
+    assert st == 0
+    torch.cuda.synchronize()
+    scale = dg_ref.abs().max().item()
+    assert_close(dg, dg_ref, 1e-4, 1e-5 * scale, "dgates"); assert_close(dcp, dcp_ref, 1e-4, 1e-5 * scale, "dc_prev")
+    assert_close(dgx, dgx_ref, 1e-4, 1e-5 * scale, "dgx")
+    assert torch.equal(dg16, dg.to(torch.bfloat16)) and torch.equal(dgx16, dgx.to(torch.bfloat16))
+    # the pointwise backward of the last step with its mirror
+    pw_ref = torch.empty_like(gx); pw_dc = torch.empty_like(c_prev)
+    assert L.air_lstm_pointwise_bwd(P(act_ref), P(c_prev), P(c_ref), P(dh_a), P(dh_b), None, P(pw_ref), P(pw_dc), M, Hd, sp) == 0
+    pw, pw_dc2, pw16 = torch.empty_like(gx), torch.empty_like(c_prev), torch.zeros(M, 4 * Hd, dtype=torch.bfloat16, device="cuda")
+    assert L.air_lstm_pointwise_bwd_bf16(P(act_ref), P(c_prev), P(c_ref), P(dh_a), P(dh_b), None, P(pw), v(pw16), P(pw_dc2), M, Hd, sp) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pw, pw_ref) and torch.equal(pw_dc, pw_dc2) and torch.equal(pw16, pw.to(torch.bfloat16))
