@@ -51,7 +51,7 @@ def main():
                         "WRITE_SIZE_KiB": round(write_kib, 3), "fetch_bytes_corrected": int(fetch_kib * 1024 * 2),
                         "write_bytes": int(write_kib * 1024),
                         "traffic_bytes": int(fetch_kib * 1024 * 2 + write_kib * 1024)}
-    print(json.dumps({"_note": __doc__.strip().split("\n\n")[1].replace("\n", " "), "build_digest": a.digest,
+    print(json.dumps({"_note": __doc__.strip().split("\n\n")[2].replace("\n", " "), "build_digest": a.digest,
                       "shape": a.shape, "kernels": kernels}, indent=1))
 
 

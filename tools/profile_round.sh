@@ -51,8 +51,8 @@ if [ "$MODE" = pmc ] || [ "$MODE" = all ]; then
   # kernel trace + per-position picture of the replayed step at every named shape
   rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $PY --no-cpu-baseline --no-sweep > "$OUT/${TAG}_bench_c2_b64_profiled.json" 2> "$OUT/trace.log"
   python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --steps 2600 > "$OUT/${TAG}_bench_c2_b64_kernel_stats.txt"
-  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --by-position step_epilogue_kernel --every ${EVERY:-4} > "$OUT/${TAG}_positions_c2_b64.txt"
-  EVERY_C4=${EVERY:-4} positions c4_b64 --config c4
+  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --by-position step_epilogue_kernel --every ${EVERY:-1} > "$OUT/${TAG}_positions_c2_b64.txt"
+  EVERY_C4=${EVERY:-1} positions c4_b64 --config c4
   positions c5_b1024 --config c5
   positions c2_b1024_f32 --batch 1024
   rm -rf "$OUT"/trace "$OUT"/pmc_*/   # the SQLite traces are large; the text summaries are what travels back
