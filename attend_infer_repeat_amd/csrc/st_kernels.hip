@@ -1088,7 +1088,7 @@ extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *wher
     const size_t lds = lds_f > lds_b ? lds_f : lds_b;
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     // one launch only pays while both roles fit the chip side by side (the latency regime); beyond that the two launches
-    AIR_REQUIRE((long)B * NB <= 2048 && (long)B * T <= 2048, AIR_E_UNSUPPORTED);
+    AIR_REQUIRE((long)B * NB <= 4096 && (long)B * T <= 4096, AIR_E_UNSUPPORTED);
     const int vec4g = ((h * w) % 4 == 0) && air_aligned16(glimpse);
     const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
     { int st_ = st_allow_lds(canvas_fused_kernel, lds); if (st_) return st_; }
@@ -1097,7 +1097,8 @@ extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *wher
     const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c};
     const int n_fwd = B * NB;
-    hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B), dim3(512), lds, air_stream(stream), f, b, n_fwd);
+    const int fthreads = (long)B * T <= 512 ? 512 : ST_THREADS;      // (as the two-launch form: 256-thread workgroups once the chip is full)
+    hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B), dim3(fthreads), lds, air_stream(stream), f, b, n_fwd);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

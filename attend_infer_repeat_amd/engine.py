@@ -656,7 +656,8 @@ class AIREngine:
         # train step's forward list then ends before the canvas; NVIL, which needs the forward's reconstruction shares, rides on
         # the next pointwise launch (air_gauss_sample_bwd_nvil) and the baseline's backward, which needs NVIL, rides with the
         # three launches after that (what / glimpse-encoder backward) instead of the decoder's.  35 -> 34 dependent launches.
-        fuse_canvas = (cfg.use_reinforce and not throughput and B * NB <= 2048 and M <= 2048
+        fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
+                       and B * NB <= 4096 and M <= 4096
                        and os.environ.get("AIR_FUSE_CANVAS", "1") == "1" and os.environ.get("AIR_TWO_LANE", "0") != "1")
         bl_chain = dict(m=self.bl, g_last=self.dbase,
                         x_parts=[(self.obs, P, 0, P), (self.base_lat, cfg.baseline_in - P, P, cfg.baseline_in - P)])

@@ -107,7 +107,7 @@ int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const f
 /* Canvas forward (banded, as air_canvas_unroll_fwd_banded) and backward (as air_canvas_unroll_bwd with final_canvas = NULL: every
  * (t, b) unit re-forms the canvas on its own footprint, bit-identically to the forward, so it reads nothing the forward writes) as
  * the two roles of ONE launch: one dependent launch less on the train step's chain at small batch.  The NVIL objective, which
- * needs the forward's reconstruction shares, then rides on air_gauss_sample_bwd_nvil.  B * n_bands and B * T at most 2048.       */
+ * needs the forward's reconstruction shares, then rides on air_gauss_sample_bwd_nvil.  B * n_bands and B * T at most 4096.       */
 int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
                               float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands, float *dglimpse,
                               float *dwhere, int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
