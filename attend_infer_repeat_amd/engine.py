@@ -364,8 +364,15 @@ class AIREngine:
             self._alloc_bf16_mirrors()
         m16 = self._mirror_ptr if use16 else (lambda t: None)
 
+        harvest = [False]      # True: launch() only records its problems, one entry per call (see the fused canvas launch below)
+
         def launch(plan, descs, allow_splitk=False):
             """one dispatch for all `descs` (a lone long-K problem may use the split-K single-GEMM entry instead)"""
+            if harvest[0]:
+                arr = (_lib.AirGemmDesc * len(descs))(*descs)
+                self._keep.append(arr)
+                plan.append((L.air_gemm_grouped, (arr, len(descs)), "air_gemm_grouped"))
+                return
             if defer_dw and plan is bwd:
                 deferred_dw.extend(d for d in descs if d.ta and not d.tb)
                 descs = [d for d in descs if not (d.ta and not d.tb)]
@@ -664,7 +671,9 @@ class AIREngine:
         bl_levels = [[], [], []]
         if fuse_canvas:
             tmp = []
-            mlp_bwd_multi(tmp, [bl_chain])                 # the baseline's backward, launch by launch, to ride later launches
+            harvest[0] = True
+            mlp_bwd_multi(tmp, [bl_chain])                 # the baseline's backward, level by level, to ride later launches
+            harvest[0] = False
             lv = [list(e[1][0]) for e in tmp]
             # one level per launch, in order: the `what` backward, the glimpse encoder's first level, its last level
             slots = 1 + min(self.ge.n, 2)

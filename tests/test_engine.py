@@ -91,6 +91,9 @@ CONFIGS = {
     "b1": (O.tiny_config(step_bias=0.3, explore_eps=1e-3, output_multiplier=0.5, output_std=0.3,
                          transform_var_bias=0.5), 1),
     "mnist_b17": (O.AIRConfig(), 17),
+    # a 512-wide first hidden layer at batch 32: the consumer of the K-split obs products then has a LONG K itself (K = 512 >= 8 x
+    # min(B, N)); the library must keep it on the A-prologue kernel instead of refusing the launch
+    "enc512_b32": (O.AIRConfig(inpt_encoder_hidden=(512, 256)), 32),
     # the sizes the metric is quoted on: BASELINE configs[1] (scripts/multi_mnist.py:24-37: 50x50 / 20x20 / T=3, batch 64) and
     # configs[3] (100x100 canvas, 28x28 glimpse, T=5) at the same batch
     "mnist_b64": (O.AIRConfig(), 64),
