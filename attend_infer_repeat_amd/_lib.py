@@ -85,6 +85,8 @@ SIGNATURES = {
                                      P, c_float, P, c_int, c_int, c_int, P]),
     "air_gauss_sample_bwd_nvil": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
                                           P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, P]),
+    "air_canvas_unroll_image": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                        c_float, P]),
     "air_canvas_unroll_fwd_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_float, c_float, c_float, P]),
     "air_normal_kl_fwd": (c_int, [P, P, c_float, c_float, c_float, c_float, P, c_int, c_int, P]),

@@ -854,6 +854,236 @@ __global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, Writ
     }
 }
 
+// Throughput regime: canvas forward AND backward of one image in ONE workgroup (air_canvas_unroll_image).  Everything an image
+// needs is staged once -- its T glimpses, `where` rows, presences, the axis tables of every step -- and the canvas itself lives in
+// LDS: the forward visits only each glimpse's FOOTPRINT (work proportional to the footprint, not to the canvas: pixels outside
+// it would add exactly +0), copies the running canvas out after every step, forms the reconstruction term and dcanvas in place,
+// and the backward of the T glimpses follows on the same LDS image (pixel pass, column contraction, row contraction, exactly as
+// st_write_bwd_body).  Per image 10 KB of obs + 4.8 KB of glimpses are read ONCE (the two-launch form reads obs twice and the final
+// canvas T times more), nothing is recomputed.  Same arithmetic in the same order as the two kernels it replaces => the same bits.
+struct ImageCarve {
+    float *glm, *cv, *go, *t1, *X, *Y, *pres, *scratch;
+    float2 *xe, *ye;
+    int2 *jr, *ir;
+    int hwp;
+};
+__device__ __forceinline__ ImageCarve carve_image(float *smem, int T, int H, int W, int h, int w) {
+    ImageCarve c;
+    float *p = smem;
+    c.hwp = (h * w + 3) & ~3;
+    c.glm = p; p += (size_t)T * c.hwp;
+    c.cv = p; p += (H * W + 3) & ~3;
+    c.go = p; p += (H * W + 3) & ~3;
+    c.t1 = p; p += (H * w + 3) & ~3;
+    c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
+    c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * H;
+    c.jr = reinterpret_cast<int2 *>(p); p += 2 * w;
+    c.ir = reinterpret_cast<int2 *>(p); p += 2 * h;
+    c.X = p; p += (W + 3) & ~3;
+    c.Y = p; p += (H + 3) & ~3;
+    c.pres = p; p += (T + 3) & ~3;
+    c.scratch = p;
+    return c;
+}
+static inline size_t carve_image_bytes(int T, int H, int W, int h, int w) {
+    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + 2 * (size_t)((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 2 * (size_t)T * (W + H) +
+                            2 * w + 2 * h + ((W + 3) & ~3) + ((H + 3) & ~3) + ((T + 3) & ~3) + 160);
+}
+struct ImageArgs {
+    const float *glimpse, *where, *presence, *obs;
+    float *canvas_steps, *final_canvas, *rec, *dglimpse, *dwhere;
+    int T, B, H, W, h, w;
+    double stepX, stepY;
+    float mult, std, loss_scale;
+    int vec4_glimpse, vec4_canvas;
+};
+__global__ __launch_bounds__(ST_THREADS) void canvas_image_kernel(ImageArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w;
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+    ImageCarve c = carve_image(smem, T, H, W, h, w);
+    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
+    const float coef = a.loss_scale * a.mult / (a.std * a.std);
+    const float cst = 0.5f * logf(6.283185307179586f) + logf(a.std);
+    const float mult = a.mult, std = a.std;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (b != (int)blockIdx.x) __syncthreads();
+        // ---- stage the image's operands; axis tables of every step ---------------------------------------------------------------
+        if (a.vec4_glimpse) {
+            const int nq = hw >> 2;
+            for (int e = tid; e < T * nq; e += nt) {
+                const int t = e / nq, q = e - t * nq;
+                reinterpret_cast<float4 *>(c.glm + (size_t)t * c.hwp)[q] = reinterpret_cast<const float4 *>(a.glimpse + ((size_t)t * B + b) * hw)[q];
+            }
+        } else {
+            for (int e = tid; e < T * hw; e += nt) { const int t = e / hw, q = e - t * hw; c.glm[(size_t)t * c.hwp + q] = a.glimpse[((size_t)t * B + b) * hw + q]; }
+        }
+        for (int e = tid; e < T * (W + H); e += nt) {
+            const int t = e / (W + H), r = e - t * (W + H);
+            const float *wk = a.where + 4 * ((size_t)t * B + b);
+            if (r < W) {
+                const float sx = wk[0], tx = wk[1];
+                const float X = lin_m11(r, W, a.stepX);
+                if (t == 0) c.X[r] = X;
+                c.xe[t * W + r] = axis_entry2(grid_coord(1.0f / sx, X, -tx / sx, cxs), w);
+            } else {
+                const float sy = wk[2], ty = wk[3];
+                const int i = r - W;
+                const float Y = lin_m11(i, H, a.stepY);
+                if (t == 0) c.Y[i] = Y;
+                c.ye[t * H + i] = axis_entry2(grid_coord(1.0f / sy, Y, -ty / sy, cys), h);
+            }
+        }
+        if (tid < T) c.pres[tid] = a.presence ? a.presence[(size_t)tid * B + b] : 1.0f;
+        for (int p = tid; p < HW; p += nt) c.cv[p] = 0.f;
+        __syncthreads();
+        // ---- forward: each step adds its glimpse on its footprint (in step order: ((0 + p0 v0) + p1 v1) + ...), then the running
+        //      canvas is copied out ------------------------------------------------------------------------------------------------
+        for (int t = 0; t < T; ++t) {
+            const float2 *xe = c.xe + t * W, *ye = c.ye + t * H;
+            const float *src = c.glm + (size_t)t * c.hwp;
+            const int2 vx = valid_span(xe, W), vy = valid_span(ye, H);
+            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
+            const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
+            const float pr = c.pres[t];
+            for (int idx = tid; idx < npx; idx += nt) {
+                const int Ir = idx / fw, I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
+                const float2 ex = xe[J], ey = ye[I];
+                const float v = bilerp(load_taps_sel(src, h, w, __float_as_int(ey.x), __float_as_int(ex.x)), ex.y, ey.y);
+                c.cv[p] = c.cv[p] + pr * v;
+            }
+            __syncthreads();
+            if (a.canvas_steps) {
+                float *dst = a.canvas_steps + ((size_t)t * B + b) * HW;
+                if (a.vec4_canvas) for (int q = tid; q < (HW >> 2); q += nt) reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(c.cv)[q];
+                else for (int p = tid; p < HW; p += nt) dst[p] = c.cv[p];
+                if (t + 1 < T) __syncthreads();
+            }
+        }
+        // ---- final canvas, reconstruction term, dcanvas in place -------------------------------------------------------------------
+        {
+            const float *ob = a.obs + (size_t)b * HW;
+            float *fc = a.final_canvas ? a.final_canvas + (size_t)b * HW : nullptr;
+            float s[1] = {0.f};
+            for (int p = tid; p < HW; p += nt) {
+                const float cvp = c.cv[p], o = ob[p];
+                if (fc) fc[p] = cvp;
+                const float z = (o - mult * cvp) / std;
+                s[0] += 0.5f * z * z + cst;
+                c.cv[p] = coef * (mult * cvp - o);
+            }
+            if (a.rec) {
+                block_sum<1>(s, c.scratch);
+                if (tid == 0) a.rec[b] = s[0];
+            }
+        }
+        __syncthreads();
+        // ---- backward of every step on the same LDS image (as st_write_bwd_body, stored-canvas form) -----------------------------
+        for (int t = 0; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            const float2 *xe = c.xe + t * W, *ye = c.ye + t * H;
+            const float *src = c.glm + (size_t)t * c.hwp;
+            const float *wk = a.where + 4 * k;
+            const float sx = wk[0], tx = wk[1], sy = wk[2], ty = wk[3];
+            const float pres = c.pres[t];
+            const float bx = -tx / sx, by = -ty / sy;
+            const int2 vx = valid_span(xe, W), vy = valid_span(ye, H);
+            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
+            const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int idx = tid; idx < npx; idx += nt) {
+                const int Ir = idx / fw, I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
+                const float2 ex = xe[J], ey = ye[I];
+                const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);
+                const float dc = c.cv[p];
+                const float dx = ex.y, dy = ey.y;
+                const Taps tp = load_taps_sel(src, h, w, fy, fx);
+                const float v = bilerp(tp, dx, dy);
+                const float gx = dy * (tp.fc - tp.ff) + (1.f - dy) * (tp.cc - tp.cf);
+                const float gy = dx * (tp.cf - tp.ff) + (1.f - dx) * (tp.cc - tp.fc);
+                const float go = pres * dc;
+                const float gax = go * gx * cxs, gay = go * gy * cys;
+                acc[0] += gax * c.X[J]; acc[1] += gax;
+                acc[2] += gay * c.Y[I]; acc[3] += gay;
+                acc[4] += dc * v;
+                c.go[p] = go;
+            }
+            {
+                const float r = wave_reduce8(acc);
+                if ((lane & 7) == 0) c.scratch[wid * 8 + wave_reduce8_slot()] = r;
+            }
+            if (wid == nw - 1) for (int j = lane; j < w; j += 64) c.jr[j] = touch_range(xe, bx, sx, inv_cxs, j, W);
+            if (wid == (nw > 1 ? nw - 2 : 0)) for (int i = lane; i < h; i += 64) c.ir[i] = touch_range(ye, by, sy, inv_cys, i, H);
+            __syncthreads();
+            for (int e = tid; e < (fh > 0 ? fh : 0) * w; e += nt) {
+                const int Ir = e / w, I = I0 + Ir, j = e - Ir * w;
+                const int2 r = c.jr[j];
+                const float *grow = c.go + I * W;
+                float sacc = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int J = r.x + u;
+                    const bool in = J <= r.y;
+                    const int Jc = in ? J : r.x <= r.y ? r.x : 0;
+                    const float2 ex = xe[Jc];
+                    const float gv = grow[Jc];
+                    const int fx = __float_as_int(ex.x);
+                    const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
+                    if (in) sacc += gv * wgt;
+                }
+                for (int J = r.x + 4; J <= r.y; ++J) {
+                    const float2 ex = xe[J];
+                    const int fx = __float_as_int(ex.x);
+                    const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
+                    sacc += grow[J] * wgt;
+                }
+                c.t1[I * w + j] = sacc;
+            }
+            __syncthreads();
+            float *dg = a.dglimpse + k * hw;
+            for (int e = tid; e < hw; e += nt) {
+                const int i = e / w, j = e - i * w;
+                const int2 r = c.ir[i];
+                float sacc = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int I = r.x + u;
+                    const bool in = I <= r.y;
+                    const int Ic = in ? I : r.x <= r.y ? r.x : 0;
+                    const float2 ey = ye[Ic];
+                    const float tv = in ? c.t1[Ic * w + j] : 0.f;
+                    const int fy = __float_as_int(ey.x);
+                    const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
+                    if (in) sacc += tv * wgt;
+                }
+                for (int I = r.x + 4; I <= r.y; ++I) {
+                    const float2 ey = ye[I];
+                    const int fy = __float_as_int(ey.x);
+                    const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
+                    sacc += c.t1[I * w + j] * wgt;
+                }
+                dg[e] = sacc;
+            }
+            if (wid == nw - 1) {
+                float part[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[lane * 8 + q] : 0.f;
+                const float tot = wave_reduce8(part);
+                const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64);
+                if (lane == 0) {
+                    float *d = a.dwhere + 4 * k;
+                    d[0] = r0 * (-1.0f / (sx * sx)) + r1 * (tx / (sx * sx));
+                    d[1] = r1 * (-1.0f / sx);
+                    d[2] = r2 * (-1.0f / (sy * sy)) + r3 * (ty / (sy * sy));
+                    d[3] = r3 * (-1.0f / sy);
+                }
+            }
+            if (t + 1 < T) __syncthreads();
+        }
+    }
+}
+
 // ============================================================================================================
 // host side
 // ============================================================================================================
@@ -1099,6 +1329,31 @@ extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *wher
     const int n_fwd = B * NB;
     const int fthreads = (long)B * T <= 512 ? 512 : ST_THREADS;      // (as the two-launch form: 256-thread workgroups once the chip is full)
     hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B), dim3(fthreads), lds, air_stream(stream), f, b, n_fwd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// forward + backward of every image in ONE launch, one workgroup per image (throughput regime: the canvas stays in LDS between the
+// two; obs and the glimpses are read once).  rec[B] receives the complete per-sample reconstruction term (no row bands).
+extern "C" int air_canvas_unroll_image(const float *glimpse, const float *where, const float *presence, const float *obs,
+                                       float *canvas_steps, float *final_canvas, float *rec, float *dglimpse, float *dwhere,
+                                       int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
+                                       void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = st_check_dims(B, H, W, h, w);
+    if (st) return st;
+    const size_t lds = carve_image_bytes(T, H, W, h, w);
+    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
+    { int st_ = st_allow_lds(canvas_image_kernel, lds); if (st_) return st_; }
+    ImageArgs a;
+    a.glimpse = glimpse; a.where = where; a.presence = presence; a.obs = obs; a.canvas_steps = canvas_steps;
+    a.final_canvas = final_canvas; a.rec = rec; a.dglimpse = dglimpse; a.dwhere = dwhere;
+    a.T = T; a.B = B; a.H = H; a.W = W; a.h = h; a.w = w; a.stepX = lin_step(W); a.stepY = lin_step(H);
+    a.mult = mult; a.std = std; a.loss_scale = loss_scale;
+    a.vec4_glimpse = ((h * w) % 4 == 0) && air_aligned16(glimpse);
+    a.vec4_canvas = ((H * W) % 4 == 0) && (!canvas_steps || air_aligned16(canvas_steps));
+    hipLaunchKernelGGL(canvas_image_kernel, dim3(st_grid(B, 256 * 16)), dim3(ST_THREADS), lds, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

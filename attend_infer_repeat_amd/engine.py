@@ -663,8 +663,16 @@ class AIREngine:
         # train step's forward list then ends before the canvas; NVIL, which needs the forward's reconstruction shares, rides on
         # the next pointwise launch (air_gauss_sample_bwd_nvil) and the baseline's backward, which needs NVIL, rides with the
         # three launches after that (what / glimpse-encoder backward) instead of the decoder's.  35 -> 34 dependent launches.
-        fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
-                       and B * NB <= 4096 and M <= 4096
+        # Throughput regime: ONE workgroup per image runs forward and backward with the canvas resident in LDS
+        # (air_canvas_unroll_image); the two-role launch of the latency regime measured slower there (VALU bound chip-wide plus the
+        # recomputation: 0.594 against 0.580 ms at batch 1024).
+        hwp = (hw + 3) // 4 * 4
+        image_lds = 4 * (T * hwp + 2 * ((P + 3) // 4 * 4) + (Hi * wc + 3) // 4 * 4 + 2 * T * (Wi + Hi) + 2 * wc + 2 * hc + Wi + Hi + 176)
+        canvas_image = (cfg.use_reinforce and throughput and NB == 1 and image_lds <= 64 * 1024
+                        and os.environ.get("AIR_FUSE_CANVAS_IMAGE", "1") == "1")
+        self._canvas_image = canvas_image
+        fuse_canvas = (cfg.use_reinforce and (not throughput or canvas_image or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
+                       and (canvas_image or (B * NB <= 4096 and M <= 4096))
                        and os.environ.get("AIR_FUSE_CANVAS", "1") == "1" and os.environ.get("AIR_TWO_LANE", "0") != "1")
         bl_chain = dict(m=self.bl, g_last=self.dbase,
                         x_parts=[(self.obs, P, 0, P), (self.base_lat, cfg.baseline_in - P, P, cfg.baseline_in - P)])
@@ -683,7 +691,12 @@ class AIREngine:
                 lv = lv + [[]] * (3 - len(lv))
                 bl_levels = [lv[0], lv[1], lv[2]] if self.ge.n >= 2 else [lv[0], lv[1], []]
         self._fuse_canvas = fuse_canvas
-        if fuse_canvas:
+        if fuse_canvas and canvas_image:
+            bwd.append((L.air_canvas_unroll_image, (p(decoded), p(self.where), p(self.presence), p(self.obs), p(self.canvas_steps),
+                                                    p(self.final_canvas), p(self.rec_parts), p(self.gd.g[-1]), p(self.dwhere_w),
+                                                    T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std, inv_b),
+                        "air_canvas_unroll_image"))
+        elif fuse_canvas:
             bwd.append((L.air_canvas_unroll_fwd_bwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
                                                       p(self.canvas_steps), p(self.final_canvas), p(self.rec_parts), NB,
                                                       p(self.gd.g[-1]), p(self.dwhere_w), T, B, Hi, Wi, hc, wc,

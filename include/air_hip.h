@@ -112,6 +112,13 @@ int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const fl
                               float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands, float *dglimpse,
                               float *dwhere, int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                               void *stream);
+/* The same pair for the throughput regime: ONE workgroup per image runs the forward and then the backward of its T glimpses with
+ * the canvas resident in LDS (stored-canvas arithmetic: no recomputation; obs and the glimpses are read once; the forward visits
+ * only each glimpse's footprint).  rec[B] receives the complete reconstruction term per image (no row bands).  Bitwise the result
+ * of air_canvas_unroll_fwd + air_canvas_unroll_bwd.                                                                         */
+int air_canvas_unroll_image(const float *glimpse, const float *where, const float *presence, const float *obs,
+                            float *canvas_steps, float *final_canvas, float *rec, float *dglimpse, float *dwhere, int T, int B,
+                            int H, int W, int h, int w, float mult, float std, float loss_scale, void *stream);
 /* ---- dense layers -------------------------------------------------------------------------------------------
  * Replaces the TF MatMul/BiasAdd/Elu nodes under snt.Linear (neural.py:42-60) and snt.LSTM (mnist_model.py:35).   */
 
