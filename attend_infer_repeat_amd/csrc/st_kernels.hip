@@ -862,7 +862,7 @@ __global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, Writ
 // st_write_bwd_body).  Per image 10 KB of obs + 4.8 KB of glimpses are read ONCE (the two-launch form reads obs twice and the final
 // canvas T times more), nothing is recomputed.  Same arithmetic in the same order as the two kernels it replaces => the same bits.
 struct ImageCarve {
-    float *glm, *cv, *go, *t1, *X, *Y, *pres, *scratch;
+    float *glm, *cv, *t1, *X, *Y, *pres, *scratch;
     float2 *xe, *ye;
     int2 *jr, *ir;
     int hwp;
@@ -873,7 +873,6 @@ __device__ __forceinline__ ImageCarve carve_image(float *smem, int T, int H, int
     c.hwp = (h * w + 3) & ~3;
     c.glm = p; p += (size_t)T * c.hwp;
     c.cv = p; p += (H * W + 3) & ~3;
-    c.go = p; p += (H * W + 3) & ~3;
     c.t1 = p; p += (H * w + 3) & ~3;
     c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
     c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * H;
@@ -886,7 +885,7 @@ __device__ __forceinline__ ImageCarve carve_image(float *smem, int T, int H, int
     return c;
 }
 static inline size_t carve_image_bytes(int T, int H, int W, int h, int w) {
-    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + 2 * (size_t)((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 2 * (size_t)T * (W + H) +
+    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + (size_t)((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 2 * (size_t)T * (W + H) +
                             2 * w + 2 * h + ((W + 3) & ~3) + ((H + 3) & ~3) + ((T + 3) & ~3) + 160);
 }
 struct ImageArgs {
@@ -1007,7 +1006,6 @@ __global__ __launch_bounds__(ST_THREADS) void canvas_image_kernel(ImageArgs a) {
                 acc[0] += gax * c.X[J]; acc[1] += gax;
                 acc[2] += gay * c.Y[I]; acc[3] += gay;
                 acc[4] += dc * v;
-                c.go[p] = go;
             }
             {
                 const float r = wave_reduce8(acc);
@@ -1019,15 +1017,15 @@ __global__ __launch_bounds__(ST_THREADS) void canvas_image_kernel(ImageArgs a) {
             for (int e = tid; e < (fh > 0 ? fh : 0) * w; e += nt) {
                 const int Ir = e / w, I = I0 + Ir, j = e - Ir * w;
                 const int2 r = c.jr[j];
-                const float *grow = c.go + I * W;
-                float sacc = 0.f;
+                const float *grow = c.cv + I * W;              // dcanvas; go = pres * dcanvas is re-formed here (the same rounded
+                float sacc = 0.f;                              // product the two-launch form stores): dcanvas survives for every step
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int J = r.x + u;
                     const bool in = J <= r.y;
                     const int Jc = in ? J : r.x <= r.y ? r.x : 0;
                     const float2 ex = xe[Jc];
-                    const float gv = grow[Jc];
+                    const float gv = pres * grow[Jc];
                     const int fx = __float_as_int(ex.x);
                     const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
                     if (in) sacc += gv * wgt;
@@ -1036,7 +1034,7 @@ __global__ __launch_bounds__(ST_THREADS) void canvas_image_kernel(ImageArgs a) {
                     const float2 ex = xe[J];
                     const int fx = __float_as_int(ex.x);
                     const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                    sacc += grow[J] * wgt;
+                    sacc += (pres * grow[J]) * wgt;
                 }
                 c.t1[I * w + j] = sacc;
             }

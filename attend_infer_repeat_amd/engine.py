@@ -663,12 +663,15 @@ class AIREngine:
         # train step's forward list then ends before the canvas; NVIL, which needs the forward's reconstruction shares, rides on
         # the next pointwise launch (air_gauss_sample_bwd_nvil) and the baseline's backward, which needs NVIL, rides with the
         # three launches after that (what / glimpse-encoder backward) instead of the decoder's.  35 -> 34 dependent launches.
-        # Throughput regime: ONE workgroup per image runs forward and backward with the canvas resident in LDS
-        # (air_canvas_unroll_image); the two-role launch of the latency regime measured slower there (VALU bound chip-wide plus the
-        # recomputation: 0.594 against 0.580 ms at batch 1024).
+        # Far into the throughput regime (more images than the chip holds workgroups): ONE workgroup per image runs forward and backward
+        # with the canvas resident in LDS (air_canvas_unroll_image: 23 % less time than the two launches at 65536 images, obs and
+        # glimpses read once).  Around batch 1024 a workgroup per image is a ~40 us chain of 20 barriers with nothing to overlap it:
+        # no faster than the two launches (0.5803 against 0.5799 ms), slower at batch 256.  The two-role launch of the latency regime
+        # measured slower in this regime too (VALU bound chip-wide plus the recomputation: 0.594 against 0.580 ms at batch 1024).
         hwp = (hw + 3) // 4 * 4
-        image_lds = 4 * (T * hwp + 2 * ((P + 3) // 4 * 4) + (Hi * wc + 3) // 4 * 4 + 2 * T * (Wi + Hi) + 2 * wc + 2 * hc + Wi + Hi + 176)
+        image_lds = 4 * (T * hwp + ((P + 3) // 4 * 4) + (Hi * wc + 3) // 4 * 4 + 2 * T * (Wi + Hi) + 2 * wc + 2 * hc + Wi + Hi + 176)
         canvas_image = (cfg.use_reinforce and throughput and NB == 1 and image_lds <= 64 * 1024
+                        and B >= int(os.environ.get("AIR_FUSE_CANVAS_IMAGE_MIN_BATCH", "2048"))
                         and os.environ.get("AIR_FUSE_CANVAS_IMAGE", "1") == "1")
         self._canvas_image = canvas_image
         fuse_canvas = (cfg.use_reinforce and (not throughput or canvas_image or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
