@@ -672,7 +672,7 @@ class AIREngine:
         image_lds = 4 * (T * hwp + ((P + 3) // 4 * 4) + (Hi * wc + 3) // 4 * 4 + 2 * T * (Wi + Hi) + 2 * wc + 2 * hc + Wi + Hi + 176)
         canvas_image = (cfg.use_reinforce and throughput and NB == 1 and image_lds <= 64 * 1024
                         and B >= int(os.environ.get("AIR_FUSE_CANVAS_IMAGE_MIN_BATCH", "2048"))
-                        and os.environ.get("AIR_FUSE_CANVAS_IMAGE", "1") == "1")
+                        and os.environ.get("AIR_FUSE_CANVAS_IMAGE", "0") == "1")
         self._canvas_image = canvas_image
         fuse_canvas = (cfg.use_reinforce and (not throughput or canvas_image or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
                        and (canvas_image or (B * NB <= 4096 and M <= 4096))
