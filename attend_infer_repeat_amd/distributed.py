@@ -160,6 +160,9 @@ class DataParallelEngine(object):
         engine.world_size = self.world
         with self._stream():
             broadcast_parameters(engine.flat_params, 0, group)
+        sync_shadow = getattr(engine, "_sync_param_shadow", None)
+        if sync_shadow is not None and self.world > 1:
+            sync_shadow()                                   # the bf16 shadow of the parameters follows whatever wrote them
         engine.synchronize()
         want = (collective or os.environ.get("AIR_DP_COLLECTIVE", "").strip().lower() or "torch-split")
         want = {"captured": "rccl-captured", "split": "torch-split", "torch": "torch-split", "rccl": "rccl-split"}.get(want, want)

@@ -406,7 +406,11 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if torch.cuda.device_count() < args.gpus:
+    # AIR_BENCH_SHARE_GPU=1 (testing aid, tests/test_bench_multirank.py): every rank on GPU 0 with the gloo backend, so that the
+    # N > 1 control flow of this script -- barriers, the max-over-ranks clock, collectives inside the timed steps -- can be
+    # exercised on a single-GPU box.  Never a measurement.
+    share_gpu = os.environ.get("AIR_BENCH_SHARE_GPU", "0") == "1"
+    if torch.cuda.device_count() < args.gpus and not share_gpu:
         raise SystemExit(f"--gpus {args.gpus} but this node exposes {torch.cuda.device_count()} GPU(s)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
@@ -415,6 +419,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from attend_infer_repeat_amd import build as air_build
@@ -422,7 +428,7 @@ def main():
     import torch.distributed as dist
     from attend_infer_repeat_amd import distributed as D
     if world > 1:
-        D.init_from_env(backend="nccl")                       # RCCL over xGMI
+        D.init_from_env(backend="gloo" if share_gpu else "nccl")   # "nccl" = RCCL over xGMI
     from attend_infer_repeat_amd.data import synthetic_multi_mnist
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
     from attend_infer_repeat_amd import hip as H, _lib
@@ -464,32 +470,35 @@ def main():
         elapsed = t.item()
     finite = bool(torch.isfinite(eng.flat_params).all().item())
 
+    # SURVEY 8(d) asks for the median step time: HIP events around every step of a second, shorter run on the engine stream (the
+    # headline `value` stays "exactly K steps between two barriers", as the driver contract defines it).  EVERY rank runs these
+    # steps -- with world > 1 each of them contains the gradient all-reduce, which one rank cannot enter alone.
+    lib = H.lib()
+    sp = eng._sp()
+    n_ev = min(args.steps // spr, 400)
+    evs = [ctypes.c_void_p() for _ in range(n_ev + 1)]
+    for e in evs:
+        _lib.check(lib.air_event_create(ctypes.byref(e)))
+    _lib.check(lib.air_event_record(evs[0], sp))
+    for i in range(n_ev):
+        dp.train_step()
+        _lib.check(lib.air_event_record(evs[i + 1], sp))
+    eng.synchronize()
+    per = []
+    for i in range(n_ev):
+        ms = ctypes.c_float()
+        _lib.check(lib.air_event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
+        per.append(ms.value)
+    for e in evs:
+        lib.air_event_destroy(e)
+    per.sort()
+    median_ms = per[len(per) // 2] / spr                       # per update
+    barrier()
+
     line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        # SURVEY 8(d) asks for the median step time: HIP events around every step of a second, shorter run on the engine stream
-        # (the headline `value` stays "exactly K steps between two barriers", as the driver contract defines it)
-        lib = H.lib()
-        sp = eng._sp()
-        n_ev = min(args.steps // spr, 400)
-        evs = [ctypes.c_void_p() for _ in range(n_ev + 1)]
-        for e in evs:
-            _lib.check(lib.air_event_create(ctypes.byref(e)))
-        _lib.check(lib.air_event_record(evs[0], sp))
-        for i in range(n_ev):
-            dp.train_step()
-            _lib.check(lib.air_event_record(evs[i + 1], sp))
-        eng.synchronize()
-        per = []
-        for i in range(n_ev):
-            ms = ctypes.c_float()
-            _lib.check(lib.air_event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
-            per.append(ms.value)
-        for e in evs:
-            lib.air_event_destroy(e)
-        per.sort()
-        median_ms = per[len(per) // 2] / spr                   # per update
         if args.breakdown:
             plan_breakdown(eng)
         roof = st_rooflines(eng)
@@ -506,7 +515,8 @@ def main():
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "median_ms_per_step": round(median_ms, 4),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "bf16 operands / f32 accumulate+storage", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "bf16 operands / f32 accumulate+storage",
+            "data": "synthetic" if not share_gpu else "synthetic; NOT A MEASUREMENT: all ranks share one GPU (AIR_BENCH_SHARE_GPU)",
             "config": {"workload": workload, "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "steps_per_graph_replay": spr,
                        "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),

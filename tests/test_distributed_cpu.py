@@ -100,7 +100,12 @@ def _dp_worker(rank, world, port, out_dir):
     from attend_infer_repeat_amd import distributed as D
     D.init_from_env(backend="gloo")
     eng = _StandInEngine(7, rank)
+    # rank 1 ASKS for the captured-RCCL protocol through the environment, rank 0 does not: an engine that is not on a GPU must end
+    # up in the host-issued protocol on every rank alike (the own-communicator protocols are GPU-only and opt-in)
+    if rank == 1:
+        os.environ["AIR_DP_COLLECTIVE"] = "rccl-captured"
     dp = D.DataParallelEngine(eng)
+    assert dp.rccl_nranks is None and dp.comm is None
     start = eng.flat_params.clone()
     for _ in range(3):
         dp.train_step()
@@ -127,6 +132,15 @@ def test_data_parallel_engine_control_flow_two_ranks(tmp_path):
         g = sum(torch.arange(7, dtype=torch.float32) * (rk + 1) + s for rk in range(world))
         expect = expect - 0.1 * g / world
     assert torch.allclose(res[0]["params"], expect, rtol=1e-6) and torch.equal(res[0]["params"], res[1]["params"])
+
+
+def test_collective_name_is_validated():
+    from attend_infer_repeat_amd import distributed as D
+    eng = _StandInEngine(3, 0)
+    with pytest.raises(ValueError):
+        D.DataParallelEngine(eng, collective="allreduce-in-a-thread")
+    dp = D.DataParallelEngine(eng, collective="captured")              # alias; world 1: nothing to reduce
+    assert dp.collective == "none" and dp.world == 1 and eng.captured == [{}]
 
 
 def test_shard_and_seed_helpers():
