@@ -697,19 +697,20 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
         dist.destroy_process_group()
 
 
-def _dp_rank_main(rank, world, port, out_dir, collective):
-    """one rank of test_data_parallel_two_ranks_on_two_gpus (spawned: one process per GPU)"""
+def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
+    """one rank of test_data_parallel_two_ranks_on_two_gpus (spawned: one process per GPU; share_gpu: both on GPU 0 over gloo)"""
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
+    dev_index = 0 if share_gpu else rank
+    torch.cuda.set_device(dev_index)
     from attend_infer_repeat_amd import distributed as D
-    D.init_from_env(backend="nccl")
+    D.init_from_env(backend="gloo" if share_gpu else "nccl")
     ocfg, B = CONFIGS["mnist_b8"]
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
     fields = {f.name for f in dataclasses.fields(EngineConfig)}
     eng = AIREngine(EngineConfig(**{k: v for k, v in dataclasses.asdict(ocfg).items() if k in fields}), B,
-                    device=torch.device("cuda", rank), seed=D.rank_seed(3, rank))
+                    device=torch.device("cuda", dev_index), seed=D.rank_seed(3, rank))
     eng.load_parameters(O.init_params(ocfg, seed=3 + rank, bias_std=0.1))     # deliberately different before the broadcast
     obs, _ = O.synthetic_batch(ocfg, B, seed=40 + rank)
     eng.set_obs(obs.cuda())
@@ -731,13 +732,17 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     """The real thing where the box has it: min(device_count, 2) = 2 ranks, one process per GPU, each protocol of
     DataParallelEngine.  After three steps both replicas must hold IDENTICAL parameters (they started from rank 0's, every
     update used the same all-reduced gradient, scaled by 1/2), their summed gradient buffers must be identical, their noise
-    must differ, and RCCL itself must report two ranks.  Skips on a single-GPU box (the driver's 1-GPU tier)."""
+    must differ, and RCCL itself must report two ranks.  On a single-GPU box (the driver's 1-GPU tier) the torch-split protocol
+    still runs, with both ranks on GPU 0 over gloo; the two RCCL protocols skip."""
     import socket
     import torch.multiprocessing as mp
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
+    share_gpu = torch.cuda.device_count() < 2
+    if share_gpu and collective != "torch-split":
+        pytest.skip("the own-communicator protocols need two GPUs (RCCL refuses two ranks on one device)")
+    # one GPU only: the host-issued protocol is still run for real -- two processes, two engines on GPU 0, gradients summed over
+    # gloo -- so the data-parallel step (broadcast, split graphs, all-reduce in between, 1/world scaling) is exercised end to end
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_dp_rank_main, args=(2, port, str(tmp_path), collective), nprocs=2, join=True)
+    mp.spawn(_dp_rank_main, args=(2, port, str(tmp_path), collective, share_gpu), nprocs=2, join=True)
     r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(2)]
     assert r[0]["collective"] == r[1]["collective"] == collective
     if collective != "torch-split":
