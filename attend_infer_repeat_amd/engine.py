@@ -1136,7 +1136,7 @@ class AIREngine:
         dh_init_c = self.dh_init.data_ptr()
         seg = self.param_offsets
         for e in plan:
-            fn, args, name = e
+            _, args, name = e
             if name == "air_gemm_grouped":
                 descs = list(args[0])
                 side_d = [d for d in descs if is_side(d) and int(d.C) not in lstm_dw_c]
