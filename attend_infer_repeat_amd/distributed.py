@@ -8,7 +8,11 @@ own 64 images with its own Philox stream, the flat fp32 gradient bucket (model +
 mean of `world_size` independent B=64 reference steps (the NVIL mean-baseline quirk stays per rank).
 
 Where the collective runs (AIR_DP_COLLECTIVE / the `collective` argument):
-  "torch-split"   (default): graph A (forward + backward) -> torch.distributed.all_reduce on the engine stream (backend
+  "torch-overlap" (default where the engine's backward has a gradient bucket that is final early -- the latency regime):
+                  graph A1 (forward + backward up to the cut) -> async torch.distributed.all_reduce of the TAIL bucket (decoder /
+                  baseline / what / glimpse-encoder gradients, ~half of the bytes) -> graph A2 (rest of the backward, running
+                  underneath the collective) -> all_reduce of the head -> wait -> graph B (update).  Eager RCCL calls only.
+  "torch-split"   (default otherwise): graph A (forward + backward) -> torch.distributed.all_reduce on the engine stream (backend
                   "nccl" = RCCL on ROCm; "gloo" in the CPU tests) -> graph B (update).  The plain, eager use of RCCL.
   "rccl-split"    : the same two graphs, the all-reduce issued by the engine itself through the C ABI (air_allreduce_sum ->
                   ncclAllReduce on the engine stream, eager) on a communicator of its own.
@@ -164,10 +168,12 @@ class DataParallelEngine(object):
         if sync_shadow is not None and self.world > 1:
             sync_shadow()                                   # the bf16 shadow of the parameters follows whatever wrote them
         engine.synchronize()
-        want = (collective or os.environ.get("AIR_DP_COLLECTIVE", "").strip().lower() or "torch-split")
-        want = {"captured": "rccl-captured", "split": "torch-split", "torch": "torch-split", "rccl": "rccl-split"}.get(want, want)
-        if want not in ("torch-split", "rccl-split", "rccl-captured"):
-            raise ValueError("AIR_DP_COLLECTIVE / collective must be torch-split, rccl-split or rccl-captured, got %r" % want)
+        want = (collective or os.environ.get("AIR_DP_COLLECTIVE", "").strip().lower() or "torch-overlap")
+        want = {"captured": "rccl-captured", "split": "torch-split", "torch": "torch-split", "rccl": "rccl-split",
+                "overlap": "torch-overlap"}.get(want, want)
+        if want not in ("torch-overlap", "torch-split", "rccl-split", "rccl-captured"):
+            raise ValueError("AIR_DP_COLLECTIVE / collective must be torch-overlap, torch-split, rccl-split or rccl-captured, "
+                             "got %r" % want)
         if overlap is None:
             overlap = os.environ.get("AIR_DP_OVERLAP", "0") == "1"
         on_gpu = getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
@@ -200,7 +206,12 @@ class DataParallelEngine(object):
                             return
                         want = "rccl-split"
                     self.collective = "rccl-split"
-            if capture_graph:
+            bucketed = (want == "torch-overlap" and capture_graph and getattr(engine, "supports_bucketed_backward", False)
+                        and engine.tail_bucket() is not None)
+            if bucketed:
+                engine.capture(split_optimizer=True, split_backward=True)
+                self.collective = "torch-overlap"
+            elif capture_graph:
                 engine.capture(split_optimizer=True)
         elif capture_graph:
             if steps_per_replay > 1:        # single GPU only: several updates per graph replay (engine.capture)
@@ -224,9 +235,15 @@ class DataParallelEngine(object):
             return
         allreduce_gradients(grads, self.group, average=False)
 
+    def _allreduce_async(self, grads):
+        return dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def train_step(self, obs=None):
         host_collective = self.world > 1 and not self.collective.startswith("rccl-captured")
-        self.engine.train_step(obs, allreduce=self._allreduce if host_collective else None)
+        if self.collective == "torch-overlap":
+            self.engine.train_step(obs, allreduce=self._allreduce, allreduce_async=self._allreduce_async)
+        else:
+            self.engine.train_step(obs, allreduce=self._allreduce if host_collective else None)
 
     def close(self):
         if self.comm is not None:

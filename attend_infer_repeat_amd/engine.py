@@ -1323,8 +1323,21 @@ class AIREngine:
         """batch for step `slot` of a multi-step replay (capture(steps_per_replay=K)); slot 0 is the ordinary obs buffer"""
         self._copy_in(self.obs if slot == 0 else self.obs_ring[slot - 1], obs)
 
+    supports_bucketed_backward = True      # capture(split_optimizer=True, split_backward=True) / train_step(allreduce_tail=...)
+
+    def tail_bucket(self):
+        """(end, lo): the backward plan's first `end` launches leave elements [lo, n_total) of the flat gradient buffer final -- the
+        EARLIEST such cut whose tail holds 30-70 % of the buffer (decoder / baseline / what / glimpse-encoder gradients: 46 % of
+        the bytes, final when 40 % of the backward is still to run: the longer the rest of the backward, the more of the tail's
+        all-reduce hides under it); None if the plan has no such cut (throughput regime: every weight gradient is formed at the
+        end of the backward)."""
+        for end, lo, hi in sorted(self._grad_buckets):
+            if end < len(self._plan_bwd) and 0.3 * self.n_total <= self.n_total - lo <= 0.7 * self.n_total:
+                return (end, lo)
+        return None
+
     def capture(self, split_optimizer: bool = False, comm=None, overlap: bool = False, steps_per_replay: int = 1,
-                comm_side=None):
+                comm_side=None, split_backward: bool = False):
         """Capture noise + forward + backward (+ gradient all-reduce) + both RMSProp updates into hipGraphs.
         comm=None, split_optimizer=False : single GPU, ONE graph.
         comm=<air_comm handle>           : data parallel, still ONE graph -- the RCCL all-reduce of the flat gradient buffer
@@ -1339,7 +1352,8 @@ class AIREngine:
         self.stream.synchronize()
         self._steps_per_replay = 1
         self._capture_kwargs = dict(split_optimizer=split_optimizer, comm=comm, overlap=overlap,
-                                    steps_per_replay=steps_per_replay, comm_side=comm_side)
+                                    steps_per_replay=steps_per_replay, comm_side=comm_side, split_backward=split_backward)
+        self._graph_b2, self._tail_lo = None, None
         L = H.lib()
         if comm is not None:
             opt = self._opt_calls_factory(1.0 / self.world_size)
@@ -1398,8 +1412,16 @@ class AIREngine:
             self._graph_has_opt = True
             self._steps_per_replay = K
             return
+        cut = self.tail_bucket() if (split_optimizer and split_backward) else None
         if not split_optimizer and self.world_size == 1:
             self._graph = self._capture_plans(self._single_gpu_step_plans())
+        elif cut is not None:
+            # host-issued collective, two gradient buckets: [forward + backward up to the cut] | all-reduce of the tail (async, on the
+            # collective library's stream) | [rest of the backward] | all-reduce of the head | [update]
+            end, lo = cut
+            self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd[:end]])
+            self._graph_b2 = self._capture_plans([self._plan_bwd[end:]])
+            self._tail_lo = lo
         else:
             self._graph = self._capture_plans([self._plan_fwd_train, self._plan_bwd] + ([] if split_optimizer else [self._plan_opt]))
         self._graph_has_opt = not split_optimizer
@@ -1434,19 +1456,21 @@ class AIREngine:
 
     def release_graphs(self):
         L = H.lib()
-        for g in (self._graph_opt, self._graph):
+        for g in (self._graph_opt, getattr(self, "_graph_b2", None), self._graph):
             if g is not None:
                 L.air_graph_destroy(g)
-        self._graph = self._graph_opt = None
+        self._graph = self._graph_opt = self._graph_b2 = None
 
     def stream_context(self):
         """torch stream context of the engine's stream (collectives issued through torch.distributed run inside it)."""
         return torch.cuda.stream(self.stream)
 
-    def train_step(self, obs=None, allreduce=None):
+    def train_step(self, obs=None, allreduce=None, allreduce_async=None):
         """One full update: fresh noise, forward, backward, (all-reduce), centred RMSProp x2.
-        `allreduce(flat_grads)`: optional callable run on the engine stream between backward and the update (used when the
-        collective is NOT part of the captured graph)."""
+        `allreduce(grads)`: optional callable run on the engine stream between backward and the update (used when the
+        collective is NOT part of the captured graph).  `allreduce_async(grads) -> handle with .wait()`: with a graph captured as
+        capture(split_optimizer=True, split_backward=True) the tail bucket of the gradients is handed to it as soon as it is
+        final, the rest of the backward runs underneath, the head goes through `allreduce`, and the update waits for both."""
         if obs is not None:
             self.set_obs(obs)
         sp = self._sp()
@@ -1455,7 +1479,21 @@ class AIREngine:
             if getattr(self, "_steps_per_replay", 1) > 1:
                 self.global_step += self._steps_per_replay
                 return
-            if not self._graph_has_opt:
+            if getattr(self, "_graph_b2", None) is not None:
+                lo, handle = self._tail_lo, None
+                with torch.cuda.stream(self.stream):
+                    if allreduce_async is not None:
+                        handle = allreduce_async(self.flat_grads[lo:])
+                    elif allreduce is not None:
+                        allreduce(self.flat_grads[lo:])
+                _lib.check(H.lib().air_graph_launch(self._graph_b2, sp), "air_graph_launch")
+                with torch.cuda.stream(self.stream):
+                    if allreduce is not None:
+                        allreduce(self.flat_grads[:lo])
+                    if handle is not None:
+                        handle.wait()
+                _lib.check(H.lib().air_graph_launch(self._graph_opt, sp), "air_graph_launch")
+            elif not self._graph_has_opt:
                 if allreduce is not None:
                     with torch.cuda.stream(self.stream):
                         allreduce(self.flat_grads)

@@ -41,6 +41,10 @@ def main(argv=None):
                     help="no multi-MNIST pickles: synthesise the dataset with the reference's generator (data.create_multi_mnist) "
                          "from procedural digit templates instead of stroke blobs")
     ap.add_argument("--learning-rate", type=float, default=1e-4)
+    ap.add_argument("--check-every", type=int, default=0,
+                    help="diagnostics (read-only: does not touch the noise stream): every N updates from --check-from on, write the "
+                         "extreme values of the latents' scales, of the parameters, gradients and RMSProp slots to log.jsonl")
+    ap.add_argument("--check-from", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device-feeder", action="store_true",
                     help="draw every training batch inside the captured step from the HBM-resident training set (engine "
@@ -110,6 +114,29 @@ def main(argv=None):
         else:
             xb, yb = train_feed()
             train_itr = int(train_step(xb, yb, refresh=False))
+        if args.check_every and train_itr >= args.check_from and train_itr % args.check_every == 0:
+            eng = air._engine
+            o = eng.outputs()
+            fin = lambda t: bool(torch.isfinite(t).all().item())
+            diag = dict(step=train_itr, data="check",
+                        where_scale_min=float(o["where_scale"].min()), where_scale_max=float(o["where_scale"].max()),
+                        what_scale_min=float(o["what_scale"].min()), what_scale_max=float(o["what_scale"].max()),
+                        where_abs_max=float(o["where"].abs().max()), what_abs_max=float(o["what"].abs().max()),
+                        presence_prob_min=float(o["presence_prob"].min()), presence_prob_max=float(o["presence_prob"].max()),
+                        num_step=float(o["num_step_per_sample"].mean()), rec=float(o["rec_loss"]),
+                        kl_what=float(o["kl_what"]), kl_where=float(o["kl_where"]),
+                        imp_var=float(o["imp_weight_var"]), baseline_abs_max=float(o["baseline"].abs().max()),
+                        params_abs_max=float(eng.flat_params.abs().max()), grads_abs_max=float(eng.flat_grads.abs().max()),
+                        ms_max=float(eng.flat_ms.max()), ms_min=float(eng.flat_ms.min()), mom_abs_max=float(eng.flat_mom.abs().max()),
+                        finite=dict(params=fin(eng.flat_params), grads=fin(eng.flat_grads), ms=fin(eng.flat_ms), mom=fin(eng.flat_mom)))
+            # the variance slot of centred RMSProp, ms - mg^2, must stay >= 0 for the square root (model.py:265: centered=True)
+            diag["centred_var_min"] = float((eng.flat_ms - eng.flat_mg * eng.flat_mg).min())
+            worst = {}
+            for k, g in eng.named_grads().items():
+                worst[k] = float(g.abs().max())
+            top = sorted(worst.items(), key=lambda kv: -kv[1] if kv[1] == kv[1] else -float("inf"))[:3]
+            diag["largest_grads"] = top
+            writer.write(json.dumps(diag) + "\n"); writer.flush()
         if args.summary_every and train_itr % args.summary_every == 0:
             # the reference's `all_summaries` (model.py's tf.summary scalars + evaluation.gradient_summaries), every 1000 iterations
             writer.write(json.dumps(dict(step=train_itr, data="summary", **step_summaries(air))) + "\n")

@@ -37,7 +37,7 @@ def test_bench_two_ranks_sharing_one_gpu(gpu_device, launcher):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
-    assert d["config"]["collective"] == "torch-split" and d["config"]["dist_world_size"] == 2
+    assert d["config"]["collective"] == "torch-overlap" and d["config"]["dist_world_size"] == 2
     assert d["config"]["params_finite_after_run"] is True
     assert d["value"] > 0 and "NOT A MEASUREMENT" in d["data"]
 

@@ -727,7 +727,7 @@ def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("collective", ["torch-split", "rccl-split", "rccl-captured"])
+@pytest.mark.parametrize("collective", ["torch-overlap", "torch-split", "rccl-split", "rccl-captured"])
 def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     """The real thing where the box has it: min(device_count, 2) = 2 ranks, one process per GPU, each protocol of
     DataParallelEngine.  After three steps both replicas must hold IDENTICAL parameters (they started from rank 0's, every
@@ -737,7 +737,7 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     import socket
     import torch.multiprocessing as mp
     share_gpu = torch.cuda.device_count() < 2
-    if share_gpu and collective != "torch-split":
+    if share_gpu and not collective.startswith("torch-"):
         pytest.skip("the own-communicator protocols need two GPUs (RCCL refuses two ranks on one device)")
     # one GPU only: the host-issued protocol is still run for real -- two processes, two engines on GPU 0, gradients summed over
     # gloo -- so the data-parallel step (broadcast, split graphs, all-reduce in between, 1/world scaling) is exercised end to end
@@ -745,6 +745,13 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     mp.spawn(_dp_rank_main, args=(2, port, str(tmp_path), collective, share_gpu), nprocs=2, join=True)
     r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(2)]
     assert r[0]["collective"] == r[1]["collective"] == collective
+    if collective == "torch-overlap":
+        # the bucketed protocol (tail bucket reduced underneath the rest of the backward) must produce exactly what the plain
+        # two-graph protocol produces: same launches, same sums (a two-rank sum has one order)
+        port2 = port + 1 if port < 65000 else port - 1
+        mp.spawn(_dp_rank_main, args=(2, port2, str(tmp_path), "torch-split", share_gpu), nprocs=2, join=True)
+        ref = torch.load(os.path.join(tmp_path, "torch-split_0.pt"))
+        assert torch.equal(r[0]["params"], ref["params"]) and torch.equal(r[0]["grads"], ref["grads"])
     if collective != "torch-split":
         assert r[0]["nranks"] == r[1]["nranks"] == 2
     assert torch.equal(r[0]["start"], r[1]["start"])
