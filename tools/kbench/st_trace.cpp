@@ -65,7 +65,8 @@ int main(int argc, char **argv) {
     std::vector<float> obs(B * HW), where(M * 4), glm(M * hw), pres(M), dgl(M * hw), trh(M * Kt), trw(Kt * 8), trb(8), sth(M * Ks),
         stw(Ks), stb(1), eps(M * 4), u(M), imp(B), base(B), logp(B);
     for (auto &x : obs) x = frand() < 0.15f ? frand() : 0.f;
-    for (int k = 0; k < M; ++k) { where[4 * k] = 0.4f + 0.3f * frand(); where[4 * k + 1] = 0.6f * frand() - 0.3f; where[4 * k + 2] = 0.4f + 0.3f * frand(); where[4 * k + 3] = 0.6f * frand() - 0.3f; }
+    const float s_lo = argc > 7 ? atof(argv[7]) : 0.4f, s_hi = argc > 8 ? atof(argv[8]) : 0.7f;
+    for (int k = 0; k < M; ++k) { where[4 * k] = s_lo + (s_hi - s_lo) * frand(); where[4 * k + 1] = 0.6f * frand() - 0.3f; where[4 * k + 2] = s_lo + (s_hi - s_lo) * frand(); where[4 * k + 3] = 0.6f * frand() - 0.3f; }
     for (auto &x : glm) x = frand() - 0.5f;
     for (auto &x : dgl) x = frand() - 0.5f;
     for (auto &x : pres) x = frand() < 0.7f ? 1.f : 0.f;
@@ -97,6 +98,8 @@ int main(int argc, char **argv) {
     auto f_cfwd1 = [&] { air_canvas_unroll_fwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_rec, T, B, H, W, h, w, 0.5f, 0.3f, st); };
     auto f_cbwd = [&] { air_canvas_unroll_bwd_nvil(d_glm, d_where, d_pres, d_obs, d_final, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, d_recp, NB, d_rec, d_base, d_logp, d_nvil, d_dlogp, d_dbase, st); };
     auto f_cbwd0 = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, d_final, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
+    auto f_cbwd_rc = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, nullptr, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
+    auto f_cfused = [&] { air_canvas_unroll_fwd_bwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_afwd = [&] { air_attend_fwd(d_trh, d_trw, d_trb, Kt, d_sth, d_stw, d_stb, Ks, d_pre, d_logit, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_wh2, d_klrow, d_u, 0.75f, 1e-3f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, d_obs, d_glimpse, T, B, H, W, h, w, 0, st); };
     auto f_abwd = [&] { air_attend_bwd(d_obs, d_where, d_dgl, d_dwr, d_pre, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_dwhere, d_stepw, 1.0f / B, d_dpre, d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, H, W, h, w, st); };
     auto f_rfwd = [&] { air_st_read_fwd(d_obs, d_where, d_glimpse, M, B, H, W, h, w, st); };
@@ -105,6 +108,7 @@ int main(int argc, char **argv) {
     auto f_pnb = [&] { air_numsteps_presence_bwd(d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, st); };
     struct { const char *n; std::function<void()> f; int nb; } K[] = {
         {"canvas_unroll_fwd_banded", f_cfwd, B * NB}, {"canvas_unroll_fwd(1 band)", f_cfwd1, B}, {"canvas_unroll_bwd_nvil", f_cbwd, M + 1}, {"canvas_unroll_bwd", f_cbwd0, M},
+        {"canvas_unroll_bwd(recompute)", f_cbwd_rc, M}, {"canvas_fused(fwd+bwd)", f_cfused, B * NB + M},
         {"attend_fwd", f_afwd, M + (B + 63) / 64}, {"attend_bwd", f_abwd, M + (B + 63) / 64}, {"st_read_fwd", f_rfwd, B},
         {"nvil", f_nvil, 1}, {"presence_numsteps_fwd", f_pn, 1}, {"numsteps_presence_bwd", f_pnb, 1}};
     f_afwd(); CK(hipStreamSynchronize(st));
