@@ -91,7 +91,8 @@ def test_st_read_bwd(hip, H, W, h, w):
     assert_close(dwhere2, dwhere, 1e-6, 1e-6, "dwhere w/o dimg")
 
 
-@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4])
+# (21, 19, 6, 10): h*w a multiple of 4 but w not -- 16-byte groups would straddle the rows of the bordered LDS copy: scalar staging
+@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4] + [(21, 19, 6, 10)])
 def test_st_write_fwd_bit_exact(hip, H, W, h, w):
     rng = np.random.default_rng(3)
     B = 8
@@ -115,7 +116,7 @@ def test_st_write_degenerate_scales(hip):
     np.testing.assert_array_equal(np.nan_to_num(out, nan=12345.0), np.nan_to_num(ref, nan=12345.0))
 
 
-@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4])
+@pytest.mark.parametrize("H,W,h,w", ST_SHAPES[:4] + [(21, 19, 6, 10)])
 def test_st_write_bwd(hip, H, W, h, w):
     rng = np.random.default_rng(4)
     B = 6
@@ -169,7 +170,8 @@ def test_canvas_unroll_fwd_bwd(hip):
     assert torch.equal(dg, dg2) and torch.equal(dwhere, dwhere2)
 
 
-@pytest.mark.parametrize("T,B,H,W,h,w", [(5, 3, 100, 100, 28, 28), (1, 4, 17, 13, 5, 7), (4, 70, 28, 36, 9, 12), (3, 1100, 50, 50, 20, 20)])
+@pytest.mark.parametrize("T,B,H,W,h,w", [(5, 3, 100, 100, 28, 28), (1, 4, 17, 13, 5, 7), (4, 70, 28, 36, 9, 12), (3, 1100, 50, 50, 20, 20),
+                                          (2, 5, 21, 19, 6, 10)])
 def test_canvas_unroll_bwd_recompute_equals_stored_canvas(hip, T, B, H, W, h, w):
     """air_canvas_unroll_bwd(final_canvas=NULL) against the form that reads the stored final canvas, bit for bit, on the
     BASELINE configs[3] shapes, odd sizes (scalar staging paths), negative / degenerate scales and a grid-strided batch."""
