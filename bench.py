@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from attend_infer_repeat_amd import runtime_env as _runtime_env     # (importing the package applies the HIP runtime settings, before torch)
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable copy rate
 
 
@@ -526,7 +528,10 @@ def main():
                        # (rccl-split / rccl-captured), and the size of torch.distributed's process group (backend nccl = RCCL)
                        "rccl_nranks": dp.rccl_nranks, "dist_world_size": (dist.get_world_size() if world > 1 else 1),
                        "dist_backend": (dist.get_backend() if world > 1 else None),
-                       "params_finite_after_run": finite},
+                       "params_finite_after_run": finite,
+                       # HIP runtime settings the package put into the environment before the runtime initialised
+                       # (attend_infer_repeat_amd/runtime_env.py; a user's own export wins; "late": torch had initialised HIP first)
+                       "hip_runtime_env": dict(_runtime_env.applied, late=_runtime_env.late)},
             "roofline": dict(roof["st_read_fwd"], kernel="st_read_fwd_pipe_kernel (the fused affine-grid + bilinear glimpse read, "
                              "north_star's kernel) launched on its own at the in-step shape; `achieved`/`frac` use the SURVEY 8(d) "
                              "algorithmic bytes, `frac_minimal_bytes` the bytes the launch must move (image once per image). At this "
