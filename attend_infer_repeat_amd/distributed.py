@@ -245,6 +245,23 @@ class DataParallelEngine(object):
         else:
             self.engine.train_step(obs, allreduce=self._allreduce if host_collective else None)
 
+    def replicas_in_sync(self) -> bool:
+        """True when every rank holds bit-identical parameters (collective: every rank must call it).  Data-parallel replicas start
+        from a broadcast and apply the same averaged gradient, so any difference means a collective reduced a buffer that was not
+        final yet, or a rank skipped one -- the check a new overlap protocol has to pass on real multi-GPU hardware."""
+        if self.world == 1:
+            return True
+        self.engine.synchronize()
+        p = self.engine.flat_params
+        # two order-independent 64-bit digests of the raw bits, compared through MIN / MAX over the ranks
+        bits = p.view(torch.int32).to(torch.int64)
+        idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+        dig = torch.stack([bits.sum(), (bits * (idx % 65521)).sum()])          # int64, wrapping: equal bits => equal digests
+        lo, hi = dig.clone(), dig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(torch.equal(lo, hi))
+
     def close(self):
         if self.comm is not None:
             from . import hip as H

@@ -471,6 +471,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     finite = bool(torch.isfinite(eng.flat_params).all().item())
+    in_sync = dp.replicas_in_sync()          # (collective; outside the timed region) every rank ended with the same bits
 
     # SURVEY 8(d) asks for the median step time: HIP events around every step of a second, shorter run on the engine stream (the
     # headline `value` stays "exactly K steps between two barriers", as the driver contract defines it).  EVERY rank runs these
@@ -528,7 +529,7 @@ def main():
                        # (rccl-split / rccl-captured), and the size of torch.distributed's process group (backend nccl = RCCL)
                        "rccl_nranks": dp.rccl_nranks, "dist_world_size": (dist.get_world_size() if world > 1 else 1),
                        "dist_backend": (dist.get_backend() if world > 1 else None),
-                       "params_finite_after_run": finite,
+                       "params_finite_after_run": finite, "replicas_in_sync_after_run": in_sync,
                        # HIP runtime settings the package put into the environment before the runtime initialised
                        # (attend_infer_repeat_amd/runtime_env.py; a user's own export wins; "late": torch had initialised HIP first)
                        "hip_runtime_env": dict(_runtime_env.applied, late=_runtime_env.late)},

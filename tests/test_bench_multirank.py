@@ -38,7 +38,7 @@ def test_bench_two_ranks_sharing_one_gpu(gpu_device, launcher):
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
     assert d["config"]["collective"] == "torch-overlap" and d["config"]["dist_world_size"] == 2
-    assert d["config"]["params_finite_after_run"] is True
+    assert d["config"]["params_finite_after_run"] is True and d["config"]["replicas_in_sync_after_run"] is True
     assert d["value"] > 0 and "NOT A MEASUREMENT" in d["data"]
 
 
