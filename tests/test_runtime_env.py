@@ -1,0 +1,18 @@
+"""HIP runtime settings applied at package import (attend_infer_repeat_amd/runtime_env.py): host logic, no GPU needed."""
+
+def test_runtime_env_is_applied_on_import_and_yields_to_the_user(monkeypatch):
+    """attend_infer_repeat_amd.runtime_env: the HIP runtime settings are in the environment once the package is imported, a value
+    the user exported is left alone, and AIR_RUNTIME_ENV=0 switches the mechanism off."""
+    import os
+    from attend_infer_repeat_amd import runtime_env as R
+    for k, v in R.SETTINGS.items():
+        assert os.environ.get(k) is not None                       # package import ran apply()
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")      # the user's export wins
+    assert R.apply()["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "1"
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+    assert R.apply()["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == R.SETTINGS["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]
+    monkeypatch.setenv("AIR_RUNTIME_ENV", "0")
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+    assert R.apply() == {} and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ
+    monkeypatch.delenv("AIR_RUNTIME_ENV")
+    R.apply()
