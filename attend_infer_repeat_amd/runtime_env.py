@@ -6,6 +6,10 @@ DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
     short dependent kernels -- the ordinary submission path is FASTER on the GPU side: 0.2043 against 0.2084 ms per step at BASELINE
     configs[1] (three runs each on one box), 0.3253 / 0.3292 ms at configs[3], 0.4226 / 0.4289 ms at configs[4]
     (tools/runs/r03_env.sh, profiles/r03_env_sweep.txt).  Same kernels, same results; only how the runtime feeds them to the queue.
+    The price is on the HOST: the ordinary path spends ≈ 2.8 us of CPU per node against ≈ 1.9 us of pre-recorded packets
+    (tools/kbench/graph_replay_gap.cpp, profiles/r03_kbench_graph_replay_gap.txt: a chain of 34 EMPTY kernels replays in 96 us
+    instead of 64).  The train step's kernels average 6 us, so the host stays well ahead of the GPU; a workload whose kernels
+    average less than ~3 us would be host-bound on this path and should export DEBUG_CLR_GRAPH_PACKET_CAPTURE=1.
 
 Measured in the same sweep and NOT set: AMD_OPT_FLUSH=0 (system-scope fences between kernels: 0.2737 ms), HIP_FORCE_DEV_KERNARG=0
 (0.2678 ms), AMD_DIRECT_DISPATCH=0 (0.2066 ms alone: within reach of the setting above, changes the host threading model),
