@@ -910,3 +910,62 @@ def test_lstm_steps_on_the_bf16_data_path(hip, mirror_in):
     assert L.air_lstm_pointwise_bwd_bf16(P(act_ref), P(c_prev), P(c_ref), P(dh_a), P(dh_b), None, P(pw), v(pw16), P(pw_dc2), M, Hd, sp) == 0
     torch.cuda.synchronize()
     assert torch.equal(pw, pw_ref) and torch.equal(pw_dc, pw_dc2) and torch.equal(pw16, pw.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_canvas_kernels_random_shapes_and_transforms(hip, case):
+    """Seeded sweep over canvas / glimpse shapes (odd sizes, w % 4 in {0..3}, glimpses larger than the canvas), step counts, batch sizes
+    (grid-strided from ~600 units) and transforms (mirrored, tiny, huge, far off-canvas): the unrolled forward is the oracle's sequential
+    accumulation BIT FOR BIT (per-step canvases and the final one), the fused forward + backward launch equals the two launches, and the
+    recompute-form backward equals the stored-canvas one -- all bitwise; the backward itself against float64 autograd of the oracle."""
+    rng = np.random.default_rng(1000 + case)
+    H, W = int(rng.integers(3, 41)), int(rng.integers(3, 41))
+    h, w = int(rng.integers(2, 18)), int(rng.integers(2, 18))
+    T = int(rng.integers(1, 6))
+    B = int(rng.choice([1, 2, 5, 17, 64, 230]))
+    glm = rng.standard_normal((T, B, h, w)).astype(np.float32)
+    where = rand_where(T * B, rng, wide=True).reshape(T, B, 4)
+    k = rng.integers(0, T * B, 6)
+    flat = where.reshape(-1, 4)
+    flat[k[0]] = [1e-3, 0.0, 1e-3, 0.0]            # the whole glimpse inside one canvas pixel
+    flat[k[1]] = [25.0, 0.3, 40.0, -0.2]           # one glimpse pixel covers the canvas
+    flat[k[2]] = [0.5, 3.0, 0.5, -3.0]             # far off the canvas: contributes exactly zero
+    flat[k[3]] = [-1.0, 0.0, -1.0, 0.0]            # mirrored on both axes
+    pres = np.cumprod(rng.integers(0, 2, (T, B)), 0).astype(np.float32); pres[:, 0] = 1.0
+    obs = rng.random((B, H, W)).astype(np.float32)
+    mult, std = 0.5, 0.3
+    canvas = np.zeros((B, H, W), np.float32)
+    steps = []
+    for t in range(T):
+        canvas = canvas + pres[t][:, None, None] * C.st_write_fwd(glm[t], where[t], (H, W))
+        steps.append(canvas.copy())
+    st, final, rec = hip.canvas_unroll_fwd(g(glm), g(where), g(pres), (H, W), obs=g(obs), mult=mult, std=std)
+    np.testing.assert_array_equal(st.cpu().numpy(), np.stack(steps))
+    np.testing.assert_array_equal(final.cpu().numpy(), steps[-1])
+    dg, dwhere = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, mult, std, 1.0 / B)
+    dg2, dwhere2 = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), None, mult, std, 1.0 / B)
+    assert torch.equal(dg, dg2) and torch.equal(dwhere, dwhere2)
+    if B * T <= 4096:                                  # the one-launch form of the latency regime
+        lib, p = hip.lib(), hip._p
+        from attend_infer_repeat_amd import _lib
+        nb = int(lib.air_canvas_unroll_bands(B, H))
+        st3 = torch.empty(T, B, H, W, device="cuda"); fin3 = torch.empty(B, H, W, device="cuda")
+        parts = torch.empty(nb, B, device="cuda"); dg3 = torch.empty_like(dg); dw3 = torch.empty_like(dwhere)
+        d_glm, d_where, d_pres, d_obs = g(glm), g(where), g(pres), g(obs)      # (held: a raw pointer does not keep a tensor alive)
+        _lib.check(lib.air_canvas_unroll_fwd_bwd(p(d_glm), p(d_where), p(d_pres), p(d_obs), p(st3), p(fin3), p(parts), nb, p(dg3), p(dw3),
+                                                 T, B, H, W, h, w, mult, std, 1.0 / B, hip._stream()), "air_canvas_unroll_fwd_bwd")
+        torch.cuda.synchronize()
+        assert torch.equal(st3, st) and torch.equal(fin3, final) and torch.equal(dg3, dg) and torch.equal(dw3, dwhere)
+        assert_close(parts.sum(0), rec, 1e-5, 1e-3, "rec from band shares")
+    tg = torch.tensor(glm, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(where, dtype=torch.float64, requires_grad=True)
+    cv = sum(torch.tensor(pres[t], dtype=torch.float64)[:, None, None] * O.st_write(tg[t], tw[t], (H, W)) for t in range(T))
+    nll = 0.5 * ((torch.tensor(obs, dtype=torch.float64) - mult * cv) / std) ** 2 + 0.5 * np.log(2 * np.pi) + np.log(std)
+    gg, gw = torch.autograd.grad(nll.sum((1, 2)).mean(), [tg, tw])
+    # (the four extreme transforms stay out of the float64 comparison: with a scale of 1e-3 or 40 the fp32 and fp64 sampling
+    #  coordinates fall into different source cells, and d/d(scale) carries a 1/s^2 -- they are covered by the bitwise checks above)
+    keep = np.ones(T * B, bool); keep[k[:4]] = False
+    keep = keep.reshape(T, B)
+    assert_close(dg.cpu().numpy()[keep], gg.numpy()[keep], 3e-4, 2e-4 * max(gg.abs().max().item(), 1e-6), "dglimpse")
+    scale = gw.abs().amax(-1, keepdim=True).numpy() + 1.0
+    assert_close((dwhere.cpu().numpy() / scale)[keep], (gw.numpy() / scale)[keep], 1e-3, 1e-4, "dwhere")
