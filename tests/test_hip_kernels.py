@@ -969,3 +969,32 @@ def test_canvas_kernels_random_shapes_and_transforms(hip, case):
     assert_close(dg.cpu().numpy()[keep], gg.numpy()[keep], 3e-4, 2e-4 * max(gg.abs().max().item(), 1e-6), "dglimpse")
     scale = gw.abs().amax(-1, keepdim=True).numpy() + 1.0
     assert_close((dwhere.cpu().numpy() / scale)[keep], (gw.numpy() / scale)[keep], 1e-3, 1e-4, "dwhere")
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_st_read_random_shapes_and_transforms(hip, case):
+    """Seeded sweep of the glimpse read over image / glimpse shapes, T glimpses per image and transforms (mirrored, tiny, huge, off
+    the image): forward bit for bit the oracle's; backward against the oracle's float64 closed form (extreme transforms left to the
+    forward check: fp32 and fp64 coordinates fall into different cells there)."""
+    rng = np.random.default_rng(2000 + case)
+    H, W = int(rng.integers(2, 61)), int(rng.integers(2, 61))
+    h, w = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    B, T = int(rng.choice([1, 3, 8, 65, 300])), int(rng.integers(1, 5))
+    img = rng.random((B, H, W)).astype(np.float32)
+    where = rand_where(T * B, rng, wide=True)
+    k = rng.integers(0, T * B, 4)
+    where[k[0]] = [1e-3, 0.2, 1e-3, -0.1]
+    where[k[1]] = [30.0, 0.0, 30.0, 0.0]
+    where[k[2]] = [0.4, 4.0, 0.4, 4.0]
+    where[k[3]] = [-1.0, 0.0, -1.0, 0.0]
+    ref = C.st_read_fwd(np.tile(img, (T, 1, 1)), where, (h, w))
+    out = hip.st_read_fwd(g(img), g(where), (h, w)).cpu().numpy()
+    np.testing.assert_array_equal(out, ref)
+    if T == 1:
+        dout = rng.standard_normal((B, h, w)).astype(np.float32)
+        dwhere64, dimg64 = C.st_read_bwd(img.astype(np.float64), where.astype(np.float64), dout.astype(np.float64))
+        dwhere, dimg = hip.st_read_bwd(g(img), g(where), g(dout), want_dimg=True)
+        keep = np.ones(B, bool); keep[k] = False
+        scale = np.abs(dout).sum((1, 2))[:, None] * max(H, W) / 2 * 0.05 + 1.0
+        assert_close((dwhere.cpu().numpy() / scale)[keep], (dwhere64 / scale)[keep], 2e-4, 5e-5, "dwhere")
+        assert_close(dimg.cpu().numpy()[keep], dimg64[keep], 2e-4, 2e-5, "dimg")
