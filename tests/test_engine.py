@@ -104,6 +104,40 @@ CONFIGS = {
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_forward_and_gradients_match_oracle(gpu_device, name):
     ocfg, B = CONFIGS[name]
+    _forward_and_gradients_match_oracle(name, ocfg, B)
+
+
+def _random_config(case):
+    """a seeded draw of sizes the reference's constructor accepts: image / glimpse shapes (square or not, glimpse sides with every
+    residue mod 4), latent and hidden widths that are not multiples of the 16-wide MFMA tile, one to three hidden layers per network,
+    1-5 steps, batch sizes around the tile and launch-splitting boundaries"""
+    rng = np.random.default_rng(3000 + case)
+    def hidden(lo, hi, nmax=3):
+        return tuple(int(rng.integers(lo, hi)) for _ in range(int(rng.integers(1, nmax + 1))))
+    ocfg = O.AIRConfig(img_size=(int(rng.integers(12, 61)), int(rng.integers(12, 61))),
+                       crop_size=(int(rng.integers(4, 25)), int(rng.integers(4, 25))),
+                       n_appearance=int(rng.integers(3, 65)), n_hidden=int(rng.choice([24, 40, 64, 100, 256])),
+                       inpt_encoder_hidden=hidden(20, 300, 2), glimpse_encoder_hidden=hidden(16, 300, 2),
+                       glimpse_decoder_hidden=hidden(16, 300, 2), transform_estimator_hidden=hidden(8, 300, 2),
+                       steps_pred_hidden=hidden(8, 130, 2), baseline_hidden=hidden(8, 300, 2),
+                       max_steps=int(rng.integers(1, 6)), step_bias=float(rng.uniform(0.0, 1.5)),
+                       transform_var_bias=float(rng.uniform(-3.0, 0.5)), output_multiplier=float(rng.uniform(0.3, 1.0)),
+                       explore_eps=float(rng.choice([0.0, 1e-3, 0.05])))
+    B = int(rng.choice([1, 3, 15, 16, 17, 31, 48, 64, 65, 100, 130]))
+    return ocfg, B
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_configs_match_oracle(gpu_device, case):
+    """the full forward + backward against the float64 oracle on seeded random architectures and batch sizes (plan construction:
+    tile / grouping / fusion gates at sizes nobody picked by hand), same bars as the named configurations"""
+    ocfg, B = _random_config(case)
+    eng, params, obs, noise = make_pair(ocfg, B)
+    # (gradient bar: the fixed one, or twice what the oracle itself loses in fp32 on the same inputs -- _check_against_f64_oracle)
+    _check_against_f64_oracle("random_configs", "random%d" % case, eng, ocfg, params, obs, noise, out_tol=OUT_TOL)
+
+
+def _forward_and_gradients_match_oracle(name, ocfg, B):
     eng, params, obs, noise = make_pair(ocfg, B)
     eng.forward(sample_noise=False)
     eng.backward()
