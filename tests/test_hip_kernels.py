@@ -998,3 +998,56 @@ def test_st_read_random_shapes_and_transforms(hip, case):
         scale = np.abs(dout).sum((1, 2))[:, None] * max(H, W) / 2 * 0.05 + 1.0
         assert_close((dwhere.cpu().numpy() / scale)[keep], (dwhere64 / scale)[keep], 2e-4, 5e-5, "dwhere")
         assert_close(dimg.cpu().numpy()[keep], dimg64[keep], 2e-4, 2e-5, "dimg")
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_gemm_grouped_random_groups(hip, case):
+    """Seeded sweep of air_gemm_grouped: 1-8 problems of random shape (1 ... ~1500 rows / columns, K from 1 to ~1100), layout, epilogue,
+    beta, leading dimensions (row views, unaligned starts) and bias-gradient column sums, from a handful of tiles up to thousands (the
+    wide-tile dispatch), fp32 and bf16 operands -- every result against float64 (bf16: against the rounded operands)."""
+    rng = np.random.default_rng(4000 + case)
+    gen = torch.Generator().manual_seed(4000 + case)
+    precision = int(case % 4 == 3)
+    r = (lambda t: t.to(torch.bfloat16).double()) if precision else (lambda t: t.double())
+    big = case % 5 == 4                                       # a group far into the throughput regime
+    n = int(rng.integers(1, 9))
+    problems, refs = [], []
+    for _ in range(n):
+        hi = 1500 if big else 200
+        M, N = int(rng.integers(1, hi)), int(rng.integers(1, hi))
+        K = int(rng.choice([1, 3, 16, 50, 64, 100, 256, 400, 677, 1100]))
+        ta, tb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if rng.integers(0, 3) == 0:                           # multiples of 4 / 16: the aligned fast paths
+            M, N = max(16, M // 16 * 16), max(16, N // 16 * 16)
+
+        def operand(rows, cols):
+            pad, off = int(rng.integers(0, 7)), int(rng.integers(0, 4))
+            base = torch.randn(rows, cols + pad + off, generator=gen).cuda()
+            return base[:, off:off + cols] if (pad or off) else base
+        A = operand(K, M) if ta else operand(M, K)
+        Bm = operand(N, K) if tb else operand(K, N)
+        epi = int(rng.choice([hip.EPI_NONE, hip.EPI_BIAS, hip.EPI_BIAS_ELU, hip.EPI_MUL_DELU, hip.EPI_ADD_AUX, hip.EPI_ADD_AUX_ELU]))
+        bias = torch.randn(N, generator=gen).cuda() if epi in (hip.EPI_BIAS, hip.EPI_BIAS_ELU, hip.EPI_ADD_AUX, hip.EPI_ADD_AUX_ELU) else None
+        aux = torch.randn(M, N, generator=gen).cuda() if epi >= hip.EPI_MUL_DELU else None
+        beta = float(rng.choice([0.0, 0.0, 1.0]))
+        out = torch.randn(M, N, generator=gen).cuda() if beta else None
+        colsum = bool(ta and not tb and rng.integers(0, 2))   # the bias gradient rides on weight-gradient products
+        pr = dict(A=A, B=Bm, ta=ta, tb=tb, epilogue=epi, beta=beta, colsum=colsum)
+        if bias is not None: pr["bias"] = bias
+        if aux is not None: pr["aux"] = aux
+        ref = (r(A.cpu()).t() if ta else r(A.cpu())) @ (r(Bm.cpu()).t() if tb else r(Bm.cpu()))
+        if beta:
+            ref = ref + beta * out.cpu().double(); pr["out"] = out
+        if epi == hip.EPI_BIAS: ref = ref + bias.cpu().double()
+        elif epi == hip.EPI_BIAS_ELU: ref = torch.nn.functional.elu(ref + bias.cpu().double())
+        elif epi == hip.EPI_MUL_DELU:
+            y = aux.cpu().double(); ref = ref * torch.where(y > 0, torch.ones_like(y), y + 1)
+        elif epi == hip.EPI_ADD_AUX: ref = ref + aux.cpu().double() + bias.cpu().double()
+        elif epi == hip.EPI_ADD_AUX_ELU: ref = torch.nn.functional.elu(ref + aux.cpu().double() + bias.cpu().double())
+        problems.append(pr); refs.append((ref, Bm.cpu().double().sum(1 if tb else 0) if colsum else None, K))
+    outs = hip.gemm_grouped(problems, precision=precision)
+    for i, ((C_, cs), (ref, cref, K)) in enumerate(zip(outs, refs)):
+        atol = 2e-5 * np.sqrt(K) * 4 + 1e-5
+        assert_close(C_, ref, 2e-5, atol, f"problem {i} of {n} (K={K})")
+        if cref is not None:
+            assert_close(cs, cref, 1e-5, 1e-4 * np.sqrt(K), f"colsum {i}")
