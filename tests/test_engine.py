@@ -482,6 +482,25 @@ def test_train_step_updates_match_oracle(gpu_device):
     assert eng.global_step == 5 and eng.step_dev.item() == 5
 
 
+@pytest.mark.parametrize("case", [0, 3, 5, 8])
+def test_train_step_updates_match_oracle_on_random_configs(gpu_device, case):
+    """two full updates (forward, backward, both centred-RMSProp optimisers, step counter) on seeded random architectures against the
+    float64 oracle's train step: the parameter DELTAS agree (same bar as the named configuration)"""
+    ocfg, B = _random_config(case)
+    eng, params, obs, noise = make_pair(ocfg, B, gstep=3)
+    p64 = f64(params)
+    slots = O.rmsprop_init(p64)
+    for it in range(2):
+        eng.forward(sample_noise=False); eng.backward(); eng.optimizer_step()
+        O.train_step(p64, slots, ocfg, obs.double(), f64(noise), global_step=3 + it)
+    eng.synchronize()
+    for k, ref in p64.items():
+        delta_ref = ref - params[k].double()
+        delta = eng.params[k].cpu().double() - params[k].double()
+        assert rel_err(delta, delta_ref) < 5e-3, (k, rel_err(delta, delta_ref))
+    assert eng.global_step == 5 and eng.step_dev.item() == 5
+
+
 def test_graph_replay_equals_eager(gpu_device):
     """hipGraph-captured step == eager step from the same state and the same Philox counter."""
     ocfg, B = CONFIGS["mnist_b8"]
