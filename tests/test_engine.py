@@ -501,9 +501,11 @@ def test_train_step_updates_match_oracle_on_random_configs(gpu_device, case):
     assert eng.global_step == 5 and eng.step_dev.item() == 5
 
 
-def test_graph_replay_equals_eager(gpu_device):
-    """hipGraph-captured step == eager step from the same state and the same Philox counter."""
-    ocfg, B = CONFIGS["mnist_b8"]
+@pytest.mark.parametrize("which", ["mnist_b8", 1, 4, 7, 10])
+def test_graph_replay_equals_eager(gpu_device, which):
+    """hipGraph-captured step == eager step from the same state and the same Philox counter (the named configuration and four
+    seeded random architectures: whatever launches the plan is made of, capture must not change a bit)."""
+    ocfg, B = CONFIGS[which] if isinstance(which, str) else _random_config(which)
     eng_a, params, obs, noise = make_pair(ocfg, B, seed=3, gstep=0)
     eng_b, _, _, _ = make_pair(ocfg, B, seed=3, gstep=0)
     eng_b.capture()
