@@ -19,6 +19,18 @@ __device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps
     const float d = mu - pm;
     return d * d / (2.f * ps * ps) + 0.5f * (ratio - 1.f - logf(ratio));
 }
+// d KL / d scale, evaluated in the order the reference's automatic differentiation walks the expression above (TF 1.1
+// _kl_normal_normal, model.py:188-214: ratio = s^2 / ps^2; LogGrad = g * 1/ratio; RealDivGrad; SquareGrad = g * 2s):
+//     g_ratio = .5 dk - (.5 dk) / ratio,   ds = (g_ratio / ps^2) * 2 s.
+// Equal to dk * (s / ps^2 - 1 / s) wherever `ratio` is a normal number -- and non-finite exactly where the reference's gradient
+// is: -inf once s^2 underflows (s < 3.7e-23: the KL row itself is +inf there), NaN for s == 0.  The closed form would stay
+// finite down to s = 1e-38 and hide the blow-up the reference's arithmetic has (match, don't clamp).
+__device__ __forceinline__ float normal_kl_dscale(float dk, float s, float ps) {
+    const float ps2 = ps * ps;
+    const float ratio = (s * s) / ps2;
+    const float gr = 0.5f * dk - (0.5f * dk) / ratio;
+    return (gr / ps2) * (2.f * s);
+}
 // one 64-lane wave per row: D elements strided over lanes, KL reduced with a wave reduction
 __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, float raw_offset,
@@ -70,7 +82,7 @@ __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const floa
         const float ds = (dsample ? dsample[e] : 0.f) + (dsample2 ? dsample2[e] : 0.f);
         const float dk = dkl_row ? dkl_row[m] * dkl_scale : 0.f;
         float dmu = ds + dk * (mu - pm) / (ps * ps);
-        const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + dk * (s / (ps * ps) - 1.f / s);
+        const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + normal_kl_dscale(dk, s, ps);
         if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
         const float raw = pre[m * ld_pre + D + d] + raw_offset;
         const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus

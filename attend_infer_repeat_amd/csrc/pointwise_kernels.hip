@@ -268,7 +268,7 @@ __global__ __launch_bounds__(PW_THREADS) void normal_kl_bwd_kernel(const float *
         const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
         const float g = dkl[m], s = scale[e];
         dloc[e] = g * (loc[e] - pm) / (ps * ps);
-        dscale[e] = g * (s / (ps * ps) - 1.f / s);
+        dscale[e] = normal_kl_dscale(g, s, ps);
     }
 }
 extern "C" int air_normal_kl_fwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even,

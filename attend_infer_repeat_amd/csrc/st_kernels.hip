@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
                 const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
                 const float ds = s_dw + accd;
                 float dmu = ds + s_dk * (mu - pm) / (ps * ps);
-                const float dsc = ds * s_eps + s_dk * (sc / (ps * ps) - 1.f / sc);
+                const float dsc = ds * s_eps + normal_kl_dscale(s_dk, sc, ps);
                 dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
                 const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
                 g.dpre[k * 8 + d_] = dmu;
@@ -1911,7 +1911,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
             const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
             const float ds = s_dw + accd;
             float dmu = ds + s_dk * (mu - pm) / (ps * ps);
-            const float dsc = ds * s_eps + s_dk * (sc / (ps * ps) - 1.f / sc);
+            const float dsc = ds * s_eps + normal_kl_dscale(s_dk, sc, ps);
             dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
             const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
             g.dpre[(size_t)k * 8 + d_] = dmu;

@@ -87,12 +87,26 @@ class DeviceFeeder(object):
 
 # ---- multi-MNIST synthesis from digit templates (reference: data/data.py:19-107) ----------------------------------------
 def _tight_box(template):
-    """(y0, x0), (height, width) of the non-zero support of a template (data.py:19-32: first..last non-zero row / column)."""
-    rows = np.flatnonzero(template.sum(1) > 0)
-    cols = np.flatnonzero(template.sum(0) > 0)
-    if rows.size == 0 or cols.size == 0:
-        return (0, 0), (0, 0)
-    return (int(rows[0]), int(cols[0])), (int(rows[-1] - rows[0] + 1), int(cols[-1] - cols[0] + 1))
+    """(y0, x0), (height, width) of a template's support as the reference measures it (data.py:19-32, `dim_coords`): the extent
+    along an axis is the NUMBER of non-empty rows / columns and the start is `last non-empty - count + 1`.  For a support without
+    empty rows inside (every digit that is one connected blob) this is the tight bounding box; a glyph with a gap is cropped short
+    at its top / left exactly as in the reference's dataset."""
+    def axis(proj):
+        nz = proj > 0
+        count = int(nz.sum())
+        return int(np.argmax(np.arange(nz.size) * nz)) - count + 1, count
+    (y0, sh), (x0, sw) = axis(template.sum(1)), axis(template.sum(0))
+    return (y0, x0), (sh, sw)
+
+
+def _to_uint8(template):
+    """what scipy.misc.imresize (data.py:55) does to a template before any resampling: uint8 passes through, anything else is
+    scaled from [its min, its max] to [0, 255] and rounded half up (scipy.misc.bytescale's defaults)."""
+    if template.dtype == np.uint8:
+        return template
+    lo, hi = template.min(), template.max()
+    span = (hi - lo) if hi > lo else 1
+    return (((template - lo) * (255.0 / span)).clip(0, 255) + 0.5).astype(np.uint8)
 
 
 def _resize_templates(templates, obj_size):
@@ -105,19 +119,26 @@ def _resize_templates(templates, obj_size):
 
 
 def create_multi_mnist(templates, labels=None, canvas_size=(50, 50), obj_size=(28, 28), n_objects=(0, 2), n_samples=None,
-                       dtype=np.uint8, expand_nums=True, with_overlap=False, seed=0, max_tries=5):
-    """Multi-digit canvases from single-digit templates, the generator of the reference's dataset script (data.py:35-107).
+                       dtype=np.uint8, expand_nums=True, with_overlap=False, seed=0, max_tries=5, rng=None):
+    """Multi-digit canvases from single-digit templates: the generator of the reference's dataset script (data.py:35-107),
+    draw for draw.
 
-    templates [N, h, w] (uint8 0..255 or float 0..1 -- MNIST digits when available; the container has no network, so the
-    caller supplies them, e.g. `load_mnist_idx`), labels [N] optional.  Per sample: n ~ U{0..max(n_objects)} distinct templates,
-    each cropped to the tight bounding box of its non-zero pixels and pasted at a uniformly random position where the box fits;
-    without overlap a position is redrawn while the box hits an occupied box, at most `max_tries` redraws per SAMPLE, after
-    which the whole sample is started again (data.py:84-97).  Returns dict(imgs [n,H,W] dtype, labels [n,max] uint8,
-    nums [max+1,n,1] cumulative one-hot (data.py:101-105) or [n] counts)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+    templates [N, h, w] (uint8 0..255 or float -- MNIST digits when available; the container has no network, so the caller
+    supplies them, e.g. `load_mnist_idx`), labels [N] optional.  `rng`: a numpy RandomState (default RandomState(seed)) standing
+    in for the global np.random the reference draws from; the calls on it are the reference's, in its order --
+    randint(max + 1, size=n_samples, dtype=uint8) for the object counts (data.py:52), then per sample attempt
+    choice(n_templates, n, replace=False) (:73) and per placement try rand(n) (:58-60) -- so that the same templates and the same
+    generator state give the reference's dataset element for element (tests/test_data.py checks this against oracle/data_oracle.py).
+    That includes its quirks: with ONE object both coordinates come from the same draw (rand(1) broadcast over the two free
+    ranges: the digit lies on the canvas diagonal), a sample is started again when the try counter -- kept per sample, over all
+    of its objects -- reaches `max_tries`, even if the last draw was free (:84-97), and a template's box is `_tight_box`.
+    The reference cannot place three or more objects (rand(3) does not broadcast against two ranges: ValueError); here samples
+    with n > 2 draw rand(2) per try instead (BASELINE configs[3]: 0-4 digits).
+    Returns dict(imgs [n,H,W] dtype, labels [n,max] uint8, nums [max+1,n,1] cumulative one-hot (data.py:101-105) or [n] counts)."""
+    rng = np.random.RandomState(seed) if rng is None else rng
     templates = np.asarray(templates)
-    if templates.dtype != np.uint8 and dtype == np.uint8:
-        templates = np.clip(np.round(templates * 255.0), 0, 255).astype(np.uint8)
+    if templates.dtype != np.uint8:
+        templates = np.stack([_to_uint8(t) for t in templates])
     templates = _resize_templates(templates, obj_size)
     n_templates = templates.shape[0]
     n_samples = n_templates if n_samples is None else int(n_samples)
@@ -125,34 +146,36 @@ def create_multi_mnist(templates, labels=None, canvas_size=(50, 50), obj_size=(2
     H, W = canvas_size
     imgs = np.zeros((n_samples, H, W), dtype=dtype)
     lab = np.zeros((n_samples, max_objects), dtype=np.uint8)
-    nums = rng.integers(0, max_objects + 1, size=n_samples).astype(np.uint8)
-    boxes = [_tight_box(t) for t in templates]
+    nums = rng.randint(max_objects + 1, size=n_samples, dtype=np.uint8)
+    boxes = {}
     occupancy = np.zeros((H, W), dtype=bool)
-
-    def position(size):
-        return np.round(rng.random(2) * (np.asarray([H, W]) - np.asarray(size))).astype(np.int64)
-
     i = 0
     while i < n_samples:
         n, tries, retry = int(nums[i]), 0, False
-        occupancy[...] = False
-        idx = rng.choice(n_templates, size=n, replace=False) if n > 0 else []
-        for j, k in enumerate(idx):
-            (y0, x0), (sh, sw) = boxes[k]
-            if sh > H or sw > W:
-                raise ValueError("template box %s does not fit the canvas %s" % ((sh, sw), (H, W)))
-            p = position((sh, sw))
-            if not with_overlap:
-                while occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw].any() and tries < max_tries:
-                    p = position((sh, sw))
-                    tries += 1
-                if tries == max_tries and occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw].any():
-                    retry = True
-                    break
-            imgs[i, p[0]:p[0] + sh, p[1]:p[1] + sw] = templates[k, y0:y0 + sh, x0:x0 + sw]
-            occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw] = True
-            if labels is not None:
-                lab[i, j] = labels[k]
+        if n > 0:
+            idx = rng.choice(n_templates, n, replace=False)
+            occupancy[...] = False
+            n_draw = n if n <= 2 else 2
+            for j in range(n):
+                k = int(idx[j])
+                if k not in boxes:
+                    boxes[k] = _tight_box(templates[k])
+                (y0, x0), (sh, sw) = boxes[k]
+                if sh > H or sw > W:
+                    raise ValueError("template box %s does not fit the canvas %s" % ((sh, sw), (H, W)))
+                free = np.asarray([H - sh, W - sw])
+                p = np.round(rng.rand(n_draw) * free).astype(np.int32)
+                if not with_overlap:
+                    while occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw].any() and tries < max_tries:
+                        p = np.round(rng.rand(n_draw) * free).astype(np.int32)
+                        tries += 1
+                    if tries == max_tries:
+                        retry = True
+                        break
+                imgs[i, p[0]:p[0] + sh, p[1]:p[1] + sw] = templates[k, y0:y0 + sh, x0:x0 + sw]
+                occupancy[p[0]:p[0] + sh, p[1]:p[1] + sw] = True
+                if labels is not None:
+                    lab[i, j] = labels[k]
         if retry:
             imgs[i] = 0
             lab[i] = 0

@@ -111,10 +111,14 @@ def create_rccl_comm(device, group=None):
     if not isinstance(ident[0], (bytes, bytearray)):                 # the same object on every rank: all raise together
         raise _lib.AirHipError("rank 0 could not create an RCCL unique id: %r" % (ident[0],))
     comm = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        st = L.air_comm_init(ctypes.byref(comm), world, rank, ctypes.create_string_buffer(bytes(ident[0]), 128))
-    n = ctypes.c_int(0)
-    ok = st == 0 and L.air_comm_count(comm, ctypes.byref(n)) == 0 and n.value == world
+    st, ok = -1, False
+    try:                      # rank-local failures are folded into `ok`: the agreement below is reached by every rank
+        with torch.cuda.device(device):
+            st = L.air_comm_init(ctypes.byref(comm), world, rank, ctypes.create_string_buffer(bytes(ident[0]), 128))
+        n = ctypes.c_int(0)
+        ok = st == 0 and L.air_comm_count(comm, ctypes.byref(n)) == 0 and n.value == world
+    except Exception:         # noqa: BLE001
+        ok = False
     if not _agree(ok, device, group):
         if st == 0:
             L.air_comm_destroy(comm)
@@ -138,12 +142,15 @@ def selftest_comm(comm, device, stream, group=None) -> bool:
     L = H.lib()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ok = True
-    with torch.cuda.device(device), torch.cuda.stream(stream):
-        probe = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=device)
-        st = L.air_allreduce_sum(ctypes.c_void_p(probe.data_ptr()), ctypes.c_size_t(probe.numel()), comm,
-                                 ctypes.c_void_p(stream.cuda_stream))
-        stream.synchronize()
-        ok = st == 0 and bool((probe == world * (world + 1) / 2.0).all().item())
+    try:                      # anything rank-local that fails (allocation, a HIP error) must still reach the agreement below:
+        with torch.cuda.device(device), torch.cuda.stream(stream):      # a rank that skipped it would leave its peers blocked in it
+            probe = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=device)
+            st = L.air_allreduce_sum(ctypes.c_void_p(probe.data_ptr()), ctypes.c_size_t(probe.numel()), comm,
+                                     ctypes.c_void_p(stream.cuda_stream))
+            stream.synchronize()
+            ok = st == 0 and bool((probe == world * (world + 1) / 2.0).all().item())
+    except Exception:         # noqa: BLE001 -- reported as "not ok"; every rank then takes the host-issued protocol together
+        ok = False
     return _agree(ok, device, group)
 
 

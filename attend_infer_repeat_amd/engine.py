@@ -504,7 +504,10 @@ class AIREngine:
         #  library only has on 16x16 tiles: its launch must stay below the 1536-tile switch to 32x32 tiles)
         n_after = self.enc.shapes[1][1] if self.enc.n > 1 else 4 * Hd
         split0 = (lvl0_tiles * (2 if cfg.use_reinforce else 1) <= 128 and P >= 2048 and P % 4 == 0 and E0 % 16 == 0
-                  and ((B + 15) // 16) * ((n_after + 15) // 16) <= 1536 and os.environ.get("AIR_SPLIT_K0", "1") == "1")
+                  and ((B + 15) // 16) * ((n_after + 15) // 16) <= 1536 and os.environ.get("AIR_SPLIT_K0", "1") == "1"
+                  # (not on the bf16 data path -- many steps at a small batch, e.g. B = 64, T = 12: the consumer's A-prologue has no
+                  #  bf16-mirror form and the first layer's activation would be a mirrored buffer no epilogue writes)
+                  and not use16)
         self._split0 = split0
         if split0:
             kh = (P // 2) // 16 * 16                       # both halves start 16-byte aligned (and on a chunk boundary)
@@ -976,8 +979,10 @@ class AIREngine:
             if self.T > 1:
                 trusted.append((self.dgx, self.dgx16))
         gemm_made = []
-        for m in (self.enc, self.tr, self.st, self.ge, self.gd, self.bl):
+        for m in (self.enc, self.ge, self.gd, self.bl):
             gemm_made += list(m.out)
+        for m in (self.tr, self.st):     # the heads' output layers are written by air_attend_fwd when it is fused (and no product
+            gemm_made += list(m.out[:-1])  # reads them as an operand either way): no mirror to trust
         for m in (self.enc, self.ge, self.gd, self.bl):      # (transform / steps: attend_bwd writes part of their gradient chain)
             gemm_made += list(m.g[:-1])
         gemm_made += [self.ge.g[-1], self.enc.g[-1]]
@@ -990,7 +995,9 @@ class AIREngine:
     def _lstm16_ok(self):
         """the shapes air_lstm_step_*_bf16 take (the library's wide-tile LSTM form)"""
         Hd, E = self.cfg.n_hidden, int(self.cfg.inpt_encoder_hidden[-1])
-        return (((self.B + 15) // 16) * ((Hd + 15) // 16) > 512 and Hd % 64 == 0 and E % 4 == 0
+        # (the same threshold _build_plans uses for `fuse_lstm`: below it the fp32 fused steps run and write no mirror)
+        return (((self.B + 15) // 16) * ((Hd + 15) // 16) > int(os.environ.get("AIR_FUSE_LSTM_TILES", "512"))
+                and Hd % 64 == 0 and E % 4 == 0
                 and os.environ.get("AIR_FUSE_LSTM_WIDE", "1") == "1" and os.environ.get("AIR_BF16_LSTM", "1") == "1")
 
     def _mirror_ptr(self, t):

@@ -1,5 +1,8 @@
 """HIP runtime settings the engine is measured with.  They are read by libamdhip64 when the runtime initialises (the first HIP call of
 the process), so they are put into the environment when this package is imported -- `setdefault`: anything the user exported wins.
+The setting is PROCESS-WIDE: it changes how every hipGraph of the process is replayed, torch's own CUDA graphs included (same
+results, different submission path).  `AIR_RUNTIME_ENV=0` leaves the runtime's defaults alone; importing the package after the
+runtime is up raises a RuntimeWarning (the setting can no longer apply) and `runtime_env.late` says so.
 
 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
     ROCm 7 replays a captured graph from pre-recorded AQL packets ("graph packet capture").  For the train step -- a chain of 34-40
@@ -38,4 +41,9 @@ def apply():
     for k, v in SETTINGS.items():
         os.environ.setdefault(k, v)
         applied[k] = os.environ[k]
+    if late:
+        import warnings
+        warnings.warn("attend_infer_repeat_amd was imported after the HIP runtime was initialised: %s cannot take effect in this "
+                      "process (the documented step times assume it; import the package, or export the setting, before the first "
+                      "HIP call)" % ", ".join("%s=%s" % kv for kv in SETTINGS.items()), RuntimeWarning, stacklevel=3)
     return applied

@@ -391,6 +391,27 @@ def st_write_gridsample(glimpse: Tensor, where: Tensor, img_size) -> Tensor:
 # --------------------------------------------------------------------------------------
 # one AIR step (cell.py:116-171) and the unroll (model.py:66-104)
 # --------------------------------------------------------------------------------------
+class _SoftplusTF(torch.autograd.Function):
+    """softplus with the BACKWARD in the form TF 1.1 registers for it (SoftplusGrad: gradients / (exp(-features) + 1)); the
+    forward is log1p(exp(x)) (identity beyond 20, as F.softplus).  For finite gradients this equals torch's g * z / (z + 1),
+    z = exp(x), to an ulp.  The forms differ only where the incoming gradient is already infinite (a KL row whose sigma^2 has
+    underflowed, model.py:188-214) AND x < -88.7: TF divides inf by inf (NaN), torch multiplies inf by a denormal (inf).  Either way
+    the update is non-finite; the oracle follows the reference's stack (tests/golden/ASSUMPTIONS.md #12)."""
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return F.softplus(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g / (torch.exp(-x) + 1.0)
+
+
+def softplus(x: Tensor) -> Tensor:
+    return _SoftplusTF.apply(x)
+
+
 def transform_params(emb: Tensor, cfg: AIRConfig):
     """StochasticTransformParam._build (modules.py:58-63) + _transform (:41-46)."""
     sx, tx, sy, ty = (emb[:, k:k + 1] for k in range(4))
@@ -427,7 +448,7 @@ def cell_step(params, cfg: AIRConfig, state, eps_where: Tensor, eps_what: Tensor
 
     emb = mlp(h_out, params, "transform", len(cfg.transform_estimator_hidden) + 1, last_linear=True)
     where_loc, where_raw = transform_params(emb, cfg)                                               # cell.py:129
-    where_scale = F.softplus(where_raw)                                                             # cell.py:130-132
+    where_scale = softplus(where_raw)                                                             # cell.py:130-132
     where = where_loc + where_scale * eps_where                                                     # cell.py:133
 
     cropped = st_read(img, where, cfg.crop_size)                                                    # cell.py:135
@@ -446,7 +467,7 @@ def cell_step(params, cfg: AIRConfig, state, eps_where: Tensor, eps_what: Tensor
     q = mm(g, params["what/w"]) + params["what/b"]                                                     # modules.py:20-21
     A = cfg.n_appearance
     what_loc, what_raw = q[:, :A], q[:, A:]
-    what_scale = F.softplus(what_raw + cfg.what_scale_offset)                                       # modules.py:23
+    what_scale = softplus(what_raw + cfg.what_scale_offset)                                       # modules.py:23
     what = what_loc + what_scale * eps_what                                                         # cell.py:156
 
     decoded = mlp(what, params, "glimpse_decoder", len(cfg.glimpse_decoder_hidden) + 1, last_linear=True)

@@ -294,6 +294,16 @@ def test_training_script_counterpart_runs(amd, tmp_path):
     air.refresh()
     make_fig(air, str(tmp_path), 40, n_samples=4)
     assert os.path.getsize(os.path.join(tmp_path, "progress_fig_40.png")) > 10_000
+    # ... and its CONTENT, panel by panel, from what the engine produced (where / presence / canvases of the last evaluated batch):
+    # the attention boxes are those of evaluation.py:23-28 for the engine's `where`, drawn exactly for the steps it marks present
+    from test_data import check_progress_figure
+    fig = make_fig(air, n_samples=8)
+    host = lambda t: t.detach().cpu().numpy()
+    pres = host(air.presence)[..., 0]
+    assert pres[:, :8].sum() > 0                                    # (step_bias .75: an untrained model takes steps)
+    n = check_progress_figure(fig, host(air.obs), host(air.canvas), host(air.glimpse), pres, host(air.where),
+                              host(air.num_steps_distrib.prob()[..., 1:]), 8)
+    assert n == int(pres[:, :8].sum())
 
 
 def test_generic_path_decay_rate_and_l2_match_oracle(amd):

@@ -25,7 +25,7 @@ def test_tight_box_matches_construction():
     t, boxes = _templates()
     for img, box in zip(t, boxes):
         assert D._tight_box(img) == ((int(box[0][0]), int(box[0][1])), (int(box[1][0]), int(box[1][1])))
-    assert D._tight_box(np.zeros((28, 28))) == ((0, 0), (0, 0))
+    assert D._tight_box(np.zeros((28, 28))) == ((1, 1), (0, 0))             # data.py:19-23 on an empty projection: 0 - 0 + 1
 
 
 def test_create_multi_mnist_contract_and_no_overlap():
@@ -58,8 +58,12 @@ def test_create_multi_mnist_is_reproducible_and_float_templates_work():
     a = D.create_multi_mnist(t, None, n_samples=50, seed=5)
     b = D.create_multi_mnist(t, None, n_samples=50, seed=5)
     assert np.array_equal(a["imgs"], b["imgs"]) and np.array_equal(a["nums"], b["nums"])
-    c = D.create_multi_mnist(t.astype(np.float32) / 255.0, None, n_samples=50, seed=5)
-    assert np.array_equal(a["imgs"], c["imgs"])
+    # float templates go through scipy.misc.bytescale's arithmetic (data.py:55): [min, max] -> [0, 255]; MNIST's floats are
+    # uint8 / 255 with min 0 and (almost always) max 1, which maps back to the original bytes
+    t2 = t.copy(); t2[:, 14, 14] = 255
+    a2 = D.create_multi_mnist(t2, None, n_samples=50, seed=5)
+    c = D.create_multi_mnist(t2.astype(np.float32) / 255.0, None, n_samples=50, seed=5)
+    assert np.array_equal(a2["imgs"], c["imgs"])
     d = D.create_multi_mnist(t, None, n_samples=20, seed=5, expand_nums=False)
     assert d["nums"].shape == (20,)
 
@@ -146,3 +150,129 @@ def test_gradient_summaries_and_attention_box():
     assert attention_box([1.0, 0.0, 1.0, 0.0], 50, 40) == (0.0, 0.0, 50.0, 40.0)
     left, top, w, h = attention_box([0.5, 0.5, 0.5, 0.0], 50, 40)
     assert (left, top, w, h) == (25.0, 10.0, 25.0, 20.0)
+
+
+# ---- f2: the generator against the restatement of data.py:35-107 (oracle/data_oracle.py), element for element ----------------
+def _gappy_templates(n=60, seed=9):
+    """procedural digits plus the cases the reference's box arithmetic treats specially: supports with an empty row / column
+    inside (dim_coords counts non-empty rows), a single pixel, a full-field template, an empty one"""
+    t, labels = D.procedural_digit_templates(n, seed=seed)
+    t = t.copy()
+    t[0] = 0; t[0, 5:9, 6:20] = 200; t[0, 15:22, 8:12] = 90          # two blobs, rows 9..14 empty
+    t[1] = 0; t[1, 4:24, 3:8] = 255; t[1, 6:20, 16:21] = 17          # columns 8..15 empty
+    t[2] = 0; t[2, 13, 13] = 1
+    t[3] = 131
+    return t, labels
+
+
+@pytest.mark.parametrize("n_objects,canvas,seed,overlap", [((0, 2), (50, 50), 0, False), ((0, 2), (50, 50), 1, False),
+                                                           ((1, 2), (40, 64), 2, False), ((2,), (34, 34), 3, False),
+                                                           ((0, 1), (28, 28), 4, True), ((0, 2), (50, 50), 5, True)])
+def test_create_multi_mnist_equals_the_reference_generator_draw_for_draw(n_objects, canvas, seed, overlap):
+    """Same templates, same generator state => the same canvases, labels and counts as data.py:35-107, including its quirks (one
+    object: both coordinates from one draw; five tries per SAMPLE; count-based boxes) -- and the SAME generator state afterwards,
+    i.e. not one draw more or less."""
+    from oracle import data_oracle as DO
+    t, labels = _gappy_templates()
+    if canvas == (28, 28):
+        t = t[4:]; labels = labels[4:]                     # (keep the full-field template out of a canvas of its own size)
+    ra, rb = np.random.RandomState(100 + seed), np.random.RandomState(100 + seed)
+    want = DO.create_mnist(t, labels, ra, canvas_size=canvas, n_objects=n_objects, n_samples=300, with_overlap=overlap)
+    got = D.create_multi_mnist(t, labels, canvas_size=canvas, n_objects=n_objects, n_samples=300, with_overlap=overlap, rng=rb)
+    for k in ("imgs", "labels", "nums"):
+        assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), k
+    assert ra.randint(1 << 30) == rb.randint(1 << 30)
+    # seed= is RandomState(seed): the reference's `np.random.seed(seed)` before running its script
+    again = D.create_multi_mnist(t, labels, canvas_size=canvas, n_objects=n_objects, n_samples=300, with_overlap=overlap, seed=100 + seed)
+    assert np.array_equal(again["imgs"], want["imgs"])
+
+
+def test_single_objects_lie_on_the_diagonal_like_the_reference():
+    """data.py:58-60: make_p draws rand(n) with n = the sample's object count, so one object gets ONE number for both coordinates."""
+    t, labels = D.procedural_digit_templates(50, seed=1)
+    d = D.create_multi_mnist(t, labels, n_objects=(1,), n_samples=100, seed=7)
+    assert d["nums"].sum() > 30
+    for img in d["imgs"]:
+        ys, xs = np.nonzero(img.sum(1))[0], np.nonzero(img.sum(0))[0]
+        if ys.size == 0:                                    # randint(max + 1): counts 0 or 1
+            continue
+        (y0, h), (x0, w) = (ys[0], ys[-1] - ys[0] + 1), (xs[0], xs[-1] - xs[0] + 1)
+        u_y, u_x = y0 / max(50 - h, 1), x0 / max(50 - w, 1)
+        assert abs(u_y - u_x) <= 0.5 / max(50 - h, 1) + 0.5 / max(50 - w, 1) + 1e-9
+
+
+def test_multi_mnist_fixture():
+    """tests/golden/multi_mnist_case.npz (written by tests/golden/make_data_golden.py from oracle/data_oracle.py): templates in,
+    dataset out.  Both the oracle and the product reproduce it."""
+    import os
+    from oracle import data_oracle as DO
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "multi_mnist_case.npz"))
+    for make in (lambda: DO.create_mnist(z["templates"], z["labels"], np.random.RandomState(int(z["seed"])), n_samples=int(z["n_samples"])),
+                 lambda: D.create_multi_mnist(z["templates"], z["labels"], n_samples=int(z["n_samples"]), seed=int(z["seed"]))):
+        d = make()
+        assert np.array_equal(d["imgs"], z["imgs"]) and np.array_equal(d["labels"], z["out_labels"]) and np.array_equal(d["nums"], z["nums"])
+
+
+def test_more_than_two_objects_is_an_extension():
+    """The reference cannot broadcast rand(3) against two free ranges (ValueError in make_p); the product places 3-4 digits
+    (BASELINE configs[3]) with two draws per try."""
+    from oracle import data_oracle as DO
+    t, labels = D.procedural_digit_templates(40, seed=2)
+    with pytest.raises(ValueError):
+        DO.create_mnist(t, labels, np.random.RandomState(0), canvas_size=(100, 100), n_objects=(3,), n_samples=4)
+    d = D.create_multi_mnist(t, labels, canvas_size=(100, 100), n_objects=(0, 4), n_samples=60, seed=0)
+    assert d["nums"].shape == (5, 60, 1) and set(np.unique(d["nums"].sum(0))) == {0, 1, 2, 3, 4}
+
+
+# ---- f3: content of the progress figure (evaluation.py:31-65) ------------------------------------------------------------------
+def check_progress_figure(fig, obs, canvas, glimpse, presence, where, step_probs, n_cols):
+    """Every panel of the reference's figure, read back from the matplotlib objects: row 0 the inputs, rows 1..T the canvas after
+    each step with ONE red rectangle -- the box of evaluation.py:23-28 -- exactly where the step is present, rows T+1..2T the
+    glimpses titled '<presence> with p(<t+1>) = <prob>'."""
+    from matplotlib.patches import Rectangle
+    from attend_infer_repeat_amd.evaluation import attention_box
+    T = canvas.shape[0]
+    H, W = obs.shape[1:]
+    axes = np.array(fig.axes).reshape(2 * T + 1, n_cols)
+    n_boxes = 0
+    for col in range(n_cols):
+        assert np.array_equal(axes[0, col].images[0].get_array(), obs[col])
+        for t in range(T):
+            ax = axes[1 + t, col]
+            assert np.array_equal(ax.images[0].get_array(), canvas[t, col]) and ax.images[0].get_clim() == (0, 1)
+            boxes = [p for p in ax.patches if isinstance(p, Rectangle)]
+            if presence[t, col] > .5:
+                assert len(boxes) == 1
+                left, top, bw, bh = attention_box(where[t, col], W, H)
+                r = boxes[0]
+                assert np.allclose([r.get_x(), r.get_y(), r.get_width(), r.get_height()], [left - .5, top - .5, bw, bh], atol=1e-4)
+                assert r.get_edgecolor()[:3] == (1.0, 0.0, 0.0) and r.get_facecolor()[3] == 0.0
+                # the same box in the reference's own variables (evaluation.py:23-28: bbox = [y - .5, x - .5, height * sy, width * sx])
+                sx, tx, sy, ty = (float(v) for v in where[t, col])
+                assert np.allclose([r.get_x(), r.get_y()], [W * (1. - sx + tx) / 2 - .5, H * (1. - sy + ty) / 2 - .5], atol=1e-4)
+                n_boxes += 1
+            else:
+                assert len(boxes) == 0
+            gax = axes[1 + T + t, col]
+            assert np.array_equal(gax.images[0].get_array(), glimpse[t, col])
+            assert gax.get_title() == '{:d} with p({:d}) = {:.02f}'.format(int(presence[t, col]), t + 1, float(step_probs[col, t]))
+    return n_boxes
+
+
+def test_make_fig_content_with_a_stand_in_model():
+    import torch
+    from attend_infer_repeat_amd.evaluation import make_fig
+    from attend_infer_repeat_amd.utils import AttrDict
+    rng = np.random.default_rng(0)
+    T, B, H, W, h, w = 3, 12, 50, 40, 20, 16
+    f = lambda *s: torch.from_numpy(rng.random(s).astype(np.float32))
+    pres = torch.from_numpy((rng.random((T, B, 1)) > 0.4).astype(np.float32))
+    probs = f(B, T + 1)
+    air = AttrDict(obs=f(B, H, W), canvas=f(T, B, H, W), glimpse=f(T, B, h, w), presence=pres, where=f(T, B, 4) * 2 - 0.5,
+                   max_steps=T, batch_size=B, num_steps_distrib=AttrDict(prob=lambda: probs))
+    fig = make_fig(air, n_samples=10)
+    n = check_progress_figure(fig, air.obs.numpy(), air.canvas.numpy(), air.glimpse.numpy(), pres.numpy()[..., 0], air.where.numpy(),
+                              probs.numpy()[:, 1:], 10)
+    assert n == int(pres[:, :10].sum())
+    import matplotlib.pyplot as plt
+    plt.close(fig)

@@ -1,0 +1,210 @@
+"""The regime where long training runs die: the transform head's raw scale wanders to
+-44 ... -100, sigma = softplus(raw) reaches 1e-20 ... 0, sigma^2 turns denormal and then underflows.  In the reference's fp32
+arithmetic (model.py:188-214 -- the Normal KL is written over ratio = sigma^2 / prior^2 and differentiated as written,
+cell.py:130-133 / modules.py:62-63 -- softplus without a floor) the KL row is then +inf and the scale gradient -inf or NaN.
+SURVEY section 7: "match, don't clamp".  These tests hold the HIP kernels to the SAME inf / NaN placement as the fp32 oracle,
+element for element, and to its values wherever both are finite:
+
+  * kernel level (air_gauss_sample_fwd/bwd, air_normal_kl_fwd/bwd): exact inputs on both sides;
+  * engine level (air_attend_fwd / air_attend_bwd / canvas kernels / the whole backward): the transform head's (and the `what`
+    head's) scale biases are set to the extreme values, |where| reaches +-250, and every output and gradient tensor must be
+    finite, +inf, -inf or NaN exactly where the fp32 oracle's is.
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import air_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# raw scales: ordinary | sigma^2 denormal | sigma^2 = 0 (KL = +inf, gradient -inf) | exp(-raw) = inf (gradient inf/inf = NaN) |
+# sigma denormal | sigma = 0
+RAWS = [86.0, 21.0, 20.0, 0.0, -13.0, -20.0, -30.0, -43.0, -44.0, -46.0, -51.0, -53.0, -60.0, -88.0, -89.0, -103.0, -104.0,
+        -110.0, -200.0]
+
+
+def classes(t):
+    """0 finite, 1 +inf, 2 -inf, 3 NaN"""
+    t = t.detach().cpu()
+    c = torch.zeros(t.shape, dtype=torch.int8)
+    c[torch.isposinf(t)] = 1
+    c[torch.isneginf(t)] = 2
+    c[torch.isnan(t)] = 3
+    return c
+
+
+def same_placement(name, got, ref):
+    cg, cr = classes(got), classes(ref.reshape(got.shape))
+    bad = (cg != cr).nonzero()
+    assert bad.numel() == 0, "%s: %d elements differ in class (0 finite, 1 +inf, 2 -inf, 3 NaN); first at %s: kernel %d, oracle %d" % (
+        name, bad.shape[0], bad[0].tolist(), int(cg[tuple(bad[0])]), int(cr[tuple(bad[0])]))
+    return cr == 0
+
+
+def close_where_finite(name, got, ref, tol, floor=0.0):
+    fin = same_placement(name, got, ref)
+    g, r = got.detach().cpu().double().reshape(fin.shape)[fin], ref.detach().cpu().double().reshape(fin.shape)[fin]
+    if g.numel():
+        err = ((g - r).abs() / (r.abs() + floor)).max().item()
+        assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("D,loc_mode,offset", [(4, 1, 0.5), (50, 0, 0.5)])
+def test_gauss_sample_kl_extreme_scales_same_placement_as_fp32_oracle(gpu_device, D, loc_mode, offset):
+    """air_gauss_sample_fwd / _bwd (cell.py:130-133,154-156 + the KL rows of model.py:177-214) on rows whose raw scale walks
+    through RAWS: sample, scale, KL row and d(pre) against the fp32 oracle on the SAME inputs."""
+    from attend_infer_repeat_amd import hip as H
+    rng = np.random.default_rng(7)
+    M = len(RAWS) * 3
+    pre = torch.from_numpy(rng.standard_normal((M, 2 * D)).astype(np.float32))
+    for m in range(M):
+        pre[m, D:] = RAWS[m % len(RAWS)] - offset          # whole row at one raw value ...
+    for m in range(len(RAWS), 2 * len(RAWS)):              # ... or one column only (the rest of the row ordinary)
+        keep = pre[m, D].clone(); pre[m, D:] = torch.from_numpy(rng.standard_normal(D).astype(np.float32)); pre[m, D] = keep
+    eps = torch.from_numpy(rng.standard_normal((M, D)).astype(np.float32))
+    dsample = torch.from_numpy(rng.standard_normal((M, D)).astype(np.float32))
+    dkl = torch.from_numpy((rng.uniform(1e-6, 1e-2, M)).astype(np.float32))
+    dkl[2 * len(RAWS):] = 0.0                              # third block: zero KL weight (0 * inf = NaN where the reference's is)
+    prior4 = (0.0, 1.0, 0.0, 1.0)
+
+    p = pre.clone().requires_grad_(True)
+    mu, raw = p[:, :D], p[:, D:]
+    if loc_mode == 1:
+        ocfg = O.AIRConfig(transform_var_bias=offset)
+        mu, raw = O.transform_params(p, ocfg)
+    else:
+        raw = raw + offset
+    sc = O.softplus(raw)
+    smp = mu + sc * eps
+    one = torch.ones(())
+    kl = O.normal_kl(mu, sc, 0.0 * one, one).sum(-1)
+    ((smp * dsample).sum() + (kl * dkl).sum()).backward()
+
+    loc_d, scale_d, sample_d, kl_d = H.gauss_sample_fwd(pre.cuda(), eps.cuda(), offset, loc_mode, prior4)
+    close_where_finite("loc", loc_d, mu, 2e-6, 1e-30)
+    # softplus of a raw below -87 is a denormal on both sides: a handful of bits, compared to an ulp of the denormal grid
+    close_where_finite("scale", scale_d, sc, 4e-6, 3e-45)
+    close_where_finite("sample", sample_d, smp, 1e-5, 1e-6)
+    same_placement("kl_row", kl_d, kl)
+    assert torch.isposinf(kl_d.cpu()[[m for m in range(M) if RAWS[m % len(RAWS)] <= -53.0 and m < len(RAWS)]]).all()
+    dpre = H.gauss_sample_bwd(pre.cuda(), eps.cuda(), offset, loc_mode, prior4, loc_d, scale_d, dsample.cuda(), dkl.cuda())
+    fin = same_placement("dpre", dpre, p.grad)
+    # values: the scale handed to the backward is the kernel's own (an ulp from the oracle's); where sigma^2 is denormal an ulp of
+    # sigma moves 1 / ratio by up to a few per cent, so those rows are held to placement + sign + 10 %, everything else to 2e-4
+    g, r = dpre.cpu().double(), p.grad.double()
+    den = torch.zeros(M, dtype=torch.bool)
+    for m in range(M):
+        den[m] = -51.5 < RAWS[m % len(RAWS)] < -43.5
+    for rows, tol in ((~den, 2e-4), (den, 0.1)):
+        sel = fin & rows[:, None]
+        if sel.any():
+            err = ((g[sel] - r[sel]).abs() / (r[sel].abs() + 1e-6 * r[fin].abs().max())).max().item()
+            assert err < tol, (tol, err)
+
+
+def test_normal_kl_extreme_scales_same_placement_as_fp32_oracle(gpu_device):
+    """air_normal_kl_fwd / _bwd with the scale given directly (bit-identical inputs on both sides): every class boundary of
+    ratio = s^2 in fp32 -- last normal, denormal, smallest denormal, underflow -- and of 0.5 g / ratio overflowing."""
+    from attend_infer_repeat_amd import hip as H
+    scales = [86.0, 1.0, 0.3, 1e-9, 1.1e-19, 1.0e-19, 7.8e-20, 1e-20, 1e-21, 2e-22, 1e-22, 5e-23, 3.8e-23, 3.0e-23, 1e-23, 1e-30,
+              1.2e-38, 1e-38, 1e-42, 1.4e-45, 0.0]
+    M, D = len(scales), 4
+    rng = np.random.default_rng(11)
+    loc = torch.from_numpy(rng.standard_normal((M, D)).astype(np.float32))
+    scale = torch.tensor(scales, dtype=torch.float32)[:, None].repeat(1, D).contiguous()
+    dkl = torch.from_numpy(rng.uniform(1e-6, 1e-2, M).astype(np.float32))
+    prior4 = (0.0, 1.0, 0.5, 2.0)
+    lo, sc = loc.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+    pm = torch.tensor([0.0, 0.5, 0.0, 0.5]); ps = torch.tensor([1.0, 2.0, 1.0, 2.0])
+    kl = O.normal_kl(lo, sc, pm, ps).sum(-1)
+    (kl * dkl).sum().backward()
+    kl_d = H.normal_kl_fwd(loc.cuda(), scale.cuda(), prior4)
+    close_where_finite("kl", kl_d, kl, 1e-5, 1e-6)
+    dloc, dscale = H.normal_kl_bwd(loc.cuda(), scale.cuda(), prior4, dkl.cuda())
+    close_where_finite("dloc", dloc, lo.grad, 1e-5, 1e-9)
+    close_where_finite("dscale", dscale, sc.grad, 1e-5, 1e-9)
+    c = classes(dscale)
+    assert (c[scales.index(1e-30)] == 2).all() and (c[scales.index(0.0)] == 3).all() and (c[scales.index(1.0e-19)] == 0).all()
+
+
+# (name, raw scale of [sx, tx, sy, ty], raw scale of the first `what` columns or None)
+ENGINE_CASES = [
+    ("sigma2_normal", (-20.0, -30.0, -40.0, -43.0), None),           # everything finite, sigma^2 down to the last normal decade
+    ("sigma2_denormal_and_wide", (-44.0, -46.0, 20.0, 86.0), None),   # sigma^2 denormal; scale 86 => |where| up to +-250
+    ("sigma2_underflow", (-60.0, 0.0, -88.0, 0.0), None),            # KL = +inf, scale gradient -inf
+    ("sigma_zero", (-89.0, -104.0, -110.0, -200.0), None),           # -inf / inf and -inf * 0 = NaN
+    ("what_underflow", (0.0, 0.0, 0.0, 0.0), (-60.0, -104.0, -44.0)),
+]
+
+
+@pytest.mark.parametrize("case", ENGINE_CASES, ids=[c[0] for c in ENGINE_CASES])
+@pytest.mark.parametrize("B", [8, 64])
+def test_engine_extreme_scales_same_placement_as_fp32_oracle(gpu_device, case, B):
+    """The whole train-step arithmetic (air_attend_fwd / air_attend_bwd with the where-sampling backward on 4 lanes, the canvas
+    kernels, air_gauss_sample_bwd_nvil, every GEMM behind them) with the scale heads forced to the extreme regime: outputs, losses
+    and ALL gradient tensors are finite / +inf / -inf / NaN exactly where the fp32 oracle's are, and equal where both are finite."""
+    from test_engine import make_pair
+    name, where_raw, what_raw = case
+    ocfg = O.AIRConfig()
+    eng, params, obs, noise = make_pair(ocfg, B, seed=5)
+    params = {k: v.clone() for k, v in params.items()}
+    last = "transform/%d" % len(ocfg.transform_estimator_hidden)
+    params[last + "/w"][:, 4:] = 0.0                                    # the raw scales come from the bias alone: every row the same
+    params[last + "/b"][4:] = torch.tensor(where_raw) - ocfg.transform_var_bias
+    if what_raw is not None:
+        A, n = ocfg.n_appearance, len(what_raw)
+        params["what/w"][:, A:A + n] = 0.0
+        params["what/b"][A:A + n] = torch.tensor(what_raw) - ocfg.what_scale_offset
+    eng.load_parameters(params)
+    eng.forward(sample_noise=False); eng.backward()
+    out, grads = eng.outputs(), eng.named_grads()
+    res, ref = O.forward_backward(params, ocfg, obs, noise, global_step=20000)          # fp32: placement is a property of fp32
+
+    assert torch.isfinite(out["where"]).all() and torch.isfinite(res["where"]).all()
+    if name == "sigma2_denormal_and_wide":
+        assert out["where"].abs().max().item() > 140.0
+    for k in ("where", "where_loc", "what_loc", "presence_prob", "final_canvas", "rec_loss_per_sample",
+              "kl_num_steps_per_sample"):
+        close_where_finite(k, out[k], res[k], 2e-3, 1e-3 * res[k].abs().max().item() + 1e-30)
+    for k in ("where_scale", "what_scale"):
+        close_where_finite(k, out[k], res[k], 1e-4, 3e-45)
+    for k in ("kl_where_per_sample", "kl_what_per_sample", "loss", "opt_loss", "kl_where", "kl_what"):
+        fin = same_placement(k, out[k], res[k])
+        if name in ("sigma2_underflow", "sigma_zero") and k in ("kl_where_per_sample", "kl_where", "loss", "opt_loss"):
+            assert torch.isposinf(out[k]).all(), k
+        if name == "what_underflow" and k in ("kl_what_per_sample", "kl_what", "loss", "opt_loss"):
+            assert torch.isposinf(out[k]).all(), k
+        if fin.all():
+            close_where_finite(k, out[k], res[k], 1e-3, 1e-3 * res[k].abs().max().item() + 1e-30)
+    n_bad = 0
+    for k, r in ref.items():
+        fin = same_placement("grad " + k, grads[k], r)
+        n_bad += int((~fin).sum())
+        if fin.any():
+            g, rr = grads[k].detach().cpu().double()[fin], r.double()[fin]
+            # denormal sigma^2: an ulp of sigma moves the gradient's 1 / ratio term by per cents (see the kernel-level test)
+            tol = 0.1 if name in ("sigma2_denormal_and_wide", "what_underflow") else 2e-3
+            err = ((g - rr).abs().max() / (rr.abs().max() + 1e-30)).item()
+            assert err < tol, (k, err)
+    if name in ("sigma2_normal", "sigma2_denormal_and_wide"):
+        assert n_bad == 0
+    else:
+        assert n_bad > 0
+        # the heads downstream of the latents never see the scale gradient: they stay finite while everything upstream of the
+        # transform (or `what`) head is poisoned -- in the oracle and in the engine alike
+        for k in ref:
+            if k.startswith("steps/") or k.startswith("baseline/") or k.startswith("glimpse_decoder/"):
+                assert torch.isfinite(grads[k]).all(), k
+        assert not torch.isfinite(grads[(last if what_raw is None else "what") + "/b"]).all()
+    # one update: RMSProp carries any non-finite gradient into the parameter (ms - mg^2 = inf - inf), as DESIGN section 6 describes
+    eng.optimizer_step(); eng.synchronize()
+    got_finite = bool(torch.isfinite(eng.flat_params).all())
+    slots = O.rmsprop_init(params)
+    O.rmsprop_centered_step(params, ref, slots, ocfg)
+    ref_finite = all(bool(torch.isfinite(v).all()) for v in params.values())
+    assert got_finite == ref_finite == (n_bad == 0)
+    for k, v in params.items():
+        same_placement("updated " + k, eng.params[k], v)

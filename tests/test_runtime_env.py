@@ -16,3 +16,17 @@ def test_runtime_env_is_applied_on_import_and_yields_to_the_user(monkeypatch):
     assert R.apply() == {} and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ
     monkeypatch.delenv("AIR_RUNTIME_ENV")
     R.apply()
+
+
+def test_runtime_env_warns_when_the_hip_runtime_is_already_up(monkeypatch):
+    """the setting is read once by the HIP runtime; an import after torch initialised HIP cannot apply it and says so."""
+    import pytest
+    import torch
+    from attend_infer_repeat_amd import runtime_env as R
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    with pytest.warns(RuntimeWarning, match="cannot take effect"):
+        R.apply()
+    assert R.late is True
+    monkeypatch.undo()
+    R.apply()
+    assert R.late is False
