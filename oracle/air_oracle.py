@@ -319,6 +319,12 @@ def resample_bilinear(src: Tensor, x: Tensor, y: Tensor) -> Tensor:
     src [B,Hs,Ws]; x, y [B,Ho,Wo] in source-pixel units -> [B,Ho,Wo]."""
     B, Hs, Ws = src.shape
     inside = (x > -1) & (y > -1) & (x < Ws) & (y < Hs)
+    # Sample points outside the source (incl. NaN / inf coordinates: an inverse warp with sx == 0 has 1/sx = inf) produce 0 and
+    # receive EXACTLY zero gradient -- the resampler's registered gradient op skips them (ASSUMPTIONS.md #3).  Their coordinates
+    # are therefore replaced by a constant before any arithmetic: a mask applied afterwards would turn 0 * NaN into NaN in the
+    # gradient of the OTHER coordinate, which the reference's op does not do.  Values of inside points are unchanged.
+    x = torch.where(inside, x, torch.zeros_like(x))
+    y = torch.where(inside, y, torch.zeros_like(y))
     fx, fy = torch.floor(x), torch.floor(y)
     cx, cy = fx + 1, fy + 1
     dx, dy = cx - x, cy - y

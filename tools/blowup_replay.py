@@ -62,10 +62,19 @@ def main():
     ap.add_argument("--samples", type=int, default=60000)
     ap.add_argument("--out", default="gpurun_out/blowup")
     ap.add_argument("--oracle-threads", type=int, default=8)
+    ap.add_argument("--legacy-data", action="store_true",
+                    help="the round-3 dataset generator (tools/legacy/data_r03.py: PCG64 draws, two position draws per object) instead of "
+                         "the reference-order one -- reproduces runs recorded before the generator was made draw-for-draw faithful")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
 
-    from attend_infer_repeat_amd.data import procedural_multi_mnist
+    if args.legacy_data:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("data_r03", os.path.join(ROOT, "tools", "legacy", "data_r03.py"))
+        legacy = importlib.util.module_from_spec(spec); spec.loader.exec_module(legacy)
+        procedural_multi_mnist = legacy.procedural_multi_mnist
+    else:
+        from attend_infer_repeat_amd.data import procedural_multi_mnist
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
     from oracle import air_oracle as O
 
@@ -130,6 +139,21 @@ def main():
                 if want_states_from is not None:
                     states[k] = eng.state_dict()
                     states["grads_at_%d" % k] = {n: g.detach().cpu().clone() for n, g in eng.named_grads().items()}
+                    # where the non-finite values FIRST appear in the step's intermediates (every buffer the engine holds)
+                    where_rows = eng.where.reshape(-1, 4)
+                    diag = {}
+                    for name, t in sorted(eng._bufs.items()):
+                        if t.is_floating_point():
+                            bad = ~torch.isfinite(t)
+                            if bool(bad.any()):
+                                diag[name] = dict(nonfinite=int(bad.sum()), shape=list(t.shape))
+                                if t.dim() == 2 and t.shape[0] == where_rows.shape[0]:
+                                    rows = bad.any(1).nonzero().reshape(-1)[:6]
+                                    diag[name]["rows"] = rows.tolist()
+                                    diag[name]["where_of_rows"] = where_rows[rows].tolist()
+                                    diag[name]["values"] = t[rows][:, :12].tolist()
+                                    diag[name]["presence_of_rows"] = eng.presence.reshape(-1)[rows].tolist()
+                    states["nonfinite_buffers_at_%d" % k] = diag
             if u_star is not None and k >= u_star + stop_after_bad:
                 break
         return rec, u_star, states
@@ -207,6 +231,7 @@ def main():
                     row[name]["delta_rel_err_vs_engine"] = worst
             if k + 1 == u_star:
                 eg = states["grads_at_%d" % u_star]
+                report["engine_nonfinite_buffers"] = states["nonfinite_buffers_at_%d" % u_star]
                 row[name]["engine_nonfinite_grads"] = nonfinite_names(eg)
                 row[name]["same_nonfinite_gradient_tensors"] = nonfinite_names(eg) == nonfinite_names(grads)
                 cls = lambda t: (torch.isnan(t).to(torch.int8) * 3 + torch.isposinf(t).to(torch.int8) + torch.isneginf(t).to(torch.int8) * 2)
