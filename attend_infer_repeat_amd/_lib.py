@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 5  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 6  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -63,10 +63,10 @@ SIGNATURES = {
     "air_attend_fwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, c_float, c_float, c_float, c_float, c_float,
                                P, P, P, P, P, c_float, c_float, P, P, P, P, P, P, P, P, P,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "air_attend_bwd": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, P, c_float, P,
+    "air_attend_bwd": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, c_int, P, c_float, P,
                                P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
                                c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "air_attend_bwd_dx": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, P, c_float, P,
+    "air_attend_bwd_dx": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, c_int, P, c_float, P,
                                   P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
                                   c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, c_int, c_int,
                                   c_int, P]),
@@ -85,9 +85,8 @@ SIGNATURES = {
                                      P, c_float, P, c_int, c_int, c_int, P]),
     "air_gauss_sample_bwd_nvil": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
                                           P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, P]),
-    "air_canvas_unroll_image": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
-                                        c_float, P]),
-    "air_canvas_unroll_fwd_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+    "air_canvas_unroll_fwd_bwd_fits": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "air_canvas_unroll_fwd_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_float, c_float, c_float, P]),
     "air_normal_kl_fwd": (c_int, [P, P, c_float, c_float, c_float, c_float, P, c_int, c_int, P]),
     "air_normal_kl_bwd": (c_int, [P, P, c_float, c_float, c_float, c_float, P, P, P, c_int, c_int, P]),

@@ -494,12 +494,16 @@ __device__ __forceinline__ void canvas_bwd_body(const WriteBwdArgs &a, const Nvi
             const float r0 = __shfl(tot, 0, 64) * cxs, r1 = __shfl(tot, 8, 64) * cxs, r2 = __shfl(tot, 16, 64) * cys,
                         r3 = __shfl(tot, 24, 64) * cys, r4 = __shfl(tot, 32, 64);
             if (lane == 0) {
-                // chain through a = 1/s, b = -t/s (linear in the partial sums: each of the NS slabs carries its share)
+                // chain through a = 1/s, b = (-t)/s (linear in the partial sums: each of the NS slabs carries its share), written as
+                // automatic differentiation evaluates the two divisions -- d(x/y) = g/y for x, -g * ((x/y)/y) for y -- so that a
+                // degenerate scale (0, denormal: 1/s = inf; 1e-20: 1/s^2 = inf) gives NaN / inf / 0 exactly where the reference's
+                // gradient does (tests/test_extreme_scales.py): e.g. a zero partial sum over s = 1e-40 is 0/s = 0, not 0 * (1/s) = NaN
                 float *d = dwhere + 4 * ((size_t)sp * n + k);
-                d[0] = r0 * (-1.0f / (sx * sx)) + r1 * (tx / (sx * sx));
-                d[1] = r1 * (-1.0f / sx);
-                d[2] = r2 * (-1.0f / (sy * sy)) + r3 * (ty / (sy * sy));
-                d[3] = r3 * (-1.0f / sy);
+                const float ax = 1.0f / sx, bx = (-tx) / sx, ay = 1.0f / sy, by = (-ty) / sy;
+                d[0] = -(r0 * (ax / sx)) - r1 * (bx / sx);
+                d[1] = -(r1 / sx);
+                d[2] = -(r2 * (ay / sy)) - r3 * (by / sy);
+                d[3] = -(r3 / sy);
                 if (dpresence) dpresence[(size_t)sp * n + k] = r4;
             }
         }
@@ -533,4 +537,238 @@ __global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, Writ
         const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
         canvas_bwd_body<true>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
     }
+}
+
+// ============================================================================================================
+// host side
+// ============================================================================================================
+static inline double lin_step(int n) { return n > 1 ? 2.0 / (double)(n - 1) : 0.0; }
+static inline int cv_grid(long items, int cap) { return (int)(items < cap ? items : cap); }
+static inline int cv_check_dims(int n, int H, int W, int h, int w) {
+    if (n <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return AIR_E_SHAPE;
+    return AIR_OK;
+}
+#define CV_MAX_LDS (160 * 1024)
+template <typename K>
+static inline int cv_allow_lds(K kernel, size_t lds) {      // dynamic LDS above 64 KiB must be opted into per kernel
+    if (lds <= 64 * 1024) return AIR_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e == hipSuccess ? AIR_OK : (int)e;
+}
+// rows per band / number of bands actually used for a request of `want` bands
+static inline void wr_bands(int H, int want, int *NB, int *RB) {
+    int nb = want < 1 ? 1 : (want > H ? H : want);
+    const int rb = (H + nb - 1) / nb;
+    nb = (H + rb - 1) / rb;                                  // drop empty trailing bands
+    *NB = nb; *RB = rb;
+}
+// Workgroup shapes.  Latency regime (the launch does not fill the chip): many waves per unit, each with a row or two, so the
+// unit's chain is short; throughput regime: few waves per unit, many units resident per CU (the kernels are VALU-issue bound:
+// what matters there is that every SIMD always has a wave to issue from).
+static inline int fwd_threads(long units, int RB) {
+    if (units > 512) return 256;
+    int nw = RB < 16 ? RB : 16;
+    if (units > 256 && nw > 8) nw = 8;
+    return 64 * (nw < 1 ? 1 : nw);
+}
+static inline int bwd_threads(long units_x_ns, int h) {
+    if (units_x_ns > 1024) return 64;
+    if (units_x_ns > 512) return 128;
+    int nw = h < 8 ? h : 8;
+    return 64 * (nw < 1 ? 1 : nw);
+}
+static int launch_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
+                            const float *obs, float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
+                            int T, int B, int H, int W, int h, int w, float mult, float std, void *stream) {
+    int NB, RB;
+    wr_bands(H, n_bands, &NB, &RB);
+    AIR_REQUIRE(NB == n_bands || !rec_parts, AIR_E_SHAPE);   // the caller sized rec_parts for exactly n_bands shares
+    const size_t lds = carve_fwd_bytes(T, RB, W, h, w);
+    AIR_REQUIRE(lds <= CV_MAX_LDS, AIR_E_UNSUPPORTED);
+    const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);   // 16-byte groups that never straddle a glimpse row
+    const long units = (long)B * NB;
+    const int threads = fwd_threads(units, RB);
+    const WriteFwdArgs a = {glimpse, where, presence, canvas_in, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, vec4g};
+    if (threads <= 256) {
+        { int st_ = cv_allow_lds(canvas_fwd_small_kernel, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(canvas_fwd_small_kernel, dim3(cv_grid(units, 256 * 8)), dim3(threads), lds, air_stream(stream), a);
+    } else {
+        { int st_ = cv_allow_lds(canvas_fwd_kernel, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(canvas_fwd_kernel, dim3(cv_grid(units, 256 * 8)), dim3(threads), lds, air_stream(stream), a);
+    }
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+extern "C" int air_st_write_fwd(const float *glimpse, const float *where, const float *presence,
+                                const float *canvas_in, float *canvas_out, int n, int H, int W, int h, int w,
+                                void *stream) {
+    AIR_REQUIRE(glimpse && where && canvas_out, AIR_E_NULL);
+    int st = cv_check_dims(n, H, W, h, w);
+    if (st) return st;
+    return launch_write_fwd(glimpse, where, presence, canvas_in, nullptr, nullptr, canvas_out, nullptr, 1, 1, n, H, W, h,
+                            w, 1.0f, 1.0f, stream);
+}
+
+extern "C" int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence,
+                                     const float *obs, float *canvas_steps, float *final_canvas,
+                                     float *rec_per_sample, int T, int B, int H, int W, int h, int w, float mult,
+                                     float std, void *stream) {
+    AIR_REQUIRE(glimpse && where && (final_canvas || canvas_steps), AIR_E_NULL);
+    AIR_REQUIRE(!rec_per_sample || obs, AIR_E_NULL);
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = cv_check_dims(B, H, W, h, w);
+    if (st) return st;
+    // the complete per-sample reconstruction term needs the whole image in one workgroup; without it the bands are free
+    int nb = 1;
+    if (!rec_per_sample && (long)B * T <= 1024) nb = 256 / B < 1 ? 1 : 256 / B;
+    int NB, RB;
+    wr_bands(H, nb, &NB, &RB);
+    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_per_sample, NB, T, B,
+                            H, W, h, w, mult, std, stream);
+}
+
+extern "C" int air_canvas_unroll_bands(int B, int H) {
+    int nb = 256 / (B < 1 ? 1 : B);
+    if (nb > 8) nb = 8;
+    int NB, RB;
+    wr_bands(H, nb, &NB, &RB);
+    return NB;
+}
+
+extern "C" int air_canvas_unroll_fwd_banded(const float *glimpse, const float *where, const float *presence,
+                                            const float *obs, float *canvas_steps, float *final_canvas,
+                                            float *rec_parts, int n_bands, int T, int B, int H, int W, int h, int w,
+                                            float mult, float std, void *stream) {
+    AIR_REQUIRE(glimpse && where && (final_canvas || canvas_steps), AIR_E_NULL);
+    AIR_REQUIRE(!rec_parts || obs, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n_bands > 0, AIR_E_SHAPE);
+    int st = cv_check_dims(B, H, W, h, w);
+    if (st) return st;
+    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, n_bands, T, B,
+                            H, W, h, w, mult, std, stream);
+}
+
+static int launch_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
+                            const float *final_canvas, const float *obs, float *dglimpse, float *dwhere,
+                            float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
+                            float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
+    const bool rc = !dcanvas && !final_canvas;                // recompute form: the canvas is re-formed on the unit's footprint
+    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
+    if (nvil) nv = *nvil;
+    const long units = (long)T * B;
+    const int threads = bwd_threads(units, h), nw = threads / 64;
+    const size_t lds = carve_bwd_bytes(H, W, h, w, rc ? T : 1, rc, nw, nw);
+    AIR_REQUIRE(lds <= CV_MAX_LDS, AIR_E_UNSUPPORTED);
+    const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);
+    const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
+    const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, 1};
+    const int grid = cv_grid(units, 256 * 16) + (nvil ? 1 : 0);
+    // (the NVIL rider is one wave-0 chain with a workgroup broadcast: any workgroup size serves it)
+    if (threads <= 128) {
+        if (rc) {
+            { int st_ = cv_allow_lds(canvas_bwd_small_kernel<true>, lds); if (st_) return st_; }
+            hipLaunchKernelGGL(canvas_bwd_small_kernel<true>, dim3(grid), dim3(threads), lds, air_stream(stream), a, nv);
+        } else {
+            { int st_ = cv_allow_lds(canvas_bwd_small_kernel<false>, lds); if (st_) return st_; }
+            hipLaunchKernelGGL(canvas_bwd_small_kernel<false>, dim3(grid), dim3(threads), lds, air_stream(stream), a, nv);
+        }
+    } else if (rc) {
+        { int st_ = cv_allow_lds(canvas_bwd_kernel<true>, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(canvas_bwd_kernel<true>, dim3(grid), dim3(threads), lds, air_stream(stream), a, nv);
+    } else {
+        { int st_ = cv_allow_lds(canvas_bwd_kernel<false>, lds); if (st_) return st_; }
+        hipLaunchKernelGGL(canvas_bwd_kernel<false>, dim3(grid), dim3(threads), lds, air_stream(stream), a, nv);
+    }
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+extern "C" int air_st_write_bwd(const float *glimpse, const float *where, const float *presence,
+                                const float *dcanvas, float *dglimpse, float *dwhere, float *dpresence, int n, int H,
+                                int W, int h, int w, void *stream) {
+    AIR_REQUIRE(glimpse && where && dcanvas && dglimpse && dwhere, AIR_E_NULL);
+    int st = cv_check_dims(n, H, W, h, w);
+    if (st) return st;
+    return launch_write_bwd(glimpse, where, presence, dcanvas, nullptr, nullptr, dglimpse, dwhere, dpresence, 1, n, H,
+                            W, h, w, 1.0f, 1.0f, 1.0f, stream);
+}
+
+extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence,
+                                     const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
+                                     int T, int B, int H, int W, int h, int w, float mult, float std,
+                                     float loss_scale, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = cv_check_dims(B, H, W, h, w);
+    if (st) return st;
+    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
+                            h, w, mult, std, loss_scale, stream);
+}
+
+extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence,
+                                          const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
+                                          int T, int B, int H, int W, int h, int w, float mult, float std,
+                                          float loss_scale, const float *imp_parts, int n_parts, float *imp_sum,
+                                          const float *baseline, const float *logp, float *nvil_out, float *dlogp,
+                                          float *dbaseline, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
+    AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n_parts > 0, AIR_E_SHAPE);
+    int st = cv_check_dims(B, H, W, h, w);
+    if (st) return st;
+    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
+    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
+                            h, w, mult, std, loss_scale, stream, &nv);
+}
+
+// The fused launch's shape for a problem: threads per workgroup, and whether it fits (LDS of both roles, both grids small
+// enough to run side by side).  n_split = workgroups per backward unit (1 or 2).
+static int fused_shape(int n_bands, int n_split, int T, int B, int H, int W, int h, int w, int *threads, size_t *lds) {
+    int NB, RB;
+    wr_bands(H, n_bands, &NB, &RB);
+    if (NB != n_bands) return AIR_E_SHAPE;
+    if (n_split < 1 || n_split > 4) return AIR_E_SHAPE;
+    if ((long)B * NB > 4096 || (long)B * T * n_split > 4096) return AIR_E_UNSUPPORTED;
+    const int nt = bwd_threads((long)B * T * n_split, h) < 512 ? bwd_threads((long)B * T * n_split, h) : 512;
+    const int nw = nt / 64;
+    const size_t lds_f = carve_fwd_bytes(T, RB, W, h, w), lds_b = carve_bwd_bytes(H, W, h, w, T, true, nw, n_split * nw);
+    *lds = lds_f > lds_b ? lds_f : lds_b;
+    *threads = nt;
+    return *lds <= CV_MAX_LDS ? AIR_OK : AIR_E_UNSUPPORTED;
+}
+// 1 when air_canvas_unroll_fwd_bwd takes this problem, 0 otherwise (the caller then plans the two launches)
+extern "C" int air_canvas_unroll_fwd_bwd_fits(int n_bands, int n_split, int T, int B, int H, int W, int h, int w) {
+    int threads; size_t lds;
+    if (T <= 0 || cv_check_dims(B, H, W, h, w)) return 0;
+    return fused_shape(n_bands, n_split, T, B, H, W, h, w, &threads, &lds) == AIR_OK ? 1 : 0;
+}
+// forward (banded, as air_canvas_unroll_fwd_banded) + backward (recompute form of air_canvas_unroll_bwd) as ONE launch.
+// n_split workgroups per backward unit: dwhere then holds n_split slabs [n_split][T*B][4] whose SUM is the gradient.
+extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+                                         float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
+                                         float *dglimpse, float *dwhere, int n_split, int T, int B, int H, int W, int h, int w,
+                                         float mult, float std, float loss_scale, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && (final_canvas || canvas_steps) && rec_parts && dglimpse && dwhere, AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && n_bands > 0, AIR_E_SHAPE);
+    int st = cv_check_dims(B, H, W, h, w);
+    if (st) return st;
+    int threads; size_t lds;
+    st = fused_shape(n_bands, n_split, T, B, H, W, h, w, &threads, &lds);
+    if (st) return st;
+    int NB, RB;
+    wr_bands(H, n_bands, &NB, &RB);
+    const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);
+    const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
+    { int st_ = cv_allow_lds(canvas_fused_kernel, lds); if (st_) return st_; }
+    const WriteFwdArgs f = {glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, vec4g};
+    const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
+                            lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, n_split};
+    const int n_fwd = B * NB;
+    hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }

@@ -1,4 +1,5 @@
-// Spatial-transformer kernels for gfx950: fused affine-grid + bilinear glimpse read, and the inverse canvas write.
+// Spatial-transformer kernels for gfx950: fused affine-grid + bilinear glimpse read and the "attend" fusions around it
+// (the inverse canvas write lives in canvas_kernels.hip).
 //
 // Replaces snt.AffineGridWarper + snt.resampler (+ gradient) behind attend_infer_repeat/modules.py:94-109
 // (called at cell.py:135 and cell.py:159-165).  Semantics: SURVEY.md Appendix A.4 / A.7; oracle: oracle/air_oracle.py
@@ -232,756 +233,6 @@ __global__ __launch_bounds__(1024) void st_read_bwd_kernel(
 }
 
 // ============================================================================================================
-// write: canvas += presence * bilinear(glimpse; x_g = (w-1)/2*(X_J/sx - tx/sx + 1), y_g likewise)
-// One workgroup per image accumulates all T steps in LDS, optionally emitting every intermediate canvas and the
-// per-sample reconstruction term of the final canvas.
-// ============================================================================================================
-// Single-phase form: ALL T glimpses of an image and their T axis tables are staged in LDS behind ONE barrier, then
-// each thread walks its canvas pixels with the running canvas in a register (t inner, in order, so the accumulation is
-// the oracle's ((0 + p0*v0) + p1*v1) + ...).  One memory round trip per image instead of one per step.
-struct CarveWr {
-    float *glm, *pres, *scratch;
-    float2 *xe, *ye;                 // per (t, column) / (t, band row): {floor index as int bits | ST_INVALID, d}
-    int hwp;
-};
-__device__ __forceinline__ CarveWr carve_wr(float *smem, int T, int RB, int W, int h, int w) {
-    CarveWr c;
-    c.hwp = pad_count(h, w);
-    float *p = smem;
-    c.glm = p; p += (size_t)T * c.hwp;
-    c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
-    c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * RB;
-    c.pres = p; p += (T + 3) & ~3;
-    c.scratch = p;
-    return c;
-}
-static inline size_t carve_wr_bytes(int T, int RB, int W, int h, int w) {
-    return sizeof(float) * ((size_t)T * pad_count_host(h, w) + 2 * (size_t)T * (W + RB) + ((T + 3) & ~3) + 128);
-}
-// One workgroup per (image, row band): band `q` of `NB` covers canvas rows [q*RB, min(H, (q+1)*RB)).  A batch of 64 images in
-// 4 bands fills the 256 CUs (one workgroup per image left three quarters of the chip idle while each busy CU was bound by
-// VALU issue: 2500 pixels x T steps x ~45 instructions on 4 SIMDs).  Every global operand (all T glimpses, the `where` rows,
-// presence, this thread's observation pixels) is requested up front -- one memory round trip -- then ONE barrier, then each
-// thread walks its pixels with the running canvas in a register (t inner, in order, so the accumulation is the oracle's
-// ((0 + p0*v0) + p1*v1) + ...).  rec_parts[q*B + b] receives the band's share of the reconstruction term; with NB = 1 that
-// IS rec[b], with NB > 1 the consumer (air_nvil_parts / air_canvas_unroll_bwd_nvil / air_sum_leading) adds the NB shares
-// in band order (no float atomics: bitwise reproducible).
-struct WriteFwdArgs {
-    const float *glimpse, *where, *presence, *canvas_in, *obs;
-    float *canvas_steps, *final_canvas, *rec_parts;
-    int T, B, NB, RB, H, W, h, w;
-    double stepX, stepY;
-    float mult, std;
-    int vec4_glimpse;
-};
-// (vblock of vgrid: the workgroup's index among the workgroups that run this role -- the whole grid of st_write_fwd_kernel, the
-//  first part of the grid of canvas_fused_kernel)
-__device__ __forceinline__ void st_write_fwd_body(const WriteFwdArgs &a, float *smem, const int vblock, const int vgrid) {
-    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
-    const float *__restrict__ canvas_in = a.canvas_in, *__restrict__ obs = a.obs;
-    float *__restrict__ canvas_steps = a.canvas_steps, *__restrict__ final_canvas = a.final_canvas, *__restrict__ rec_parts = a.rec_parts;
-    const int T = a.T, B = a.B, NB = a.NB, RB = a.RB, H = a.H, W = a.W, h = a.h, w = a.w, vec4_glimpse = a.vec4_glimpse;
-    const double stepX = a.stepX, stepY = a.stepY;
-    const float mult = a.mult, std = a.std;
-    AIR_TR_INIT();
-    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x;
-    CarveWr c = carve_wr(smem, T, RB, W, h, w);
-    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
-    const float cst = 0.5f * logf(6.283185307179586f) + logf(std);
-    const int n_units = B * NB;
-    const int pitch = w + 2;
-    const float inv_w = 1.0f / (float)w, inv_W = 1.0f / (float)W;
-    // the zero borders of the T bordered glimpses: written once, never overwritten (visible after the first barrier below)
-    for (int e = tid; e < T * pad_border(h, w); e += nt) {
-        const int t = e / pad_border(h, w);
-        c.glm[(size_t)t * c.hwp + pad_border_index(e - t * pad_border(h, w), h, w)] = 0.f;
-    }
-    for (int unit = vblock; unit < n_units; unit += vgrid) {
-        const int b = unit % B, band = unit / B;
-        const int r0 = band * RB, r1 = (r0 + RB < H) ? r0 + RB : H, npx = (r1 - r0) * W, pbase = r0 * W;
-        AIR_TR(0);
-        // ---- every global load of this unit --------------------------------------------------------------------------
-        const float *ob = rec_parts ? obs + (size_t)b * HW + pbase : where;     // (any valid address when rec is not wanted)
-        const int ob_last = rec_parts ? npx - 1 : 0;
-        float xo[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                          // unconditional loads from clamped addresses (no branches)
-            const int p = tid + u * nt;
-            xo[u] = ob[p < ob_last ? p : ob_last];
-        }
-        if (unit != vblock) __syncthreads();                   // grid-stride reuse of the carve
-        if (vec4_glimpse) {                                    // (w % 4 == 0: a 16-byte group never straddles a glimpse row)
-            const int nq = hw >> 2;
-            for (int e = tid; e < T * nq; e += nt) {
-                const int t = e / nq, q = e - t * nq;
-                const float4 v = reinterpret_cast<const float4 *>(glimpse + ((size_t)t * B + b) * hw)[q];
-                float *d = c.glm + (size_t)t * c.hwp + pad_index(4 * q, w, inv_w);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int e = tid; e < T * hw; e += nt) {
-                const int t = e / hw, q = e - t * hw;
-                c.glm[(size_t)t * c.hwp + pad_index(q, w, inv_w)] = glimpse[((size_t)t * B + b) * hw + q];
-            }
-        }
-        const int nrow = r1 - r0;
-        for (int a = tid; a < T * (W + nrow); a += nt) {
-            const int t = a / (W + nrow), r = a - t * (W + nrow);
-            const float *wk = where + 4 * ((size_t)t * B + b);
-            if (r < W) {
-                const float sx = wk[0], tx = wk[1];
-                c.xe[t * W + r] = axis_entry2(grid_coord(1.0f / sx, lin_m11(r, W, stepX), -tx / sx, cxs), w);
-            } else {
-                const float sy = wk[2], ty = wk[3];
-                const int i = r - W;
-                c.ye[t * RB + i] = axis_entry2(grid_coord(1.0f / sy, lin_m11(r0 + i, H, stepY), -ty / sy, cys), h);
-            }
-        }
-        if (tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
-        AIR_TR(1);
-        __syncthreads();
-        AIR_TR(2);
-        float s[1] = {0.f};
-        for (int p0 = tid; p0 < npx; p0 += 4 * nt) {
-            float xn[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p0 + 4 * nt < npx) {                           // next chunk's observations (bands above 4 pixels per thread)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + (4 + u) * nt;
-                    xn[u] = ob[p < ob_last ? p : ob_last];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = p0 + u * nt;
-                if (p >= npx) break;
-                const int Ib = div_small(p, W, inv_W), J = p - Ib * W;
-                const size_t gp = (size_t)b * HW + pbase + p;
-                float acc = canvas_in ? canvas_in[gp] : 0.f;
-                for (int t = 0; t < T; ++t) {
-                    const float2 ex = c.xe[t * W + J], ey = c.ye[t * RB + Ib];
-                    const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);
-                    float v = 0.f;
-                    if (fx != ST_INVALID && fy != ST_INVALID)
-                        v = bilerp(load_taps_pad(c.glm + (size_t)t * c.hwp, pitch, fy, fx), ex.y, ey.y);
-                    acc = acc + c.pres[t] * v;
-                    if (canvas_steps) canvas_steps[((size_t)t * B + b) * HW + pbase + p] = acc;
-                }
-                if (final_canvas) final_canvas[gp] = acc;
-                if (rec_parts) {
-                    const float z = (xo[u] - mult * acc) / std;
-                    s[0] += 0.5f * z * z + cst;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xo[u] = xn[u];
-        }
-        AIR_TR(3);
-        if (rec_parts) {
-            block_sum<1>(s, c.scratch);
-            if (tid == 0) rec_parts[(size_t)band * B + b] = s[0];
-        }
-        AIR_TR(4);
-    }
-    AIR_TR_FLUSH();
-}
-__global__ __launch_bounds__(1024) void st_write_fwd_kernel(WriteFwdArgs a) {
-    extern __shared__ __align__(16) float smem[];
-    st_write_fwd_body(a, smem, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// Backward of the write for every (t, b): dglimpse, dwhere, optional dpresence.
-// dcanvas either given per step ([T*B,H,W]) or formed on the fly from the reconstruction term:
-//   dcanvas[b,p] = loss_scale * mult * (mult*final[b,p] - obs[b,p]) / std^2   (shared by all t)
-// dglimpse is the transpose of a separable bilinear map, dG = Wy^T . g . Wx with two non-zeros per row of Wy / Wx,
-// evaluated as two small LDS passes in a fixed order (no float atomics => bitwise reproducible):
-//   T1[I,j] = sum_J g[I,J] * wx[J,j]   over the contiguous J-range that touches glimpse column j
-//   dG[i,j] = sum_I wy[I,i] * T1[I,j]  over the contiguous I-range that touches glimpse row i
-struct CarveBwd {
-    float *src, *g, *t1, *X, *Y, *scratch, *pres;
-    float2 *xe, *ye;
-    int2 *jr, *ir;               // exact [lo, hi] canvas column / row range that touches glimpse column j / row i
-    int hwp;
-};
-// n_src = 1: the unit's own glimpse and axis tables; n_src = T (recompute form): those of all T steps of the unit's image,
-// step-major (src + t*hwp, xe + t*W, ye + t*H)
-__device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, int w, int n_src) {
-    CarveBwd c;
-    float *p = smem;
-    c.hwp = pad_count(h, w);             // bordered LDS copies (load_taps_pad)
-    c.src = p; p += n_src * c.hwp;
-    c.g = p; p += (H * W + 3) & ~3;
-    c.t1 = p; p += (H * w + 3) & ~3;
-    c.xe = reinterpret_cast<float2 *>(p); p += 2 * W * n_src;
-    c.ye = reinterpret_cast<float2 *>(p); p += 2 * H * n_src;
-    c.jr = reinterpret_cast<int2 *>(p); p += 2 * w;
-    c.ir = reinterpret_cast<int2 *>(p); p += 2 * h;
-    c.X = p; p += W;
-    c.Y = p; p += H;
-    c.pres = p; p += (n_src + 3) & ~3;
-    c.scratch = p;
-    return c;
-}
-static inline size_t carve_bwd_bytes(int H, int W, int h, int w, int n_src) {
-    return sizeof(float) * (size_t)(n_src * pad_count_host(h, w) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + W + H +
-                                    2 * n_src * (W + H) + 2 * w + 2 * h + ((n_src + 3) & ~3) + 128 + 16);
-}
-
-// Workgroup barriers per unit: [operands staged + axis tables] | footprint pixel pass (+ exact contraction ranges) | column
-// contraction | row contraction.  What the r01 kernel spent its 10 us on (traced with tools/kbench/st_trace.cpp: 2.7 us in
-// three serialised load round trips, 2.3 us walking all H*W canvas pixels on one CU, 1.3 + 2.1 us in the two contractions
-// with data-dependent loop bounds behind LDS min/max atomics) is cut by: requesting every global operand first and building
-// the axis tables -- which only need `where`, the oldest request -- while the rest is in flight; walking only the glimpse's
-// FOOTPRINT on the canvas (the ~(W*sx)*(H*sy) pixels with a valid source coordinate; all others contribute exactly zero;
-// found with two ballots over the tables); exact per-column / per-row source ranges from the inverse affine map, re-checked
-// against the tables, computed by the idlest wave during the pixel pass; 4-wide predicated contraction loops (one LDS round
-// trip); and multi-value wave reductions.
-// RC ("recompute") form: no final canvas is read.  The unit stages ALL T glimpses, `where` rows and presences of its image,
-// re-forms the canvas on its own footprint exactly as st_write_fwd_kernel does (same table entries, same taps, t in order:
-// bit-identical values) and derives dcanvas from it and the observation.  The backward then no longer depends on the canvas
-// forward launch: in the two-lane step the forward (needed for the outputs and the NVIL loss value) leaves the dX chain.
-struct WriteBwdArgs {
-    const float *glimpse, *where, *presence, *dcanvas, *final_canvas, *obs;
-    float *dglimpse, *dwhere, *dpresence;
-    int T, B, H, W, h, w;
-    double stepX, stepY;
-    float mult, std, loss_scale;
-    int vec4_glimpse, vec4_canvas;
-};
-template <bool RC>
-__device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const NvilArgs &nv, float *smem, const int vblock, const int vgrid) {
-    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
-    const float *__restrict__ dcanvas = a.dcanvas, *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
-    float *__restrict__ dglimpse = a.dglimpse, *__restrict__ dwhere = a.dwhere, *__restrict__ dpresence = a.dpresence;
-    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w, vec4_glimpse = a.vec4_glimpse, vec4_canvas = a.vec4_canvas;
-    const double stepX = a.stepX, stepY = a.stepY;
-    const float mult = a.mult, std = a.std, loss_scale = a.loss_scale;
-    // optional second role: one workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
-    // has to precede the baseline / logit backward that follow this launch)
-    AIR_TR_INIT();
-    // the NVIL workgroup is the FIRST of the role's workgroups (a long float64 chain: at the end of a grid that fills the chip it
-    // would only start when the first glimpse workgroups retire)
-    const int grid_st = nv.imp ? vgrid - 1 : vgrid;
-    const int bid0 = nv.imp ? vblock - 1 : vblock;
-    if (bid0 < 0) {
-        AIR_TR(5);
-        nvil_body(nv);
-        AIR_TR(6);
-        AIR_TR_FLUSH();
-        return;
-    }
-    AIR_TR(0);
-    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    CarveBwd c = carve_bwd(smem, H, W, h, w, RC ? T : 1);
-    float *const src_all = c.src;
-    float2 *const xe_all = c.xe, *const ye_all = c.ye;
-    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
-    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
-    const float coef = loss_scale * mult / (std * std);
-    const int n = T * B;
-    const int pitch = w + 2;
-    const float inv_w = 1.0f / (float)w;
-    // the zero borders of the bordered glimpse copies: written once, never overwritten (visible after barrier (1) of the first unit)
-    for (int e = tid; e < (RC ? T : 1) * pad_border(h, w); e += nt) {
-        const int tt = e / pad_border(h, w);
-        src_all[(size_t)tt * c.hwp + pad_border_index(e - tt * pad_border(h, w), h, w)] = 0.f;
-    }
-    for (int k = bid0; k < n; k += grid_st) {
-        const int b = k % B;
-        const int t_own = k / B;
-        if (RC) { c.src = src_all + (size_t)t_own * c.hwp; c.xe = xe_all + t_own * W; c.ye = ye_all + t_own * H; }
-        if (k != bid0) __syncthreads();                      // grid-stride reuse of the LDS carve
-        // ---- every global load of the unit is requested first; the axis tables (which only need `where`, the oldest
-        //      request) are built while the rest is still in flight, then the staged operands are written to LDS
-        const int z0 = opaque_zero();                          // vector-path loads of the wave-uniform operands (see opaque_zero)
-        const float sx = where[4 * (size_t)k + z0], tx = where[4 * (size_t)k + 1 + z0];
-        const float sy = where[4 * (size_t)k + 2 + z0], ty = where[4 * (size_t)k + 3 + z0];
-        const float pres = presence ? presence[k + z0] : 1.0f;
-        const float *dcp = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
-        const float *fcp = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
-        const float *obp = obs ? obs + (size_t)b * HW : nullptr;
-        const float *gsrc = glimpse + (size_t)k * hw;
-        // 16-byte requests from clamped addresses, all issued before anything waits (a per-element `if (p < HW) load` makes
-        // hipcc branch around every load and wait for each one separately -- eight serialised round trips, measured 4 us;
-        // dword requests cost four times the load and LDS-store instructions)
-        const bool v4 = vec4_canvas != 0;
-        const int nQ = HW >> 2;
-        const float *pa = RC ? obp : (dcp ? dcp : fcp), *pb = RC ? obp : (dcp ? dcp : obp);
-        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
-        if (v4) {
-            const int q = tid < nQ ? tid : nQ - 1;
-            if (!RC) qa = reinterpret_cast<const float4 *>(pa)[q];
-            qb = reinterpret_cast<const float4 *>(pb)[q];
-            if (RC) qa = qb;
-        }
-        const int nq = hw >> 2;
-        const int n_gq = RC ? T * nq : nq;                     // recompute form: the T glimpses of image b, step-major in LDS
-        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec4_glimpse && tid < n_gq) {
-            if (RC) { const int tt = tid / nq; gq = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[tid - tt * nq]; }
-            else gq = reinterpret_cast<const float4 *>(gsrc)[tid];
-        }
-        const float ax = 1.0f / sx, bx = -tx / sx;
-        const float ay = 1.0f / sy, by = -ty / sy;
-        {   // axis tables: columns by the first ceil(W/64) waves, rows by the next ceil(H/64) (no divergence inside a wave);
-            // recompute form: one such block per step, each from that step's `where` row
-            const int Wp = (W + 63) & ~63, Hp = (H + 63) & ~63;
-            const int n_tab = RC ? T : 1;
-            for (int a0 = tid; a0 < n_tab * (Wp + Hp); a0 += nt) {
-                const int tt = RC ? a0 / (Wp + Hp) : 0, a = a0 - tt * (Wp + Hp);
-                float axt = ax, bxt = bx, ayt = ay, byt = by;
-                if (RC) {
-                    const float *wk = where + 4 * ((size_t)tt * B + b);
-                    if (a < Wp) { const float s_ = wk[0], t_ = wk[1]; axt = 1.0f / s_; bxt = -t_ / s_; }
-                    else { const float s_ = wk[2], t_ = wk[3]; ayt = 1.0f / s_; byt = -t_ / s_; }
-                }
-                float2 *xe_t = RC ? xe_all + tt * W : c.xe, *ye_t = RC ? ye_all + tt * H : c.ye;
-                if (a < Wp) {
-                    if (a < W) {
-                        const float X = lin_m11(a, W, stepX);
-                        if (!RC || tt == 0) c.X[a] = X;
-                        xe_t[a] = axis_entry2(grid_coord(axt, X, bxt, cxs), w);
-                    }
-                } else {
-                    const int i = a - Wp;
-                    if (i < H) {
-                        const float Y = lin_m11(i, H, stepY);
-                        if (!RC || tt == 0) c.Y[i] = Y;
-                        ye_t[i] = axis_entry2(grid_coord(ayt, Y, byt, cys), h);
-                    }
-                }
-            }
-            if (RC && tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
-        }
-        AIR_TR(7);
-        if (RC) {
-            if (vec4_glimpse) {
-                if (tid < n_gq) {
-                    const int tt = tid / nq;
-                    float *d = src_all + (size_t)tt * c.hwp + pad_index(4 * (tid - tt * nq), w, inv_w);
-                    d[0] = gq.x; d[1] = gq.y; d[2] = gq.z; d[3] = gq.w;
-                }
-                for (int q = tid + nt; q < n_gq; q += nt) {
-                    const int tt = q / nq;
-                    const float4 v = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[q - tt * nq];
-                    float *d = src_all + (size_t)tt * c.hwp + pad_index(4 * (q - tt * nq), w, inv_w);
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                }
-            } else {
-                for (int q = tid; q < T * hw; q += nt) {
-                    const int tt = q / hw;
-                    src_all[(size_t)tt * c.hwp + pad_index(q - tt * hw, w, inv_w)] = glimpse[((size_t)tt * B + b) * hw + (q - tt * hw)];
-                }
-            }
-        } else if (vec4_glimpse) {
-            if (tid < nq) { float *d = c.src + pad_index(4 * tid, w, inv_w); d[0] = gq.x; d[1] = gq.y; d[2] = gq.z; d[3] = gq.w; }
-            for (int q = tid + nt; q < nq; q += nt) {
-                const float4 v = reinterpret_cast<const float4 *>(gsrc)[q];
-                float *d = c.src + pad_index(4 * q, w, inv_w);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int q = tid; q < hw; q += nt) c.src[pad_index(q, w, inv_w)] = gsrc[q];
-        }
-        if (RC) {                                              // c.g holds the OBSERVATION until the pixel pass replaces it
-            if (v4) {
-                if (tid < nQ) reinterpret_cast<float4 *>(c.g)[tid] = qb;
-                for (int q = tid + nt; q < nQ; q += nt) reinterpret_cast<float4 *>(c.g)[q] = reinterpret_cast<const float4 *>(obp)[q];
-            } else {
-                for (int p = tid; p < HW; p += nt) c.g[p] = obp[p];
-            }
-        } else if (v4) {
-            if (tid < nQ) {
-                float4 gv = qa;
-                if (!dcp) { gv.x = coef * (mult * qa.x - qb.x); gv.y = coef * (mult * qa.y - qb.y);
-                            gv.z = coef * (mult * qa.z - qb.z); gv.w = coef * (mult * qa.w - qb.w); }
-                reinterpret_cast<float4 *>(c.g)[tid] = gv;
-            }
-            for (int q = tid + nt; q < nQ; q += nt) {            // images above 4096 pixels
-                const float4 a4 = reinterpret_cast<const float4 *>(pa)[q], b4 = reinterpret_cast<const float4 *>(pb)[q];
-                float4 gv = a4;
-                if (!dcp) { gv.x = coef * (mult * a4.x - b4.x); gv.y = coef * (mult * a4.y - b4.y);
-                            gv.z = coef * (mult * a4.z - b4.z); gv.w = coef * (mult * a4.w - b4.w); }
-                reinterpret_cast<float4 *>(c.g)[q] = gv;
-            }
-        } else {
-            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : coef * (mult * fcp[p] - obp[p]);
-        }
-        AIR_TRT(128, 6);
-        __syncthreads();                                       // (1)
-        AIR_TR(1);
-        // footprint of the glimpse on the canvas (valid columns x valid rows): two ballots per wave over the tables
-        const int2 vx = valid_span(c.xe, W), vy = valid_span(c.ye, H);
-        const int J0 = vx.x, J1 = vx.y, I0 = vy.x, I1 = vy.y;
-        const int fw = J1 - J0 + 1, fh = I1 - I0 + 1;
-        const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
-        AIR_TR(8);
-        const float inv_fw = 1.0f / (float)(fw > 0 ? fw : 1);
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence, -, -, -
-        for (int idx = tid; idx < npx; idx += nt) {
-            const int Ir = div_small(idx, fw, inv_fw), I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
-            const float2 ex = c.xe[J], ey = c.ye[I];
-            const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);       // valid by construction of the footprint
-            const float dx = ex.y, dy = ey.y;
-            const Taps t = load_taps_pad(c.src, pitch, fy, fx);
-            const float v = bilerp(t, dx, dy);
-            float dc = c.g[p];
-            if (RC) {
-                // the canvas at this pixel, accumulated as the forward does: ((0 + p0*v0) + p1*v1) + ... over ALL steps
-                float cv = 0.f;
-                for (int tt = 0; tt < T; ++tt) {
-                    float vt = v;
-                    if (tt != t_own) {
-                        const float2 ext = xe_all[tt * W + J], eyt = ye_all[tt * H + I];
-                        const int fxt = __float_as_int(ext.x), fyt = __float_as_int(eyt.x);
-                        vt = 0.f;
-                        if (fxt != ST_INVALID && fyt != ST_INVALID)
-                            vt = bilerp(load_taps_pad(src_all + (size_t)tt * c.hwp, pitch, fyt, fxt), ext.y, eyt.y);
-                    }
-                    cv = cv + c.pres[tt] * vt;
-                }
-                dc = coef * (mult * cv - dc);                  // (dc held the observation)
-            }
-            const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
-            const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
-            const float go = pres * dc;
-            const float gax = go * gx * cxs, gay = go * gy * cys;
-            acc[0] += gax * c.X[J]; acc[1] += gax;
-            acc[2] += gay * c.Y[I]; acc[3] += gay;
-            acc[4] += dc * v;
-            c.g[p] = go;
-        }
-        AIR_TR(9); AIR_TRT(nt - 64, 10);
-        {
-            const float r = wave_reduce8(acc);
-            if ((lane & 7) == 0) c.scratch[wid * 8 + wave_reduce8_slot()] = r;
-        }
-        // exact source ranges of the two contractions, by the two waves with the fewest footprint pixels
-        if (wid == nw - 1) for (int j = lane; j < w; j += 64) c.jr[j] = touch_range(c.xe, bx, sx, inv_cxs, j, W);   // 1/ax = sx
-        if (wid == (nw > 1 ? nw - 2 : 0)) for (int i = lane; i < h; i += 64) c.ir[i] = touch_range(c.ye, by, sy, inv_cys, i, H);
-        AIR_TRT(nt - 64, 11);
-        __syncthreads();                                       // (2)
-        AIR_TR(2);
-        // pass 1: T1[I, j] = sum_J go[I, J] * wx[J, j] over the exact column range of j, valid rows only
-        for (int e = tid; e < (fh > 0 ? fh : 0) * w; e += nt) {
-            const int Ir = div_small(e, w, inv_w), I = I0 + Ir, j = e - Ir * w;
-            const int2 r = c.jr[j];
-            const float *grow = c.g + I * W;
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                  // the first four candidates: loads issued together
-                const int J = r.x + u;
-                const bool in = J <= r.y;
-                const int Jc = in ? J : r.x <= r.y ? r.x : 0;
-                const float2 ex = c.xe[Jc];
-                const float gv = grow[Jc];
-                const int fx = __float_as_int(ex.x);
-                const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                if (in) s += gv * wgt;
-            }
-            for (int J = r.x + 4; J <= r.y; ++J) {
-                const float2 ex = c.xe[J];
-                const int fx = __float_as_int(ex.x);
-                const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                s += grow[J] * wgt;
-            }
-            c.t1[I * w + j] = s;
-        }
-        __syncthreads();                                       // (3)
-        AIR_TR(3);
-        float *dg = dglimpse + (size_t)k * hw;
-        for (int e = tid; e < hw; e += nt) {               // pass 2: dG[i, j] = sum_I wy[I, i] * T1[I, j]
-            const int i = div_small(e, w, inv_w), j = e - i * w;
-            const int2 r = c.ir[i];
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int I = r.x + u;
-                const bool in = I <= r.y;
-                const int Ic = in ? I : r.x <= r.y ? r.x : 0;
-                const float2 ey = c.ye[Ic];
-                const float tv = in ? c.t1[Ic * w + j] : 0.f;
-                const int fy = __float_as_int(ey.x);
-                const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
-                if (in) s += tv * wgt;
-            }
-            for (int I = r.x + 4; I <= r.y; ++I) {
-                const float2 ey = c.ye[I];
-                const int fy = __float_as_int(ey.x);
-                const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
-                s += c.t1[I * w + j] * wgt;
-            }
-            dg[e] = s;
-        }
-        if (wid == nw - 1) {                               // the per-wave dwhere partials (visible since barrier 2), fixed order;
-            float part[8];                                 // by the LAST wave: it has the least contraction work
-#pragma unroll
-            for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[lane * 8 + q] : 0.f;
-            const float tot = wave_reduce8(part);
-            const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64),
-                        r4 = __shfl(tot, 32, 64);
-            if (lane == 0) {
-                // chain through a = 1/s, b = -t/s
-                float *d = dwhere + 4 * (size_t)k;
-                d[0] = r0 * (-1.0f / (sx * sx)) + r1 * (tx / (sx * sx));
-                d[1] = r1 * (-1.0f / sx);
-                d[2] = r2 * (-1.0f / (sy * sy)) + r3 * (ty / (sy * sy));
-                d[3] = r3 * (-1.0f / sy);
-                if (dpresence) dpresence[k] = r4;
-            }
-        }
-        AIR_TR(4);
-    }
-    AIR_TR_FLUSH();
-}
-template <bool RC>
-__global__ __launch_bounds__(1024) void st_write_bwd_kernel(WriteBwdArgs a, NvilArgs nv) {
-    extern __shared__ __align__(16) float smem[];
-    st_write_bwd_body<RC>(a, nv, smem, (int)blockIdx.x, (int)gridDim.x);
-}
-// Canvas forward and backward of a train step in ONE launch (latency regime).  The recompute form of the backward reads nothing
-// the forward writes, so the two are independent roles of one grid: workgroups [0, n_fwd) run st_write_fwd_body (image x row
-// band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_body<true> (one per glimpse).  One
-// dependent launch less on the step's chain; NVIL -- which needs the forward's reconstruction shares -- rides on a later launch
-// (air_gauss_sample_bwd_nvil).
-__global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, WriteBwdArgs b, int n_fwd) {
-    extern __shared__ __align__(16) float smem[];
-    if ((int)blockIdx.x < n_fwd) st_write_fwd_body(f, smem, (int)blockIdx.x, n_fwd);
-    else {
-        const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
-        st_write_bwd_body<true>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
-    }
-}
-
-// Throughput regime: canvas forward AND backward of one image in ONE workgroup (air_canvas_unroll_image).  Everything an image
-// needs is staged once -- its T glimpses, `where` rows, presences, the axis tables of every step -- and the canvas itself lives in
-// LDS: the forward visits only each glimpse's FOOTPRINT (work proportional to the footprint, not to the canvas: pixels outside
-// it would add exactly +0), copies the running canvas out after every step, forms the reconstruction term and dcanvas in place,
-// and the backward of the T glimpses follows on the same LDS image (pixel pass, column contraction, row contraction, exactly as
-// st_write_bwd_body).  Per image 10 KB of obs + 4.8 KB of glimpses are read ONCE (the two-launch form reads obs twice and the final
-// canvas T times more), nothing is recomputed.  Same arithmetic in the same order as the two kernels it replaces => the same bits.
-struct ImageCarve {
-    float *glm, *cv, *t1, *X, *Y, *pres, *scratch;
-    float2 *xe, *ye;
-    int2 *jr, *ir;
-    int hwp;
-};
-__device__ __forceinline__ ImageCarve carve_image(float *smem, int T, int H, int W, int h, int w) {
-    ImageCarve c;
-    float *p = smem;
-    c.hwp = (h * w + 3) & ~3;
-    c.glm = p; p += (size_t)T * c.hwp;
-    c.cv = p; p += (H * W + 3) & ~3;
-    c.t1 = p; p += (H * w + 3) & ~3;
-    c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
-    c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * H;
-    c.jr = reinterpret_cast<int2 *>(p); p += 2 * w;
-    c.ir = reinterpret_cast<int2 *>(p); p += 2 * h;
-    c.X = p; p += (W + 3) & ~3;
-    c.Y = p; p += (H + 3) & ~3;
-    c.pres = p; p += (T + 3) & ~3;
-    c.scratch = p;
-    return c;
-}
-static inline size_t carve_image_bytes(int T, int H, int W, int h, int w) {
-    return sizeof(float) * ((size_t)T * ((h * w + 3) & ~3) + (size_t)((H * W + 3) & ~3) + ((H * w + 3) & ~3) + 2 * (size_t)T * (W + H) +
-                            2 * w + 2 * h + ((W + 3) & ~3) + ((H + 3) & ~3) + ((T + 3) & ~3) + 160);
-}
-struct ImageArgs {
-    const float *glimpse, *where, *presence, *obs;
-    float *canvas_steps, *final_canvas, *rec, *dglimpse, *dwhere;
-    int T, B, H, W, h, w;
-    double stepX, stepY;
-    float mult, std, loss_scale;
-    int vec4_glimpse, vec4_canvas;
-};
-__global__ __launch_bounds__(ST_THREADS) void canvas_image_kernel(ImageArgs a) {
-    extern __shared__ __align__(16) float smem[];
-    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w;
-    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    ImageCarve c = carve_image(smem, T, H, W, h, w);
-    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
-    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
-    const float coef = a.loss_scale * a.mult / (a.std * a.std);
-    const float cst = 0.5f * logf(6.283185307179586f) + logf(a.std);
-    const float mult = a.mult, std = a.std;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        if (b != (int)blockIdx.x) __syncthreads();
-        // ---- stage the image's operands; axis tables of every step ---------------------------------------------------------------
-        if (a.vec4_glimpse) {
-            const int nq = hw >> 2;
-            for (int e = tid; e < T * nq; e += nt) {
-                const int t = e / nq, q = e - t * nq;
-                reinterpret_cast<float4 *>(c.glm + (size_t)t * c.hwp)[q] = reinterpret_cast<const float4 *>(a.glimpse + ((size_t)t * B + b) * hw)[q];
-            }
-        } else {
-            for (int e = tid; e < T * hw; e += nt) { const int t = e / hw, q = e - t * hw; c.glm[(size_t)t * c.hwp + q] = a.glimpse[((size_t)t * B + b) * hw + q]; }
-        }
-        for (int e = tid; e < T * (W + H); e += nt) {
-            const int t = e / (W + H), r = e - t * (W + H);
-            const float *wk = a.where + 4 * ((size_t)t * B + b);
-            if (r < W) {
-                const float sx = wk[0], tx = wk[1];
-                const float X = lin_m11(r, W, a.stepX);
-                if (t == 0) c.X[r] = X;
-                c.xe[t * W + r] = axis_entry2(grid_coord(1.0f / sx, X, -tx / sx, cxs), w);
-            } else {
-                const float sy = wk[2], ty = wk[3];
-                const int i = r - W;
-                const float Y = lin_m11(i, H, a.stepY);
-                if (t == 0) c.Y[i] = Y;
-                c.ye[t * H + i] = axis_entry2(grid_coord(1.0f / sy, Y, -ty / sy, cys), h);
-            }
-        }
-        if (tid < T) c.pres[tid] = a.presence ? a.presence[(size_t)tid * B + b] : 1.0f;
-        for (int p = tid; p < HW; p += nt) c.cv[p] = 0.f;
-        __syncthreads();
-        // ---- forward: each step adds its glimpse on its footprint (in step order: ((0 + p0 v0) + p1 v1) + ...), then the running
-        //      canvas is copied out ------------------------------------------------------------------------------------------------
-        for (int t = 0; t < T; ++t) {
-            const float2 *xe = c.xe + t * W, *ye = c.ye + t * H;
-            const float *src = c.glm + (size_t)t * c.hwp;
-            const int2 vx = valid_span(xe, W), vy = valid_span(ye, H);
-            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
-            const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
-            const float pr = c.pres[t];
-            for (int idx = tid; idx < npx; idx += nt) {
-                const int Ir = idx / fw, I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
-                const float2 ex = xe[J], ey = ye[I];
-                const float v = bilerp(load_taps_sel(src, h, w, __float_as_int(ey.x), __float_as_int(ex.x)), ex.y, ey.y);
-                c.cv[p] = c.cv[p] + pr * v;
-            }
-            __syncthreads();
-            if (a.canvas_steps) {
-                float *dst = a.canvas_steps + ((size_t)t * B + b) * HW;
-                if (a.vec4_canvas) for (int q = tid; q < (HW >> 2); q += nt) reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(c.cv)[q];
-                else for (int p = tid; p < HW; p += nt) dst[p] = c.cv[p];
-                if (t + 1 < T) __syncthreads();
-            }
-        }
-        // ---- final canvas, reconstruction term, dcanvas in place -------------------------------------------------------------------
-        {
-            const float *ob = a.obs + (size_t)b * HW;
-            float *fc = a.final_canvas ? a.final_canvas + (size_t)b * HW : nullptr;
-            float s[1] = {0.f};
-            for (int p = tid; p < HW; p += nt) {
-                const float cvp = c.cv[p], o = ob[p];
-                if (fc) fc[p] = cvp;
-                const float z = (o - mult * cvp) / std;
-                s[0] += 0.5f * z * z + cst;
-                c.cv[p] = coef * (mult * cvp - o);
-            }
-            if (a.rec) {
-                block_sum<1>(s, c.scratch);
-                if (tid == 0) a.rec[b] = s[0];
-            }
-        }
-        __syncthreads();
-        // ---- backward of every step on the same LDS image (as st_write_bwd_body, stored-canvas form) -----------------------------
-        for (int t = 0; t < T; ++t) {
-            const size_t k = (size_t)t * B + b;
-            const float2 *xe = c.xe + t * W, *ye = c.ye + t * H;
-            const float *src = c.glm + (size_t)t * c.hwp;
-            const float *wk = a.where + 4 * k;
-            const float sx = wk[0], tx = wk[1], sy = wk[2], ty = wk[3];
-            const float pres = c.pres[t];
-            const float bx = -tx / sx, by = -ty / sy;
-            const int2 vx = valid_span(xe, W), vy = valid_span(ye, H);
-            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
-            const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int idx = tid; idx < npx; idx += nt) {
-                const int Ir = idx / fw, I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
-                const float2 ex = xe[J], ey = ye[I];
-                const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);
-                const float dc = c.cv[p];
-                const float dx = ex.y, dy = ey.y;
-                const Taps tp = load_taps_sel(src, h, w, fy, fx);
-                const float v = bilerp(tp, dx, dy);
-                const float gx = dy * (tp.fc - tp.ff) + (1.f - dy) * (tp.cc - tp.cf);
-                const float gy = dx * (tp.cf - tp.ff) + (1.f - dx) * (tp.cc - tp.fc);
-                const float go = pres * dc;
-                const float gax = go * gx * cxs, gay = go * gy * cys;
-                acc[0] += gax * c.X[J]; acc[1] += gax;
-                acc[2] += gay * c.Y[I]; acc[3] += gay;
-                acc[4] += dc * v;
-            }
-            {
-                const float r = wave_reduce8(acc);
-                if ((lane & 7) == 0) c.scratch[wid * 8 + wave_reduce8_slot()] = r;
-            }
-            if (wid == nw - 1) for (int j = lane; j < w; j += 64) c.jr[j] = touch_range(xe, bx, sx, inv_cxs, j, W);
-            if (wid == (nw > 1 ? nw - 2 : 0)) for (int i = lane; i < h; i += 64) c.ir[i] = touch_range(ye, by, sy, inv_cys, i, H);
-            __syncthreads();
-            for (int e = tid; e < (fh > 0 ? fh : 0) * w; e += nt) {
-                const int Ir = e / w, I = I0 + Ir, j = e - Ir * w;
-                const int2 r = c.jr[j];
-                const float *grow = c.cv + I * W;              // dcanvas; go = pres * dcanvas is re-formed here (the same rounded
-                float sacc = 0.f;                              // product the two-launch form stores): dcanvas survives for every step
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int J = r.x + u;
-                    const bool in = J <= r.y;
-                    const int Jc = in ? J : r.x <= r.y ? r.x : 0;
-                    const float2 ex = xe[Jc];
-                    const float gv = pres * grow[Jc];
-                    const int fx = __float_as_int(ex.x);
-                    const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                    if (in) sacc += gv * wgt;
-                }
-                for (int J = r.x + 4; J <= r.y; ++J) {
-                    const float2 ex = xe[J];
-                    const int fx = __float_as_int(ex.x);
-                    const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                    sacc += (pres * grow[J]) * wgt;
-                }
-                c.t1[I * w + j] = sacc;
-            }
-            __syncthreads();
-            float *dg = a.dglimpse + k * hw;
-            for (int e = tid; e < hw; e += nt) {
-                const int i = e / w, j = e - i * w;
-                const int2 r = c.ir[i];
-                float sacc = 0.f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int I = r.x + u;
-                    const bool in = I <= r.y;
-                    const int Ic = in ? I : r.x <= r.y ? r.x : 0;
-                    const float2 ey = ye[Ic];
-                    const float tv = in ? c.t1[Ic * w + j] : 0.f;
-                    const int fy = __float_as_int(ey.x);
-                    const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
-                    if (in) sacc += tv * wgt;
-                }
-                for (int I = r.x + 4; I <= r.y; ++I) {
-                    const float2 ey = ye[I];
-                    const int fy = __float_as_int(ey.x);
-                    const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
-                    sacc += c.t1[I * w + j] * wgt;
-                }
-                dg[e] = sacc;
-            }
-            if (wid == nw - 1) {
-                float part[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[lane * 8 + q] : 0.f;
-                const float tot = wave_reduce8(part);
-                const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64);
-                if (lane == 0) {
-                    float *d = a.dwhere + 4 * k;
-                    d[0] = r0 * (-1.0f / (sx * sx)) + r1 * (tx / (sx * sx));
-                    d[1] = r1 * (-1.0f / sx);
-                    d[2] = r2 * (-1.0f / (sy * sy)) + r3 * (ty / (sy * sy));
-                    d[3] = r3 * (-1.0f / sy);
-                }
-            }
-            if (t + 1 < T) __syncthreads();
-        }
-    }
-}
-
-// ============================================================================================================
 // host side
 // ============================================================================================================
 static inline double lin_step(int n) { return n > 1 ? 2.0 / (double)(n - 1) : 0.0; }
@@ -1049,209 +300,6 @@ extern "C" int air_st_read_bwd(const float *img, const float *where, const float
     hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(per_glimpse ? n : n_img)), dim3(ST_THREADS), lds,
                        air_stream(stream), img, where, dglimpse, dwhere, dimg, n, n_img, H, W, h, w, lin_step(w),
                        lin_step(h), vec4, per_glimpse);
-    AIR_LAUNCH_CHECK();
-    return AIR_OK;
-}
-
-// rows per band / number of bands actually used for a request of `want` bands
-static inline void wr_bands(int H, int want, int *NB, int *RB) {
-    int nb = want < 1 ? 1 : (want > H ? H : want);
-    const int rb = (H + nb - 1) / nb;
-    nb = (H + rb - 1) / rb;                                  // drop empty trailing bands
-    *NB = nb; *RB = rb;
-}
-static int launch_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
-                            const float *obs, float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
-                            int T, int B, int H, int W, int h, int w, float mult, float std, void *stream) {
-    int NB, RB;
-    wr_bands(H, n_bands, &NB, &RB);
-    AIR_REQUIRE(NB == n_bands || !rec_parts, AIR_E_SHAPE);   // the caller sized rec_parts for exactly n_bands shares
-    const size_t lds = carve_wr_bytes(T, RB, W, h, w);
-    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
-    const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);   // 16-byte groups that never straddle a glimpse row
-    { int st_ = st_allow_lds(st_write_fwd_kernel, lds); if (st_) return st_; }
-    // one pixel per thread while the launch is far from filling the chip (latency regime), 256-thread workgroups beyond
-    const long units = (long)B * NB;
-    int wr_threads = units <= 512 ? 512 : ST_THREADS;          // (measured at 50x50: 512 units 14 us with 512 threads, 16 / 17.5 with 1024 / 256)
-    if (units <= 256) {
-        const int px = RB * W;
-        wr_threads = px >= 1024 ? 1024 : ((px + 63) / 64) * 64;
-        if (wr_threads < 64) wr_threads = 64;
-    }
-    const WriteFwdArgs a = {glimpse, where, presence, canvas_in, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
-                            lin_step(W), lin_step(H), mult, std, vec4g};
-    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(st_grid((int)units)), dim3(wr_threads), lds, air_stream(stream), a);
-    AIR_LAUNCH_CHECK();
-    return AIR_OK;
-}
-
-extern "C" int air_st_write_fwd(const float *glimpse, const float *where, const float *presence,
-                                const float *canvas_in, float *canvas_out, int n, int H, int W, int h, int w,
-                                void *stream) {
-    AIR_REQUIRE(glimpse && where && canvas_out, AIR_E_NULL);
-    int st = st_check_dims(n, H, W, h, w);
-    if (st) return st;
-    return launch_write_fwd(glimpse, where, presence, canvas_in, nullptr, nullptr, canvas_out, nullptr, 1, 1, n, H, W, h,
-                            w, 1.0f, 1.0f, stream);
-}
-
-extern "C" int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence,
-                                     const float *obs, float *canvas_steps, float *final_canvas,
-                                     float *rec_per_sample, int T, int B, int H, int W, int h, int w, float mult,
-                                     float std, void *stream) {
-    AIR_REQUIRE(glimpse && where && (final_canvas || canvas_steps), AIR_E_NULL);
-    AIR_REQUIRE(!rec_per_sample || obs, AIR_E_NULL);
-    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
-    int st = st_check_dims(B, H, W, h, w);
-    if (st) return st;
-    // the complete per-sample reconstruction term needs the whole image in one workgroup; without it the bands are free
-    int nb = 1;
-    if (!rec_per_sample && (long)B * T <= 1024) nb = 256 / B < 1 ? 1 : 256 / B;
-    int NB, RB;
-    wr_bands(H, nb, &NB, &RB);
-    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_per_sample, NB, T, B,
-                            H, W, h, w, mult, std, stream);
-}
-
-extern "C" int air_canvas_unroll_bands(int B, int H) {
-    int nb = 256 / (B < 1 ? 1 : B);
-    if (nb > 8) nb = 8;
-    int NB, RB;
-    wr_bands(H, nb, &NB, &RB);
-    return NB;
-}
-
-extern "C" int air_canvas_unroll_fwd_banded(const float *glimpse, const float *where, const float *presence,
-                                            const float *obs, float *canvas_steps, float *final_canvas,
-                                            float *rec_parts, int n_bands, int T, int B, int H, int W, int h, int w,
-                                            float mult, float std, void *stream) {
-    AIR_REQUIRE(glimpse && where && (final_canvas || canvas_steps), AIR_E_NULL);
-    AIR_REQUIRE(!rec_parts || obs, AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && n_bands > 0, AIR_E_SHAPE);
-    int st = st_check_dims(B, H, W, h, w);
-    if (st) return st;
-    return launch_write_fwd(glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, n_bands, T, B,
-                            H, W, h, w, mult, std, stream);
-}
-
-static int launch_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
-                            const float *final_canvas, const float *obs, float *dglimpse, float *dwhere,
-                            float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
-                            float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
-    const bool rc = !dcanvas && !final_canvas;                // recompute form: the canvas is re-formed on the unit's footprint
-    const size_t lds = carve_bwd_bytes(H, W, h, w, rc ? T : 1);
-    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
-    if (nvil) nv = *nvil;
-    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
-    const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);   // 16-byte groups that never straddle a glimpse row
-    const int vec4c = ((H * W) % 4 == 0) && (dcanvas ? air_aligned16(dcanvas) : ((rc || air_aligned16(final_canvas)) && air_aligned16(obs)));
-    { int st_ = rc ? st_allow_lds(st_write_bwd_kernel<true>, lds) : st_allow_lds(st_write_bwd_kernel<false>, lds); if (st_) return st_; }
-    // 512 threads (about one per footprint pixel) while the launch does not fill the chip: 7.5 us at 192 units against 8.2 with
-    // 1024; beyond that 256-thread workgroups, 8 per CU, hide each other's barriers (29 vs 74 us at 3072 units, 11 vs 21 at 768)
-    const int wr_threads = (long)B * T <= 512 ? 512 : ST_THREADS;
-    const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
-                            lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c};
-    if (rc)
-        hipLaunchKernelGGL(st_write_bwd_kernel<true>, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
-                           air_stream(stream), a, nv);
-    else
-        hipLaunchKernelGGL(st_write_bwd_kernel<false>, dim3(st_grid(T * B) + (nvil ? 1 : 0)), dim3(wr_threads), lds,
-                           air_stream(stream), a, nv);
-    AIR_LAUNCH_CHECK();
-    return AIR_OK;
-}
-
-extern "C" int air_st_write_bwd(const float *glimpse, const float *where, const float *presence,
-                                const float *dcanvas, float *dglimpse, float *dwhere, float *dpresence, int n, int H,
-                                int W, int h, int w, void *stream) {
-    AIR_REQUIRE(glimpse && where && dcanvas && dglimpse && dwhere, AIR_E_NULL);
-    int st = st_check_dims(n, H, W, h, w);
-    if (st) return st;
-    return launch_write_bwd(glimpse, where, presence, dcanvas, nullptr, nullptr, dglimpse, dwhere, dpresence, 1, n, H,
-                            W, h, w, 1.0f, 1.0f, 1.0f, stream);
-}
-
-extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence,
-                                     const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
-                                     int T, int B, int H, int W, int h, int w, float mult, float std,
-                                     float loss_scale, void *stream) {
-    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
-    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
-    int st = st_check_dims(B, H, W, h, w);
-    if (st) return st;
-    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
-                            h, w, mult, std, loss_scale, stream);
-}
-
-extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence,
-                                          const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
-                                          int T, int B, int H, int W, int h, int w, float mult, float std,
-                                          float loss_scale, const float *imp_parts, int n_parts, float *imp_sum,
-                                          const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                                          float *dbaseline, void *stream) {
-    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
-    AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && n_parts > 0, AIR_E_SHAPE);
-    int st = st_check_dims(B, H, W, h, w);
-    if (st) return st;
-    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
-    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
-                            h, w, mult, std, loss_scale, stream, &nv);
-}
-
-// forward (banded, as air_canvas_unroll_fwd_banded) + backward (recompute form of air_canvas_unroll_bwd) as ONE launch
-extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
-                                         float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
-                                         float *dglimpse, float *dwhere, int T, int B, int H, int W, int h, int w, float mult,
-                                         float std, float loss_scale, void *stream) {
-    AIR_REQUIRE(glimpse && where && obs && (final_canvas || canvas_steps) && rec_parts && dglimpse && dwhere, AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && n_bands > 0, AIR_E_SHAPE);
-    int st = st_check_dims(B, H, W, h, w);
-    if (st) return st;
-    int NB, RB;
-    wr_bands(H, n_bands, &NB, &RB);
-    AIR_REQUIRE(NB == n_bands, AIR_E_SHAPE);
-    const size_t lds_f = carve_wr_bytes(T, RB, W, h, w), lds_b = carve_bwd_bytes(H, W, h, w, T);
-    const size_t lds = lds_f > lds_b ? lds_f : lds_b;
-    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
-    // one launch only pays while both roles fit the chip side by side (the latency regime); beyond that the two launches
-    AIR_REQUIRE((long)B * NB <= 4096 && (long)B * T <= 4096, AIR_E_UNSUPPORTED);
-    const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);   // 16-byte groups that never straddle a glimpse row
-    const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
-    { int st_ = st_allow_lds(canvas_fused_kernel, lds); if (st_) return st_; }
-    const WriteFwdArgs f = {glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
-                            lin_step(W), lin_step(H), mult, std, vec4g};
-    const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
-                            lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c};
-    const int n_fwd = B * NB;
-    // (as the two-launch form: 256-thread workgroups once the chip is full; 1024 threads at 192 units: 15.6 against 11.6 us)
-    const int fthreads = (long)B * T <= 512 ? 512 : ST_THREADS;
-    hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B), dim3(fthreads), lds, air_stream(stream), f, b, n_fwd);
-    AIR_LAUNCH_CHECK();
-    return AIR_OK;
-}
-
-// forward + backward of every image in ONE launch, one workgroup per image (throughput regime: the canvas stays in LDS between the
-// two; obs and the glimpses are read once).  rec[B] receives the complete per-sample reconstruction term (no row bands).
-extern "C" int air_canvas_unroll_image(const float *glimpse, const float *where, const float *presence, const float *obs,
-                                       float *canvas_steps, float *final_canvas, float *rec, float *dglimpse, float *dwhere,
-                                       int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
-                                       void *stream) {
-    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);
-    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
-    int st = st_check_dims(B, H, W, h, w);
-    if (st) return st;
-    const size_t lds = carve_image_bytes(T, H, W, h, w);
-    AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
-    { int st_ = st_allow_lds(canvas_image_kernel, lds); if (st_) return st_; }
-    ImageArgs a;
-    a.glimpse = glimpse; a.where = where; a.presence = presence; a.obs = obs; a.canvas_steps = canvas_steps;
-    a.final_canvas = final_canvas; a.rec = rec; a.dglimpse = dglimpse; a.dwhere = dwhere;
-    a.T = T; a.B = B; a.H = H; a.W = W; a.h = h; a.w = w; a.stepX = lin_step(W); a.stepY = lin_step(H);
-    a.mult = mult; a.std = std; a.loss_scale = loss_scale;
-    a.vec4_glimpse = ((h * w) % 4 == 0) && air_aligned16(glimpse);
-    a.vec4_canvas = ((H * W) % 4 == 0) && (!canvas_steps || air_aligned16(canvas_steps));
-    hipLaunchKernelGGL(canvas_image_kernel, dim3(st_grid(B, 256 * 16)), dim3(ST_THREADS), lds, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -1500,10 +548,13 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
 // tables / fixed-order reduction as st_read_bwd_kernel, then -- in the same workgroup -- the where-sampling backward of row k
 // (needs dwhere from the canvas write AND from the read, plus the KL term): d pre[k, 0:8].  Role B: backward of the
 // num-steps KL / step weights / REINFORCE term wrt the steps logit (numsteps_presence_bwd_body).
+struct AttendBwdArgs;
+__device__ __forceinline__ float attend_dwhere_w(const AttendBwdArgs &g, size_t e);
 struct AttendBwdArgs {
     const float *img, *where, *dglimpse; float *dwhere_r;
     const float *pre, *eps; float raw_offset, pl0, ps0, pl1, ps1;
     const float *loc, *scale, *dwhere_w, *dkl_row; float dkl_scale; float *dpre;
+    int dwhere_w_slabs;   // dwhere_w[slabs][T*B][4]: the canvas backward may write its dwhere as several partial slabs (their sum, in order)
     const float *prob, *presence; const double *prior; float kl_scale; const float *kl_a, *kl_b; float w_scale;
     const float *dlogp, *logit; float step_bias, explore_eps; float *dlogit;
     int T, B, H, W, h, w, vec4;
@@ -1517,6 +568,12 @@ struct AttendBwdArgs {
     int bf16;
     int img_major;      // role A: one workgroup per IMAGE runs the backward of its T glimpses (image staged once)
 };
+__device__ __forceinline__ float attend_dwhere_w(const AttendBwdArgs &g, size_t e) {
+    float v = g.dwhere_w[e];
+    const size_t slab = (size_t)g.T * g.B * 4;
+    for (int q = 1; q < g.dwhere_w_slabs; ++q) v += g.dwhere_w[(size_t)q * slab + e];
+    return v;
+}
 
 template <int MT, int NT, bool EXACT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 5 : 4))) void attend_bwd_kernel(AttendBwdArgs g) {
@@ -1631,7 +688,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
             if (lane < 4) {
                 const int d_ = lane;
                 const size_t e = k * 4 + d_;
-                const float mu = g.loc[e], sc = g.scale[e], s_dw = g.dwhere_w[e], s_eps = g.eps[e];
+                const float mu = g.loc[e], sc = g.scale[e], s_dw = attend_dwhere_w(g, e), s_eps = g.eps[e];
                 const float s_raw = g.pre[k * 8 + 4 + d_] + g.raw_offset;
                 const float s_dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
                 g.dwhere_r[4 * k + d_] = accd;
@@ -1693,7 +750,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
     float s_mu = 0.f, s_sc = 1.f, s_dw = 0.f, s_eps = 0.f, s_raw = 0.f, s_dk = 0.f;
     if (tid < 4) {
         const size_t e = (size_t)k * 4 + tid;
-        s_mu = g.loc[e]; s_sc = g.scale[e]; s_dw = g.dwhere_w[e]; s_eps = g.eps[e];
+        s_mu = g.loc[e]; s_sc = g.scale[e]; s_dw = attend_dwhere_w(g, e); s_eps = g.eps[e];
         s_raw = g.pre[(size_t)k * 8 + 4 + tid] + g.raw_offset;
         s_dk = g.dkl_row ? g.dkl_row[k] * g.dkl_scale : 0.f;
     }
@@ -1811,7 +868,7 @@ static int attend_bwd_launch(AttendBwdArgs &g, int T, int B, int H, int W, int h
 extern "C" int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r,
                               const float *pre, const float *eps, float raw_offset, float p_loc_even, float p_scale_even,
                               float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
-                              const float *dwhere_w, const float *dkl_row, float dkl_scale, float *dpre,
+                              const float *dwhere_w, int dwhere_w_slabs, const float *dkl_row, float dkl_scale, float *dpre,
                               const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
                               const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
                               const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
@@ -1819,7 +876,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
     AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
                     prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && T <= 32, AIR_E_SHAPE);
+    AIR_REQUIRE(T > 0 && T <= 32 && dwhere_w_slabs >= 1 && dwhere_w_slabs <= 4, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
     const size_t lds = carve_bytes(H * W, 0, w, h);
@@ -1827,7 +884,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
     AttendBwdArgs g;
     g.img = img; g.where = where; g.dglimpse = dglimpse; g.dwhere_r = dwhere_r; g.pre = pre; g.eps = eps;
     g.raw_offset = raw_offset; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
-    g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
+    g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dwhere_w_slabs = dwhere_w_slabs; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
     g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
     g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
     g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;
@@ -1842,7 +899,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
 extern "C" int air_attend_bwd_dx(const float *img, const float *where, const float *dglimpse, float *dwhere_r,
                               const float *pre, const float *eps, float raw_offset, float p_loc_even, float p_scale_even,
                               float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
-                              const float *dwhere_w, const float *dkl_row, float dkl_scale, float *dpre,
+                              const float *dwhere_w, int dwhere_w_slabs, const float *dkl_row, float dkl_scale, float *dpre,
                               const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
                               const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
                               const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
@@ -1852,7 +909,7 @@ extern "C" int air_attend_bwd_dx(const float *img, const float *where, const flo
     AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
                     prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
-    AIR_REQUIRE(T > 0 && T <= 32, AIR_E_SHAPE);
+    AIR_REQUIRE(T > 0 && T <= 32 && dwhere_w_slabs >= 1 && dwhere_w_slabs <= 4, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
     const size_t lds = carve_bytes(H * W, 0, w, h);
@@ -1860,7 +917,7 @@ extern "C" int air_attend_bwd_dx(const float *img, const float *where, const flo
     AttendBwdArgs g;
     g.img = img; g.where = where; g.dglimpse = dglimpse; g.dwhere_r = dwhere_r; g.pre = pre; g.eps = eps;
     g.raw_offset = raw_offset; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
-    g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
+    g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dwhere_w_slabs = dwhere_w_slabs; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
     g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
     g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
     g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;

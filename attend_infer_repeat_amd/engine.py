@@ -311,7 +311,8 @@ class AIREngine:
         self.nvil_out = b("nvil_out", (4,)); self.dlogp = b("dlogp", (B,)); self.dbase = b("dbase", (B,))
         # backward scratch
         self.d_what = b("d_what", (M, A)); self.d_glimpse_in = b("d_glimpse_in", (M, hw))
-        self.dwhere_w = b("dwhere_w", (M, 4)); self.dwhere_r = b("dwhere_r", (M, 4)); self.dwhere = b("dwhere", (M, 4))
+        self.dwhere_w = b("dwhere_w", (4 * M, 4));    # (up to four partial slabs: air_canvas_unroll_fwd_bwd's n_split)
+        self.dwhere_r = b("dwhere_r", (M, 4)); self.dwhere = b("dwhere", (M, 4))
         self.dkl_row = b("dkl_row", (M,)); self.dstep_w = b("dstep_w", (T, B)); self.dprob = b("dprob", (T, B))
         self.dH = b("dH", (T, B, Hd)); self.dH_b = b("dH_b", (T, B, Hd)); self.dh_init = b("dh_init", (B, Hd))
         self.ones_b = b("ones_b", (B, 1)); self.ones_b.fill_(1.0)
@@ -659,27 +660,22 @@ class AIREngine:
         # ---- backward of opt_loss = mean(rec) + pw*(mean kl_n + mean sum_t w*(kl_what+kl_where)) + reinforce -------
         pw = 1.0 if cfg.use_prior else 0.0
         inv_b = 1.0 / B
-        cu_args = (p(decoded), p(self.where), p(self.presence), p(self.obs), p(self.final_canvas), p(self.gd.g[-1]),
-                   p(self.dwhere_w), T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std, inv_b)
         # Latency regime with REINFORCE: the canvas forward and the (recompute-form) backward are ONE launch -- the backward
         # re-forms the canvas on each glimpse's footprint, so it reads nothing the forward writes (air_canvas_unroll_fwd_bwd) -- the
         # train step's forward list then ends before the canvas; NVIL, which needs the forward's reconstruction shares, rides on
         # the next pointwise launch (air_gauss_sample_bwd_nvil) and the baseline's backward, which needs NVIL, rides with the
         # three launches after that (what / glimpse-encoder backward) instead of the decoder's.  35 -> 34 dependent launches.
-        # Far into the throughput regime (more images than the chip holds workgroups): ONE workgroup per image runs forward and backward
-        # with the canvas resident in LDS (air_canvas_unroll_image: 23 % less time than the two launches at 65536 images, obs and
-        # glimpses read once).  Around batch 1024 a workgroup per image is a ~40 us chain of 20 barriers with nothing to overlap it:
-        # no faster than the two launches (0.5803 against 0.5799 ms), slower at batch 256.  The two-role launch of the latency regime
-        # measured slower in this regime too (VALU bound chip-wide plus the recomputation: 0.594 against 0.580 ms at batch 1024).
-        hwp = (hw + 3) // 4 * 4
-        image_lds = 4 * (T * hwp + ((P + 3) // 4 * 4) + (Hi * wc + 3) // 4 * 4 + 2 * T * (Wi + Hi) + 2 * wc + 2 * hc + Wi + Hi + 176)
-        canvas_image = (cfg.use_reinforce and throughput and NB == 1 and image_lds <= 64 * 1024
-                        and B >= int(os.environ.get("AIR_FUSE_CANVAS_IMAGE_MIN_BATCH", "2048"))
-                        and os.environ.get("AIR_FUSE_CANVAS_IMAGE", "0") == "1")
-        self._canvas_image = canvas_image
-        fuse_canvas = (cfg.use_reinforce and (not throughput or canvas_image or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
-                       and (canvas_image or (B * NB <= 4096 and M <= 4096))
-                       and os.environ.get("AIR_FUSE_CANVAS", "1") == "1" and os.environ.get("AIR_TWO_LANE", "0") != "1")
+        # The two-role launch of the latency regime measured slower in the throughput regime (VALU bound chip-wide plus the
+        # recomputation: 0.594 against 0.580 ms at batch 1024).
+        # n_split: workgroups per backward unit of that launch (disjoint dglimpse rows, dwhere as n_split slabs that air_attend_bwd_dx
+        # adds): while the launch leaves CUs idle (192 units + 256 forward workgroups at batch 64), halving a unit's chain is free.
+        n_split = int(os.environ.get("AIR_CANVAS_SPLIT", "2")) if (fuse_attend and M * 2 + B * NB <= 1024) else 1
+        n_split = max(1, min(4, n_split))
+        self._canvas_split = n_split
+        fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
+                       and os.environ.get("AIR_FUSE_CANVAS", "1") == "1" and os.environ.get("AIR_TWO_LANE", "0") != "1"
+                       # (what the library's launch takes: both grids at most 4096 workgroups, the LDS of both roles)
+                       and L.air_canvas_unroll_fwd_bwd_fits(NB, n_split, T, B, Hi, Wi, hc, wc) == 1)
         bl_chain = dict(m=self.bl, g_last=self.dbase,
                         x_parts=[(self.obs, P, 0, P), (self.base_lat, cfg.baseline_in - P, P, cfg.baseline_in - P)])
         bl_levels = [[], [], []]
@@ -697,15 +693,14 @@ class AIREngine:
                 lv = lv + [[]] * (3 - len(lv))
                 bl_levels = [lv[0], lv[1], lv[2]] if self.ge.n >= 2 else [lv[0], lv[1], []]
         self._fuse_canvas = fuse_canvas
-        if fuse_canvas and canvas_image:
-            bwd.append((L.air_canvas_unroll_image, (p(decoded), p(self.where), p(self.presence), p(self.obs), p(self.canvas_steps),
-                                                    p(self.final_canvas), p(self.rec_parts), p(self.gd.g[-1]), p(self.dwhere_w),
-                                                    T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std, inv_b),
-                        "air_canvas_unroll_image"))
-        elif fuse_canvas:
+        if not fuse_canvas:
+            n_split = self._canvas_split = 1
+        cu_args = (p(decoded), p(self.where), p(self.presence), p(self.obs), p(self.final_canvas), p(self.gd.g[-1]),
+                   p(self.dwhere_w), T, B, Hi, Wi, hc, wc, cfg.output_multiplier, cfg.output_std, inv_b)
+        if fuse_canvas:
             bwd.append((L.air_canvas_unroll_fwd_bwd, (p(decoded), p(self.where), p(self.presence), p(self.obs),
                                                       p(self.canvas_steps), p(self.final_canvas), p(self.rec_parts), NB,
-                                                      p(self.gd.g[-1]), p(self.dwhere_w), T, B, Hi, Wi, hc, wc,
+                                                      p(self.gd.g[-1]), p(self.dwhere_w), n_split, T, B, Hi, Wi, hc, wc,
                                                       cfg.output_multiplier, cfg.output_std, inv_b),
                         "air_canvas_unroll_fwd_bwd"))
         elif cfg.use_reinforce:
@@ -743,7 +738,7 @@ class AIREngine:
             st_y, st_dx, st_kk, st_ld = last_dx(self.st, self.dH_b)
             bwd.append((L.air_attend_bwd_dx, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r),
                                               p(self.tr.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
-                                              shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w),
+                                              shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w), n_split,
                                               p(self.step_w), pw * inv_b, p(self.tr.g[-1]),
                                               p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
                                               p(self.kl_what_row), p(self.kl_where_row), pw * inv_b, dlogp_p,

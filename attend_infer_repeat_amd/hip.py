@@ -138,25 +138,6 @@ def canvas_unroll_bwd(glimpse, where, presence, obs, final_canvas, mult, std, lo
     return dg, dwhere
 
 
-def canvas_unroll_image(glimpse, where, presence, obs, mult, std, loss_scale, keep_steps=True):
-    """forward + backward of the canvas, one workgroup per image (air_canvas_unroll_image) ->
-    (canvas_steps | None, final, rec, dglimpse, dwhere)"""
-    glimpse = _f32(glimpse, "glimpse", 4); where = _f32(where, "where", 3); presence = _f32(presence, "presence")
-    obs = _f32(obs, "obs", 3)
-    T, B, h, w = glimpse.shape
-    H, W = obs.shape[1:]
-    dev = glimpse.device
-    steps = torch.empty((T, B, H, W), dtype=torch.float32, device=dev) if keep_steps else None
-    final = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    rec = torch.empty((B,), dtype=torch.float32, device=dev)
-    dg = torch.empty_like(glimpse)
-    dwhere = torch.empty((T, B, 4), dtype=torch.float32, device=dev)
-    _lib.check(lib().air_canvas_unroll_image(_p(glimpse), _p(where), _p(presence), _p(obs), _p(steps), _p(final), _p(rec), _p(dg),
-                                             _p(dwhere), T, B, H, W, h, w, float(mult), float(std), float(loss_scale), _stream()),
-               "air_canvas_unroll_image")
-    return steps, final, rec, dg, dwhere
-
-
 # ---- dense ---------------------------------------------------------------------------------------------------------
 def gemm(A, B, ta=False, tb=False, bias=None, epilogue=EPI_NONE, aux=None, beta=0.0, out=None, colsum=False,
          use_workspace=True):

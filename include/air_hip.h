@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 5
+#define AIR_ABI_VERSION 6
 
 enum {
     AIR_OK = 0,
@@ -107,18 +107,16 @@ int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const f
 /* Canvas forward (banded, as air_canvas_unroll_fwd_banded) and backward (as air_canvas_unroll_bwd with final_canvas = NULL: every
  * (t, b) unit re-forms the canvas on its own footprint, bit-identically to the forward, so it reads nothing the forward writes) as
  * the two roles of ONE launch: one dependent launch less on the train step's chain at small batch.  The NVIL objective, which
- * needs the forward's reconstruction shares, then rides on air_gauss_sample_bwd_nvil.  B * n_bands and B * T at most 4096.       */
+ * needs the forward's reconstruction shares, then rides on air_gauss_sample_bwd_nvil.
+ * n_split (1..4): workgroups per backward unit.  They own disjoint rows of the unit's dglimpse; dwhere is then written as
+ * n_split slabs, dwhere[n_split][T*B][4], whose SUM (slab 0 + slab 1 + ..., in that order) is the gradient -- the consumer adds
+ * them (air_attend_bwd's `dwhere_w_slabs`).  B * n_bands and B * T * n_split at most 4096, and the launch's LDS must fit:
+ * air_canvas_unroll_fwd_bwd_fits(...) == 1 says so without launching (plan builders ask it and keep the two launches otherwise). */
+int air_canvas_unroll_fwd_bwd_fits(int n_bands, int n_split, int T, int B, int H, int W, int h, int w);
 int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
                               float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands, float *dglimpse,
-                              float *dwhere, int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
-                              void *stream);
-/* The same pair for the throughput regime: ONE workgroup per image runs the forward and then the backward of its T glimpses with
- * the canvas resident in LDS (stored-canvas arithmetic: no recomputation; obs and the glimpses are read once; the forward visits
- * only each glimpse's footprint).  rec[B] receives the complete reconstruction term per image (no row bands).  Bitwise the result
- * of air_canvas_unroll_fwd + air_canvas_unroll_bwd.                                                                         */
-int air_canvas_unroll_image(const float *glimpse, const float *where, const float *presence, const float *obs,
-                            float *canvas_steps, float *final_canvas, float *rec, float *dglimpse, float *dwhere, int T, int B,
-                            int H, int W, int h, int w, float mult, float std, float loss_scale, void *stream);
+                              float *dwhere, int n_split, int T, int B, int H, int W, int h, int w, float mult, float std,
+                              float loss_scale, void *stream);
 /* ---- dense layers -------------------------------------------------------------------------------------------
  * Replaces the TF MatMul/BiasAdd/Elu nodes under snt.Linear (neural.py:42-60) and snt.LSTM (mnist_model.py:35).   */
 
@@ -395,11 +393,12 @@ int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int 
                    int T, int B, int H, int W, int h, int w, int precision /* of the two output-layer products */,
                    void *stream);
 /* Backward, one launch: air_st_read_bwd (d where through the read, one workgroup per glimpse) followed in the same
- * workgroup by the where-sampling backward of that row (dsample = dwhere_w + dwhere_r, KL term dkl_row*dkl_scale) ->
+ * workgroup by the where-sampling backward of that row (dsample = dwhere_w + dwhere_r, KL term dkl_row*dkl_scale;
+ * dwhere_w[dwhere_w_slabs][T*B][4]: the canvas backward's gradient as 1..4 partial slabs, added here in slab order) ->
  * dpre[T*B,8]; and, in separate workgroups, the steps-logit backward of air_heads_bwd -> dlogit[T*B].                */
 int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
                    const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
-                   float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w,
+                   float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w, int dwhere_w_slabs,
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
                    const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
@@ -411,7 +410,7 @@ int air_attend_bwd(const float *img, const float *where, const float *dglimpse, 
  * Their dW (and bias gradients) remain ordinary air_gemm problems over dpre / dlogit.                                        */
 int air_attend_bwd_dx(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
                    const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
-                   float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w,
+                   float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w, int dwhere_w_slabs,
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
                    const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,

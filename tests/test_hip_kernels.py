@@ -189,34 +189,57 @@ def test_canvas_unroll_bwd_recompute_equals_stored_canvas(hip, T, B, H, W, h, w)
     assert torch.equal(dg, dg2) and torch.equal(dwhere, dwhere2)
 
 
-@pytest.mark.parametrize("T,B,H,W,h,w", [(3, 1100, 50, 50, 20, 20), (5, 40, 100, 100, 28, 28), (1, 300, 17, 13, 5, 7), (4, 600, 28, 36, 9, 12)])
-def test_canvas_unroll_image_equals_the_two_launch_form(hip, T, B, H, W, h, w):
-    """air_canvas_unroll_image (throughput regime: one workgroup per image, canvas resident in LDS, footprint-only forward) against
-    air_canvas_unroll_fwd + air_canvas_unroll_bwd: per-step canvases, final canvas, reconstruction term, dglimpse and dwhere BIT
-    for bit (same arithmetic in the same order), incl. mirrored / oversized glimpses, absent steps, odd sizes and a grid-strided
-    batch."""
+@pytest.mark.parametrize("T,B,H,W,h,w", [(3, 1100, 50, 50, 20, 20), (5, 40, 100, 100, 28, 28), (1, 300, 17, 13, 5, 7), (4, 600, 28, 36, 9, 12),
+                                          (3, 200, 50, 50, 20, 20), (2, 9, 70, 130, 24, 70)])
+def test_canvas_kernels_in_every_workgroup_shape_match_the_oracle(hip, T, B, H, W, h, w):
+    """The row-streaming canvas kernels pick their workgroup shape from the number of units (many waves per unit while the launch
+    does not fill the chip, one wave per unit beyond; canvases wider than 64 columns and glimpses wider than 64 take several lane
+    chunks): per-step canvases and the final canvas BIT for bit the oracle's sequential accumulation in every shape, the
+    reconstruction term, dglimpse and dwhere against float64 autograd -- incl. mirrored / oversized / off-canvas glimpses, absent
+    steps, odd sizes and grid-strided batches.  dglimpse does not depend on the shape at all (every element is accumulated by
+    one lane in row order): the latency-regime and throughput-regime launches of the same problem agree bit for bit."""
     rng = np.random.default_rng(T * 100 + B)
     glm = rng.standard_normal((T, B, h, w)).astype(np.float32)
     where = rand_where(T * B, rng).reshape(T, B, 4)
-    where[0, 0] = [-0.7, 0.2, 0.9, -0.1]
+    where[0, 0] = [-0.7, 0.2, 0.9, -0.13]        # mirrored (not -0.1: canvas row 0 would land EXACTLY on glimpse row 0, where the
+                                                 # fp32 and fp64 coordinates fall on different sides of the cell boundary and d/dy jumps)
     if B > 2:
         where[-1, 2] = [3.0, 0.0, 3.0, 0.0]
         where[0, 1] = [0.3, 5.0, 0.3, 0.0]                                  # entirely outside the canvas
     pres = np.cumprod(rng.integers(0, 2, (T, B)), 0).astype(np.float32); pres[:, 0] = 1.0
     obs = rng.random((B, H, W)).astype(np.float32)
-    st, final, rec = hip.canvas_unroll_fwd(g(glm), g(where), g(pres), (H, W), obs=g(obs), mult=0.5, std=0.3)
-    dg, dwhere = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, 0.5, 0.3, 1.0 / B)
-    st2, final2, rec2, dg2, dwhere2 = hip.canvas_unroll_image(g(glm), g(where), g(pres), g(obs), 0.5, 0.3, 1.0 / B)
-    assert torch.equal(st, st2) and torch.equal(final, final2)
-    assert torch.equal(dg, dg2)
-    # the reduction trees of rec / dwhere depend on the workgroup size the two-launch form picks for this batch (256 threads from
-    # 513 units on, as the image kernel always uses): bitwise there, to rounding otherwise
-    if B * T > 512 and B > 512:
-        assert torch.equal(rec, rec2) and torch.equal(dwhere, dwhere2)
-    else:
-        assert_close(rec2, rec, 1e-5, 1e-3, "rec"); assert_close(dwhere2, dwhere, 2e-4, 1e-5 * float(dwhere.abs().max()) + 1e-7, "dwhere")
-    _, _, _, dg3, _ = hip.canvas_unroll_image(g(glm), g(where), g(pres), g(obs), 0.5, 0.3, 1.0 / B, keep_steps=False)
-    assert torch.equal(dg3, dg)
+    mult, std = 0.5, 0.3
+    st, final, rec = hip.canvas_unroll_fwd(g(glm), g(where), g(pres), (H, W), obs=g(obs), mult=mult, std=std)
+    nb_chk = min(B, 48)                                                     # oracle on a slice of the batch (it is a CPU loop)
+    canvas = np.zeros((nb_chk, H, W), np.float32)
+    for t in range(T):
+        canvas = canvas + pres[t, :nb_chk][:, None, None] * C.st_write_fwd(glm[t, :nb_chk], where[t, :nb_chk], (H, W))
+        np.testing.assert_array_equal(st[t, :nb_chk].cpu().numpy(), canvas)
+    np.testing.assert_array_equal(final[:nb_chk].cpu().numpy(), canvas)
+    # gradients against the oracle evaluated in FLOAT32: d/dwhere jumps at cell boundaries, and with tens of thousands of sampling
+    # coordinates per case some land within an fp32 rounding of an integer -- the fp64 oracle then differentiates another cell.
+    # (The forward check above proves the kernel's coordinates, floors and weights ARE the fp32 oracle's.)
+    tg = torch.tensor(glm[:, :nb_chk], requires_grad=True)
+    tw = torch.tensor(where[:, :nb_chk], requires_grad=True)
+    cv = sum(torch.tensor(pres[t, :nb_chk])[:, None, None] * O.st_write(tg[t], tw[t], (H, W)) for t in range(T))
+    nll = 0.5 * ((torch.tensor(obs[:nb_chk]) - mult * cv) / std) ** 2 + 0.5 * np.log(2 * np.pi) + np.log(std)
+    rec32 = nll.double().sum((1, 2))
+    assert_close(rec[:nb_chk], rec32, 1e-5, 1e-3, "rec_per_sample")
+    gg, gw = torch.autograd.grad(nll.sum() / B, [tg, tw])
+    dg, dwhere = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, mult, std, 1.0 / B)
+    assert_close(dg[:, :nb_chk], gg, 5e-4, 2e-4 * gg.abs().max().item(), "dglimpse")
+    scale = gw.abs().amax(-1, keepdim=True).numpy() + 1.0 / B
+    assert_close(dwhere[:, :nb_chk].cpu().numpy() / scale, gw.numpy() / scale, 2e-3, 2e-4, "dwhere")
+    # the same images as a small batch (another workgroup shape): forward and dglimpse bit for bit, dwhere / rec to rounding
+    nb2 = min(B, 5)
+    sl = lambda a: g(np.ascontiguousarray(a[:, :nb2]))
+    st2, final2, rec2 = hip.canvas_unroll_fwd(sl(glm), sl(where), sl(pres), (H, W), obs=g(obs[:nb2]), mult=mult, std=std)
+    assert torch.equal(st2, st[:, :nb2]) and torch.equal(final2, final[:nb2])
+    assert_close(rec2, rec[:nb2], 1e-5, 1e-3, "rec")
+    for fc in (final2, None):
+        dg2, dwhere2 = hip.canvas_unroll_bwd(sl(glm), sl(where), sl(pres), g(obs[:nb2]), fc, mult, std, 1.0 / B)
+        assert torch.equal(dg2, dg[:, :nb2])
+        assert_close(dwhere2, dwhere[:, :nb2], 2e-4, 1e-5 * float(dwhere.abs().max()) + 1e-7, "dwhere")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -949,14 +972,21 @@ def test_canvas_kernels_random_shapes_and_transforms(hip, case):
         lib, p = hip.lib(), hip._p
         from attend_infer_repeat_amd import _lib
         nb = int(lib.air_canvas_unroll_bands(B, H))
-        st3 = torch.empty(T, B, H, W, device="cuda"); fin3 = torch.empty(B, H, W, device="cuda")
-        parts = torch.empty(nb, B, device="cuda"); dg3 = torch.empty_like(dg); dw3 = torch.empty_like(dwhere)
         d_glm, d_where, d_pres, d_obs = g(glm), g(where), g(pres), g(obs)      # (held: a raw pointer does not keep a tensor alive)
-        _lib.check(lib.air_canvas_unroll_fwd_bwd(p(d_glm), p(d_where), p(d_pres), p(d_obs), p(st3), p(fin3), p(parts), nb, p(dg3), p(dw3),
-                                                 T, B, H, W, h, w, mult, std, 1.0 / B, hip._stream()), "air_canvas_unroll_fwd_bwd")
-        torch.cuda.synchronize()
-        assert torch.equal(st3, st) and torch.equal(fin3, final) and torch.equal(dg3, dg) and torch.equal(dw3, dwhere)
-        assert_close(parts.sum(0), rec, 1e-5, 1e-3, "rec from band shares")
+        for ns in (1, 2, 3):          # workgroups per backward unit: disjoint dglimpse rows, dwhere as `ns` slabs whose sum is the gradient
+            if lib.air_canvas_unroll_fwd_bwd_fits(nb, ns, T, B, H, W, h, w) != 1:
+                continue
+            st3 = torch.empty(T, B, H, W, device="cuda"); fin3 = torch.empty(B, H, W, device="cuda")
+            parts = torch.empty(nb, B, device="cuda"); dg3 = torch.empty_like(dg); dw3 = torch.full((ns,) + tuple(dwhere.shape), float("nan"), device="cuda")
+            _lib.check(lib.air_canvas_unroll_fwd_bwd(p(d_glm), p(d_where), p(d_pres), p(d_obs), p(st3), p(fin3), p(parts), nb, p(dg3), p(dw3),
+                                                     ns, T, B, H, W, h, w, mult, std, 1.0 / B, hip._stream()), "air_canvas_unroll_fwd_bwd")
+            torch.cuda.synchronize()
+            assert torch.equal(st3, st) and torch.equal(fin3, final) and torch.equal(dg3, dg)
+            if ns == 1:
+                assert torch.equal(dw3[0], dwhere)
+            else:
+                assert_close(dw3.sum(0), dwhere, 2e-4, 1e-5 * float(dwhere.abs().max()) + 1e-7, "dwhere from %d slabs" % ns)
+            assert_close(parts.sum(0), rec, 1e-5, 1e-3, "rec from band shares")
     tg = torch.tensor(glm, dtype=torch.float64, requires_grad=True)
     tw = torch.tensor(where, dtype=torch.float64, requires_grad=True)
     cv = sum(torch.tensor(pres[t], dtype=torch.float64)[:, None, None] * O.st_write(tg[t], tw[t], (H, W)) for t in range(T))

@@ -10,6 +10,7 @@
 #include <string>
 #include <functional>
 #include "../../attend_infer_repeat_amd/csrc/st_kernels.hip"
+#include "../../attend_infer_repeat_amd/csrc/canvas_kernels.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -85,13 +86,14 @@ int main(int argc, char **argv) {
           *d_imp = dev(imp), *d_base = dev(base), *d_logp = dev(logp);
     double *d_prior = dev(prior);
     float *d_steps = devz((size_t)M * HW), *d_final = devz((size_t)B * HW), *d_rec = devz(B), *d_dglm = devz((size_t)M * hw),
-          *d_dwhere = devz(M * 4), *d_nvil = devz(4), *d_dlogp = devz(B), *d_dbase = devz(B), *d_pre = devz(M * 8), *d_logit = devz(M),
+          *d_dwhere = devz(M * 4 * 4), *d_nvil = devz(4), *d_dlogp = devz(B), *d_dbase = devz(B), *d_pre = devz(M * 8), *d_logit = devz(M),
           *d_loc = devz(M * 4), *d_scale = devz(M * 4), *d_wh2 = devz(M * 4), *d_klrow = devz(M), *d_prob = devz(M), *d_pr2 = devz(M),
           *d_q = devz(B * (T + 1)), *d_klps = devz(B), *d_lp2 = devz(B), *d_stepw = devz(M), *d_glimpse = devz((size_t)M * hw),
           *d_dwr = devz(M * 4), *d_dpre = devz(M * 8), *d_dlogit = devz(M), *d_kla = devz(M), *d_klb = devz(M);
     hipStream_t st; CK(hipStreamCreate(&st));
     const int keep = argc > 5 ? atoi(argv[5]) : 1;
     const int NB = argc > 6 ? atoi(argv[6]) : air_canvas_unroll_bands(B, H);
+    const int NS = getenv("NS") ? atoi(getenv("NS")) : 1;      // workgroups per backward unit of the fused canvas launch
     float *d_recp = devz((size_t)NB * B);
     { std::vector<float> ip((size_t)NB * B); for (auto &x : ip) x = (-500.f + 100.f * frand()) / NB; CK(hipMemcpy(d_recp, ip.data(), ip.size() * 4, hipMemcpyHostToDevice)); }
     auto f_cfwd = [&] { air_canvas_unroll_fwd_banded(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, T, B, H, W, h, w, 0.5f, 0.3f, st); };
@@ -99,9 +101,9 @@ int main(int argc, char **argv) {
     auto f_cbwd = [&] { air_canvas_unroll_bwd_nvil(d_glm, d_where, d_pres, d_obs, d_final, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, d_recp, NB, d_rec, d_base, d_logp, d_nvil, d_dlogp, d_dbase, st); };
     auto f_cbwd0 = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, d_final, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_cbwd_rc = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, nullptr, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
-    auto f_cfused = [&] { air_canvas_unroll_fwd_bwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
+    auto f_cfused = [&] { air_canvas_unroll_fwd_bwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, d_dglm, d_dwhere, NS, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_afwd = [&] { air_attend_fwd(d_trh, d_trw, d_trb, Kt, d_sth, d_stw, d_stb, Ks, d_pre, d_logit, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_wh2, d_klrow, d_u, 0.75f, 1e-3f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, d_obs, d_glimpse, T, B, H, W, h, w, 0, st); };
-    auto f_abwd = [&] { air_attend_bwd(d_obs, d_where, d_dgl, d_dwr, d_pre, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_dwhere, d_stepw, 1.0f / B, d_dpre, d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, H, W, h, w, st); };
+    auto f_abwd = [&] { air_attend_bwd(d_obs, d_where, d_dgl, d_dwr, d_pre, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_dwhere, NS, d_stepw, 1.0f / B, d_dpre, d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, H, W, h, w, st); };
     auto f_rfwd = [&] { air_st_read_fwd(d_obs, d_where, d_glimpse, M, B, H, W, h, w, st); };
     auto f_nvil = [&] { air_nvil(d_imp, d_base, d_logp, d_nvil, d_dlogp, d_dbase, B, st); };
     auto f_pn = [&] { air_presence_numsteps_fwd(d_logit, d_u, 0.75f, 1e-3f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, T, B, st); };

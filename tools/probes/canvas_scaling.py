@@ -15,6 +15,7 @@ stream = torch.cuda.Stream(device=dev)
 sp = ctypes.c_void_p(stream.cuda_stream)
 p = H._p
 T, Hh, Ww, h, w = 3, 50, 50, 20, 20
+NS = int(os.environ.get("NS", "1"))          # workgroups per backward unit of the fused launch
 HW, hw = Hh * Ww, h * w
 print(f"{'scale':>10s} {'B':>5s} {'bands':>5s} {'fused':>8s} {'fwd':>8s} {'bwd_rc':>8s} {'bwd_st':>8s}   (us per launch)")
 for lo, hi in ((0.2, 0.3), (0.45, 0.65), (0.9, 1.0)):
@@ -29,10 +30,10 @@ for lo, hi in ((0.2, 0.3), (0.45, 0.65), (0.9, 1.0)):
         obs = torch.rand(B, HW, device=dev, generator=g)
         steps = torch.empty(T, B, HW, device=dev); final = torch.empty(B, HW, device=dev)
         nb = int(lib.air_canvas_unroll_bands(B, Hh))
-        parts = torch.empty(nb, B, device=dev); dgl = torch.empty(n, hw, device=dev); dwh = torch.empty(n, 4, device=dev)
+        parts = torch.empty(nb, B, device=dev); dgl = torch.empty(n, hw, device=dev); dwh = torch.empty(4 * n, 4, device=dev)
         torch.cuda.synchronize()
         fused = lambda: lib.air_canvas_unroll_fwd_bwd(p(glm), p(where), p(pres), p(obs), p(steps), p(final), p(parts), nb, p(dgl), p(dwh),
-                                                      T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
+                                                      NS, T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
         f = lambda: lib.air_canvas_unroll_fwd_banded(p(glm), p(where), p(pres), p(obs), p(steps), p(final), p(parts), nb, T, B,
                                                      Hh, Ww, h, w, 1.0, 0.3, sp)
         brc = lambda: lib.air_canvas_unroll_bwd(p(glm), p(where), p(pres), p(obs), None, p(dgl), p(dwh), T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
