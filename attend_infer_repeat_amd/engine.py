@@ -668,8 +668,11 @@ class AIREngine:
         # The two-role launch of the latency regime measured slower in the throughput regime (VALU bound chip-wide plus the
         # recomputation: 0.594 against 0.580 ms at batch 1024).
         # n_split: workgroups per backward unit of that launch (disjoint dglimpse rows, dwhere as n_split slabs that air_attend_bwd_dx
-        # adds): while the launch leaves CUs idle (192 units + 256 forward workgroups at batch 64), halving a unit's chain is free.
-        n_split = int(os.environ.get("AIR_CANVAS_SPLIT", "2")) if (fuse_attend and M * 2 + B * NB <= 1024) else 1
+        # adds).  Measured (profiles/r04_canvas_split_ab.txt): with 2 the launch is FASTER only while it leaves CUs idle (batch 8:
+        # 9.0 against 9.5 us); at batch 64 (192 units + 256 forward workgroups on 256 CUs) every workgroup repeats the unit's
+        # staging and tables and the launch is slower (15.0 against 11.3 us; the step 0.2093 against 0.2070 ms): default 1 above
+        # 128 glimpses, AIR_CANVAS_SPLIT overrides.
+        n_split = int(os.environ.get("AIR_CANVAS_SPLIT", "2" if M <= 128 else "1")) if (fuse_attend and M * 2 + B * NB <= 1024) else 1
         n_split = max(1, min(4, n_split))
         self._canvas_split = n_split
         fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")

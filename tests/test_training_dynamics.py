@@ -97,7 +97,10 @@ def test_engine_and_oracle_learning_curves_agree(gpu_device):
                 assert o["rec_loss"] < orc[c - 1]["rec_loss"] and a["rec_loss"] < e1[c - 1]["rec_loss"]
             continue
         for k in KEYS:
-            mid, spread = 0.5 * (a[k] + b[k]), abs(a[k] - b[k])
+            # seed-to-seed spread: the largest over the late checkpoints (two curves can cross: at one checkpoint of the round-4 run
+            # the two engine seeds sat 0.006 apart in kl_where while they were 1.2 apart 250 and 500 updates earlier)
+            late = [i for i, cp in enumerate(report["checkpoints"]) if cp >= 1000]
+            mid, spread = 0.5 * (a[k] + b[k]), max(abs(e1[i][k] - e2[i][k]) for i in late)
             band = max(floors[k], 4.0 * spread)
             assert abs(o[k] - mid) <= band, (report["checkpoints"][c], k, o[k], a[k], b[k], band)
     # the annealed num-steps prior enters both identically: once it moves, the KL of the step count follows it to the digit
