@@ -37,9 +37,40 @@ def test_bench_two_ranks_sharing_one_gpu(gpu_device, launcher):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
-    assert d["config"]["collective"] == "torch-overlap" and d["config"]["dist_world_size"] == 2
-    assert d["config"]["params_finite_after_run"] is True and d["config"]["replicas_in_sync_after_run"] is True
+    c = d["config"]
+    assert c["dist_world_size"] == 2
+    # one invocation times the safe protocol, the bare collective and the overlapped protocol; the headline is the fastest VALIDATED one
+    ab = c["protocol_ab"]
+    assert set(ab) == {"torch-split", "torch-overlap"}, ab
+    for name, r in ab.items():
+        assert r["replicas_in_sync_after_run"] is True and r["params_finite_after_run"] is True and r["images_per_sec"] > 0, (name, r)
+    assert c["collective"] in ab and d["value"] == max(r["images_per_sec"] for r in ab.values())
+    assert c["allreduce_us"] > 0 and 4 * 2629118 <= c["allreduce_bytes"] <= 4 * 2640000 and c["allreduce_busbw_GBs"] > 0
+    assert d["roofline_comm"]["bound"] == "xgmi" and d["roofline"] is not None
+    assert c["params_finite_after_run"] is True and c["replicas_in_sync_after_run"] is True
     assert d["value"] > 0 and "NOT A MEASUREMENT" in d["data"]
+
+
+def test_bench_watchdog_prints_the_safe_protocols_line_when_a_later_protocol_hangs(gpu_device):
+    """A protocol that never returns (AIR_BENCH_FAKE_HANG: the overlapped one sleeps forever on every rank) must not cost the run its
+    result: every rank's watchdog ends the process with exit code 0 and rank 0 prints the line of the torch-split measurement that
+    had already finished -- what `bench.py --gpus N` does if the overlapped protocol deadlocks on its first contact with RCCL."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, AIR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AIR_BENCH_FAKE_HANG="torch-overlap",
+               AIR_BENCH_PROTOCOL_TIMEOUT_S="25")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--no-sweep",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["collective"] == "torch-split" and set(d["config"]["protocol_ab"]) == {"torch-split"}
+    assert "did not finish" in d["config"]["protocol_note"] and d["value"] > 0 and d["n_gpus"] == 2
+    assert d["config"]["allreduce_us"] > 0                      # (the bare collective ran before the hanging protocol)
 
 
 def test_bench_refuses_more_gpus_than_the_node_has(gpu_device):
