@@ -16,6 +16,7 @@
 #pragma clang fp contract(off)
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include "air_common.h"
 #include "nvil_device.h"
 
@@ -112,37 +113,99 @@ template <bool NT>
 __device__ __forceinline__ void st_stream(float *p, float v) {
     if (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
+// Software-pipelined read used when the image is 16-byte addressable: while a workgroup computes the glimpses of image b out of
+// LDS, the 16-byte loads of its NEXT image are already in flight in registers, so the HBM stream never stops between images
+// (three NAMED float4 registers per thread: an indexed array is demoted to scratch here), behind LDS-only barriers.
+// Round 4 put it on an instruction diet.  At 65536 images the round-2/3 form was bound by VALU ISSUE, not by memory: ~90
+// instructions per output pixel (a runtime integer division for (row, column), four bounds-checked taps with their selects, the
+// un-fused bilinear form) x 1200 outputs per image = ~2000 wave-instructions per image, 0.2 ms for the chip at one wave-instruction per
+// four cycles per SIMD -- exactly the measured launch.  Here the image sits in LDS with a one-element ZERO BORDER ((H+2) x (W+2): an
+// out-of-range tap of a valid floor pair reads the +0.0f the bounds check would have selected -- same bits), so the four taps are two
+// ds_read2 off one address; an axis entry is one 8-byte LDS read {floor, d}; (row, column) come from a float reciprocal (div_small).
+// The oracle's arithmetic (grid_coord, axis_entry, bilerp) is untouched: results stay bit-identical.
 template <bool NT>
-__global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
+__device__ __forceinline__ void st_stream4(float *p, float a, float b, float c, float d) {
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 v = {a, b, c, d};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<nt_f4 *>(p)); else *reinterpret_cast<nt_f4 *>(p) = v;
+}
+// VEC (w % 4 == 0, 16-byte aligned output): the axis tables of ALL R glimpses of the staged image are built behind ONE barrier pair
+// (2 barriers per image instead of 1 + 2R) and a thread forms FOUR consecutive outputs of a glimpse row -- one row entry, four
+// column entries, one 16-byte (non-temporal) store.
+template <bool NT, bool VEC>
+__global__ __launch_bounds__(1024) void st_read_fwd_lean_kernel(
     const float *__restrict__ img, const float *__restrict__ where, float *__restrict__ out,
     int n, int n_img, int H, int W, int h, int w, double stepx, double stepy) {
     extern __shared__ __align__(16) float smem[];
     const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, nq = HW >> 2;
-    Carve c = carve_lds(smem, HW, 0, w, h);
+    const int R = n / n_img;                                          // glimpses per staged image
+    const int pitch = W + 2, padn = ((H + 2) * pitch + 3) & ~3;
+    float *s_img = smem;                                              // bordered image
+    float2 *xe = reinterpret_cast<float2 *>(smem + padn), *ye = xe + (VEC ? R : 1) * w;      // [R][w], [R][h] when VEC
+    float *sX = reinterpret_cast<float *>(ye + (VEC ? R : 1) * h), *sY = sX + w;
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
+    const float inv_W = 1.0f / (float)W, inv_w = 1.0f / (float)w;
     const float4 *where4 = reinterpret_cast<const float4 *>(where);
     const int q0 = tid < nq ? tid : nq - 1, q1 = tid + nt < nq ? tid + nt : nq - 1;
     const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
+    // where element 4q of the row-major image lands in the bordered copy: e + 2 row(e) + pitch + 1; an element past the end of
+    // its row sits two further (the two border elements between rows)
+    const int r0 = div_small(4 * q0, W, inv_W), r1 = div_small(4 * q1, W, inv_W), r2 = div_small(4 * q2, W, inv_W);
+    const int c0 = 4 * q0 - r0 * W, c1 = 4 * q1 - r1 * W, c2 = 4 * q2 - r2 * W;
+    const int b0 = 4 * q0 + 2 * r0 + pitch + 1, b1 = 4 * q1 + 2 * r1 + pitch + 1, b2 = 4 * q2 + 2 * r2 + pitch + 1;
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
     int b = blockIdx.x;
     if (b < n_img) {
         const float4 *s4 = reinterpret_cast<const float4 *>(img + (size_t)b * HW);
         p0 = ld_stream4<NT>(s4 + q0); p1 = ld_stream4<NT>(s4 + q1); p2 = ld_stream4<NT>(s4 + q2);
     }
-    float4 wnext = (b < n_img) ? where4[b] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 wnext = (b < n_img && !VEC) ? where4[b] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = tid; a < w + h; a += nt) {                   // the linspace tables do not depend on the image
-        if (a < w) c.X[a] = lin_m11(a, w, stepx); else c.Y[a - w] = lin_m11(a - w, h, stepy);
+        if (a < w) sX[a] = lin_m11(a, w, stepx); else sY[a - w] = lin_m11(a - w, h, stepy);
     }
-    float4 *d4 = reinterpret_cast<float4 *>(c.src);
+    for (int e = tid; e < 2 * pitch + 2 * H; e += nt) {       // the border, once: rows 0 and H+1, columns 0 and W+1
+        int idx;
+        if (e < pitch) idx = e;
+        else if (e < 2 * pitch) idx = (H + 1) * pitch + (e - pitch);
+        else { const int k2 = e - 2 * pitch; idx = (1 + (k2 >> 1)) * pitch + ((k2 & 1) ? W + 1 : 0); }
+        s_img[idx] = 0.f;
+    }
+    const int wq = w >> 2, hwq = hw >> 2;
     for (; b < n_img; b += gridDim.x) {
-        lds_barrier();                                        // readers of the previous image are done
-        if (tid < nq) d4[tid] = p0;
-        if (tid + nt < nq) d4[tid + nt] = p1;
-        if (tid + 2 * nt < nq) d4[tid + 2 * nt] = p2;
+        lds_barrier();                                        // readers of the previous image (and of its tables) are done
+        if (tid < nq) { s_img[b0] = p0.x; s_img[b0 + 1 + (c0 + 1 >= W ? 2 : 0)] = p0.y; s_img[b0 + 2 + (c0 + 2 >= W ? 2 : 0)] = p0.z; s_img[b0 + 3 + (c0 + 3 >= W ? 2 : 0)] = p0.w; }
+        if (tid + nt < nq) { s_img[b1] = p1.x; s_img[b1 + 1 + (c1 + 1 >= W ? 2 : 0)] = p1.y; s_img[b1 + 2 + (c1 + 2 >= W ? 2 : 0)] = p1.z; s_img[b1 + 3 + (c1 + 3 >= W ? 2 : 0)] = p1.w; }
+        if (tid + 2 * nt < nq) { s_img[b2] = p2.x; s_img[b2 + 1 + (c2 + 1 >= W ? 2 : 0)] = p2.y; s_img[b2 + 2 + (c2 + 2 >= W ? 2 : 0)] = p2.z; s_img[b2 + 3 + (c2 + 3 >= W ? 2 : 0)] = p2.w; }
         const int nb = b + gridDim.x;
         if (nb < n_img) {                                     // next image: in flight during this image's compute
             const float4 *s4 = reinterpret_cast<const float4 *>(img + (size_t)nb * HW);
             p0 = ld_stream4<NT>(s4 + q0); p1 = ld_stream4<NT>(s4 + q1); p2 = ld_stream4<NT>(s4 + q2);
+        }
+        if (VEC) {
+            for (int a = tid; a < R * (w + h); a += nt) {     // every glimpse's tables (its `where` row: an L2 / L1 hit, 16 B)
+                const int r = a / (w + h), e = a - r * (w + h);
+                const float4 wk = where4[b + (size_t)r * n_img];
+                if (e < w) xe[r * w + e] = axis_entry2(grid_coord(wk.x, sX[e], wk.y, cxs), W);
+                else ye[r * h + (e - w)] = axis_entry2(grid_coord(wk.z, sY[e - w], wk.w, cys), H);
+            }
+            lds_barrier();
+            for (int g = tid; g < R * hwq; g += nt) {         // four consecutive outputs of one glimpse row per thread
+                const int r = g / hwq, q = g - r * hwq;
+                const int i = div_small(q, wq, 1.0f / (float)wq), j = 4 * (q - i * wq);
+                const float2 ey = ye[r * h + i];
+                const int fy = __float_as_int(ey.x);
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (fy != ST_INVALID) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float2 ex = xe[r * w + j + u];
+                        const int fx = __float_as_int(ex.x);
+                        if (fx != ST_INVALID) v[u] = bilerp(load_taps_pad(s_img, pitch, fy, fx), ex.y, ey.y);
+                    }
+                }
+                st_stream4<NT>(out + ((size_t)b + (size_t)r * n_img) * hw + 4 * q, v[0], v[1], v[2], v[3]);
+            }
+            continue;
         }
         for (int k = b; k < n; k += n_img) {
             const float4 wk = wnext;
@@ -150,20 +213,24 @@ __global__ __launch_bounds__(1024) void st_read_fwd_pipe_kernel(
             if (more || nb < n_img) wnext = where4[more ? k + n_img : nb];
             lds_barrier();
             for (int a = tid; a < w + h; a += nt) {
-                if (a < w) axis_entry(grid_coord(wk.x, c.X[a], wk.y, cxs), W, &c.fx[a], &c.dx[a]);
-                else axis_entry(grid_coord(wk.z, c.Y[a - w], wk.w, cys), H, &c.fy[a - w], &c.dy[a - w]);
+                if (a < w) xe[a] = axis_entry2(grid_coord(wk.x, sX[a], wk.y, cxs), W);
+                else ye[a - w] = axis_entry2(grid_coord(wk.z, sY[a - w], wk.w, cys), H);
             }
             lds_barrier();
             float *o = out + (size_t)k * hw;
             for (int p = tid; p < hw; p += nt) {
-                const int i = p / w, j = p - i * w;
-                const int fx = c.fx[j], fy = c.fy[i];
+                const int i = div_small(p, w, inv_w), j = p - i * w;
+                const float2 ex = xe[j], ey = ye[i];
+                const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);
                 float v = 0.f;
-                if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps(c.src, H, W, fy, fx), c.dx[j], c.dy[i]);
+                if (fx != ST_INVALID && fy != ST_INVALID) v = bilerp(load_taps_pad(s_img, pitch, fy, fx), ex.y, ey.y);
                 st_stream<NT>(o + p, v);
             }
         }
     }
+}
+static inline size_t read_lean_bytes(int H, int W, int h, int w, int R) {
+    return sizeof(float) * (size_t)((((H + 2) * (W + 2) + 3) & ~3) + 2 * R * (w + h) + (w + h) + 32);
 }
 
 // dwhere[k,4] = sum_ij dglimpse * d out / d(x,y) * d(x,y)/d where ; optional dimg (n_img == n)
@@ -266,17 +333,29 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
         const int threads = nq <= 3 * 256 ? 256 : 1024;
         // out of cache (more than ~1/4 of the 256 MiB Infinity Cache touched once): streaming loads / stores, many short workgroups
         const size_t touched = sizeof(float) * ((size_t)n_img * H * W + (size_t)n * h * w);
-        if (touched > ((size_t)64 << 20)) {
-            { int st_ = st_allow_lds(st_read_fwd_pipe_kernel<true>, lds); if (st_) return st_; }
-            hipLaunchKernelGGL(st_read_fwd_pipe_kernel<true>, dim3(st_grid(n_img, 16384)), dim3(threads), lds, air_stream(stream),
-                               img, where, glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h));
-        } else {
-            { int st_ = st_allow_lds(st_read_fwd_pipe_kernel<false>, lds); if (st_) return st_; }
-            hipLaunchKernelGGL(st_read_fwd_pipe_kernel<false>, dim3(st_grid(n_img)), dim3(threads), lds, air_stream(stream),
-                               img, where, glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h));
+        const int R = n / n_img;
+        static const int lean = getenv("AIR_ST_READ_LEAN") ? atoi(getenv("AIR_ST_READ_LEAN")) : 2;      // 1: one glimpse at a time (probes)
+        // (one glimpse per image: nothing to share behind the barrier pair, and four outputs per thread would leave 100 threads busy)
+        const bool vec = lean >= 2 && R >= 2 && (w % 4 == 0) && air_aligned16(glimpse) && read_lean_bytes(H, W, h, w, R) <= ST_MAX_LDS;
+        const size_t lds_l = read_lean_bytes(H, W, h, w, vec ? R : 1);
+        if (lean && lds_l <= ST_MAX_LDS) {
+            const bool big = touched > ((size_t)64 << 20);
+            int nthr = threads;
+            {   // (measured, profiles/r04_st_read_lean.txt: 256 threads beat 320 / 384 / 512 out of cache although 320 would form the
+                //  300 output groups of a 50x50 / 20x20 / T=3 image in one round: 186 against 198 / 212 / 210 us at 65536 images)
+                static const int forced = getenv("AIR_ST_READ_THREADS") ? atoi(getenv("AIR_ST_READ_THREADS")) : 0;
+                if (forced >= 64 && forced <= 1024 && forced % 64 == 0 && 3 * forced >= nq) nthr = forced;
+            }
+            const dim3 gr(big ? st_grid(n_img, 16384) : st_grid(n_img)), th(nthr);
+#define AIR_READ_CASE(NT_, VEC_) do { { int st_ = st_allow_lds(st_read_fwd_lean_kernel<NT_, VEC_>, lds_l); if (st_) return st_; } \
+            hipLaunchKernelGGL((st_read_fwd_lean_kernel<NT_, VEC_>), gr, th, lds_l, air_stream(stream), img, where, glimpse, n, n_img, H, W, \
+                               h, w, lin_step(w), lin_step(h)); } while (0)
+            if (big) { if (vec) AIR_READ_CASE(true, true); else AIR_READ_CASE(true, false); }
+            else { if (vec) AIR_READ_CASE(false, true); else AIR_READ_CASE(false, false); }
+#undef AIR_READ_CASE
+            AIR_LAUNCH_CHECK();
+            return AIR_OK;
         }
-        AIR_LAUNCH_CHECK();
-        return AIR_OK;
     }
     { int st_ = st_allow_lds(st_read_fwd_kernel, lds); if (st_) return st_; }
     hipLaunchKernelGGL(st_read_fwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
