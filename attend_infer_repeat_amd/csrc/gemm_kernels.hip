@@ -1411,21 +1411,9 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     } else if (long_k) AIR_GROUP_LAUNCH(1, 1, 16, 1024);
     else if (T_ == 16) AIR_GROUP_LAUNCH(1, 1, 4, 256);
     else {
-        // thousands of tiles with a SHORT contraction (the weight gradients of the wide first layers at a small batch: 2500 x 256
-        // outputs over K = 64): splitting 4 chunks of K over 4 waves and reducing through LDS is all overhead -- each wave takes a
-        // whole 32x32 tile instead (4 neighbouring N tiles per workgroup, no reduction)
-        static const int smallk = getenv("AIR_GEMM_SMALLK_MAXK") ? atoi(getenv("AIR_GEMM_SMALLK_MAXK")) : 0;
-        int max_k = 0;
-        for (int i = 0; i < count; ++i) max_k = descs[i].K > max_k ? descs[i].K : max_k;
-        if (smallk > 0 && max_k <= smallk) {
-            tiles = 0;
-            for (int i = 0; i < count; ++i) {
-                ga.tile_start[i] = tiles;
-                tiles += air_cdiv(descs[i].M, 32) * air_cdiv(descs[i].N, 128);
-            }
-            for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
-            AIR_GROUP_LAUNCH(2, 2, 1, 256);
-        } else AIR_GROUP_LAUNCH(2, 2, 4, 256);
+        // (whole-tile waves instead of a 4-way K split for short contractions -- K = batch in the weight gradients of the wide
+        //  first layers -- were measured in round 3 and removed in round 4: 0.2131-0.2223 against 0.2077 ms at configs[1])
+        AIR_GROUP_LAUNCH(2, 2, 4, 256);
     }
 #undef AIR_SINGLE_LAUNCH
 #undef AIR_GROUP_LAUNCH

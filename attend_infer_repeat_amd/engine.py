@@ -676,7 +676,7 @@ class AIREngine:
         n_split = max(1, min(4, n_split))
         self._canvas_split = n_split
         fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
-                       and os.environ.get("AIR_FUSE_CANVAS", "1") == "1" and os.environ.get("AIR_TWO_LANE", "0") != "1"
+                       and os.environ.get("AIR_FUSE_CANVAS", "1") == "1"
                        # (what the library's launch takes: both grids at most 4096 workgroups, the LDS of both roles)
                        and L.air_canvas_unroll_fwd_bwd_fits(NB, n_split, T, B, Hi, Wi, hc, wc) == 1)
         bl_chain = dict(m=self.bl, g_last=self.dbase,
@@ -956,7 +956,6 @@ class AIREngine:
                                            p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
                      "air_step_epilogue")]
         # ... or, better, the two-lane form of the whole step (None where it does not apply)
-        self._plan_two_lane = self._build_two_lane_step()
 
     def _alloc_bf16_mirrors(self):
         """bf16 mirrors (same shape) of every buffer ALL of whose writers keep the mirror up to date -- see _apply_bf16_mirrors"""
@@ -1048,150 +1047,11 @@ class AIREngine:
             _lib.check(st, "air_f32_to_bf16")
 
     def _run(self, plan, stream_ptr):
-        """Issue a plan.  Entries: (fn, args, name) on the main stream; (fn, args, name, lane) with lane 1 = the engine's side
-        stream (two-lane plans: independent work next to the critical chain); ("record", event, lane) / ("wait", event, lane)
-        = hipEventRecord / hipStreamWaitEvent on that lane -- the edges between the lanes, captured as graph dependencies."""
-        side = None
+        """Issue a plan: entries (fn, args, name[, ...]) on the engine stream, in order."""
         for e in plan:
-            if e[0] == "record" or e[0] == "wait":
-                if side is None:
-                    side = ctypes.c_void_p(self._side_stream.cuda_stream)
-                sp = side if e[2] else stream_ptr
-                L = H.lib()
-                if e[0] == "record":
-                    _lib.check(L.air_event_record(e[1], sp), "air_event_record")
-                else:
-                    _lib.check(L.air_stream_wait_event(sp, e[1]), "air_stream_wait_event")
-                continue
-            fn, args, name = e[0], e[1], e[2]
-            sp = stream_ptr
-            if len(e) > 3 and e[3]:
-                if side is None:
-                    side = ctypes.c_void_p(self._side_stream.cuda_stream)
-                sp = side
-            st = fn(*args, sp)
+            st = e[0](*e[1], stream_ptr)
             if st != 0:
-                _lib.check(st, name)
-
-    # ------------------------------------------------------------------------------------------------------------
-    # two-lane train step (single GPU, latency regime)
-    # ------------------------------------------------------------------------------------------------------------
-    def _new_event(self):
-        ev = ctypes.c_void_p()
-        _lib.check(H.lib().air_event_create(ctypes.byref(ev)), "air_event_create")
-        self._lane_events.append(ev)
-        return ev
-
-    def _build_two_lane_step(self):
-        """The train step as TWO lanes of one captured graph (model.py:224-230,253-259: the baseline and every weight
-        gradient are off the ELBO's dX chain).  The step at batch 64 is one chain of ~35 dependent launches of 4.5-11 us on a
-        quarter of the chip; what is not on the chain's data path leaves it:
-          side lane : the baseline MLP forward (its obs product from the very start, the rest next to the decoder), NVIL, the
-                      baseline backward, EVERY weight-gradient product (each needs only the dX chain's g of its layer), and the
-                      RMSProp update of each parameter segment as soon as its gradients are final and the chain has read the
-                      weights for the last time;
-          main lane : the dX chain alone (single-problem launches: descriptor in kernarg SGPRs), joined by the side lane
-                      where it consumes its results -- d log q(z) from NVIL before the attend backward, everything before the
-                      closing update of the input encoder's segment.
-        Built by splitting the launches of the linear plans, so both forms run the same kernels on the same operands; every
-        side launch waits for the main launch that preceded it in the linear order (its inputs were complete there).
-        Reductions keep their fixed order: the result is bitwise the linear plan's."""
-        L = H.lib()
-        cfg = self.cfg
-        if (self._defer_dw or self.world_size != 1 or not cfg.use_reinforce
-                or os.environ.get("AIR_TWO_LANE", "0") != "1"):
-            return None
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        self._lane_events = getattr(self, "_lane_events", [])
-        g_lo, g_hi = self.flat_grads.data_ptr() + 4 * self.n_model, self.flat_grads.data_ptr() + 4 * self.n_total
-        side_c = {t.data_ptr() for t in list(self.bl.out) + list(self.bl.g) + [self.bl_obs]}
-
-        def is_side(d):
-            c = int(d.C)
-            return c in side_c or g_lo <= c < g_hi or bool(d.ta and not d.tb)
-
-        lstm_dw_c = {self.grads["lstm/w_gates"].data_ptr(), self.grads["lstm/w_gates"][self.enc.shapes[-1][1]:].data_ptr()}
-        out = []
-        n_main = [0]
-        last_wait = [-1]
-
-        def flush_side(entries):
-            """side entries whose inputs are complete once everything issued on the main lane so far has run"""
-            if not entries:
-                return
-            if last_wait[0] != n_main[0]:
-                ev = self._new_event()
-                out.append(("record", ev, 0)); out.append(("wait", ev, 1))
-                last_wait[0] = n_main[0]
-            out.extend(entries)
-
-        def regroup(descs):
-            arr = (_lib.AirGemmDesc * len(descs))(*descs)
-            self._keep.append(arr)
-            return (L.air_gemm_grouped, (arr, len(descs)), "air_gemm_grouped")
-
-        nvil_args = self._nvil_args
-        ev_nvil = None
-        recompute = os.environ.get("AIR_CANVAS_RECOMPUTE", "1") == "1"
-        plan = list(self._plan_fwd_train) + list(self._plan_bwd)
-        # the LSTM weight gradients sit in the LAST launch of the linear plan; here they are issued where their inputs are
-        # complete: next to the launch that closes the BPTT chain (d h_init / d enc_out)
-        hoisted = [d for e in plan if e[2] == "air_gemm_grouped" for d in e[1][0] if int(d.C) in lstm_dw_c]
-        dh_init_c = self.dh_init.data_ptr()
-        seg = self.param_offsets
-        for e in plan:
-            _, args, name = e
-            if name == "air_gemm_grouped":
-                descs = list(args[0])
-                side_d = [d for d in descs if is_side(d) and int(d.C) not in lstm_dw_c]
-                main_d = [d for d in descs if not is_side(d)]
-                side_now = [regroup(side_d) + (1,)] if side_d else []
-                if any(int(d.C) == dh_init_c for d in descs):
-                    # BPTT done (dgates / dgx final) and the chain has read the transform / steps weights for the last time
-                    side_now = ([regroup(hoisted) + (1,)] if hoisted else []) + side_now
-                    side_now.append(self._opt_slice_entry(seg["transform/0/w"], seg["glimpse_encoder/0/w"], 1))
-                main_e = (regroup(main_d) if len(main_d) != len(descs) else e) if main_d else None
-                if n_main[0] == 0 and main_e is not None:        # (the side lane forks BEHIND the first node of the graph)
-                    out.append(main_e); n_main[0] += 1
-                    flush_side(side_now)
-                    continue
-                flush_side(side_now)
-                if main_e is not None:
-                    out.append(main_e); n_main[0] += 1
-                continue
-            if name == "air_canvas_unroll_fwd_banded" and recompute:
-                # the canvas forward (per-step canvases, final canvas, reconstruction shares for NVIL) is not on the dX chain
-                # any more: the backward re-forms the canvas on each glimpse's footprint itself
-                flush_side([e + (1,)])
-                continue
-            if name == "air_canvas_unroll_bwd_nvil":
-                # NVIL leaves the canvas backward: it runs on the side lane behind the baseline's forward
-                flush_side([(L.air_nvil_parts, nvil_args + (self.B,), "air_nvil_parts", 1)])
-                ev_nvil = self._new_event()
-                out.append(("record", ev_nvil, 1))
-                cu = list(args[:len(args) - len(nvil_args)])
-                if recompute:
-                    cu[4] = None                                 # final_canvas = NULL: the recompute form
-                out.append((L.air_canvas_unroll_bwd, tuple(cu), "air_canvas_unroll_bwd"))
-                n_main[0] += 1
-                continue
-            if name in ("air_attend_bwd_dx", "air_st_read_bwd"):
-                # glimpse encoder .. baseline: gradients final (side lane, in order), weights read for the last time
-                flush_side([self._opt_slice_entry(seg["glimpse_encoder/0/w"], self.n_total, 1)])
-            if name in ("air_attend_bwd_dx", "air_heads_bwd"):
-                out.append(("wait", ev_nvil, 0))                 # d log q(z) for REINFORCE comes from NVIL
-            out.append(e)
-            n_main[0] += 1
-        if ev_nvil is None:
-            return None
-        # the LSTM's weights are read by the chain until the launch that closes the BPTT (already issued); its gradients and
-        # the input encoder's were the side lane's last products
-        flush_side([self._opt_slice_entry(seg["lstm/w_gates"], seg["transform/0/w"], 1)])
-        ev_end = self._new_event()
-        out.append(("record", ev_end, 1)); out.append(("wait", ev_end, 0))
-        out.append(self._opt_slice_entry(0, seg["lstm/w_gates"], 0, counters=True))
-        return out
+                _lib.check(st, e[2])
 
     def _opt_slice_entry(self, lo, hi, lane, counters=False):
         """centred RMSProp over elements [lo, hi) of the flat buffers (two learning rates around n_model) as one launch;
@@ -1294,9 +1154,10 @@ class AIREngine:
             self.obs = saved
 
     def _single_gpu_step_plans(self):
-        """the plans of one complete single-GPU update, best form first: two lanes, optimiser riders, plain"""
-        if self._plan_two_lane is not None:
-            return [self._plan_two_lane]
+        """the plans of one complete single-GPU update, best form first: optimiser riders, plain.  (A two-lane form -- a captured
+        graph with a forked side lane for the baseline, the weight gradients and the updates -- was built and measured in round 3:
+        0.4287 against 0.2117 ms, a fork/join costs 25-45 us per replay on ROCm 7.2; removed in round 4, the numbers are in
+        DESIGN section 3 and profiles/r03_c_bench_c2_b64_two_lane_rejected.json.)"""
         if self._plan_bwd_riders is not None:
             return [self._plan_fwd_train, self._plan_bwd_riders, self._plan_opt_rest]
         return [self._plan_fwd_train, self._plan_bwd, self._plan_opt]
@@ -1588,10 +1449,5 @@ class AIREngine:
         return dict(self.grads)
 
     def kernel_launch_count(self) -> Dict[str, int]:
-        """launches per train step of the linear plans; with the two-lane step also its split: launches on the main lane (the
-        dependent chain) and on the side lane"""
-        out = {"forward": len(self._plan_fwd_train), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}
-        if self._plan_two_lane is not None and self.world_size == 1:
-            k = [e for e in self._plan_two_lane if e[0] not in ("record", "wait")]
-            out = {"main_lane": sum(1 for e in k if not (len(e) > 3 and e[3])), "side_lane": sum(1 for e in k if len(e) > 3 and e[3])}
-        return out
+        """launches per train step of the linear plans"""
+        return {"forward": len(self._plan_fwd_train), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}

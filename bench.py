@@ -87,11 +87,9 @@ def st_rooflines(eng, reps=200):
     HW, hw = Hh * Ww, h * w
     p, sp = H._p, eng._sp()
     dec, dgl = eng.gd.out[-1], eng.gd.g[-1]
-    # the canvas backward in the form the step runs it: the two-lane step re-forms the canvas on each glimpse's footprint
+    # the canvas backward in the form the step runs it: the fused launch re-forms the canvas on each glimpse's footprint
     # (final_canvas = NULL) instead of reading the stored final canvas
-    rc = (any(e[0] not in ("record", "wait") and e[2] == "air_canvas_unroll_bwd" and e[1][4] is None
-              for e in (getattr(eng, "_plan_two_lane", None) or []))
-          or any(e[2] == "air_canvas_unroll_fwd_bwd" for e in eng._plan_bwd))
+    rc = any(e[2] == "air_canvas_unroll_fwd_bwd" for e in eng._plan_bwd)
     calls = {
         "st_read_fwd": (lambda: lib.air_st_read_fwd(p(eng.obs), p(eng.where), p(eng.glimpse_in), M, B, Hh, Ww, h, w, sp),
                         4 * (HW + hw + 4) * M),

@@ -526,9 +526,7 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     workgroups of the BPTT launches (air_lstm_pointwise_bwd_opt / air_lstm_step_bwd_opt) and only the head of the flat buffer
     in the closing launch: bit-identical parameters and RMSProp slots to the single closing air_step_epilogue."""
     ocfg, B = CONFIGS[name]
-    monkeypatch.setenv("AIR_TWO_LANE", "0")              # (the two-lane step supersedes the riders where it applies)
     eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
-    assert eng_a._plan_two_lane is None
     assert eng_a._plan_bwd_riders is not None and any(n.endswith("_opt") for _, _, n in eng_a._plan_bwd_riders)
     covered = sorted((s.lo, s.hi) for s in eng_a._rider_slices)
     assert covered[-1][1] == eng_a.n_total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
@@ -543,48 +541,6 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads"):
         assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
     assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
-
-
-@pytest.mark.parametrize("name", ["mnist_b8", "tiny", "t1_b5", "rect_t5", "mnist_b64"])
-@pytest.mark.parametrize("captured", [True, False])
-def test_two_lane_step_equals_linear_plan(gpu_device, monkeypatch, name, captured):
-    """AIR_TWO_LANE=1 (opt-in: measured slower under hipGraph on ROCm 7.2, see DESIGN): the single-GPU latency-regime step as two
-    lanes of one graph -- the dX chain on the main lane; the baseline MLP, the canvas forward, NVIL, every weight gradient and
-    the RMSProp update of each finished segment on a side lane -- built by splitting the launches of the linear plan.  Same
-    operands and the same arithmetic per problem; a problem that leaves a grouped launch may get another tile shape / K split
-    (the library picks them per launch), so the comparison with the linear plan is to fp32 summation-order noise: gradients
-    1e-5 of each tensor's max after the first update, parameters 1e-5 of the update after three; the noise stream, the step
-    counter and the forward results of the first step are identical."""
-    ocfg, B = CONFIGS[name]
-    monkeypatch.setenv("AIR_TWO_LANE", "1")
-    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
-    assert eng_a._plan_two_lane is not None
-    lanes = eng_a.kernel_launch_count()
-    assert lanes["side_lane"] >= 8 and lanes["main_lane"] < len(eng_a._plan_fwd_train) + len(eng_a._plan_bwd) + 1
-    names_main = [e[2] for e in eng_a._plan_two_lane if e[0] not in ("record", "wait") and not (len(e) > 3 and e[3])]
-    assert "air_canvas_unroll_bwd" in names_main and "air_canvas_unroll_bwd_nvil" not in names_main
-    monkeypatch.setenv("AIR_TWO_LANE", "0"); monkeypatch.setenv("AIR_OPT_RIDERS", "0")
-    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
-    assert eng_b._plan_two_lane is None and eng_b._plan_bwd_riders is None
-    if captured:
-        eng_a.capture()
-    eng_b.capture()
-    p0 = eng_a.flat_params.clone()
-    eng_a.train_step(); eng_b.train_step()
-    eng_a.synchronize(); eng_b.synchronize()
-    for k in ("noise_normal", "u_pres", "presence"):                                  # same noise stream, same discrete draws
-        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
-    for k in ("rec", "final_canvas", "what", "where"):                               # (a product that left a grouped launch may
-        assert rel_err(getattr(eng_a, k), getattr(eng_b, k)) < 1e-5, k               #  reduce in another order)
-    ga, gb = eng_a.named_grads(), eng_b.named_grads()
-    for k in ga:
-        assert rel_err(ga[k], gb[k]) < 1e-5, (k, rel_err(ga[k], gb[k]))
-    for _ in range(2):
-        eng_a.train_step(); eng_b.train_step()
-    eng_a.synchronize(); eng_b.synchronize()
-    assert rel_err(eng_a.flat_params - p0, eng_b.flat_params - p0) < 1e-3       # (later steps draw from slightly different weights)
-    assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
-    assert torch.equal(eng_a.rng_state, eng_b.rng_state)
 
 
 @pytest.mark.parametrize("name", ["mnist_b8", "t1_b5"])
