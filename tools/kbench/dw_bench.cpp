@@ -28,6 +28,7 @@ struct DwArgs { const DwProblem *prob; const DwItem *items; };
 template <int U>
 __global__ __launch_bounds__(256) void dw128_kernel(DwArgs a) {
     const DwItem it = a.items[blockIdx.x];
+    if (it.p < 0) return;
     const DwProblem pr = a.prob[it.p];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int m0 = it.m0 + 64 * (wave >> 1), n0 = it.n0 + 64 * (wave & 1);
@@ -75,6 +76,98 @@ __global__ __launch_bounds__(256) void dw128_kernel(DwArgs a) {
             const int row = m0 + 4 * (4 * lg + r) + i, col = n0 + 4 * li;
             if (row < pr.M && col + 3 < pr.N)          // (M, N multiples of 4: a clamped fragment lane is entirely out of range)
                 *(f32x4 *)(C + (size_t)row * pr.N + col) = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        }
+}
+// LDS-staged form: the 128x128 tile's operand chunks ([32 k][128 m] and [32 k][128 n], bf16, k-major as they sit in memory) are
+// fetched ONCE per workgroup with 16-byte loads (a quarter of the load instructions per flop of the register-direct forms, half
+// the unique bytes of the 64x64 tile), double-buffered in LDS, and the MFMA fragments -- 8 consecutive k per lane -- come out of
+// the gfx950 transposing LDS read: ds_read_b64_tr_b16 hands lane (li, lg) column li of a [4 k][16 m] block whose rows the 16
+// lanes of the group address (tools/kbench/tr16_probe.cpp), two reads per fragment, sixteen per sixteen MFMAs.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s16 *lds_v4;
+constexpr int LP = 128 + 16;                       // LDS row pitch in elements (288 B: rows 4 apart land 8 banks apart)
+template <bool A8, bool B8>                        // A8 / B8: the operand's row length is a multiple of 8 elements (16-byte loads)
+__global__ __launch_bounds__(256) void dw_lds_kernel(DwArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][32 * LP], sB[2][32 * LP];
+    const DwItem it = a.items[blockIdx.x];
+    if (it.p < 0) return;
+    const DwProblem pr = a.prob[it.p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const gch hA = (gch)pr.A16, hB = (gch)pr.B16;
+    // global -> register staging: thread (row = tid >> 4, group = tid & 15) fetches 8 elements of rows row and row + 16
+    const int lrow = tid >> 4, lcol = 8 * (tid & 15);
+    auto fetch = [&](gch h, int ld, int lim, int c0, int k, bool w8, u32x4 &v) {
+        const int col = c0 + lcol;
+        const size_t base = (size_t)k * ld;
+        if (w8) {
+            const int cc = col + 8 <= lim ? col : (lim >= 8 ? lim - 8 : 0);
+            v = *(gcu4)(h + base + cc);
+            if (col + 8 > lim) v = (u32x4){0u, 0u, 0u, 0u};
+        } else {
+            const int c_lo = col + 4 <= lim ? col : lim - 4, c_hi = col + 8 <= lim ? col + 4 : lim - 4;
+            u32x2 lo = *(gcu2)(h + base + c_lo), hi = *(gcu2)(h + base + c_hi);
+            if (col + 4 > lim) lo = (u32x2){0u, 0u};
+            if (col + 8 > lim) hi = (u32x2){0u, 0u};
+            v = (u32x4){lo.x, lo.y, hi.x, hi.y};
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c_begin = it.k0 >> 5, c_end = it.k1 >> 5;
+    u32x4 ra0, ra1, rb0, rb1;
+    auto fetch_chunk = [&](int c) {
+        const int k = c << 5;
+        fetch(hA, pr.lda, pr.M, it.m0, k + lrow, A8, ra0); fetch(hA, pr.lda, pr.M, it.m0, k + lrow + 16, A8, ra1);
+        fetch(hB, pr.ldb, pr.N, it.n0, k + lrow, B8, rb0); fetch(hB, pr.ldb, pr.N, it.n0, k + lrow + 16, B8, rb1);
+    };
+    auto stash = [&](int buf) {
+        *(u32x4 *)&sA[buf][lrow * LP + lcol] = ra0; *(u32x4 *)&sA[buf][(lrow + 16) * LP + lcol] = ra1;
+        *(u32x4 *)&sB[buf][lrow * LP + lcol] = rb0; *(u32x4 *)&sB[buf][(lrow + 16) * LP + lcol] = rb1;
+    };
+    fetch_chunk(c_begin);
+    stash(0);
+    __syncthreads();
+    const int rowsel = 8 * lg + (li >> 2), colsel = 4 * (li & 3);
+    const int wm = 64 * (wave >> 1), wn = 64 * (wave & 1);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        if (c + 1 < c_end) fetch_chunk(c + 1);                 // in flight during this chunk's MFMAs
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const v4s16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)&sA[buf][rowsel * LP + wm + 16 * t + colsel]);
+            const v4s16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)&sA[buf][(rowsel + 4) * LP + wm + 16 * t + colsel]);
+            const v4s16 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)&sB[buf][rowsel * LP + wn + 16 * t + colsel]);
+            const v4s16 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)&sB[buf][(rowsel + 4) * LP + wn + 16 * t + colsel]);
+            typedef short v8s16 __attribute__((ext_vector_type(8)));
+            const v8s16 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const v8s16 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            fa[t] = __builtin_bit_cast(bf16x8, av);
+            fb[t] = __builtin_bit_cast(bf16x8, bv);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (c + 1 < c_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // accumulator (i, j)[r] of lane (li, lg) = C[m0 + wm + 16 i + 4 lg + r][n0 + wn + 16 j + li]
+    float *C = pr.slabs + (size_t)it.slab * pr.M * pr.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = it.m0 + wm + 16 * i + 4 * lg + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = it.n0 + wn + 16 * j + li;
+                if (row < pr.M && col < pr.N) C[(size_t)row * pr.N + col] = acc[i][j][r];
+            }
         }
 }
 struct RedProblem { float *slabs, *C; int n4, S; };
@@ -175,6 +268,27 @@ int main(int argc, char **argv) {
             start[p + 1] = start[p] + s.M * s.N / 4;
         }
         if (!ok) continue;
+        if (getenv("DW_XCD") && atoi(getenv("DW_XCD"))) {
+            // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement).  All tiles of one (problem, K slice) read the same
+            // operand rows; they go to ONE XCD, so that every operand block crosses the Infinity Cache -> L2 path once
+            std::vector<std::vector<DwItem>> per(8);
+            std::vector<size_t> load(8, 0);
+            size_t i0 = 0;
+            std::vector<DwItem> sorted = items;
+            std::stable_sort(sorted.begin(), sorted.end(), [](const DwItem &x, const DwItem &y) { return x.p != y.p ? x.p < y.p : x.slab < y.slab; });
+            while (i0 < sorted.size()) {
+                size_t i1 = i0;
+                while (i1 < sorted.size() && sorted[i1].p == sorted[i0].p && sorted[i1].slab == sorted[i0].slab) ++i1;
+                int x = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                for (size_t i = i0; i < i1; ++i) per[x].push_back(sorted[i]);
+                load[x] += i1 - i0;
+                i0 = i1;
+            }
+            size_t mx = 0; for (auto &v : per) mx = std::max(mx, v.size());
+            items.clear();
+            for (size_t j = 0; j < mx; ++j)
+                for (int x = 0; x < 8; ++x) items.push_back(j < per[x].size() ? per[x][j] : DwItem{-1, 0, 0, 0, 0, 0});
+        }
         // long slices first (all equal here), problems interleaved so that neighbours in the grid share operand slabs
         DwItem *d_items; DwProblem *d_prob; RedProblem *d_red; int *d_start;
         CK(hipMalloc(&d_items, items.size() * sizeof(DwItem))); CK(hipMemcpy(d_items, items.data(), items.size() * sizeof(DwItem), hipMemcpyHostToDevice));
@@ -189,7 +303,7 @@ int main(int argc, char **argv) {
             else hipLaunchKernelGGL(dw128_kernel<3>, dim3(n_items), dim3(256), 0, 0, a);
         };
         auto run_red = [&] { hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid), dim3(256), 0, 0, d_red, d_start, P); };
-        for (int U : {1, 2, 3}) {
+        for (int U : {2}) {
             run_mm(U); run_red();
             CK(hipDeviceSynchronize());
             // check against the shipped result (different summation order: tolerance)
@@ -205,6 +319,29 @@ int main(int argc, char **argv) {
             const double t_mm = time_us([&] { run_mm(U); }, 100), t_red = time_us(run_red, 100), t_both = time_us([&] { run_mm(U); run_red(); }, 100);
             printf("128x128, slice %4d, U=%d: %5d items  product %7.2f us (%4.0f TF)  slab sum %6.2f us  both %7.2f us   max rel diff vs shipped %.1e\n",
                    slice, U, n_items, t_mm, flops / t_mm / 1e6, t_red, t_both, worst);
+        }
+        {   // the LDS-staged form on the same items
+            bool all8 = true;
+            for (int p = 0; p < P; ++p) all8 = all8 && shapes[p].M % 8 == 0 && shapes[p].N % 8 == 0;
+            auto run_lds = [&] {
+                if (all8) hipLaunchKernelGGL((dw_lds_kernel<true, true>), dim3(n_items), dim3(256), 0, 0, a);
+                else hipLaunchKernelGGL((dw_lds_kernel<false, false>), dim3(n_items), dim3(256), 0, 0, a);
+            };
+            for (int p = 0; p < P; ++p) CK(hipMemset(Cnew[p], 0, (size_t)shapes[p].M * shapes[p].N * 4));
+            run_lds(); run_red();
+            CK(hipDeviceSynchronize());
+            double worst = 0;
+            for (int p = 0; p < P; ++p) {
+                const size_t n = (size_t)shapes[p].M * shapes[p].N;
+                std::vector<float> r(n), g(n);
+                CK(hipMemcpy(r.data(), Cref[p], n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(g.data(), Cnew[p], n * 4, hipMemcpyDeviceToHost));
+                double mx = 0, err = 0;
+                for (size_t i = 0; i < n; ++i) { mx = std::max(mx, (double)fabsf(r[i])); err = std::max(err, (double)fabsf(r[i] - g[i])); }
+                worst = std::max(worst, err / (mx + 1e-30));
+            }
+            const double t_mm = time_us(run_lds, 100), t_both = time_us([&] { run_lds(); run_red(); }, 100);
+            printf("128x128 LDS + tr16, slice %4d: %5d items  product %7.2f us (%4.0f TF)  both %7.2f us   max rel diff vs shipped %.1e%s\n",
+                   slice, n_items, t_mm, flops / t_mm / 1e6, t_both, worst, all8 ? "" : "  (8-byte loads: row lengths not multiples of 8)");
         }
         for (int p = 0; p < P; ++p) CK(hipFree(slabs[p]));
         CK(hipFree(d_items)); CK(hipFree(d_prob)); CK(hipFree(d_red)); CK(hipFree(d_start));
