@@ -35,6 +35,25 @@ __device__ __forceinline__ int2 floor_span(const float2 *tab, int n, int f_lo, i
     }
     return make_int2(first, last);
 }
+// The backward's per-pixel arithmetic with its FMAs spelled out (and implicit contraction off): the recompute form, the stored-canvas
+// form and the split / unsplit instantiations are separate compilations of the same expressions, and "the same bits in every form" (the
+// tests compare them with torch.equal) must not depend on which products the compiler chooses to fuse in each.
+__device__ __forceinline__ float dcanvas_of(float coef, float mult, float canvas, float obs) {
+#pragma clang fp contract(off)
+    return coef * __builtin_fmaf(mult, canvas, -obs);
+}
+__device__ __forceinline__ void where_grad_accum(float (&acc)[8], const Taps &t, float dx, float dy, float go, float dc, float v,
+                                                 float cxs, float cys, float X, float Y, bool own) {
+#pragma clang fp contract(off)
+    const float gx = __builtin_fmaf(dy, t.fc - t.ff, (1.f - dy) * (t.cc - t.cf));
+    const float gy = __builtin_fmaf(dx, t.cf - t.ff, (1.f - dx) * (t.cc - t.fc));
+    const float gax = (go * gx) * cxs, gay = (go * gy) * cys;
+    if (own) {
+        acc[0] = __builtin_fmaf(gax, X, acc[0]); acc[1] = acc[1] + gax;
+        acc[2] = __builtin_fmaf(gay, Y, acc[2]); acc[3] = acc[3] + gay;
+        acc[4] = __builtin_fmaf(dc, v, acc[4]);
+    }
+}
 // canvas accumulation step, rounded as the oracle's `canvas + presence * inversed` (cell.py:164)
 __device__ __forceinline__ float acc_step(float acc, float p, float v) {
 #pragma clang fp contract(off)
@@ -261,7 +280,7 @@ struct WriteBwdArgs {
     int vec4_glimpse, vec4_canvas;
     int NS;                           // workgroups per unit: dglimpse rows are disjoint, dwhere is written as NS slabs [NS][T*B][4]
 };
-template <bool RC>
+template <bool RC, bool SPLIT = false>      // SPLIT: a.NS > 1 workgroups per unit (otherwise NS is the constant 1: no ownership tests)
 __device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const NvilArgs &nv, float *smem, const int vblock, const int vgrid) {
     const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
     const float *__restrict__ dcanvas = a.dcanvas, *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
@@ -299,7 +318,7 @@ __device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const N
         const int tt = e / pad_border(h, w);
         src_all[(size_t)tt * c.hwp + pad_border_index(e - tt * pad_border(h, w), h, w)] = 0.f;
     }
-    const int NS = a.NS;
+    const int NS = SPLIT ? a.NS : 1;
     for (int u = bid0; u < n * NS; u += grid_st) {
         // NS workgroups per unit: workgroup `sp` of unit k owns rows [i0, i1) of the unit's dglimpse.  It walks the canvas rows
         // whose taps touch those rows (neighbouring workgroups overlap by the rows between two glimpse rows), contracts them
@@ -413,25 +432,25 @@ __device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const N
         } else if (v4) {
             if (tid < nQ) {
                 float4 gv = qa;
-                if (!dcp) { gv.x = coef * (mult * qa.x - qb.x); gv.y = coef * (mult * qa.y - qb.y);
-                            gv.z = coef * (mult * qa.z - qb.z); gv.w = coef * (mult * qa.w - qb.w); }
+                if (!dcp) { gv.x = dcanvas_of(coef, mult, qa.x, qb.x); gv.y = dcanvas_of(coef, mult, qa.y, qb.y);
+                            gv.z = dcanvas_of(coef, mult, qa.z, qb.z); gv.w = dcanvas_of(coef, mult, qa.w, qb.w); }
                 reinterpret_cast<float4 *>(c.g)[tid] = gv;
             }
             for (int q = tid + nt; q < nQ; q += nt) {            // images above 4096 pixels
                 const float4 a4 = reinterpret_cast<const float4 *>(pa)[q], b4 = reinterpret_cast<const float4 *>(pb)[q];
                 float4 gv = a4;
-                if (!dcp) { gv.x = coef * (mult * a4.x - b4.x); gv.y = coef * (mult * a4.y - b4.y);
-                            gv.z = coef * (mult * a4.z - b4.z); gv.w = coef * (mult * a4.w - b4.w); }
+                if (!dcp) { gv.x = dcanvas_of(coef, mult, a4.x, b4.x); gv.y = dcanvas_of(coef, mult, a4.y, b4.y);
+                            gv.z = dcanvas_of(coef, mult, a4.z, b4.z); gv.w = dcanvas_of(coef, mult, a4.w, b4.w); }
                 reinterpret_cast<float4 *>(c.g)[q] = gv;
             }
         } else {
-            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : coef * (mult * fcp[p] - obp[p]);
+            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : dcanvas_of(coef, mult, fcp[p], obp[p]);
         }
         AIR_TRT(128, 6);
         __syncthreads();                                       // (1)
         AIR_TR(1);
         // footprint of the glimpse on the canvas (valid columns x valid rows): two ballots per wave over the tables
-        const int2 vx = valid_span(c.xe, W), vy = (NS == 1) ? valid_span(c.ye, H) : floor_span(c.ye, H, i0 - 1, i1 - 1);
+        const int2 vx = valid_span(c.xe, W), vy = !SPLIT ? valid_span(c.ye, H) : floor_span(c.ye, H, i0 - 1, i1 - 1);
         const int J0 = vx.x, J1 = vx.y, I0 = vy.x, I1 = vy.y;
         const int fw = J1 - J0 + 1, fh = I1 - I0 + 1;
         const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
@@ -460,18 +479,12 @@ __device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const N
                     }
                     cv = acc_step(cv, c.pres[tt], vt);
                 }
-                dc = coef * (mult * cv - dc);                  // (dc held the observation)
+                dc = dcanvas_of(coef, mult, cv, dc);           // (dc held the observation)
             }
-            const float gx = dy * (t.fc - t.ff) + (1.f - dy) * (t.cc - t.cf);
-            const float gy = dx * (t.cf - t.ff) + (1.f - dx) * (t.cc - t.fc);
             const float go = pres * dc;
-            const float gax = go * gx * cxs, gay = go * gy * cys;
             const int fyc = fy < 0 ? 0 : (fy > h - 1 ? h - 1 : fy);
-            if (NS == 1 || (fyc >= i0 && fyc < i1)) {          // (this canvas row's owner among the unit's NS workgroups)
-                acc[0] += gax * c.X[J]; acc[1] += gax;
-                acc[2] += gay * c.Y[I]; acc[3] += gay;
-                acc[4] += dc * v;
-            }
+            // (SPLIT: this canvas row's owner among the unit's NS workgroups adds it to dwhere / dpresence)
+            where_grad_accum(acc, t, dx, dy, go, dc, v, cxs, cys, c.X[J], c.Y[I], !SPLIT || (fyc >= i0 && fyc < i1));
             c.g[p] = go;
         }
         AIR_TR(9); AIR_TRT(nt - 64, 10);
@@ -571,20 +584,15 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(WriteBwdArgs a, Nvil
 // band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_body<true> (one per glimpse).  One
 // dependent launch less on the step's chain; NVIL -- which needs the forward's reconstruction shares -- rides on a later launch
 // (air_gauss_sample_bwd_nvil).
+template <bool SPLIT>
 __global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, WriteBwdArgs b, int n_fwd) {
     extern __shared__ __align__(16) float smem[];
     if ((int)blockIdx.x < n_fwd) st_write_fwd_body(f, smem, (int)blockIdx.x, n_fwd);
     else {
         const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
-        st_write_bwd_body<true>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
+        st_write_bwd_body<true, SPLIT>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
     }
 }
-
-// Throughput regime: canvas forward AND backward of one image in ONE workgroup (air_canvas_unroll_image).  Everything an image
-// needs is staged once -- its T glimpses, `where` rows, presences, the axis tables of every step -- and the canvas itself lives in
-// LDS: the forward visits only each glimpse's FOOTPRINT (work proportional to the footprint, not to the canvas: pixels outside
-// it would add exactly +0), copies the running canvas out after every step, forms the reconstruction term and dcanvas in place,
-// and the backward of the T glimpses follows on the same LDS image (pixel pass, column contraction, row contraction, exactly as
 
 // ============================================================================================================
 // host side
@@ -785,13 +793,14 @@ extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *wher
     wr_bands(H, n_bands, &NB, &RB);
     const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);
     const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
-    { int st_ = cv_allow_lds(canvas_fused_kernel, lds); if (st_) return st_; }
+    { int st_ = n_split > 1 ? cv_allow_lds(canvas_fused_kernel<true>, lds) : cv_allow_lds(canvas_fused_kernel<false>, lds); if (st_) return st_; }
     const WriteFwdArgs f = {glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, vec4g};
     const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, n_split};
     const int n_fwd = B * NB;
-    hipLaunchKernelGGL(canvas_fused_kernel, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    if (n_split > 1) hipLaunchKernelGGL(canvas_fused_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    else hipLaunchKernelGGL(canvas_fused_kernel<false>, dim3(n_fwd + T * B), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
