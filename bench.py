@@ -656,13 +656,13 @@ def main():
             # the dominant ST kernel AS IT RUNS IN THE TIMED STEP: attend_fwd_kernel (the fused affine-grid + bilinear glimpse read of
             # all T steps + the tiny heads around it), launched from the step's own plan entry on the step's buffers and timed with
             # HIP events on the engine stream; charged with the read's SURVEY 8(d) bytes only.  The stand-alone read kernel
-            # (st_read_fwd_pipe_kernel, what the sweeps scale out of cache) is next to it in roofline_standalone_read.
+            # (st_read_fwd_lean_kernel, what the sweeps scale out of cache) is next to it in roofline_standalone_read.
             line["roofline"] = (dict(roof["attend_fwd"], kernel="attend_fwd_kernel (in-step: fused glimpse read of all T steps + where sampling + "
                                      "presence / num-steps heads), from the step's own plan entry; `achieved`/`frac` = SURVEY 8(d) read bytes "
                                      "(11,616 B x T*B at 50x50 / 20x20) / HIP-event launch time; latency bound at this size -- the bandwidth "
                                      "regime is roofline_sweep_st_read_fwd") if "attend_fwd" in roof else
-                                dict(roof["st_read_fwd"], kernel="st_read_fwd_pipe_kernel (this plan has no fused attend launch: the read runs on its own)"))
-            line["roofline_standalone_read"] = dict(roof["st_read_fwd"], kernel="st_read_fwd_pipe_kernel launched on its own at the in-step shape")
+                                dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel (this plan has no fused attend launch: the read runs on its own)"))
+            line["roofline_standalone_read"] = dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel launched on its own at the in-step shape")
             line["roofline_other_kernels"] = {k: v for k, v in roof.items() if k not in ("st_read_fwd", "attend_fwd")}
             line["roofline_gemm"] = gemm_roofline(eng)
             if not args.no_sweep and world == 1:
