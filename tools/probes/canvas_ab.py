@@ -9,13 +9,15 @@ from attend_infer_repeat_amd import hip as H
 from bench import event_time_ms
 
 new = H.lib()
-old_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kbench", "bin", "libair_hip_r03.so")
+old_name = os.environ.get("OLD_LIB", "libair_hip_r03.so")      # libair_hip_prev.so: a build of the previous commit (ABI 6: the fused launch takes n_split)
+old_abi6 = old_name != "libair_hip_r03.so"
+old_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kbench", "bin", old_name)
 old = ctypes.CDLL(old_path) if os.path.exists(old_path) else None
 P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 if old is not None:
     old.air_canvas_unroll_fwd_banded.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, P]
     old.air_canvas_unroll_bwd.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P]
-    old.air_canvas_unroll_fwd_bwd.argtypes = [P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, I, F, F, F, P]
+    old.air_canvas_unroll_fwd_bwd.argtypes = [P, P, P, P, P, P, P, I, P, P] + ([I] if old_abi6 else []) + [I, I, I, I, I, I, F, F, F, P]
     for f in (old.air_canvas_unroll_fwd_banded, old.air_canvas_unroll_bwd, old.air_canvas_unroll_fwd_bwd):
         f.restype = I
 dev = torch.device("cuda:0")
@@ -39,6 +41,7 @@ for lo, hi in ((0.2, 0.3), (0.45, 0.65), (0.9, 1.0)):
         pres = (torch.rand(n, device=dev, generator=g) < 0.7).float()
         obs = torch.rand(B, HW, device=dev, generator=g)
         nb = int(new.air_canvas_unroll_bands(B, Hh))
+        torch.cuda.synchronize()               # the inputs are written on torch's stream, the launches go to `stream`
         out = {}
         for name, lib in (("old", old), ("new", new)):
             if lib is None:
@@ -49,7 +52,7 @@ for lo, hi in ((0.2, 0.3), (0.45, 0.65), (0.9, 1.0)):
             f = lambda: lib.air_canvas_unroll_fwd_banded(p(glm), p(where), p(pres), p(obs), p(steps), p(final), p(parts), nb, T, B, Hh, Ww, h, w, 1.0, 0.3, sp)
             bst = lambda: lib.air_canvas_unroll_bwd(p(glm), p(where), p(pres), p(obs), p(final), p(dgl), p(dwh), T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
             brc = lambda: lib.air_canvas_unroll_bwd(p(glm), p(where), p(pres), p(obs), None, p(dgl), p(dwh), T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
-            if name == "old":
+            if name == "old" and not old_abi6:
                 fu = lambda: lib.air_canvas_unroll_fwd_bwd(p(glm), p(where), p(pres), p(obs), p(steps), p(final), p(parts), nb, p(dgl), p(dwh), T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
             else:
                 fu = lambda: lib.air_canvas_unroll_fwd_bwd(p(glm), p(where), p(pres), p(obs), p(steps), p(final), p(parts), nb, p(dgl), p(dwh), NS, T, B, Hh, Ww, h, w, 1.0, 0.3, 1.0 / B, sp)
