@@ -676,7 +676,11 @@ class AIREngine:
         n_split = max(1, min(4, n_split))
         self._canvas_split = n_split
         fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
-                       and os.environ.get("AIR_FUSE_CANVAS", "1") == "1"
+                       # (the fused launch's backward re-forms the canvas from ALL T glimpses on each unit's footprint -- T^2 taps:
+                       #  measured 0.2095 against 0.2111 ms per step at T = 3 (50x50 / 20x20), 0.3231 against 0.3194 ms at T = 5
+                       #  (100x100 / 28x28; tools/runs/r04_x.sh): by default only up to T = 3; "1" / "0" force it on / off)
+                       and (os.environ.get("AIR_FUSE_CANVAS", "auto") == "1"
+                            or (os.environ.get("AIR_FUSE_CANVAS", "auto") == "auto" and T <= 3))
                        # (what the library's launch takes: both grids at most 4096 workgroups, the LDS of both roles)
                        and L.air_canvas_unroll_fwd_bwd_fits(NB, n_split, T, B, Hi, Wi, hc, wc) == 1)
         bl_chain = dict(m=self.bl, g_last=self.dbase,
