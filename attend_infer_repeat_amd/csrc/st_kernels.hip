@@ -346,7 +346,14 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
                 static const int forced = getenv("AIR_ST_READ_THREADS") ? atoi(getenv("AIR_ST_READ_THREADS")) : 0;
                 if (forced >= 64 && forced <= 1024 && forced % 64 == 0 && 3 * forced >= nq) nthr = forced;
             }
-            const dim3 gr(big ? st_grid(n_img, 16384) : st_grid(n_img)), th(nthr);
+            // out of cache: at least four images per workgroup (the per-workgroup preamble -- linspace, border, index set-up -- and the
+            // register prefetch of the next image only pay then: 25.1 against 26.8-27.2 us at 8192 images, 49.5-51 against 55-57 us at
+            // 16384, profiles/r04_st_read_grid.txt), at most 16384 workgroups (177.6 against 186 us with 2048 at 65536 images)
+            static const int grid_forced = getenv("AIR_ST_READ_GRID") ? atoi(getenv("AIR_ST_READ_GRID")) : 0;
+            int grid_cap = n_img / 4;
+            grid_cap = grid_cap < 2048 ? 2048 : (grid_cap > 16384 ? 16384 : grid_cap);
+            if (grid_forced > 0) grid_cap = grid_forced;
+            const dim3 gr(big ? st_grid(n_img, grid_cap) : st_grid(n_img)), th(nthr);
 #define AIR_READ_CASE(NT_, VEC_) do { { int st_ = st_allow_lds(st_read_fwd_lean_kernel<NT_, VEC_>, lds_l); if (st_) return st_; } \
             hipLaunchKernelGGL((st_read_fwd_lean_kernel<NT_, VEC_>), gr, th, lds_l, air_stream(stream), img, where, glimpse, n, n_img, H, W, \
                                h, w, lin_step(w), lin_step(h)); } while (0)
