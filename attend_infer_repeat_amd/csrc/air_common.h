@@ -13,6 +13,19 @@ static inline hipStream_t air_stream(void *s) { return reinterpret_cast<hipStrea
 static inline bool air_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool air_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int air_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// Grid of a grid-stride ("persistent") launch whose work items outnumber the workgroups the chip holds at once: exactly the resident
+// workgroups (CUs x what the kernel's registers and LDS allow per CU).  A cap that is not a multiple of that number runs in two
+// unequal phases -- the workgroups past the resident set only start when the first ones have finished ALL their items: canvas forward
+// (6 per CU: 1536 resident) 132 us with 1536 or 3072, 167 us with 2048, 176 with 1792; stored-canvas backward (5 per CU) 171 us with 1280,
+// 200 with 1536, 177 with 2048 at 8192 images (profiles/r04_canvas_grid_sweep.txt).
+template <typename K>
+static inline int air_resident_grid(K kernel, int threads, size_t lds, int fallback) {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1 || cus < 1)
+        return fallback;
+    return per_cu * cus;
+}
 
 // A zero the compiler cannot see through.  Adding it to a wave-uniform index moves that load from the scalar path (s_load,
 // lgkmcnt) to the vector path (global_load, vmcnt).  Scalar loads return out of order, so the first use of ANY scalar-loaded

@@ -14,6 +14,7 @@
 // (no full-image dcanvas staging, two pixels in flight per thread: -7 % at mid scales without spills, slower at 6-8 waves per SIMD
 // with them).  At 65536 images the backward costs 0.9 ms + 0.6 us per thousand footprint pixels: two thirds of it is the
 // per-unit fixed part (tables, staging, the two contractions, three barriers), not the pixel pass.
+#include <stdlib.h>
 #include "st_device.h"
 #include "nvil_device.h"
 
@@ -599,6 +600,12 @@ __global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, Writ
 // ============================================================================================================
 static inline double lin_step(int n) { return n > 1 ? 2.0 / (double)(n - 1) : 0.0; }
 static inline int cv_grid(long items, int cap) { return (int)(items < cap ? items : cap); }
+// (developer override of the resident-workgroup cap of the throughput-regime launches: air_resident_grid in air_common.h)
+template <typename K>
+static inline int cv_resident_cap(K kernel, int threads, size_t lds, int fallback) {
+    static const int forced = getenv("AIR_CANVAS_GRID") ? atoi(getenv("AIR_CANVAS_GRID")) : 0;
+    return forced > 0 ? forced : air_resident_grid(kernel, threads, lds, fallback);
+}
 static inline int cv_check_dims(int n, int H, int W, int h, int w) {
     if (n <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return AIR_E_SHAPE;
     return AIR_OK;
@@ -638,7 +645,8 @@ static int launch_write_fwd(const float *glimpse, const float *where, const floa
     }
     const WriteFwdArgs a = {glimpse, where, presence, canvas_in, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, vec4g};
-    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(cv_grid(units, 256 * 8)), dim3(wr_threads), lds, air_stream(stream), a);
+    const int cap = units > 256 * 8 ? cv_resident_cap(st_write_fwd_kernel, wr_threads, lds, 256 * 8) : 256 * 8;
+    hipLaunchKernelGGL(st_write_fwd_kernel, dim3(cv_grid(units, cap)), dim3(wr_threads), lds, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -709,7 +717,10 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     const int wr_threads = bwd_threads((long)B * T);
     const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, 1};
-    const int grid = cv_grid((long)T * B, 256 * 8) + (nvil ? 1 : 0);
+    int cap = 256 * 8;
+    // (the recompute form -- 118 VGPRs, four workgroups per CU -- measured 1-2 % SLOWER with the resident cap: it keeps 2048)
+    if ((long)T * B > cap && !rc) cap = cv_resident_cap(st_write_bwd_kernel<false>, wr_threads, lds, cap);
+    const int grid = cv_grid((long)T * B, cap) + (nvil ? 1 : 0);
     if (rc)
         hipLaunchKernelGGL(st_write_bwd_kernel<true>, dim3(grid), dim3(wr_threads), lds, air_stream(stream), a, nv);
     else

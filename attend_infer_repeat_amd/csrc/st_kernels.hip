@@ -350,13 +350,19 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
             // register prefetch of the next image only pay then: 25.1 against 26.8-27.2 us at 8192 images, 49.5-51 against 55-57 us at
             // 16384, profiles/r04_st_read_grid.txt), at most 16384 workgroups (177.6 against 186 us with 2048 at 65536 images)
             static const int grid_forced = getenv("AIR_ST_READ_GRID") ? atoi(getenv("AIR_ST_READ_GRID")) : 0;
-            int grid_cap = n_img / 4;
-            grid_cap = grid_cap < 2048 ? 2048 : (grid_cap > 16384 ? 16384 : grid_cap);
-            if (grid_forced > 0) grid_cap = grid_forced;
-            const dim3 gr(big ? st_grid(n_img, grid_cap) : st_grid(n_img)), th(nthr);
+            // The grid is a whole multiple of the workgroups resident at once (air_resident_grid: other caps run in unequal phases).
+            const dim3 th(nthr);
 #define AIR_READ_CASE(NT_, VEC_) do { { int st_ = st_allow_lds(st_read_fwd_lean_kernel<NT_, VEC_>, lds_l); if (st_) return st_; } \
-            hipLaunchKernelGGL((st_read_fwd_lean_kernel<NT_, VEC_>), gr, th, lds_l, air_stream(stream), img, where, glimpse, n, n_img, H, W, \
-                               h, w, lin_step(w), lin_step(h)); } while (0)
+            int cap_ = 256 * 8;                                                                                               \
+            if (n_img > cap_) {                                                                                               \
+                const int res_ = air_resident_grid(st_read_fwd_lean_kernel<NT_, VEC_>, nthr, lds_l, 256 * 8);                 \
+                int want_ = big ? (VEC_ ? n_img / 4 : 16384) : res_;    /* (one glimpse per image: 46 against 50 us at 24576 images with 16384) */ \
+                want_ = want_ > 16384 ? 16384 : want_;                                                                        \
+                if (grid_forced > 0) want_ = grid_forced;                                                                     \
+                cap_ = want_ <= res_ ? res_ : (want_ / res_) * res_;                                                          \
+            }                                                                                                                 \
+            hipLaunchKernelGGL((st_read_fwd_lean_kernel<NT_, VEC_>), dim3(st_grid(n_img, cap_)), th, lds_l, air_stream(stream), img, where, glimpse, \
+                               n, n_img, H, W, h, w, lin_step(w), lin_step(h)); } while (0)
             if (big) { if (vec) AIR_READ_CASE(true, true); else AIR_READ_CASE(true, false); }
             else { if (vec) AIR_READ_CASE(false, true); else AIR_READ_CASE(false, false); }
 #undef AIR_READ_CASE
@@ -365,7 +371,8 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
         }
     }
     { int st_ = st_allow_lds(st_read_fwd_kernel, lds); if (st_) return st_; }
-    hipLaunchKernelGGL(st_read_fwd_kernel, dim3(st_grid(n_img)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
+    const int cap_f = n_img > 256 * 8 ? air_resident_grid(st_read_fwd_kernel, ST_THREADS, lds, 256 * 8) : 256 * 8;
+    hipLaunchKernelGGL(st_read_fwd_kernel, dim3(st_grid(n_img, cap_f)), dim3(ST_THREADS), lds, air_stream(stream), img, where,
                        glimpse, n, n_img, H, W, h, w, lin_step(w), lin_step(h), vec4);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
@@ -383,7 +390,9 @@ extern "C" int air_st_read_bwd(const float *img, const float *where, const float
     const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
     { int st_ = st_allow_lds(st_read_bwd_kernel, lds); if (st_) return st_; }
     const int per_glimpse = (!dimg && n <= 2048 && n_img < n) ? 1 : 0;
-    hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(per_glimpse ? n : n_img)), dim3(ST_THREADS), lds,
+    const int units_b = per_glimpse ? n : n_img;
+    const int cap_b = units_b > 256 * 8 ? air_resident_grid(st_read_bwd_kernel, ST_THREADS, lds, 256 * 8) : 256 * 8;
+    hipLaunchKernelGGL(st_read_bwd_kernel, dim3(st_grid(units_b, cap_b)), dim3(ST_THREADS), lds,
                        air_stream(stream), img, where, dglimpse, dwhere, dimg, n, n_img, H, W, h, w, lin_step(w),
                        lin_step(h), vec4, per_glimpse);
     AIR_LAUNCH_CHECK();
