@@ -1081,3 +1081,60 @@ def test_gemm_grouped_random_groups(hip, case):
         assert_close(C_, ref, 2e-5, atol, f"problem {i} of {n} (K={K})")
         if cref is not None:
             assert_close(cs, cref, 1e-5, 1e-4 * np.sqrt(K), f"colsum {i}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# grid-stride launches (more work items than resident workgroups: the grid is a multiple of the resident count)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,B,H,W,h,w", [(2, 9000, 50, 50, 20, 20), (3, 5000, 28, 36, 9, 12), (1, 7001, 17, 13, 5, 7)])
+def test_grid_stride_launches_equal_small_launches_bit_for_bit(hip, T, B, H, W, h, w):
+    """Every ST / canvas launch whose items outnumber the resident workgroups (read forward in both forms, read backward, canvas
+    forward, stored-canvas and recompute backward) against the SAME kernels launched on chunks of 600 images (one item per
+    workgroup, the same 256-thread workgroup shape): a unit's arithmetic does not depend on which workgroup of which grid works on it,
+    so the bits must agree."""
+    gen = torch.Generator(device="cuda").manual_seed(T * 1000 + B)
+    dev = torch.device("cuda")
+    img = torch.rand(B, H, W, device=dev, generator=gen)
+    where = torch.empty(T, B, 4, device=dev)
+    where[..., 0] = 0.3 + 0.9 * torch.rand(T, B, device=dev, generator=gen)
+    where[..., 2] = 0.3 + 0.9 * torch.rand(T, B, device=dev, generator=gen)
+    where[..., 1] = 1.2 * torch.rand(T, B, device=dev, generator=gen) - 0.6
+    where[..., 3] = 1.2 * torch.rand(T, B, device=dev, generator=gen) - 0.6
+    pres = (torch.rand(T, B, device=dev, generator=gen) < 0.7).float()
+    glm = torch.randn(T, B, h, w, device=dev, generator=gen)
+    dgl = torch.randn(T * B, h, w, device=dev, generator=gen)
+    CH = 600
+
+    def chunks():          # every chunk holds 600 .. 1199 images: the 256-thread, one-band workgroup shape of the large launch
+        b0 = 0
+        while B - b0 >= 2 * CH:
+            yield b0, b0 + CH
+            b0 += CH
+        yield b0, B
+
+    # read forward: T glimpses per staged image (the vectorised / lean forms), and one image per glimpse
+    out = hip.st_read_fwd(img, where.reshape(T * B, 4), (h, w), n_img=B).view(T, B, h, w)
+    for b0, b1 in chunks():
+        ref = hip.st_read_fwd(img[b0:b1].contiguous(), where[:, b0:b1].reshape(-1, 4).contiguous(), (h, w), n_img=b1 - b0)
+        assert torch.equal(out[:, b0:b1], ref.view(T, b1 - b0, h, w)), f"read forward, images {b0}..{b1}"
+    out1 = hip.st_read_fwd(img, where[0].contiguous(), (h, w))
+    for b0, b1 in chunks():
+        assert torch.equal(out1[b0:b1], hip.st_read_fwd(img[b0:b1].contiguous(), where[0, b0:b1].contiguous(), (h, w)))
+    # read backward (dwhere): one workgroup per image beyond 2048 glimpses
+    dwh, _ = hip.st_read_bwd(img, where.reshape(T * B, 4), dgl)
+    for b0, b1 in chunks():
+        ref, _ = hip.st_read_bwd(img[b0:b1].contiguous(), where[:, b0:b1].reshape(-1, 4).contiguous(),
+                                 dgl.view(T, B, h, w)[:, b0:b1].reshape(-1, h, w).contiguous())
+        assert torch.equal(dwh.view(T, B, 4)[:, b0:b1], ref.view(T, b1 - b0, 4)), f"read backward, images {b0}..{b1}"
+    # canvas forward, stored-canvas backward, recompute backward
+    steps, final, rec = hip.canvas_unroll_fwd(glm, where, pres, (H, W), obs=img, mult=1.0, std=0.3)
+    dg_s, dw_s = hip.canvas_unroll_bwd(glm, where, pres, img, final, 1.0, 0.3, 1.0 / B)
+    dg_r, dw_r = hip.canvas_unroll_bwd(glm, where, pres, img, None, 1.0, 0.3, 1.0 / B)
+    for b0, b1 in chunks():
+        gl_c, wh_c, pr_c = glm[:, b0:b1].contiguous(), where[:, b0:b1].contiguous(), pres[:, b0:b1].contiguous()
+        st_c, fi_c, re_c = hip.canvas_unroll_fwd(gl_c, wh_c, pr_c, (H, W), obs=img[b0:b1].contiguous(), mult=1.0, std=0.3)
+        assert torch.equal(steps[:, b0:b1], st_c) and torch.equal(final[b0:b1], fi_c), f"canvas forward, images {b0}..{b1}"
+        assert torch.equal(rec[b0:b1], re_c), f"reconstruction term, images {b0}..{b1}"          # (same workgroup shape: same sum order)
+        for name, (dg, dw), fc in (("stored", (dg_s, dw_s), fi_c), ("recompute", (dg_r, dw_r), None)):
+            dg_c, dw_c = hip.canvas_unroll_bwd(gl_c, wh_c, pr_c, img[b0:b1].contiguous(), fc, 1.0, 0.3, 1.0 / B)
+            assert torch.equal(dg[:, b0:b1], dg_c) and torch.equal(dw[:, b0:b1], dw_c), f"canvas backward ({name}), images {b0}..{b1}"
