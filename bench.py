@@ -65,7 +65,16 @@ def event_time_ms(lib, stream_ptr, fn, reps):
     from attend_infer_repeat_amd import _lib
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     _lib.check(lib.air_event_create(ctypes.byref(e0))); _lib.check(lib.air_event_create(ctypes.byref(e1)))
+    # warm-up: three launches, then -- a fresh box clocks up over the first tens of milliseconds of load (the same 170 us launch
+    # measures 192 us in its first ~50 repetitions, profiles/r04_read_placement_and_warmup.txt) -- about 40 ms of the launch itself
     for _ in range(3):
+        fn()
+    _lib.check(lib.air_event_record(e0, stream_ptr))
+    fn()
+    _lib.check(lib.air_event_record(e1, stream_ptr))
+    ms1 = ctypes.c_float()
+    _lib.check(lib.air_event_elapsed_ms(e0, e1, ctypes.byref(ms1)))
+    for _ in range(min(2000, int(40.0 / max(ms1.value, 1e-3)))):
         fn()
     _lib.check(lib.air_event_record(e0, stream_ptr))
     for _ in range(reps):
