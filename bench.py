@@ -318,15 +318,15 @@ def stream_reference(device, mib=1024):
     n = mib * (1 << 20) // 4
     a = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
     b = torch.empty_like(a)
-    for _ in range(2):
+    for _ in range(80):                      # ~40 ms: the same warm-up the event-timed kernels get (event_time_ms)
         b.copy_(a)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
     e0.record()
-    for _ in range(5):
+    for _ in range(20):
         b.copy_(a)
     e1.record(); torch.cuda.synchronize(device)
-    ms = e0.elapsed_time(e1) / 5
+    ms = e0.elapsed_time(e1) / 20
     gbs = 2 * n * 4 / (ms * 1e-3) / 1e9
     del a, b
     return {"kind": "torch device-to-device copy, 1 GiB read + 1 GiB written", "achieved": round(gbs, 1), "unit": "GB/s",
