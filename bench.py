@@ -163,6 +163,25 @@ def pmc_traffic(lib, shape):
     return best, note
 
 
+def instep_durations(lib, shape, mfma_dtype):
+    """In-graph average duration of every kernel of the replayed step from the committed rocprofv3 kernel trace of THIS binary and
+    shape (tools/profile_round.sh -> tools/rocpd_summary.py --json): {kernel-name prefix: avg_us}, or {} when no file matches."""
+    import glob
+    digest = lib.air_build_digest().decode()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_instep_durations.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("build_digest") == digest and tuple(d.get("shape", ())) == tuple(shape) and d.get("mfma_dtype", "f32") == mfma_dtype:
+            out = {}
+            for e in d["positions"]:
+                k = e["kernel"].split("<")[0]
+                out.setdefault(k, []).append(e["avg_us"])
+            return {k: sum(v) / len(v) for k, v in out.items()}, os.path.basename(path)
+    return {}, None
+
+
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 
 
@@ -671,6 +690,16 @@ def main():
                                      "(11,616 B x T*B at 50x50 / 20x20) / HIP-event launch time; latency bound at this size -- the bandwidth "
                                      "regime is roofline_sweep_st_read_fwd") if "attend_fwd" in roof else
                                 dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel (this plan has no fused attend launch: the read runs on its own)"))
+            # ... and the same kernel's duration INSIDE the replayed graph, from the committed rocprofv3 kernel trace of this binary and
+            # shape (HIP events cannot be placed between the nodes of a captured graph; back-to-back launches of one plan entry find their
+            # operands warm, the node in the step does not): the conservative figure next to the live one
+            dur, dur_file = instep_durations(lib, (cfg.img_size[0], cfg.img_size[1], cfg.crop_size[0], cfg.crop_size[1], eng.T, B), cfg.mfma_dtype)
+            if "attend_fwd" in roof and dur.get("attend_fwd_kernel"):
+                us_g = dur["attend_fwd_kernel"]
+                line["roofline"]["in_graph_profiled"] = {
+                    "us_per_launch": round(us_g, 3), "achieved": round(line["roofline"]["algorithmic_bytes_per_launch"] / (us_g * 1e-6) / 1e9, 2),
+                    "frac": round(line["roofline"]["algorithmic_bytes_per_launch"] / (us_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "source": "profiles/" + dur_file}
             line["roofline_standalone_read"] = dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel launched on its own at the in-step shape")
             line["roofline_other_kernels"] = {k: v for k, v in roof.items() if k not in ("st_read_fwd", "attend_fwd")}
             line["roofline_gemm"] = gemm_roofline(eng)

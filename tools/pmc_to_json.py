@@ -15,7 +15,7 @@ import re
 import sqlite3
 
 KERNELS = {                      # bench.py key -> kernel-name prefix in the trace
-    "st_read_fwd": "st_read_fwd_pipe_kernel", "st_read_bwd": "st_read_bwd_kernel",
+    "st_read_fwd": "st_read_fwd_", "st_read_bwd": "st_read_bwd_kernel",
     "canvas_unroll_fwd": "st_write_fwd_kernel", "canvas_unroll_bwd": "st_write_bwd_kernel",
     "attend_fwd": "attend_fwd_kernel", "attend_bwd": "attend_bwd_kernel",
     "canvas_fused": "canvas_fused_kernel",     # forward + recompute-form backward as one launch (latency-regime train step)

@@ -26,12 +26,12 @@ pmc_pass() {      # pmc_pass <cfg name> "<H W h w T B>" <bench args...>
   python $ROOT/tools/pmc_to_json.py --fetch $(find "$OUT/pmc_${NAME}_FETCH_SIZE" -name "*.db" | head -1) \
       --write $(find "$OUT/pmc_${NAME}_WRITE_SIZE" -name "*.db" | head -1) --digest $DIGEST --shape $SHAPE > "$OUT/${TAG}_${NAME}_instep_pmc.json"
 }
-positions() {     # positions <cfg name> <bench args...>
-  local NAME=$1; shift
+positions() {     # positions <cfg name> "<H W h w T B>" <bench args...>
+  local NAME=$1 SHAPE=$2; shift 2
   rm -rf "$OUT/trace_$NAME"
   rocprofv3 --kernel-trace -d "$OUT/trace_$NAME" -o b -- $PY "$@" --no-cpu-baseline --no-sweep --steps 300 --warmup 30 > /dev/null 2>> "$OUT/trace.log"
   local DB=$(find "$OUT/trace_$NAME" -name "*.db" | head -1)
-  python $ROOT/tools/rocpd_summary.py $DB --by-position step_epilogue_kernel --every ${EVERY_C4:-1} > "$OUT/${TAG}_positions_$NAME.txt"
+  python $ROOT/tools/rocpd_summary.py $DB --by-position step_epilogue_kernel --every ${EVERY_C4:-1} --json "$OUT/${TAG}_${NAME}_instep_durations.json" --digest $DIGEST --dtype ${DTYPE:-f32} --shape $SHAPE > "$OUT/${TAG}_positions_$NAME.txt"
   python $ROOT/tools/rocpd_summary.py $DB > "$OUT/${TAG}_bench_${NAME}_kernel_stats.txt"
   rm -rf "$OUT/trace_$NAME"
 }
@@ -51,10 +51,10 @@ if [ "$MODE" = pmc ] || [ "$MODE" = all ]; then
   # kernel trace + per-position picture of the replayed step at every named shape
   rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $PY --no-cpu-baseline --no-sweep > "$OUT/${TAG}_bench_c2_b64_profiled.json" 2> "$OUT/trace.log"
   python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --steps 2600 > "$OUT/${TAG}_bench_c2_b64_kernel_stats.txt"
-  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --by-position step_epilogue_kernel --every ${EVERY:-1} > "$OUT/${TAG}_positions_c2_b64.txt"
-  EVERY_C4=${EVERY:-1} positions c4_b64 --config c4
-  positions c5_b1024 --config c5
-  positions c2_b1024_f32 --batch 1024
+  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --by-position step_epilogue_kernel --every ${EVERY:-1} --json "$OUT/${TAG}_c2_b64_instep_durations.json" --digest $DIGEST --shape 50 50 20 20 3 64 > "$OUT/${TAG}_positions_c2_b64.txt"
+  EVERY_C4=${EVERY:-1} positions c4_b64 "100 100 28 28 5 64" --config c4
+  DTYPE=bf16 positions c5_b1024 "50 50 20 20 3 1024" --config c5
+  positions c2_b1024_f32 "50 50 20 20 3 1024" --batch 1024
   rm -rf "$OUT"/trace "$OUT"/pmc_*/   # the SQLite traces are large; the text summaries are what travels back
 fi
 if [ "$MODE" = bench ] || [ "$MODE" = all ]; then

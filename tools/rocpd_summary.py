@@ -55,6 +55,17 @@ def by_position(db, last, every=1):
     for k in range(P):
         mark = "*" if gap[k] / n < -50.0 else " "          # started >50 ns before the previous kernel ended: overlapped
         print(f"{k:3d} {ref[k][:60]:60s} {dur[k] / n / 1e3:8.2f} {mx[k] / 1e3:8.2f} {gap[k] / n / 1e3:8.2f} {mark}")
+    if "--json" in sys.argv:      # --json <path> --digest <build digest> --shape H W h w T B: what bench.py reads for the in-graph durations
+        import json
+        i = sys.argv.index("--shape")
+        out = {"_note": "average duration of each kernel of the replayed step graph, rocprofv3 --kernel-trace of `bench.py` (begin -> end "
+                        "timestamps of the dispatches inside identical graph replays; isolated launches of the same kernels are not counted)",
+               "build_digest": sys.argv[sys.argv.index("--digest") + 1], "shape": [int(x) for x in sys.argv[i + 1:i + 7]],
+               "mfma_dtype": sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv else "f32",
+               "replays": n, "kernels_per_step": P, "step_kernel_time_us": round(sum(dur) / n / 1e3, 2),
+               "positions": [{"pos": k, "kernel": ref[k], "avg_us": round(dur[k] / n / 1e3, 3), "max_us": round(mx[k] / 1e3, 3)} for k in range(P)]}
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+            json.dump(out, f, indent=1)
 
 
 def main():
