@@ -10,7 +10,9 @@
 #include <string>
 #include <functional>
 #include "../../attend_infer_repeat_amd/csrc/st_kernels.hip"
+#define lin_step lin_step_cv          // (both translation units define this host helper)
 #include "../../attend_infer_repeat_amd/csrc/canvas_kernels.hip"
+#undef lin_step
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -105,14 +107,10 @@ int main(int argc, char **argv) {
     auto f_afwd = [&] { air_attend_fwd(d_trh, d_trw, d_trb, Kt, d_sth, d_stw, d_stb, Ks, d_pre, d_logit, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_wh2, d_klrow, d_u, 0.75f, 1e-3f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, d_obs, d_glimpse, T, B, H, W, h, w, 0, st); };
     auto f_abwd = [&] { air_attend_bwd(d_obs, d_where, d_dgl, d_dwr, d_pre, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_dwhere, NS, d_stepw, 1.0f / B, d_dpre, d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, H, W, h, w, st); };
     auto f_rfwd = [&] { air_st_read_fwd(d_obs, d_where, d_glimpse, M, B, H, W, h, w, st); };
-    auto f_nvil = [&] { air_nvil(d_imp, d_base, d_logp, d_nvil, d_dlogp, d_dbase, B, st); };
-    auto f_pn = [&] { air_presence_numsteps_fwd(d_logit, d_u, 0.75f, 1e-3f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, T, B, st); };
-    auto f_pnb = [&] { air_numsteps_presence_bwd(d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, st); };
     struct { const char *n; std::function<void()> f; int nb; } K[] = {
         {"canvas_unroll_fwd_banded", f_cfwd, B * NB}, {"canvas_unroll_fwd(1 band)", f_cfwd1, B}, {"canvas_unroll_bwd_nvil", f_cbwd, M + 1}, {"canvas_unroll_bwd", f_cbwd0, M},
         {"canvas_unroll_bwd(recompute)", f_cbwd_rc, M}, {"canvas_fused(fwd+bwd)", f_cfused, B * NB + M},
-        {"attend_fwd", f_afwd, M + (B + 63) / 64}, {"attend_bwd", f_abwd, M + (B + 63) / 64}, {"st_read_fwd", f_rfwd, B},
-        {"nvil", f_nvil, 1}, {"presence_numsteps_fwd", f_pn, 1}, {"numsteps_presence_bwd", f_pnb, 1}};
+        {"attend_fwd", f_afwd, M + (B + 63) / 64}, {"attend_bwd", f_abwd, M + (B + 63) / 64}, {"st_read_fwd", f_rfwd, B}};
     f_afwd(); CK(hipStreamSynchronize(st));
     printf("B=%d T=%d %dx%d glimpse %dx%d keep_steps=%d bands=%d\n", B, T, H, W, h, w, keep, NB);
     for (auto &k : K) {
