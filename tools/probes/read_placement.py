@@ -19,7 +19,7 @@ where[:, 1] = 0.6 * torch.rand(n, device=dev) - 0.3; where[:, 3] = 0.6 * torch.r
 pool_img.uniform_(0, 1)
 minimal = 4 * (B * Hh * Ww + n * (h * w + 4))
 print(f"pool_img at {pool_img.data_ptr():#x}, pool_out at {pool_out.data_ptr():#x}, where at {where.data_ptr():#x}")
-offs = [0, 256, 4096, 65536, 1 << 20, 2 << 20, 3 << 20, 4 << 20, 8 << 20, 16 << 20, 17 << 20, 32 << 20, 33 << 20 + 4096]
+offs = [0, 256, 4096, 65536, 1 << 20, 2 << 20, 3 << 20, 4 << 20, 8 << 20, 16 << 20, 17 << 20, 32 << 20, (33 << 20) + 4096]
 for which in ("out", "img"):
     for off in offs:
         o_img = pool_img[(off // 4 if which == "img" else 0):][: B * Hh * Ww].view(B, Hh, Ww)
