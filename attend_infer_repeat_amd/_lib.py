@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 6  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 7  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -29,6 +29,15 @@ class AirRmspropSlice(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("ms", c_void_p), ("mg", c_void_p), ("mom", c_void_p),
                 ("lo", c_size_t), ("hi", c_size_t), ("n_model", c_size_t), ("lr_dev", c_void_p),
                 ("lr_mult_tail", c_float), ("decay", c_float), ("momentum", c_float), ("eps", c_float), ("grad_scale", c_float)]
+
+
+class AirOptFold(ctypes.Structure):
+    """mirror of `struct AirOptFold` (include/air_hip.h)"""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("ms", c_void_p), ("mg", c_void_p), ("mom", c_void_p),
+                ("n_model", c_size_t), ("lr_dev", c_void_p),
+                ("lr_mult_tail", c_float), ("decay", c_float), ("momentum", c_float), ("eps", c_float), ("grad_scale", c_float),
+                ("fold_mask", ctypes.c_uint), ("n_ranges", c_int), ("range_lo", c_size_t * 4), ("range_hi", c_size_t * 4),
+                ("global_step_dev", c_void_p), ("rng_state_dev", c_void_p), ("rng_increment", c_uint64)]
 
 
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
@@ -56,6 +65,7 @@ SIGNATURES = {
                               c_float, P, P, c_size_t, P]),
     "air_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "air_gemm_grouped": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, P]),
+    "air_gemm_grouped_opt": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, ctypes.POINTER(AirOptFold), P]),
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_what_sample_pack": (c_int, [P, c_int, P, c_float, c_float, c_float, P, P, P, P, c_int, P, P, P, P, P,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/air_hip.h"
 
 #define AIR_WAVE 64
@@ -20,10 +21,23 @@ static inline int air_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // 200 with 1536, 177 with 2048 at 8192 images (profiles/r04_canvas_grid_sweep.txt).
 template <typename K>
 static inline int air_resident_grid(K kernel, int threads, size_t lds, int fallback) {
-    int per_cu = 0, cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    // memoised per (kernel, threads, lds, device): the occupancy query is three host-side runtime calls, paid in front of EVERY
+    // eager launch otherwise.  A handful of distinct keys per process.
+    struct Entry { const void *k; int threads; size_t lds; int dev; int grid; };
+    static Entry cache[32];
+    static int n_cached = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fallback;
+    const void *key = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_cached; ++i)
+        if (cache[i].k == key && cache[i].threads == threads && cache[i].lds == lds && cache[i].dev == dev) return cache[i].grid;
+    int per_cu = 0, cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1 || cus < 1)
         return fallback;
+    if (n_cached < 32) cache[n_cached++] = Entry{key, threads, lds, dev, per_cu * cus};
     return per_cu * cus;
 }
 

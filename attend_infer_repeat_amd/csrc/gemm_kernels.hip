@@ -82,6 +82,21 @@ struct AproArgs {
     float *a_out;
     int a_elu;
 };
+// the centred-RMSProp update folded into the epilogue of the weight-gradient tiles that FORM the gradients (single GPU: a tile's
+// gradient is final when formed), plus rider workgroups for slices whose gradients earlier launches left final, plus the step
+// counters: the closing launch of the train step disappears (air_gemm_grouped_opt).  A separate kernel argument of the kernels
+// that use it, like AproArgs.
+#define AIR_OPT_MAX_RANGES 4
+struct OptFold {
+    float *p; const float *g0; float *ms, *mg, *mom;       // bases of the flat buffers; g0: the flat gradient buffer C / colsum point into
+    size_t n_model;
+    const float *lr_dev;
+    float lr_mult_tail, decay, momentum, eps, gscale;
+    unsigned fold_mask;                                     // bit i: problem i's C and colsum elements are updated where they are formed
+    int n_ranges, tiles;                                    // rider slices [lo, hi) (multiples of 4); workgroups >= tiles are riders
+    size_t lo[AIR_OPT_MAX_RANGES], hi[AIR_OPT_MAX_RANGES];
+    int64_t *gstep; uint64_t *rng_state; uint64_t rng_inc;
+};
 struct GemmArgs {
     const float *A, *B, *bias, *aux;
     float *C, *colsum, *ws;
@@ -161,9 +176,9 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // MT x NT 16x16 MFMA tiles per wave.  KW = 4 / 16: the workgroup's KW waves split K for ONE tile (LDS reduce; 16
 // waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
-template <int MT, int NT, int KW, bool BF, bool APRO = false>
+template <int MT, int NT, int KW, bool BF, bool APRO = false, bool OPT = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split, const AproArgs pro = AproArgs(),
-                                          void *c16 = nullptr) {
+                                          void *c16 = nullptr, const OptFold *opt = nullptr, const bool fold = false) {
     const gh_t hC = (gh_t)c16;             // bf16 mirror of C (bf16 data path: the next product reads it instead of the fp32 value)
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
@@ -218,6 +233,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
             e_bias[i] = (ok && g.bias != nullptr) ? gBias[n] : 0.f;
             e_aux[i] = (ok && g.epi >= AIR_EPI_MUL_DELU) ? gAux[(size_t)m * g.ldaux + n] : 0.f;
             e_c[i] = (ok && g.beta != 0.f) ? gC[(size_t)m * g.ldc + n] : 0.f;
+        }
+    }
+    // folded update: the element's parameter and RMSProp slots are requested NOW, with the operands (same flat offset as its gradient)
+    float o_p[OPT ? EPT : 1], o_ms[OPT ? EPT : 1], o_mg[OPT ? EPT : 1], o_mom[OPT ? EPT : 1];
+    float o_lr0 = 0.f;
+    if (OPT && KW > 1 && fold) {
+        o_lr0 = ((gcf)opt->lr_dev)[0];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = threadIdx.x + NTH * i;
+            const int r = e / TN, cidx = e - r * TN;
+            const int m = m0 + r, n = n0 + cidx;
+            const bool ok = (e < TM * TN) && m < g.M && n < g.N;
+            const size_t idx = ok ? (size_t)((gC + (size_t)m * g.ldc + n) - (gf)opt->g0) : 0;
+            o_p[i] = ok ? ((gf)opt->p)[idx] : 0.f;
+            o_ms[i] = ok ? ((gf)opt->ms)[idx] : 0.f;
+            o_mg[i] = ok ? ((gf)opt->mg)[idx] : 0.f;
+            o_mom[i] = ok ? ((gf)opt->mom)[idx] : 0.f;
         }
     }
 
@@ -350,6 +383,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                 }
                 gC[(size_t)m * g.ldc + n] = v;
                 if (BF && hC) hC[(size_t)m * g.ldc + n] = bf16_bits(v);
+                if (OPT && fold) {
+                    const size_t idx = (size_t)((gC + (size_t)m * g.ldc + n) - (gf)opt->g0);
+                    const float lr = idx < opt->n_model ? o_lr0 : o_lr0 * opt->lr_mult_tail;
+                    float pv = o_p[i], a = o_ms[i], b = o_mg[i], c = o_mom[i];
+                    rmsprop_elem(pv, v, a, b, c, lr, opt->decay, opt->momentum, opt->eps, opt->gscale);
+                    ((gf)opt->ms)[idx] = a; ((gf)opt->mg)[idx] = b; ((gf)opt->mom)[idx] = c; ((gf)opt->p)[idx] = pv;
+                }
             }
         }
         if (want_colsum && threadIdx.x < TN) {
@@ -360,6 +400,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                 for (int q = 0; q < NWV; q += 4)
                     v += (s_col[q][threadIdx.x] + s_col[q + 1][threadIdx.x]) + (s_col[q + 2][threadIdx.x] + s_col[q + 3][threadIdx.x]);
                 gCol[n] = v;
+                if (OPT && fold) {                          // the bias gradient this tile column finishes: same treatment
+                    const size_t idx = (size_t)((gCol + n) - (gf)opt->g0);
+                    const float lr = idx < opt->n_model ? o_lr0 : o_lr0 * opt->lr_mult_tail;
+                    float pv = ((gf)opt->p)[idx], a = ((gf)opt->ms)[idx], b = ((gf)opt->mg)[idx], c = ((gf)opt->mom)[idx];
+                    rmsprop_elem(pv, v, a, b, c, lr, opt->decay, opt->momentum, opt->eps, opt->gscale);
+                    ((gf)opt->ms)[idx] = a; ((gf)opt->mg)[idx] = b; ((gf)opt->mom)[idx] = c; ((gf)opt->p)[idx] = pv;
+                }
             }
         }
     } else {
@@ -916,6 +963,48 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(G
     }
 }
 
+// gemm_grouped_kernel whose weight-gradient problems (fold_mask) apply the centred-RMSProp update to the elements they finish, with
+// rider workgroups (blockIdx >= tiles) updating the slices earlier launches left final and advancing the step counters
+template <int MT, int NT, int KW, bool BF>
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_opt_kernel(GroupArgs ga, OptFold opt) {
+    if ((int)blockIdx.x >= opt.tiles) {
+        const int vb = (int)blockIdx.x - opt.tiles, vg = (int)gridDim.x - opt.tiles;
+        for (int r = 0; r < opt.n_ranges; ++r) {
+            RmspropSlice sl;
+            sl.p = opt.p; sl.g = opt.g0; sl.ms = opt.ms; sl.mg = opt.mg; sl.mom = opt.mom;
+            sl.lo = opt.lo[r]; sl.hi = opt.hi[r]; sl.n_model = opt.n_model; sl.lr_dev = opt.lr_dev;
+            sl.lr_mult_tail = opt.lr_mult_tail; sl.decay = opt.decay; sl.momentum = opt.momentum; sl.eps = opt.eps; sl.gscale = opt.gscale;
+            rmsprop_slice_body(sl, vb, vg);
+        }
+        if (vb == 0 && threadIdx.x == 0) {
+            if (opt.gstep) opt.gstep[0] += 1;
+            if (opt.rng_state) opt.rng_state[1] += opt.rng_inc;
+        }
+        return;
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    // (ONE instantiation of the body per slot, the fold a wave-uniform run-time flag: two instantiations would each bring their own
+    //  static LDS tile and halve the workgroups a CU holds)
+#define AIR_OPT_CASE(I_)                                                                                                          \
+    gemm_body<MT, NT, KW, BF, false, true>(ga.g[I_], (int)blockIdx.x - ga.tile_start[I_], blockIdx.y, AproArgs(), nullptr, &opt,  \
+                                           ((opt.fold_mask >> I_) & 1u) != 0)
+    switch (p) {
+        case 0: AIR_OPT_CASE(0); break;
+        case 1: AIR_OPT_CASE(1); break;
+        case 2: AIR_OPT_CASE(2); break;
+        case 3: AIR_OPT_CASE(3); break;
+        case 4: AIR_OPT_CASE(4); break;
+        case 5: AIR_OPT_CASE(5); break;
+        case 6: AIR_OPT_CASE(6); break;
+        default: AIR_OPT_CASE(7); break;
+    }
+#undef AIR_OPT_CASE
+}
+
 struct C16Ptrs { void *p[AIR_GEMM_GROUP_MAX]; };
 template <int MT, int NT, int KW>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_c16_kernel(GroupArgs ga, C16Ptrs c16) {
@@ -1417,6 +1506,78 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     }
 #undef AIR_SINGLE_LAUNCH
 #undef AIR_GROUP_LAUNCH
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// air_gemm_grouped with the optimiser folded in (include/air_hip.h): latency-regime tile kernels only (what the closing launch of
+// the batch-64 train step runs on); a group the wide-tile dispatch would take is declined (AIR_E_UNSUPPORTED) -- the caller keeps
+// the plain launch + air_step_epilogue there.
+extern "C" int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const AirOptFold *o, void *stream) {
+    AIR_REQUIRE(descs && o, AIR_E_NULL);
+    AIR_REQUIRE(count > 0 && count <= AIR_GEMM_GROUP_MAX, AIR_E_SHAPE);
+    AIR_REQUIRE(o->p && o->g && o->ms && o->mg && o->mom && o->lr_dev, AIR_E_NULL);
+    AIR_REQUIRE(o->n_ranges >= 0 && o->n_ranges <= AIR_OPT_MAX_RANGES && o->n_model % 4 == 0, AIR_E_SHAPE);
+    AIR_REQUIRE(air_aligned16(o->p) && air_aligned16(o->g) && air_aligned16(o->ms) && air_aligned16(o->mg) && air_aligned16(o->mom), AIR_E_ALIGN);
+    GroupArgs ga;
+    long tiles16 = 0;
+    for (int i = 0; i < count; ++i) tiles16 += (long)air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+    const int T_ = tiles16 > 1536 ? 32 : 16;
+    int tiles = 0;
+    const bool bf = descs[0].precision == AIR_PREC_BF16;
+    bool long_k = tiles16 <= 1024;
+    for (int i = 0; i < count; ++i) {
+        const AirGemmDesc &d = descs[i];
+        AIR_REQUIRE(d.precision == AIR_PREC_F32 || d.precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+        AIR_REQUIRE((d.precision == AIR_PREC_BF16) == bf && !d.A2 && !d.C16, AIR_E_UNSUPPORTED);
+        int st = fill_gemm_args(ga.g[i], d);
+        if (st) return st;
+        ga.tile_start[i] = tiles;
+        tiles += air_cdiv(d.M, T_) * air_cdiv(d.N, T_);
+        long_k = long_k && d.K >= 512 && d.K >= 8 * (d.M < d.N ? d.M : d.N);
+        if ((o->fold_mask >> i) & 1u) {
+            // a folded problem: a plain weight gradient written into the flat gradient buffer (its parameter sits at the same offset)
+            AIR_REQUIRE(d.beta == 0.f && d.epilogue == AIR_EPI_NONE, AIR_E_UNSUPPORTED);
+            AIR_REQUIRE(d.C >= o->g && (!d.colsum || d.colsum >= o->g), AIR_E_SHAPE);
+        }
+    }
+    {   // the wide-tile regime has its own kernels (and its own fold, air_gemm_grouped's deferred-gradient launch): not here
+        static const long wide_min = getenv("AIR_GEMM_WIDE_MIN_TILES") ? atol(getenv("AIR_GEMM_WIDE_MIN_TILES")) : 1000;
+        int min_k = 1 << 30;
+        bool all_tn = true;
+        for (int i = 0; i < count; ++i) { all_tn = all_tn && descs[i].ta && !descs[i].tb; if (descs[i].K < min_k) min_k = descs[i].K; }
+        AIR_REQUIRE(!(tiles16 > wide_min && all_tn && min_k >= 256), AIR_E_UNSUPPORTED);
+    }
+    for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
+    for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
+    ga.count = count;
+    ga.xcd_map = 0;
+    OptFold f;
+    f.p = o->p; f.g0 = o->g; f.ms = o->ms; f.mg = o->mg; f.mom = o->mom; f.n_model = o->n_model; f.lr_dev = o->lr_dev;
+    f.lr_mult_tail = o->lr_mult_tail; f.decay = o->decay; f.momentum = o->momentum; f.eps = o->eps; f.gscale = o->grad_scale;
+    f.fold_mask = o->fold_mask & ((1u << count) - 1u);
+    f.n_ranges = o->n_ranges; f.tiles = tiles;
+    size_t nq = 0;
+    for (int r = 0; r < AIR_OPT_MAX_RANGES; ++r) {
+        f.lo[r] = r < o->n_ranges ? o->range_lo[r] : 0; f.hi[r] = r < o->n_ranges ? o->range_hi[r] : 0;
+        AIR_REQUIRE(f.lo[r] <= f.hi[r] && f.lo[r] % 4 == 0 && f.hi[r] % 4 == 0, AIR_E_SHAPE);
+        nq += (f.hi[r] - f.lo[r]) >> 2;
+    }
+    f.gstep = o->global_step_dev; f.rng_state = o->rng_state_dev; f.rng_inc = o->rng_increment;
+    const int nth = long_k ? 1024 : 256;
+    size_t extra = (nq + 2 * nth - 1) / (2 * nth);                          // about two float4 per rider thread
+    if (extra > 512) extra = 512;
+    if (extra < 1) extra = 1;                                               // (the counters live in rider workgroup 0)
+    hipStream_t st = air_stream(stream);
+#define AIR_GROUP_OPT_LAUNCH(MT_, NT_, KW_)                                                                                                   \
+    do {                                                                                                                                      \
+        if (bf) hipLaunchKernelGGL((gemm_grouped_opt_kernel<MT_, NT_, KW_, true>), dim3(tiles + (int)extra), dim3(nth), 0, st, ga, f);         \
+        else hipLaunchKernelGGL((gemm_grouped_opt_kernel<MT_, NT_, KW_, false>), dim3(tiles + (int)extra), dim3(nth), 0, st, ga, f);           \
+    } while (0)
+    if (long_k) AIR_GROUP_OPT_LAUNCH(1, 1, 16);
+    else if (T_ == 16) AIR_GROUP_OPT_LAUNCH(1, 1, 4);
+    else AIR_GROUP_OPT_LAUNCH(2, 2, 4);
+#undef AIR_GROUP_OPT_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -6,6 +6,10 @@
 
 __device__ __forceinline__ void rmsprop_elem(float &p, float gi_raw, float &ms, float &mg, float &mom, float lr, float decay,
                                              float momentum, float eps, float gscale) {
+    // no fp contraction: the same element must come out bit-identical whichever kernel applies the update (the closing launch, a
+    // rider workgroup of a BPTT launch, the epilogue of the weight-gradient tile that formed the gradient) -- and this is the
+    // oracle's own rounding (torch-CPU: every op rounded separately)
+#pragma clang fp contract(off)
     const float gi = gi_raw * gscale;
     const float msi = decay * ms + (1.f - decay) * gi * gi;
     const float mgi = decay * mg + (1.f - decay) * gi;

@@ -329,7 +329,9 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4 = ((H * W) % 4 == 0) && air_aligned16(img);
     const int nq = (H * W) / 4;
-    if (vec4 && air_aligned16(where) && nq <= 3 * 1024) {
+    // (W < 4: a 16-byte group of the row-major image can cross more than one row boundary, which the lean kernel's bordered staging
+    //  -- "+2 once past the end of the row" -- does not handle: narrow images take the generic kernel)
+    if (vec4 && W >= 4 && air_aligned16(where) && nq <= 3 * 1024) {
         const int threads = nq <= 3 * 256 ? 256 : 1024;
         // out of cache (more than ~1/4 of the 256 MiB Infinity Cache touched once): streaming loads / stores, many short workgroups
         const size_t touched = sizeof(float) * ((size_t)n_img * H * W + (size_t)n * h * w);

@@ -936,7 +936,7 @@ class AIREngine:
         # the BPTT chain (all but the input encoder and the LSTM: half of the 94 MB the update streams) rides as extra
         # workgroups of the BPTT launches -- 64 tiles each, three quarters of the chip idle -- and the closing launch only
         # updates the head of the buffer.  backward() / data-parallel steps (update after the all-reduce) keep the plain plans.
-        self._plan_bwd_riders = self._plan_opt_rest = None
+        self._plan_bwd_riders = self._plan_opt_rest = self._fold = None
         if rider_hosts and marks and not self._defer_dw and os.environ.get("AIR_OPT_RIDERS", "1") == "1":
             r_lo, r_hi = self.param_offsets[marks[-1][1]], self.n_total
             if r_lo % 4 == 0 and r_hi % 4 == 0 and self.n_model % 4 == 0 and r_lo > 0 and r_hi > r_lo:
@@ -959,7 +959,79 @@ class AIREngine:
                                            p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0,
                                            p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
                      "air_step_epilogue")]
-        # ... or, better, the two-lane form of the whole step (None where it does not apply)
+                self._fold_closing_update(riders, r_lo, tail_mult)
+
+    def _fold_closing_update(self, riders, r_lo, tail_mult):
+        """Round 5: the closing launch of the single-GPU latency-regime step (air_step_epilogue over the head [0, r_lo) of the flat
+        buffers -- input encoder + LSTM, whose gradients the last launches of the backward form) disappears: the weight-gradient
+        problems of the LAST backward launch apply centred RMSProp to the elements they finish, in the same epilogue
+        (air_gemm_grouped_opt: on one GPU a tile's gradient is final when formed; nothing in that launch reads a parameter), and
+        whatever else of the head was final before it rides as extra workgroups of the same launch, one of which advances the
+        step counter and the Philox offset.  33 launches instead of 34 at BASELINE configs[1].  Applies when the head is made
+        of whole float4 tensors that the last launch either forms or that earlier launches left final; otherwise the plan keeps
+        its closing launch.  AIR_OPT_FOLD=0 switches it off (A/B)."""
+        self._fold = None
+        if os.environ.get("AIR_OPT_FOLD", "1") != "1" or self._use16:
+            return
+        L, dp = H.lib(), (lambda t: t.data_ptr())
+        last = riders[-1]
+        if last[2] != "air_gemm_grouped":
+            return
+        arr, n = last[1]
+        g0 = self.flat_grads.data_ptr()
+        head = [(self.param_offsets[k], self.param_sizes[k]) for k in self.param_shapes if self.param_offsets[k] < r_lo]
+        if any(sz % 4 for _, sz in head) or sum(sz for _, sz in head) != r_lo:
+            return                                   # padding inside the head: the closing launch stays
+        covered, mask = [], 0
+        for i in range(n):
+            d = arr[i]
+            if not (d.ta and not d.tb):
+                continue
+            off = (int(d.C) - g0) // 4
+            if not (0 <= off < r_lo) or d.ldc != d.N or d.beta != 0.0 or d.epilogue != H.EPI_NONE:
+                continue
+            mask |= 1 << i
+            covered.append((off, off + d.M * d.N))
+            if d.colsum:
+                coff = (int(d.colsum) - g0) // 4
+                covered.append((coff, coff + d.N))
+        if not mask:
+            return
+        # any other problem of the launch must leave the head of the gradient buffer alone (and none reads parameters: the
+        # operands of weight gradients are activations / gradients; a dX problem would read its layer's weights)
+        p0, p1 = self.flat_params.data_ptr(), self.flat_params.data_ptr() + 4 * self.n_total
+        for i in range(n):
+            d = arr[i]
+            if any(p0 <= int(x or 0) < p1 for x in (d.A, d.B, d.aux, d.bias, d.A2)):
+                return
+        covered.sort()
+        for (a0, a1), (b0, b1) in zip(covered, covered[1:]):
+            if b0 < a1:
+                return                               # overlapping outputs: not a layout this fold understands
+        ranges, cur = [], 0
+        for a0, a1 in covered + [(r_lo, r_lo)]:
+            if a0 > cur:
+                ranges.append((cur, a0))
+            cur = max(cur, a1)
+        if len(ranges) > 4 or any(lo % 4 or hi % 4 for lo, hi in ranges):
+            return
+        cfg = self.cfg
+        fold = _lib.AirOptFold()
+        fold.p, fold.g, fold.ms, fold.mg, fold.mom = (dp(self.flat_params), g0, dp(self.flat_ms), dp(self.flat_mg), dp(self.flat_mom))
+        fold.n_model = self.n_model
+        fold.lr_dev = dp(self.lr_dev)
+        fold.lr_mult_tail, fold.decay, fold.momentum, fold.eps, fold.grad_scale = (tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0)
+        fold.fold_mask, fold.n_ranges = mask, len(ranges)
+        for j, (lo, hi) in enumerate(ranges):
+            fold.range_lo[j], fold.range_hi[j] = lo, hi
+        fold.global_step_dev, fold.rng_state_dev, fold.rng_increment = dp(self.step_dev), dp(self.rng_state), self._rng_inc
+        # (a dry run of the argument checks: a group the library's wide-tile dispatch would take is declined there)
+        self._keep.append(fold)
+        self._fold = fold
+        riders = list(riders)
+        riders[-1] = (L.air_gemm_grouped_opt, (arr, n, ctypes.byref(fold)), "air_gemm_grouped_opt")
+        self._plan_bwd_riders = riders
+        self._plan_opt_rest = []
 
     def _alloc_bf16_mirrors(self):
         """bf16 mirrors (same shape) of every buffer ALL of whose writers keep the mirror up to date -- see _apply_bf16_mirrors"""
@@ -1453,5 +1525,9 @@ class AIREngine:
         return dict(self.grads)
 
     def kernel_launch_count(self) -> Dict[str, int]:
-        """launches per train step of the linear plans"""
+        """launches per train step: of the plans a single-GPU step runs (riders / folded closing update included), of the plain
+        plans under data parallelism"""
+        if self.world_size == 1:
+            f, b, o = self._single_gpu_step_plans()
+            return {"forward": len(f), "backward": len(b), "optimizer": len(o)}
         return {"forward": len(self._plan_fwd_train), "backward": len(self._plan_bwd), "optimizer": len(self._plan_opt)}

@@ -38,9 +38,13 @@ def apply():
         late = bool(torch is not None and torch.cuda.is_initialized())
     except Exception:                                         # noqa: BLE001 -- a torch without the cuda module: nothing to be late for
         late = False
+    # `late` only counts when THIS package is the one trying to set something too late: a key the user exported before the process
+    # started is in effect whatever the import order
+    missing = [k for k in SETTINGS if k not in os.environ]
     for k, v in SETTINGS.items():
         os.environ.setdefault(k, v)
         applied[k] = os.environ[k]
+    late = late and bool(missing)
     if late:
         import warnings
         warnings.warn("attend_infer_repeat_amd was imported after the HIP runtime was initialised: %s cannot take effect in this "

@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager C-ABI launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short captured runs of BASELINE configs[3] / configs[4] that the default headline run appends")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="time the CPU oracle on every host cpu as well (minutes on a 256-cpu host: ~100 s per step)")
@@ -163,10 +165,14 @@ def pmc_traffic(lib, shape):
     return best, note
 
 
-def instep_durations(lib, shape, mfma_dtype):
-    """In-graph average duration of every kernel of the replayed step from the committed rocprofv3 kernel trace of THIS binary and
-    shape (tools/profile_round.sh -> tools/rocpd_summary.py --json): {kernel-name prefix: avg_us}, or {} when no file matches."""
+def instep_durations(lib, shape, mfma_dtype, n_launches=None):
+    """In-graph average duration of every kernel of the replayed step from the committed rocprofv3 kernel trace of THIS binary,
+    shape and PLAN (tools/profile_round.sh -> tools/rocpd_summary.py --json): {kernel-name prefix: avg_us}, or {} when no file matches.
+    The profiles are taken on the default plan: with any plan-changing AIR_* switch set, or when the step's launch count differs from
+    the profiled one, nothing is returned (a duration measured on a different plan must not sit next to live numbers)."""
     import glob
+    if plan_env_overrides():
+        return {}, None
     digest = lib.air_build_digest().decode()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_instep_durations.json")), reverse=True):
         try:
@@ -174,12 +180,131 @@ def instep_durations(lib, shape, mfma_dtype):
         except Exception:
             continue
         if d.get("build_digest") == digest and tuple(d.get("shape", ())) == tuple(shape) and d.get("mfma_dtype", "f32") == mfma_dtype:
+            if n_launches is not None and len(d["positions"]) != n_launches:
+                continue
             out = {}
             for e in d["positions"]:
                 k = e["kernel"].split("<")[0]
                 out.setdefault(k, []).append(e["avg_us"])
             return {k: sum(v) / len(v) for k, v in out.items()}, os.path.basename(path)
     return {}, None
+
+
+PLAN_ENV = ("AIR_DEFER_DW_MIN_ROWS", "AIR_FUSE_ATTEND_M", "AIR_FUSE_LSTM_TILES", "AIR_FUSE_LSTM_WIDE", "AIR_SPLIT_K0", "AIR_OPT_RIDERS",
+            "AIR_FUSE_CANVAS", "AIR_FUSE_CANVAS_THROUGHPUT", "AIR_CANVAS_SPLIT", "AIR_BF16_STORAGE", "AIR_BF16_LSTM", "AIR_OPT_FOLD",
+            "AIR_GEMM_WIDE_MIN_TILES", "AIR_GEMM_WIDE_TN_BF16", "AIR_GEMM_WIDE_TN_F32", "AIR_GEMM_WIDE_NT_K", "AIR_GEMM_BIG_XCD",
+            "AIR_GEMM_BF16_STORAGE")
+
+
+def plan_env_overrides():
+    """the plan-changing developer switches set in this process: a committed in-graph profile was taken without any"""
+    return {k: os.environ[k] for k in PLAN_ENV if k in os.environ}
+
+
+def in_step_event_us(eng, key, steps=200, warm=30):
+    """Duration of the plan entry `key` INSIDE the train step, live: the step's own launch list is issued eagerly on the engine
+    stream (same kernels, same order, same buffers as the captured graph) with a HIP event recorded right before and right after
+    that one entry, so the kernel finds its operands exactly as cold as it does in the replayed step (its inputs were written by the
+    launch in front of it; the weights were last touched a step ago).  Average over `steps` steps.  The interval runs from the end of
+    the previous launch to the end of this one, i.e. it includes this entry's dispatch gap: an upper bound of the kernel's own
+    duration, which the committed rocprofv3 positions file gives (`in_graph_profiled`)."""
+    from attend_infer_repeat_amd import hip as H, _lib
+    lib, sp = H.lib(), eng._sp()
+    plans = eng._single_gpu_step_plans() if eng.world_size == 1 else [eng._plan_fwd_train, eng._plan_bwd, eng._plan_opt]
+    flat = [e for pl in plans for e in pl]
+    idx = [i for i, e in enumerate(flat) if e[2] == key]
+    if not idx:
+        return None
+    i0 = idx[0]
+    e0s = [ctypes.c_void_p() for _ in range(steps)]
+    e1s = [ctypes.c_void_p() for _ in range(steps)]
+    for e in e0s + e1s:
+        _lib.check(lib.air_event_create(ctypes.byref(e)))
+    for it in range(warm + steps):
+        k = it - warm
+        for j, e in enumerate(flat):
+            if j == i0 and k >= 0:
+                _lib.check(lib.air_event_record(e0s[k], sp))
+            st = e[0](*e[1], sp)
+            if st != 0:
+                _lib.check(st, e[2])
+            if j == i0 and k >= 0:
+                _lib.check(lib.air_event_record(e1s[k], sp))
+    eng.synchronize()
+    tot = 0.0
+    for a, b in zip(e0s, e1s):
+        ms = ctypes.c_float()
+        _lib.check(lib.air_event_elapsed_ms(a, b, ctypes.byref(ms)))
+        tot += ms.value
+    for e in e0s + e1s:
+        lib.air_event_destroy(e)
+    return tot / steps * 1e3
+
+
+def attend_roofline(eng, lib, live_warm_us=None):
+    """`roofline` of the fused glimpse read as it runs in the step (SURVEY 8(d) read bytes / duration).  Primary figure: the in-step
+    duration -- from the committed rocprofv3 positions of THIS binary, shape and plan when there is one, else the live in-step event
+    timing; the back-to-back (warm-operand) launch time is kept as `frac_live`."""
+    cfg, T, B, M = eng.cfg, eng.T, eng.B, eng.M
+    (Hh, Ww), (h, w) = cfg.img_size, cfg.crop_size
+    nbytes = 4 * (Hh * Ww + h * w + 4) * M
+    us_ev = in_step_event_us(eng, "air_attend_fwd")
+    if us_ev is None:
+        return None
+    n_launch = sum(eng.kernel_launch_count().values())
+    dur, dur_file = instep_durations(lib, (Hh, Ww, h, w, T, B), cfg.mfma_dtype, n_launch)
+    us_prof = dur.get("attend_fwd_kernel")
+    us = us_prof if us_prof else us_ev
+    gbs = lambda u: nbytes / (u * 1e-6) / 1e9
+    out = {"bound": "hbm", "kernel": "attend_fwd_kernel (fused glimpse read of all T steps + where sampling + presence / num-steps heads)",
+           "achieved": round(gbs(us), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(us) / HBM_PEAK_GBS, 5),
+           "us_per_launch": round(us, 3), "algorithmic_bytes_per_launch": nbytes,
+           "duration_source": ("profiles/%s (rocprofv3 kernel trace of the replayed graph, this binary / shape / plan)" % dur_file) if us_prof
+                              else "live: HIP events around the entry inside the eagerly issued step (includes its dispatch gap)",
+           "in_step_events": {"us_per_launch": round(us_ev, 3), "frac": round(gbs(us_ev) / HBM_PEAK_GBS, 5)}}
+    if us_prof:
+        out["in_graph_profiled"] = {"us_per_launch": round(us_prof, 3), "frac": round(gbs(us_prof) / HBM_PEAK_GBS, 5), "source": "profiles/" + dur_file}
+    if live_warm_us:
+        out["frac_live"] = round(gbs(live_warm_us) / HBM_PEAK_GBS, 5)
+        out["us_per_launch_live_back_to_back"] = round(live_warm_us, 3)
+    return out
+
+
+def run_other_config(name, device, steps=400, warmup=100):
+    """A short captured run of another named single-GPU configuration (BASELINE configs[3] = c4, configs[4] = c5) inside the default
+    invocation, so that the driver's line carries driver-observed numbers for every single-GPU configuration."""
+    import torch
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+    from attend_infer_repeat_amd import hip as H
+    kw = dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5) if name == "c4" else {}
+    B = 1024 if name == "c5" else 64
+    cfg = EngineConfig(mfma_dtype="bf16" if name == "c5" else "f32", **kw)
+    eng = AIREngine(cfg, B, device=device, seed=1, keep_canvas_steps=True)
+    imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=4 if name == "c4" else 2, seed=0)
+    eng.set_obs(torch.from_numpy(imgs).to(device))
+    eng.capture()
+    for _ in range(warmup):
+        eng.train_step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step()
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    finite = bool(torch.isfinite(eng.flat_params).all().item())
+    eng.release_graphs()
+    roof = attend_roofline(eng, H.lib())
+    (Hh, Ww), (hh, ww) = cfg.img_size, cfg.crop_size
+    rec = {"workload": f"{Hh}x{Ww} canvas, max_steps={eng.T}, glimpse {hh}x{ww}, batch={B}, "
+                       f"{'bf16-operand MFMA MLP path' if name == 'c5' else 'fp32'}, hipGraph replay "
+                       f"(BASELINE configs[{3 if name == 'c4' else 4}])",
+           "value": round(B * steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+           "warmup": warmup, "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
+           "params_finite_after_run": finite, "roofline": roof}
+    del eng
+    torch.cuda.empty_cache()
+    return rec
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
@@ -685,21 +810,22 @@ def main():
             # all T steps + the tiny heads around it), launched from the step's own plan entry on the step's buffers and timed with
             # HIP events on the engine stream; charged with the read's SURVEY 8(d) bytes only.  The stand-alone read kernel
             # (st_read_fwd_lean_kernel, what the sweeps scale out of cache) is next to it in roofline_standalone_read.
-            line["roofline"] = (dict(roof["attend_fwd"], kernel="attend_fwd_kernel (in-step: fused glimpse read of all T steps + where sampling + "
-                                     "presence / num-steps heads), from the step's own plan entry; `achieved`/`frac` = SURVEY 8(d) read bytes "
-                                     "(11,616 B x T*B at 50x50 / 20x20) / HIP-event launch time; latency bound at this size -- the bandwidth "
-                                     "regime is roofline_sweep_st_read_fwd") if "attend_fwd" in roof else
-                                dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel (this plan has no fused attend launch: the read runs on its own)"))
-            # ... and the same kernel's duration INSIDE the replayed graph, from the committed rocprofv3 kernel trace of this binary and
-            # shape (HIP events cannot be placed between the nodes of a captured graph; back-to-back launches of one plan entry find their
-            # operands warm, the node in the step does not): the conservative figure next to the live one
-            dur, dur_file = instep_durations(lib, (cfg.img_size[0], cfg.img_size[1], cfg.crop_size[0], cfg.crop_size[1], eng.T, B), cfg.mfma_dtype)
-            if "attend_fwd" in roof and dur.get("attend_fwd_kernel"):
-                us_g = dur["attend_fwd_kernel"]
-                line["roofline"]["in_graph_profiled"] = {
-                    "us_per_launch": round(us_g, 3), "achieved": round(line["roofline"]["algorithmic_bytes_per_launch"] / (us_g * 1e-6) / 1e9, 2),
-                    "frac": round(line["roofline"]["algorithmic_bytes_per_launch"] / (us_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-                    "source": "profiles/" + dur_file}
+            if "attend_fwd" in roof and not args.no_graph:
+                # primary figure = the IN-STEP duration: the committed rocprofv3 positions of this binary,
+                # shape and plan when there is one, else HIP events around the entry inside the eagerly issued step; the warm
+                # back-to-back launch time (what earlier rounds printed as `frac`) is kept as `frac_live`
+                line["roofline"] = attend_roofline(eng, lib, live_warm_us=roof["attend_fwd"]["us_per_launch"])
+                line["roofline"]["traffic"] = roof["attend_fwd"].get("traffic")
+                line["roofline"]["minimal_bytes_per_launch"] = roof["attend_fwd"]["minimal_bytes_per_launch"]
+                line["roofline"]["definition_note"] = ("since round 4 the headline roofline is the in-step fused kernel (attend_fwd_kernel) charged with "
+                                                       "the read's 8(d) bytes only; rounds 1-3 printed the stand-alone read kernel: fractions are not "
+                                                       "comparable across that change; since round 5 `frac` is the in-step duration, `frac_live` the warm one")
+            elif "attend_fwd" in roof:
+                line["roofline"] = dict(roof["attend_fwd"], kernel="attend_fwd_kernel, eager launches (--no-graph): back-to-back HIP-event time")
+            else:
+                line["roofline"] = dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel (this plan has no fused attend launch: the read runs on its own)")
+            if plan_env_overrides():
+                line["config"]["plan_env_overrides"] = plan_env_overrides()
             line["roofline_standalone_read"] = dict(roof["st_read_fwd"], kernel="st_read_fwd_lean_kernel launched on its own at the in-step shape")
             line["roofline_other_kernels"] = {k: v for k, v in roof.items() if k not in ("st_read_fwd", "attend_fwd")}
             line["roofline_gemm"] = gemm_roofline(eng)
@@ -713,6 +839,14 @@ def main():
                 line["roofline_sweep_canvas_write_fwd"], line["roofline_sweep_canvas_write_bwd"] = cw_f, cw_b
                 line["roofline_sweep_canvas_write_pair"] = cw_i
                 line["stream_reference"] = stream_reference(device)
+            if (world == 1 and not args.no_other_configs and not args.no_graph and (args.config, B, args.mfma) == ("c2", 64, "f32")):
+                # the other named single-GPU configurations, driver-observed: ~2 s each
+                line["other_configs"] = {}
+                for oc in ("c4", "c5"):
+                    try:
+                        line["other_configs"][oc] = run_other_config(oc, device)
+                    except Exception as ex:             # noqa: BLE001 -- the headline line must survive whatever happens here
+                        line["other_configs"][oc] = {"error": repr(ex)}
             if not args.no_cpu_baseline and world == 1:
                 torch.cuda.synchronize(device)
                 line["cpu_baseline"] = cpu_baseline(cfg_kw, B, args.cpu_seconds, args.cpu_all_cores)

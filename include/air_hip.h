@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 6
+#define AIR_ABI_VERSION 7
 
 enum {
     AIR_OK = 0,
@@ -224,6 +224,25 @@ typedef struct AirRmspropSlice {
     const float *lr_dev;
     float lr_mult_tail, decay, momentum, eps, grad_scale;
 } AirRmspropSlice;
+/* air_gemm_grouped with the closing update of the train step folded in (single GPU, latency regime; model.py:355-367 + the weight
+ * gradients of the first layers): the problems of `fold_mask` are plain weight gradients (ta = 1, beta = 0, no epilogue) whose C /
+ * colsum point INTO the flat gradient buffer `g`; every element they finish is written to `g` as before and, in the same epilogue,
+ * taken through centred RMSProp at the same flat offset of p / ms / mg / mom -- on one GPU a tile's gradient is final when formed.
+ * Up to four further slices [range_lo, range_hi) (multiples of 4) whose gradients EARLIER launches left final are updated by rider
+ * workgroups, one of which advances the device step counter and the Philox offset (as air_step_epilogue does).  The caller
+ * guarantees that no problem of this launch reads a parameter it updates.  Groups the wide-tile dispatch of air_gemm_grouped would
+ * take are declined with AIR_E_UNSUPPORTED.                                                                                        */
+typedef struct AirOptFold {
+    float *p; const float *g; float *ms, *mg, *mom;
+    size_t n_model;
+    const float *lr_dev;
+    float lr_mult_tail, decay, momentum, eps, grad_scale;
+    unsigned fold_mask;
+    int n_ranges;
+    size_t range_lo[4], range_hi[4];
+    int64_t *global_step_dev; uint64_t *rng_state_dev; uint64_t rng_increment;
+} AirOptFold;
+int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const AirOptFold *opt, void *stream);
 /* air_lstm_step_bwd / air_lstm_pointwise_bwd with an optimiser slice riding along (opt == NULL or lo == hi: none).          */
 int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
                           const float *dc_in, const float *gate_act, const float *c_prev, const float *c,

@@ -526,6 +526,7 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     workgroups of the BPTT launches (air_lstm_pointwise_bwd_opt / air_lstm_step_bwd_opt) and only the head of the flat buffer
     in the closing launch: bit-identical parameters and RMSProp slots to the single closing air_step_epilogue."""
     ocfg, B = CONFIGS[name]
+    monkeypatch.setenv("AIR_OPT_FOLD", "0")                      # (the closing launch itself: its fold has a test of its own below)
     eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
     assert eng_a._plan_bwd_riders is not None and any(n.endswith("_opt") for _, _, n in eng_a._plan_bwd_riders)
     covered = sorted((s.lo, s.hi) for s in eng_a._rider_slices)
@@ -541,6 +542,62 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads"):
         assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
     assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
+
+
+@pytest.mark.parametrize("name", ["mnist_b8", "mnist_b64", "c4_b64", "enc512_b32", "tiny", "rect_t5", "t1_b5"])
+def test_folded_closing_update_equals_closing_launch(gpu_device, monkeypatch, name):
+    """Round 5: the closing air_step_epilogue of the single-GPU latency-regime step is folded into the LAST
+    backward launch -- its weight-gradient tiles apply centred RMSProp to the elements they finish (air_gemm_grouped_opt), rider
+    workgroups update what earlier launches left final and advance the counters.  Bit-identical parameters, slots, gradients,
+    step counter and Philox offset to the plan with the closing launch and to the plan without any rider, over several
+    graph-replayed updates; one launch fewer; layouts the fold does not understand keep their closing launch."""
+    ocfg, B = CONFIGS[name]
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    folded = eng_a._fold is not None
+    head_whole = all(eng_a.param_sizes[k] % 4 == 0 for k in eng_a.param_shapes if eng_a.param_offsets[k] < eng_a.param_offsets["transform/0/w"])
+    if name in ("mnist_b8", "mnist_b64", "c4_b64", "enc512_b32"):
+        assert folded, "the standard architectures must take the folded plan"
+    if folded:
+        assert head_whole and eng_a._plan_opt_rest == [] and eng_a._plan_bwd_riders[-1][2] == "air_gemm_grouped_opt"
+        assert sum(eng_a.kernel_launch_count().values()) == len(eng_a._plan_fwd_train) + len(eng_a._plan_bwd)
+        # the fold and the rider ranges cover the head of the flat buffers exactly once
+        f = eng_a._fold
+        ranges = [(f.range_lo[j], f.range_hi[j]) for j in range(f.n_ranges)]
+        arr, n = eng_a._plan_bwd_riders[-1][1][:2]
+        g0 = eng_a.flat_grads.data_ptr()
+        for i in range(n):
+            if (f.fold_mask >> i) & 1:
+                off = (arr[i].C - g0) // 4
+                ranges.append((off, off + arr[i].M * arr[i].N))
+                if arr[i].colsum:
+                    ranges.append(((arr[i].colsum - g0) // 4, (arr[i].colsum - g0) // 4 + arr[i].N))
+        ranges.sort()
+        assert ranges[0][0] == 0 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert ranges[-1][1] == min(s.lo for s in eng_a._rider_slices)
+    monkeypatch.setenv("AIR_OPT_FOLD", "0")
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_b._fold is None and (eng_b._plan_opt_rest is None or len(eng_b._plan_opt_rest) == 1)
+    monkeypatch.setenv("AIR_OPT_RIDERS", "0")
+    eng_c, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_c._plan_bwd_riders is None
+    for e in (eng_a, eng_b, eng_c):
+        e.capture()
+    for _ in range(4):
+        for e in (eng_a, eng_b, eng_c):
+            e.train_step()
+    for e in (eng_a, eng_b, eng_c):
+        e.synchronize()
+    for other in (eng_b, eng_c):
+        for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads", "rng_state", "step_dev"):
+            assert torch.equal(getattr(eng_a, k), getattr(other, k)), k
+    assert eng_a.step_dev.item() == 4
+    # eager launches of the folded plan give the same bits as its replay
+    eng_a.release_graphs()
+    eng_b.release_graphs()
+    eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
 
 
 @pytest.mark.parametrize("name", ["mnist_b8", "t1_b5"])

@@ -40,7 +40,9 @@ def assert_close(a, b, rtol, atol, what=""):
 # ---------------------------------------------------------------------------------------------------------------
 # spatial transformer
 # ---------------------------------------------------------------------------------------------------------------
-ST_SHAPES = [(50, 50, 20, 20), (100, 100, 28, 28), (7, 5, 3, 4), (3, 3, 2, 2), (9, 11, 9, 11)]
+ST_SHAPES = [(50, 50, 20, 20), (100, 100, 28, 28), (7, 5, 3, 4), (3, 3, 2, 2), (9, 11, 9, 11),
+             # narrow images whose pixel count is a multiple of 4 (16-byte groups cross several row boundaries: ADVICE r04)
+             (8, 1, 3, 2), (4, 2, 2, 2), (4, 3, 2, 3), (12, 1, 4, 1)]
 
 
 @pytest.mark.parametrize("H,W,h,w", ST_SHAPES)

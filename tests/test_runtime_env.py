@@ -23,7 +23,17 @@ def test_runtime_env_warns_when_the_hip_runtime_is_already_up(monkeypatch):
     import pytest
     import torch
     from attend_infer_repeat_amd import runtime_env as R
+    import os
+    import warnings
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    # the user exported the key before the process started: it IS in effect whatever the import order -- no warning, not late
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        R.apply()
+    assert R.late is False
+    # the package is the one trying to set it, too late
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
     with pytest.warns(RuntimeWarning, match="cannot take effect"):
         R.apply()
     assert R.late is True
