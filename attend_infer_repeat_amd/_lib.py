@@ -69,17 +69,17 @@ SIGNATURES = {
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_what_sample_pack": (c_int, [P, c_int, P, c_float, c_float, c_float, P, P, P, P, c_int, P, P, P, P, P,
-                                     c_int, c_int, c_int, c_int, P]),
+                                     c_int, c_int, c_int, c_int, c_float, P]),
     "air_attend_fwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, c_float, c_float, c_float, c_float, c_float,
                                P, P, P, P, P, c_float, c_float, P, P, P, P, P, P, P, P, P,
-                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "air_attend_bwd": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, c_int, P, c_float, P,
                                P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
-                               c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "air_attend_bwd_dx": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, c_int, P, c_float, P,
                                   P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
                                   c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, c_int, c_int,
-                                  c_int, P]),
+                                  c_int, c_float, P]),
     "air_lstm_step_fwd": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int, P]),
     "air_lstm_step_fwd_prologue": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int,
                                            P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
@@ -90,11 +90,11 @@ SIGNATURES = {
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_gauss_sample_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                     c_int, c_int, P]),
+                                     c_int, c_int, c_float, P]),
     "air_gauss_sample_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                     P, c_float, P, c_int, c_int, c_int, P]),
+                                     P, c_float, P, c_int, c_int, c_int, c_float, P]),
     "air_gauss_sample_bwd_nvil": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                          P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, P]),
+                                          P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P]),
     "air_canvas_unroll_fwd_bwd_fits": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "air_canvas_unroll_fwd_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_float, c_float, c_float, P]),
@@ -109,10 +109,10 @@ SIGNATURES = {
     "air_presence_numsteps_fwd": (c_int, [P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_numsteps_presence_bwd": (c_int, [P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P, c_int, c_int, P]),
     "air_heads_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P, c_int, c_int,
-                              P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, P]),
+                              P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, c_float, P]),
     "air_heads_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P, P, c_float,
                               P, c_int, c_int, c_int, P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
-                              c_int, c_int, P]),
+                              c_int, c_int, c_float, P]),
     "air_step_prologue": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
                                   c_int, P]),

@@ -21,8 +21,10 @@ class AIRCell(torch.nn.Module):
 
     def __init__(self, img_size, crop_size, n_appearance,
                  transition, input_encoder, glimpse_encoder, glimpse_decoder, transform_estimator, steps_predictor,
-                 discrete_steps=True, canvas_init=None, explore_eps=None, debug=False):
-        """Arguments as in cell.py:15-36: `transition` is an RNN core instance (rnn.LSTM / rnn.GRU / anything with
+                 discrete_steps=True, canvas_init=None, explore_eps=None, debug=False, guard_degenerate=None):
+        """Arguments as in cell.py:15-36 (+ `guard_degenerate`, default None = the reference's arithmetic: a positive value floors the
+        scale of both Gaussian heads and keeps the sampled scale components of `where` away from an exact zero -- the documented
+        stability switch, include/air_hip.h `guard_eps`): `transition` is an RNN core instance (rnn.LSTM / rnn.GRU / anything with
         output_size, state_size, initial_state); the other five are factories called here (cell.py:61-64,69)."""
         super().__init__()
         self._img_size = tuple(int(s) for s in img_size)
@@ -34,6 +36,7 @@ class AIRCell(torch.nn.Module):
         self._sample_presence = discrete_steps
         self._explore_eps = explore_eps
         self._debug = debug
+        self._guard_eps = float(guard_degenerate or 0.0)
         self._canvas_value = None
         if canvas_init is not None:                                          # cell.py:51-54: trainable canvas value
             self._canvas_value = torch.nn.Parameter(torch.tensor(float(canvas_init)))
@@ -45,6 +48,7 @@ class AIRCell(torch.nn.Module):
         self._glimpse_encoder = glimpse_encoder()
         self._glimpse_decoder = glimpse_decoder(crop_size)
         self._what_distrib = ParametrisedGaussian(n_appearance, scale_offset=0.5)   # cell.py:66
+        self._what_distrib.guard_eps = self._guard_eps
         self._steps_predictor = steps_predictor()
         self.noise = None      # optional dict(eps_where[B,4], eps_what[B,A], u_pres[B,1]) consumed by the next call
 
@@ -110,7 +114,8 @@ class AIRCell(torch.nn.Module):
         est = self._transform_estimator                                      # cell.py:129-133
         if isinstance(est, StochasticTransformParam):
             loc_pre, raw = est.embed_split(hidden_output)
-            where_distrib = NormalWithSoftplusScale(loc_pre, raw, raw_offset=est.scale_bias, loc_mode=1)
+            where_distrib = NormalWithSoftplusScale(loc_pre, raw, raw_offset=est.scale_bias, loc_mode=1,
+                                                    guard_eps=self._guard_eps)
         else:
             where_distrib = NormalWithSoftplusScale(*est(hidden_output))
         where_code = where_distrib.sample(noise.get("eps_where"))

@@ -31,9 +31,23 @@ __device__ __forceinline__ float normal_kl_dscale(float dk, float s, float ps) {
     const float gr = 0.5f * dk - (0.5f * dk) / ratio;
     return (gr / ps2) * (2.f * s);
 }
+// The raw-scale offset of a Gaussian head together with the optional numerical guard (default off: the reference's arithmetic,
+// inf / NaN placement included -- tests/test_extreme_scales.py).  guard > 0 (AIRModel(guard_degenerate=...)):
+//   * scale = max(softplus(raw + offset), guard): the KL rows of model.py:188-214 stay finite when a scale head wanders towards
+//     sigma^2 underflow (the gradient through a floored scale is 0);
+//   * transform heads (loc_mode 1): the SAMPLED scale components of `where` keep |s| >= guard (sign kept, +guard for 0;
+//     straight-through), so the inverse warp's 1/s (modules.py:101-102) never divides by an exact zero.
+struct RawOffset {
+    float v, guard;
+    __host__ __device__ RawOffset(float v_ = 0.f, float g_ = 0.f) : v(v_), guard(g_) {}
+};
+__device__ __forceinline__ float guard_scale(float s, float guard) { return (guard > 0.f && s < guard) ? guard : s; }
+__device__ __forceinline__ float guard_where(float v, int d, int loc_mode, float guard) {
+    return (guard > 0.f && loc_mode == 1 && !(d & 1) && fabsf(v) < guard) ? copysignf(guard, v) : v;
+}
 // one 64-lane wave per row: D elements strided over lanes, KL reduced with a wave reduction
 __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const float *__restrict__ pre, int ld_pre,
-                                                               const float *__restrict__ eps, float raw_offset,
+                                                               const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                float *__restrict__ loc, float *__restrict__ scale,
                                                                float *__restrict__ sample, float *__restrict__ kl_row,
@@ -50,11 +64,11 @@ __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const floa
         for (int d = lane; d < D; d += 64) {
             float mu = pr[d];
             if (loc_mode == 1) mu = (d & 1) ? tanhf(mu) : sigmoid_acc(mu);
-            const float s = softplus_acc(pr[D + d] + raw_offset);
+            const float s = guard_scale(softplus_acc(pr[D + d] + raw_offset.v), raw_offset.guard);
             const size_t o = (size_t)m * D + d;
             loc[o] = mu; scale[o] = s;
             if (sample) {
-                const float v = mu + s * eps[o];
+                const float v = guard_where(mu + s * eps[o], d, loc_mode, raw_offset.guard);
                 sample[o] = v;
                 if (sample_bm) { const int t = m / B_bm, b = m - t * B_bm; sample_bm[(size_t)b * ld_bm + t * D + d] = v; }
             }
@@ -65,7 +79,7 @@ __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const floa
     }
 }
 __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const float *__restrict__ pre, int ld_pre,
-                                                               const float *__restrict__ eps, float raw_offset,
+                                                               const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                const float *__restrict__ loc,
                                                                const float *__restrict__ scale,
@@ -84,8 +98,9 @@ __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const floa
         float dmu = ds + dk * (mu - pm) / (ps * ps);
         const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + normal_kl_dscale(dk, s, ps);
         if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
-        const float raw = pre[m * ld_pre + D + d] + raw_offset;
-        const float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);          // d softplus
+        const float raw = pre[m * ld_pre + D + d] + raw_offset.v;
+        float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);                // d softplus
+        if (raw_offset.guard > 0.f && s <= raw_offset.guard) dsp = 0.f; // a floored scale passes no gradient
         dpre[m * ld_dpre + d] = dmu;
         dpre[m * ld_dpre + D + d] = dsc * dsp;
     }

@@ -9,7 +9,7 @@
 template <int MT>
 __global__ __launch_bounds__(PW_THREADS) void heads_fwd_kernel(
     int gauss_blocks,
-    const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, float raw_offset, int loc_mode, float pl0,
+    const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, RawOffset raw_offset, int loc_mode, float pl0,
     float ps0, float pl1, float ps1, float *__restrict__ loc, float *__restrict__ scale, float *__restrict__ sample,
     float *__restrict__ kl_row, int M, int D,
     const float *__restrict__ logit, const float *__restrict__ u, float step_bias, float explore_eps,
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(PW_THREADS) void heads_fwd_kernel(
 template <int MT>
 __global__ __launch_bounds__(PW_THREADS) void heads_bwd_kernel(
     int gauss_blocks,
-    const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, float raw_offset, int loc_mode, float pl0,
+    const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, RawOffset raw_offset, int loc_mode, float pl0,
     float ps0, float pl1, float ps1, const float *__restrict__ loc, const float *__restrict__ scale,
     const float *__restrict__ dsample, const float *__restrict__ dsample2, const float *__restrict__ dkl_row,
     float dkl_scale, float *__restrict__ dpre, int ld_dpre, int M, int D,
@@ -51,19 +51,19 @@ extern "C" int air_heads_fwd(const float *pre, int ld_pre, const float *eps, flo
                              float *scale, float *sample, float *kl_row, int M, int D, const float *logit,
                              const float *u, float step_bias, float explore_eps, const double *prior_f64,
                              float *presence_prob, float *presence, float *q, float *kl_per_sample, float *logp,
-                             float *step_weight, int T, int B, void *stream) {
+                             float *step_weight, int T, int B, float guard_eps, void *stream) {
     AIR_REQUIRE(pre && eps && loc && scale && sample && kl_row && logit && u && prior_f64 && presence_prob && presence &&
                     q && kl_per_sample && logp && step_weight, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && T > 0 && T <= 32 && B > 0, AIR_E_SHAPE);
     const int gb = blocks_for((size_t)M * 64), nb = air_cdiv(B, 64);
     if (T <= 8)
         hipLaunchKernelGGL(heads_fwd_kernel<8>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
-                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, sample,
+                           eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, sample,
                            kl_row, M, D, logit, u, step_bias, explore_eps, prior_f64, presence_prob, presence, q,
                            kl_per_sample, logp, step_weight, T, B);
     else
         hipLaunchKernelGGL(heads_fwd_kernel<32>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
-                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, sample,
+                           eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, sample,
                            kl_row, M, D, logit, u, step_bias, explore_eps, prior_f64, presence_prob, presence, q,
                            kl_per_sample, logp, step_weight, T, B);
     AIR_LAUNCH_CHECK();
@@ -76,19 +76,19 @@ extern "C" int air_heads_bwd(const float *pre, int ld_pre, const float *eps, flo
                              float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *presence_prob,
                              const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
                              const float *kl_row_b, float w_scale, const float *dlogp, const float *logit,
-                             float step_bias, float explore_eps, float *dlogit, int T, int B, void *stream) {
+                             float step_bias, float explore_eps, float *dlogit, int T, int B, float guard_eps, void *stream) {
     AIR_REQUIRE(pre && eps && loc && scale && dpre && presence_prob && prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D && T > 0 && T <= 32 && B > 0, AIR_E_SHAPE);
     const int gb = blocks_for((size_t)M * D), nb = air_cdiv(B, 64);
     if (T <= 8)
         hipLaunchKernelGGL(heads_bwd_kernel<8>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
-                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
+                           eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
                            dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, presence_prob, presence, prior_f64, kl_scale,
                            kl_row_a, kl_row_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
     else
         hipLaunchKernelGGL(heads_bwd_kernel<32>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
-                           eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
+                           eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
                            dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, presence_prob, presence, prior_f64, kl_scale,
                            kl_row_a, kl_row_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
     AIR_LAUNCH_CHECK();
@@ -99,7 +99,7 @@ extern "C" int air_heads_bwd(const float *pre, int ld_pre, const float *eps, flo
 // decoder and batch-major straight into the baseline input, whose remaining latent columns (where, presence, h, c -- all
 // final by now) are copied by a second group of workgroups.  Replaces air_gauss_sample_fwd + air_baseline_pack.
 __global__ __launch_bounds__(PW_THREADS) void what_sample_pack_kernel(
-    int gauss_blocks, const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, float raw_offset,
+    int gauss_blocks, const float *__restrict__ pre, int ld_pre, const float *__restrict__ eps, RawOffset raw_offset,
     float pl, float ps, float *__restrict__ loc, float *__restrict__ scale, float *__restrict__ sample,
     float *__restrict__ kl_row, int M, int D, const float *__restrict__ where, const float *__restrict__ presence,
     const float *__restrict__ s0, const float *__restrict__ s1, float *__restrict__ pack, int T, int B, int S0, int S1) {
@@ -115,14 +115,14 @@ __global__ __launch_bounds__(PW_THREADS) void what_sample_pack_kernel(
 extern "C" int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float raw_offset, float p_loc,
                                     float p_scale, float *loc, float *scale, float *sample, float *kl_row, int D,
                                     const float *where, const float *presence, const float *state0, const float *state1,
-                                    float *pack_out, int T, int B, int S0, int S1, void *stream) {
+                                    float *pack_out, int T, int B, int S0, int S1, float guard_eps, void *stream) {
     AIR_REQUIRE(pre && eps && loc && scale && sample && kl_row && where && presence && pack_out, AIR_E_NULL);
     AIR_REQUIRE((S0 == 0 || state0) && (S1 == 0 || state1), AIR_E_NULL);
     AIR_REQUIRE(T > 0 && B > 0 && D > 0 && ld_pre >= 2 * D && S0 >= 0 && S1 >= 0, AIR_E_SHAPE);
     const int M = T * B;
     const int gb = blocks_for((size_t)M * 64), pb = blocks_for((size_t)B * (T * 5 + S0 + S1));
     hipLaunchKernelGGL(what_sample_pack_kernel, dim3(gb + pb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre, eps,
-                       raw_offset, p_loc, p_scale, loc, scale, sample, kl_row, M, D, where, presence, state0, state1,
+                       RawOffset(raw_offset, guard_eps), p_loc, p_scale, loc, scale, sample, kl_row, M, D, where, presence, state0, state1,
                        pack_out, T, B, S0, S1);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

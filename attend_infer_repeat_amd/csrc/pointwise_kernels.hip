@@ -155,7 +155,7 @@ extern "C" int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_
 #include "engine_device.h"
 #include "nvil_device.h"
 __global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__restrict__ pre, int ld_pre,
-                                                               const float *__restrict__ eps, float raw_offset,
+                                                               const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                float *__restrict__ loc, float *__restrict__ scale,
                                                                float *__restrict__ sample, float *__restrict__ kl_row,
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__re
                    kl_row, M, D);
 }
 __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__restrict__ pre, int ld_pre,
-                                                               const float *__restrict__ eps, float raw_offset,
+                                                               const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                const float *__restrict__ loc,
                                                                const float *__restrict__ scale,
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__re
 // independent, and in the step whose canvas forward + backward are one launch (air_canvas_unroll_fwd_bwd) this is the first
 // launch behind the reconstruction shares NVIL needs that has room for a rider
 __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_nvil_kernel(const float *__restrict__ pre, int ld_pre,
-                                                                    const float *__restrict__ eps, float raw_offset,
+                                                                    const float *__restrict__ eps, RawOffset raw_offset,
                                                                     int loc_mode, float pl0, float ps0, float pl1, float ps1,
                                                                     const float *__restrict__ loc,
                                                                     const float *__restrict__ scale,
@@ -197,7 +197,7 @@ extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const flo
                                          const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
                                          int ld_dpre, int M, int D, const float *imp_parts, int n_parts, float *imp_sum,
                                          const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                                         float *dbaseline, int B, void *stream) {
+                                         float *dbaseline, int B, float guard_eps, void *stream) {
     AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
     AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
@@ -205,7 +205,7 @@ extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const flo
     AIR_REQUIRE(B > 0 && n_parts > 0, AIR_E_SHAPE);
     const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
     hipLaunchKernelGGL(gauss_bwd_nvil_kernel, dim3(pw_blocks((size_t)M * D) + 1), dim3(PW_THREADS), 0, air_stream(stream), pre,
-                       ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
+                       ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
                        dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, nv);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
@@ -213,13 +213,13 @@ extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const flo
 extern "C" int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                                     float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                                     float *loc, float *scale, float *sample, float *kl_row, int M, int D,
-                                    void *stream) {
+                                    float guard_eps, void *stream) {
     AIR_REQUIRE(pre && loc && scale, AIR_E_NULL);
     AIR_REQUIRE(!sample || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D, AIR_E_SHAPE);
     AIR_REQUIRE(loc_mode == 0 || loc_mode == 1, AIR_E_UNSUPPORTED);
     hipLaunchKernelGGL(gauss_fwd_kernel, dim3(pw_blocks((size_t)M * 64)), dim3(PW_THREADS), 0, air_stream(stream), pre,
-                       ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
+                       ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
                        sample, kl_row, M, D);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
@@ -228,12 +228,12 @@ extern "C" int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *e
                                     float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                                     const float *loc, const float *scale, const float *dsample,
                                     const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
-                                    int ld_dpre, int M, int D, void *stream) {
+                                    int ld_dpre, int M, int D, float guard_eps, void *stream) {
     AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
     AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
     hipLaunchKernelGGL(gauss_bwd_kernel, dim3(pw_blocks((size_t)M * D)), dim3(PW_THREADS), 0, air_stream(stream), pre,
-                       ld_pre, eps, raw_offset, loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
+                       ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
                        dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

@@ -418,7 +418,7 @@ struct AttendFwdArgs {
     const float *tr_h, *tr_w, *tr_b; int tr_k;       // [M, tr_k] . [tr_k, 8] + [8]   -> pre[M, 8]
     const float *st_h, *st_w, *st_b; int st_k;       // [M, st_k] . [st_k, 1] + [1]   -> logit[M]
     float *pre, *logit;
-    const float *eps; float raw_offset, pl0, ps0, pl1, ps1;
+    const float *eps; float raw_offset, pl0, ps0, pl1, ps1, guard_eps;
     float *loc, *scale, *where, *kl_row;
     const float *u; float step_bias, explore_eps; const double *prior;
     float *prob, *pres, *q, *kl_ps, *logp, *step_w;
@@ -547,8 +547,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
             if (lane < 32) {
                 const float e_loc = e_o, e_raw = e_partner;
                 const float mu = (d & 1) ? tanhf(e_loc) : sigmoid_acc(e_loc);                    // modules.py:41-46
-                const float sc = softplus_acc(e_raw + g.raw_offset);
-                const float v = mu + sc * eps_d;                                                // cell.py:130-133
+                const float sc = guard_scale(softplus_acc(e_raw + g.raw_offset), g.guard_eps);
+                const float v = guard_where(mu + sc * eps_d, d, 1, g.guard_eps);                // cell.py:130-133
                 float kl = (d & 1) ? normal_kl(mu, sc, g.pl1, g.ps1) : normal_kl(mu, sc, g.pl0, g.ps0);
                 kl += __shfl_xor(kl, 8, 64);
                 kl += __shfl_xor(kl, 16, 64);
@@ -595,7 +595,7 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
                               float step_bias, float explore_eps, const double *prior_f64, float *presence_prob,
                               float *presence, float *q, float *kl_per_sample, float *logp, float *step_weight,
                               const float *img, float *glimpse, int T, int B, int H, int W, int h, int w, int precision,
-                              void *stream) {
+                              float guard_eps, void *stream) {
     AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
     AIR_REQUIRE(tr_h && tr_w && tr_b && st_h && st_w && st_b && pre && logit && eps && loc && scale && where && kl_row &&
                     u && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight && img &&
@@ -610,7 +610,7 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     AttendFwdArgs g;
     g.tr_h = tr_h; g.tr_w = tr_w; g.tr_b = tr_b; g.tr_k = tr_k; g.st_h = st_h; g.st_w = st_w; g.st_b = st_b; g.st_k = st_k;
-    g.pre = pre; g.logit = logit; g.eps = eps; g.raw_offset = raw_offset;
+    g.pre = pre; g.logit = logit; g.eps = eps; g.raw_offset = raw_offset; g.guard_eps = guard_eps;
     g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
     g.loc = loc; g.scale = scale; g.where = where; g.kl_row = kl_row; g.u = u; g.step_bias = step_bias;
     g.explore_eps = explore_eps; g.prior = prior_f64; g.prob = presence_prob; g.pres = presence; g.q = q;
@@ -649,7 +649,7 @@ struct AttendBwdArgs;
 __device__ __forceinline__ float attend_dwhere_w(const AttendBwdArgs &g, size_t e);
 struct AttendBwdArgs {
     const float *img, *where, *dglimpse; float *dwhere_r;
-    const float *pre, *eps; float raw_offset, pl0, ps0, pl1, ps1;
+    const float *pre, *eps; float raw_offset, pl0, ps0, pl1, ps1, guard_eps;
     const float *loc, *scale, *dwhere_w, *dkl_row; float dkl_scale; float *dpre;
     int dwhere_w_slabs;   // dwhere_w[slabs][T*B][4]: the canvas backward may write its dwhere as several partial slabs (their sum, in order)
     const float *prob, *presence; const double *prior; float kl_scale; const float *kl_a, *kl_b; float w_scale;
@@ -794,7 +794,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
                 float dmu = ds + s_dk * (mu - pm) / (ps * ps);
                 const float dsc = ds * s_eps + normal_kl_dscale(s_dk, sc, ps);
                 dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
-                const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
+                float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
+                if (g.guard_eps > 0.f && sc <= g.guard_eps) dsp = 0.f;
                 g.dpre[k * 8 + d_] = dmu;
                 g.dpre[k * 8 + 4 + d_] = dsc * dsp;
                 dps[t * 8 + d_] = dmu; dps[t * 8 + 4 + d_] = dsc * dsp;
@@ -898,7 +899,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
             float dmu = ds + s_dk * (mu - pm) / (ps * ps);
             const float dsc = ds * s_eps + normal_kl_dscale(s_dk, sc, ps);
             dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
-            const float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
+            float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
+            if (g.guard_eps > 0.f && sc <= g.guard_eps) dsp = 0.f;
             g.dpre[(size_t)k * 8 + d_] = dmu;
             g.dpre[(size_t)k * 8 + 4 + d_] = dsc * dsp;
             if (g.tr_dx) { c.scratch[128 + d_] = dmu; c.scratch[128 + 4 + d_] = dsc * dsp; }     // (scratch[0:128] holds the partial sums)
@@ -969,7 +971,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
                               const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
                               const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
                               const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
-                              int W, int h, int w, void *stream) {
+                              int W, int h, int w, float guard_eps, void *stream) {
     AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
                     prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
@@ -980,7 +982,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     AttendBwdArgs g;
     g.img = img; g.where = where; g.dglimpse = dglimpse; g.dwhere_r = dwhere_r; g.pre = pre; g.eps = eps;
-    g.raw_offset = raw_offset; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
+    g.raw_offset = raw_offset; g.guard_eps = guard_eps; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
     g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dwhere_w_slabs = dwhere_w_slabs; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
     g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
     g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
@@ -1002,7 +1004,7 @@ extern "C" int air_attend_bwd_dx(const float *img, const float *where, const flo
                               const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
                               int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
                                  const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision,
-                                 void *stream) {
+                                 float guard_eps, void *stream) {
     AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
                     prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
@@ -1013,7 +1015,7 @@ extern "C" int air_attend_bwd_dx(const float *img, const float *where, const flo
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     AttendBwdArgs g;
     g.img = img; g.where = where; g.dglimpse = dglimpse; g.dwhere_r = dwhere_r; g.pre = pre; g.eps = eps;
-    g.raw_offset = raw_offset; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
+    g.raw_offset = raw_offset; g.guard_eps = guard_eps; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
     g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dwhere_w_slabs = dwhere_w_slabs; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
     g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
     g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;

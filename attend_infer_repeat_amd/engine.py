@@ -65,6 +65,10 @@ class EngineConfig:
     # to bf16 in registers and multiplies on the bf16 MFMA with fp32 accumulate; parameters, activations, gradients and the
     # optimiser stay fp32 (BASELINE.json configs[4], "bf16 MFMA MLP path").
     mfma_dtype: str = "f32"
+    # Stability switch, default off (= the reference's arithmetic, inf / NaN placement included): > 0 floors the scale of both
+    # Gaussian heads at this value and keeps the sampled scale components of `where` at |s| >= it (include/air_hip.h `guard_eps`;
+    # model.py:188-214 has no clamp, cell.py:130-133 can sample an exact zero scale)
+    guard_eps: float = 0.0
 
     @property
     def n_pix(self):
@@ -606,7 +610,7 @@ class AIREngine:
                                            p(self.kl_where_row), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
                                            p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n),
                                            p(self.logp), p(self.step_w), p(self.obs), p(self.glimpse_in), T, B, Hi, Wi,
-                                           hc, wc, prec), "air_attend_fwd"))                      # cell.py:129-151
+                                           hc, wc, prec, float(cfg.guard_eps)), "air_attend_fwd"))                      # cell.py:129-151
         else:
             mlp_fwd_multi(fwd, [(self.tr, h_all, Hd), (self.st, h_all, Hd)])                # cell.py:129,138
             fwd.append((L.air_heads_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
@@ -614,7 +618,7 @@ class AIREngine:
                                           p(self.where), p(self.kl_where_row), M, 4,             # cell.py:129-133
                                           p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
                                           p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n), p(self.logp),
-                                          p(self.step_w), T, B), "air_heads_fwd"))               # cell.py:137-151, prior.py
+                                          p(self.step_w), T, B, float(cfg.guard_eps)), "air_heads_fwd"))               # cell.py:137-151, prior.py
             fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
                         "air_st_read_fwd"))                                                 # cell.py:135
         mlp_fwd_multi(fwd, [(self.ge, self.glimpse_in, hw)])                                # cell.py:153
@@ -628,7 +632,7 @@ class AIREngine:
             fwd.append((L.air_what_sample_pack, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, wp[0], wp[1],
                                                  p(self.what_loc), p(self.what_scale), p(self.what), p(self.kl_what_row),
                                                  A, p(self.where), p(self.presence), p(self.h_seq[T]), p(self.c_seq[T]),
-                                                 p(self.base_lat), T, B, Hd, Hd), "air_what_sample_pack"))
+                                                 p(self.base_lat), T, B, Hd, Hd, float(cfg.guard_eps)), "air_what_sample_pack"))
             n0 = self.bl.shapes[0][1]
             launch(fwd, [desc(0, 0, B, n0, KL, self.base_lat, KL, self.bl.w[0][P:], n0, self.bl.out[0], n0,
                               epi=ADDAUX_ELU if self.bl.n > 1 or not self.bl.last_linear else ADDAUX,
@@ -640,7 +644,7 @@ class AIREngine:
         else:
             fwd.append((L.air_gauss_sample_fwd, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0],
                                                  wp[1], wp[0], wp[1], p(self.what_loc), p(self.what_scale), p(self.what),
-                                                 p(self.kl_what_row), M, A), "air_gauss_sample_fwd"))
+                                                 p(self.kl_what_row), M, A, float(cfg.guard_eps)), "air_gauss_sample_fwd"))
             mlp_fwd_multi(fwd, [(self.gd, self.what, A)])
         decoded = self.gd.out[-1]
         NB = self.n_bands
@@ -723,9 +727,9 @@ class AIREngine:
         gb_args = (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0], wp[1], wp[0], wp[1], p(self.what_loc),
                    p(self.what_scale), p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M, A)
         if fuse_canvas:
-            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B,), "air_gauss_sample_bwd_nvil"))
+            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B, float(cfg.guard_eps)), "air_gauss_sample_bwd_nvil"))
         else:
-            bwd.append((L.air_gauss_sample_bwd, gb_args, "air_gauss_sample_bwd"))
+            bwd.append((L.air_gauss_sample_bwd, gb_args + (float(cfg.guard_eps),), "air_gauss_sample_bwd"))
         launch(bwd, [desc(1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
                           colsum=self.grads["what/b"]),
                      desc(0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
@@ -752,7 +756,7 @@ class AIREngine:
                                               p(self.st.out[-1]), cfg.step_bias, eps, p(self.st.g[-1]), T, B, Hi, Wi, hc, wc,
                                               p(self.tr.w[-1]), p(tr_y) if tr_y is not None else None, p(tr_dx), tr_kk, tr_ld,
                                               p(self.st.w[-1]), p(st_y) if st_y is not None else None, p(st_dx), st_kk, st_ld,
-                                              prec), "air_attend_bwd_dx"))
+                                              prec, float(cfg.guard_eps)), "air_attend_bwd_dx"))
         else:
             bwd.append((L.air_st_read_bwd, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r), None, M,
                                             B, Hi, Wi, hc, wc), "air_st_read_bwd"))
@@ -763,7 +767,7 @@ class AIREngine:
                                           p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
                                           p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
                                           dlogp_p, p(self.st.out[-1]), cfg.step_bias,
-                                          eps, p(self.st.g[-1]), T, B), "air_heads_bwd"))
+                                          eps, p(self.st.g[-1]), T, B, float(cfg.guard_eps)), "air_heads_bwd"))
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
                             dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)],
                       first_dx_done=fuse_attend)

@@ -148,17 +148,18 @@ class _GaussSample(torch.autograd.Function):
     """loc, scale=softplus(raw+offset), sample=loc+scale*eps from pre=[loc_pre | raw]   (cell.py:130-133,154-156)"""
 
     @staticmethod
-    def forward(ctx, pre, eps, raw_offset, loc_mode):
+    def forward(ctx, pre, eps, raw_offset, loc_mode, guard_eps=0.0):
         pre, eps = _c(pre), _c(eps)
-        loc, scale, sample, _ = H.gauss_sample_fwd(pre, eps, raw_offset, loc_mode, (0., 1., 0., 1.), want_kl=False)
+        loc, scale, sample, _ = H.gauss_sample_fwd(pre, eps, raw_offset, loc_mode, (0., 1., 0., 1.), want_kl=False,
+                                                   guard_eps=guard_eps)
         ctx.save_for_backward(pre, eps, loc, scale)
-        ctx.cfg = (raw_offset, loc_mode)
+        ctx.cfg = (raw_offset, loc_mode, guard_eps)
         return loc, scale, sample
 
     @staticmethod
     def backward(ctx, dloc, dscale, dsample):
         pre, eps, loc, scale = ctx.saved_tensors
-        raw_offset, loc_mode = ctx.cfg
+        raw_offset, loc_mode, guard_eps = ctx.cfg
         # dsample flows to (loc, scale) through the reparameterisation; direct dloc/dscale (KL terms) are folded in by
         # expressing them as an equivalent dsample/eps-free contribution: d pre = J^T [dloc + dsample, dscale + dsample*eps]
         dl = _c(dloc + dsample)
@@ -171,12 +172,15 @@ class _GaussSample(torch.autograd.Function):
             dpre[:, :D] = dl * jac
         else:
             dpre[:, :D] = dl
-        dpre[:, D:] = dsc * torch.sigmoid(pre[:, D:] + raw_offset)
-        return dpre, None, None, None
+        dsp = torch.sigmoid(pre[:, D:] + raw_offset)
+        if guard_eps > 0:                                   # a floored scale passes no gradient (include/air_hip.h: guard_eps)
+            dsp = torch.where(scale <= guard_eps, torch.zeros_like(dsp), dsp)
+        dpre[:, D:] = dsc * dsp
+        return dpre, None, None, None, None
 
 
-def gauss_sample(pre, eps, raw_offset=0.0, loc_mode=0):
-    return _GaussSample.apply(pre, eps, float(raw_offset), int(loc_mode))
+def gauss_sample(pre, eps, raw_offset=0.0, loc_mode=0, guard_eps=0.0):
+    return _GaussSample.apply(pre, eps, float(raw_offset), int(loc_mode), float(guard_eps or 0.0))
 
 
 class _NormalKL(torch.autograd.Function):

@@ -310,8 +310,9 @@ def lstm_step_bwd_opt(dgates_next, w_h, dh_a, dh_b, dc_in, gate_act, c_prev, c, 
 
 
 # ---- stochastic nodes ----------------------------------------------------------------------------------------------
-def gauss_sample_fwd(pre, eps, raw_offset, loc_mode, prior4, want_kl=True):
-    """pre[M, >=2D] (row stride allowed), eps[M,D] or None -> loc, scale, sample|None, kl_row|None"""
+def gauss_sample_fwd(pre, eps, raw_offset, loc_mode, prior4, want_kl=True, guard_eps=0.0):
+    """pre[M, >=2D] (row stride allowed), eps[M,D] or None -> loc, scale, sample|None, kl_row|None
+    guard_eps > 0: the stability switch of include/air_hip.h (scale floor, |where scale| >= guard_eps); 0 = the reference's arithmetic"""
     if not (pre.is_cuda and pre.dtype == torch.float32 and pre.dim() == 2 and pre.stride(1) == 1):
         raise _lib.AirHipError("gauss_sample: pre must be a 2-D float32 CUDA tensor with unit inner stride")
     eps = _f32(eps, "eps")
@@ -324,18 +325,18 @@ def gauss_sample_fwd(pre, eps, raw_offset, loc_mode, prior4, want_kl=True):
     kl = torch.empty((M,), dtype=torch.float32, device=dev) if want_kl else None
     a, b, c, d = (float(v) for v in prior4)
     _lib.check(lib().air_gauss_sample_fwd(_p(pre), ld, _p(eps), float(raw_offset), int(loc_mode), a, b, c, d, _p(loc),
-                                          _p(scale), _p(sample), _p(kl), M, D, _stream()), "air_gauss_sample_fwd")
+                                          _p(scale), _p(sample), _p(kl), M, D, float(guard_eps), _stream()), "air_gauss_sample_fwd")
     return loc, scale, sample, kl
 
 
-def gauss_sample_bwd(pre, eps, raw_offset, loc_mode, prior4, loc, scale, dsample, dkl_row):
+def gauss_sample_bwd(pre, eps, raw_offset, loc_mode, prior4, loc, scale, dsample, dkl_row, guard_eps=0.0):
     M, D = loc.shape
     ld = pre.stride(0) if M > 1 else pre.shape[1]
     dpre = torch.empty((M, 2 * D), dtype=torch.float32, device=pre.device)
     a, b, c, d = (float(v) for v in prior4)
     _lib.check(lib().air_gauss_sample_bwd(_p(pre), ld, _p(eps), float(raw_offset), int(loc_mode), a, b, c, d, _p(loc),
                                           _p(scale), _p(_f32(dsample, "dsample")), None, _p(_f32(dkl_row, "dkl_row")),
-                                          1.0, _p(dpre), 2 * D, M, D, _stream()), "air_gauss_sample_bwd")
+                                          1.0, _p(dpre), 2 * D, M, D, float(guard_eps), _stream()), "air_gauss_sample_bwd")
     return dpre
 
 

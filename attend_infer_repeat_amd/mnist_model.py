@@ -113,7 +113,7 @@ class AIRonMNIST(AIRModel):
             nsp_steps_div=getattr(nsp, 'steps_div', 1.), nsp_steps=getattr(nsp, 'steps', 1.),
             nsp_hold_init=getattr(nsp, 'hold_init', 0.),
             use_prior=self.use_prior, use_reinforce=self.use_reinforce, learning_rate=float(learning_rate),
-            **self._hyper)
+            guard_eps=float(getattr(self, 'guard_degenerate', 0.0)), **self._hyper)
 
     def train_step(self, learning_rate, l2_weight=0., what_prior=None, where_scale_prior=None,
                    where_shift_prior=None, num_steps_prior=None, use_prior=True, use_reinforce=True, baseline=None,

@@ -62,6 +62,7 @@ class AIRModel(object):
         self.discrete_steps = discrete_steps
         self.explore_eps = explore_eps
         self.debug = debug
+        self.guard_degenerate = float(kwargs.get('guard_degenerate') or 0.0)     # (extension, default off: AIRCell docstring)
         self.output_multiplier = torch.tensor(float(output_multiplier))        # non-trainable variable, model.py:58
         shape = list(self.obs.shape)
         self.batch_size = shape[0]

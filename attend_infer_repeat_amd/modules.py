@@ -15,16 +15,17 @@ class NormalWithSoftplusScale(object):
     """tf.contrib.distributions.NormalWithSoftplusScale as used at cell.py:130-133,154-156: loc, scale=softplus(raw),
     reparameterised sample.  Built from the fused kernel's pre-activation block [loc_pre | raw]."""
 
-    def __init__(self, loc_pre, raw_scale, raw_offset=0.0, loc_mode=0):
+    def __init__(self, loc_pre, raw_scale, raw_offset=0.0, loc_mode=0, guard_eps=0.0):
         self._pre = torch.cat([loc_pre, raw_scale], -1)
         self._raw_offset, self._loc_mode = raw_offset, loc_mode
+        self._guard_eps = float(guard_eps or 0.0)            # the optional stability switch (AIRCell(guard_degenerate=...)); 0 = off
         self._evaluated = None
 
     def _eval(self, eps=None):
         D = self._pre.shape[-1] // 2
         if eps is None:
             eps = torch.randn(self._pre.shape[:-1] + (D,), device=self._pre.device)
-        self._evaluated = F.gauss_sample(self._pre, eps, self._raw_offset, self._loc_mode)
+        self._evaluated = F.gauss_sample(self._pre, eps, self._raw_offset, self._loc_mode, self._guard_eps)
         return self._evaluated
 
     def _get(self, i):
@@ -53,6 +54,7 @@ class ParametrisedGaussian(torch.nn.Module):
         super().__init__()
         self._n_params = int(n_params)
         self._scale_offset = float(scale_offset)
+        self.guard_eps = 0.0
         self.w = None
         self.b = None
 
@@ -62,7 +64,8 @@ class ParametrisedGaussian(torch.nn.Module):
             self.b = torch.nn.Parameter(torch.zeros(2 * self._n_params, device=inpt.device))
         params = F.linear(inpt, self.w, self.b, H.ACT_NONE)
         n = self._n_params
-        return NormalWithSoftplusScale(params[..., :n], params[..., n:], raw_offset=self._scale_offset, loc_mode=0)
+        return NormalWithSoftplusScale(params[..., :n], params[..., n:], raw_offset=self._scale_offset, loc_mode=0,
+                                       guard_eps=self.guard_eps)
 
 
 class TransformParam(torch.nn.Module):

@@ -49,6 +49,9 @@ def main(argv=None):
     ap.add_argument("--device-feeder", action="store_true",
                     help="draw every training batch inside the captured step from the HBM-resident training set (engine "
                          "attach_dataset): no host work between updates")
+    ap.add_argument("--guard-degenerate", type=float, default=0.0,
+                    help="stability switch, default off (= the reference's arithmetic): floor of both Gaussian heads' scale and "
+                         "minimum |scale component| of the sampled `where` (AIRonMNIST(guard_degenerate=...); e.g. 1e-6)")
     ap.add_argument("--resume", default=None,
                     help="checkpoint written by this script (model_<iter>.pt): restores parameters, the RMSProp slots, "
                          "the step counter, the learning rate, the Philox noise state and the feeders' positions")
@@ -85,7 +88,8 @@ def main(argv=None):
     air = AIRonMNIST(x, y, max_steps=n_steps, explore_eps=init_explore_eps, inpt_encoder_hidden=n_hiddens,
                      glimpse_encoder_hidden=n_hiddens, glimpse_decoder_hidden=n_hiddens,
                      transform_estimator_hidden=n_hiddens, steps_pred_hidden=[128, 64], baseline_hidden=[256, 128],
-                     transform_var_bias=transform_var_bias, step_bias=step_bias, output_multiplier=output_multiplier)
+                     transform_var_bias=transform_var_bias, step_bias=step_bias, output_multiplier=output_multiplier,
+                     guard_degenerate=args.guard_degenerate or None)
     train_step, global_step = air.train_step(learning_rate, l2_weight, appearance_prior, where_scale_prior,
                                              where_shift_prior, num_steps_prior)
     if args.resume:

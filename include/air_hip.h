@@ -272,24 +272,30 @@ int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const
  *   pre[M,ld_pre]: columns [0,D) = loc pre-activation, [D,2D) = raw scale.
  *   loc_mode 0: loc = pre;  1: loc = [sigmoid,tanh,sigmoid,tanh,...] (TransformParam._transform).
  *   scale = softplus(raw + raw_offset); sample = loc + scale*eps.
+ *   guard_eps (every entry point that samples a Gaussian head takes it as its last argument; 0 = off = the reference's
+ *   arithmetic, inf / NaN placement included): > 0 floors the scale, scale = max(softplus(..), guard_eps), with no gradient
+ *   through a floored scale, and in loc_mode 1 keeps the SAMPLED scale components (even dims) of `where` at |s| >= guard_eps
+ *   (sign kept, straight-through) so that the inverse warp's 1/s (modules.py:101-102) never meets an exact zero -- the
+ *   documented stability switch of SURVEY section 7 / App. B-11 (model.py:188-214, cell.py:130-133).
  *   kl_row[M] (optional) = sum_d KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])); prior4 = {loc_even, scale_even,
  *   loc_odd, scale_odd} passed by value (where: even dims = scale prior, odd = shift prior; what: both equal).     */
 int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
-                         float *loc, float *scale, float *sample, float *kl_row, int M, int D, void *stream);
+                         float *loc, float *scale, float *sample, float *kl_row, int M, int D, float guard_eps, void *stream);
 /* dpre[M,ld_dpre] (both halves) from dsample[M,D] (+ dsample2[M,D]; either may be NULL) and dkl_row[M]*dkl_scale
  * (dkl_row may be NULL).                                                                                            */
 int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          const float *loc, const float *scale, const float *dsample, const float *dsample2,
-                         const float *dkl_row, float dkl_scale, float *dpre, int ld_dpre, int M, int D, void *stream);
+                         const float *dkl_row, float dkl_scale, float *dpre, int ld_dpre, int M, int D, float guard_eps,
+                         void *stream);
 /* air_gauss_sample_bwd with air_nvil_parts riding as one extra workgroup (arguments of both, in that order; B = batch).  */
 int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                               float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc,
                               const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
                               float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *imp_parts, int n_parts,
                               float *imp_sum, const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                              float *dbaseline, int B, void *stream);
+                              float *dbaseline, int B, float guard_eps, void *stream);
 
 /* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
  * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
@@ -350,14 +356,14 @@ int air_heads_fwd(const float *pre, int ld_pre, const float *eps, float raw_offs
                   float p_scale_even, float p_loc_odd, float p_scale_odd, float *loc, float *scale, float *sample,
                   float *kl_row, int M, int D, const float *logit, const float *u, float step_bias, float explore_eps,
                   const double *prior_f64, float *presence_prob, float *presence, float *q, float *kl_per_sample,
-                  float *logp, float *step_weight, int T, int B, void *stream);
+                  float *logp, float *step_weight, int T, int B, float guard_eps, void *stream);
 int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
                   float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
                   const float *dsample, const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
                   int ld_dpre, int M, int D, const float *presence_prob, const float *presence,
                   const double *prior_f64, float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
                   const float *dlogp, const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B,
-                  void *stream);
+                  float guard_eps, void *stream);
 
 /* Annealed geometric prior over the number of steps, entirely on device (model.py:106-124,139-146; prior.py:26-32):
  *   step' = max(*global_step_dev - hold_for, 0);  anneal_type 0: s = init; 1 ("exp"): s = max(final, init *
@@ -395,7 +401,7 @@ int air_baseline_pack(const float *img, const float *what, const float *where, c
 int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float raw_offset, float p_loc, float p_scale,
                          float *loc, float *scale, float *sample, float *kl_row, int D, const float *where,
                          const float *presence, const float *state0, const float *state1, float *pack_out,
-                         int T, int B, int S0, int S1, void *stream);
+                         int T, int B, int S0, int S1, float guard_eps, void *stream);
 
 /* ---- "attend": fused engine launches around the glimpse read (cell.py:129-151, modules.py:104-109) ------------------
  * Forward, one launch: the output layers of the transform MLP (tr_h[T*B,tr_k] . tr_w[tr_k,8] + tr_b -> pre[T*B,8]) and of the
@@ -410,7 +416,7 @@ int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int 
                    float explore_eps, const double *prior_f64, float *presence_prob, float *presence, float *q,
                    float *kl_per_sample, float *logp, float *step_weight, const float *img, float *glimpse,
                    int T, int B, int H, int W, int h, int w, int precision /* of the two output-layer products */,
-                   void *stream);
+                   float guard_eps, void *stream);
 /* Backward, one launch: air_st_read_bwd (d where through the read, one workgroup per glimpse) followed in the same
  * workgroup by the where-sampling backward of that row (dsample = dwhere_w + dwhere_r, KL term dkl_row*dkl_scale;
  * dwhere_w[dwhere_w_slabs][T*B][4]: the canvas backward's gradient as 1..4 partial slabs, added here in slab order) ->
@@ -421,7 +427,7 @@ int air_attend_bwd(const float *img, const float *where, const float *dglimpse, 
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
                    const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
-                   float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, void *stream);
+                   float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, float guard_eps, void *stream);
 /* The same launch plus the dX of the two MLP OUTPUT layers (transform: [.., 8], steps: [.., 1]) whose dpre / dlogit it has just
  * formed -- the 8- and 1-deep products that otherwise need a launch of their own on the backward chain:
  *   tr_dx[k, n] = (sum_o dpre[k, o] * tr_w[n, o]) * elu'(tr_y[k, n]),  n < tr_k;   st_dx[k, n] = dlogit[k] * st_w[n] * elu'(st_y[k, n]).
@@ -434,7 +440,8 @@ int air_attend_bwd_dx(const float *img, const float *where, const float *dglimps
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
                    const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
                    float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
-                      const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision, void *stream);
+                      const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision, float guard_eps,
+                      void *stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------------
  * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;

@@ -82,6 +82,10 @@ class AIRConfig:
     use_reinforce: bool = True
     decay_rate: Optional[float] = None          # model.py:232-239 (None in the script)
     l2_weight: float = 0.0                      # model.py:346-353 (0 in the script)
+    # NOT in the reference (default off): the product's documented stability switch (include/air_hip.h `guard_eps`) restated, so
+    # that the guarded arithmetic has an oracle too: scale = max(softplus(..), g) with no gradient through a floored scale, and the
+    # sampled scale components of `where` kept at |s| >= g (sign kept, straight-through)
+    guard_eps: float = 0.0
     # optimiser (model.py:265, multi_mnist.py:24)
     learning_rate: float = 1e-4
     baseline_lr_mult: float = 10.0              # model.py:363
@@ -437,6 +441,13 @@ def initial_state(params, cfg: AIRConfig, obs: Tensor):
     return [obs.reshape(B, -1), z(B, cfg.n_pix), z(B, cfg.n_appearance), z(B, 4), hidden, obs.new_ones(B, 1)]
 
 
+def _guard_scale(s: Tensor, g: float) -> Tensor:
+    """scale floor of the stability switch (AIRConfig.guard_eps): max(s, g), the floored elements constant"""
+    if not g or g <= 0:
+        return s
+    return torch.where(s < g, torch.full_like(s, g), s)
+
+
 def cell_step(params, cfg: AIRConfig, state, eps_where: Tensor, eps_what: Tensor, u_pres: Tensor):
     """AIRCell._build: returns (outputs[10], new_state[6]) in the order of cell.py:167-171."""
     img_flat, canvas_flat, _what, _where, hidden, presence = state
@@ -454,8 +465,14 @@ def cell_step(params, cfg: AIRConfig, state, eps_where: Tensor, eps_what: Tensor
 
     emb = mlp(h_out, params, "transform", len(cfg.transform_estimator_hidden) + 1, last_linear=True)
     where_loc, where_raw = transform_params(emb, cfg)                                               # cell.py:129
-    where_scale = softplus(where_raw)                                                             # cell.py:130-132
+    where_scale = _guard_scale(softplus(where_raw), cfg.guard_eps)                                # cell.py:130-132
     where = where_loc + where_scale * eps_where                                                     # cell.py:133
+    if cfg.guard_eps > 0:
+        g = torch.as_tensor(cfg.guard_eps, dtype=where.dtype)
+        sgn = torch.where(torch.signbit(where), -torch.ones_like(where), torch.ones_like(where))
+        even = torch.tensor([True, False, True, False])
+        clamped = torch.where(even & (where.abs() < g), sgn * g, where)
+        where = where + (clamped - where).detach()
 
     cropped = st_read(img, where, cfg.crop_size)                                                    # cell.py:135
 
@@ -473,7 +490,7 @@ def cell_step(params, cfg: AIRConfig, state, eps_where: Tensor, eps_what: Tensor
     q = mm(g, params["what/w"]) + params["what/b"]                                                     # modules.py:20-21
     A = cfg.n_appearance
     what_loc, what_raw = q[:, :A], q[:, A:]
-    what_scale = softplus(what_raw + cfg.what_scale_offset)                                       # modules.py:23
+    what_scale = _guard_scale(softplus(what_raw + cfg.what_scale_offset), cfg.guard_eps)          # modules.py:23
     what = what_loc + what_scale * eps_what                                                         # cell.py:156
 
     decoded = mlp(what, params, "glimpse_decoder", len(cfg.glimpse_decoder_hidden) + 1, last_linear=True)

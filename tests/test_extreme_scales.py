@@ -213,6 +213,80 @@ def test_engine_extreme_scales_same_placement_as_fp32_oracle(gpu_device, case, B
         same_placement("updated " + k, eng.params[k], v)
 
 
+GUARD = 1e-6
+GUARD32 = float(np.float32(GUARD))          # the floor as the fp32 kernels (and the fp32 oracle) hold it
+
+
+@pytest.mark.parametrize("case", ENGINE_CASES, ids=[c[0] for c in ENGINE_CASES])
+@pytest.mark.parametrize("B", [8, 64])
+def test_engine_extreme_scales_with_the_guard_stay_finite_and_match_the_guarded_oracle(gpu_device, case, B):
+    """the documented stability switch (EngineConfig.guard_eps / AIRonMNIST(guard_degenerate=...), default off).
+    The same extreme scale heads as above with guard_eps = 1e-6: every output, loss and gradient tensor is FINITE, the scales sit
+    on the floor, and everything equals the oracle's restatement of the guard (O.AIRConfig.guard_eps) -- including one update."""
+    from test_engine import make_pair
+    name, where_raw, what_raw = case
+    ocfg = O.AIRConfig(guard_eps=GUARD)
+    eng, params, obs, noise = make_pair(ocfg, B, seed=5)
+    assert eng.cfg.guard_eps == GUARD
+    params = {k: v.clone() for k, v in params.items()}
+    last = "transform/%d" % len(ocfg.transform_estimator_hidden)
+    params[last + "/w"][:, 4:] = 0.0
+    params[last + "/b"][4:] = torch.tensor(where_raw) - ocfg.transform_var_bias
+    if what_raw is not None:
+        A, n = ocfg.n_appearance, len(what_raw)
+        params["what/w"][:, A:A + n] = 0.0
+        params["what/b"][A:A + n] = torch.tensor(what_raw) - ocfg.what_scale_offset
+    eng.load_parameters(params)
+    eng.forward(sample_noise=False); eng.backward()
+    out, grads = eng.outputs(), eng.named_grads()
+    res, ref = O.forward_backward(params, ocfg, obs, noise, global_step=20000)
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            assert torch.isfinite(v).all(), k
+    assert out["where_scale"].min().item() >= GUARD32 and out["what_scale"].min().item() >= GUARD32
+    if name in ("sigma2_underflow", "sigma_zero"):
+        assert (out["where_scale"] == GUARD32).any()                     # the floor is what these heads sit on
+    for k in ("where", "where_loc", "where_scale", "what_loc", "what_scale", "presence_prob", "final_canvas", "rec_loss_per_sample",
+              "kl_num_steps_per_sample", "kl_where_per_sample", "kl_what_per_sample"):
+        close_where_finite(k, out[k], res[k], 2e-3, res[k].abs().max().item() + 1e-30)
+    for k in ("loss", "opt_loss", "kl_where", "kl_what"):
+        close_where_finite(k, out[k], res[k], 1e-3, 1e-3 * res[k].abs().max().item() + 1e-30)
+    for k, r in ref.items():
+        assert torch.isfinite(grads[k]).all() and torch.isfinite(r).all(), k
+        err = ((grads[k].cpu().double() - r.double()).abs().max() / (r.double().abs().max() + 1e-30)).item()
+        assert err < 2e-3, (k, err)
+    # the raw-scale gradient of a floored head is exactly zero (no gradient through the floor), on both sides
+    if name in ("sigma2_underflow", "sigma_zero"):
+        floored = (res["where_scale"].reshape(-1, 4) == GUARD32).all(0)
+        assert floored.any()
+        assert (grads[last + "/b"].cpu()[4:][floored] == 0).all() and (ref[last + "/b"][4:][floored] == 0).all()
+    eng.optimizer_step(); eng.synchronize()
+    assert torch.isfinite(eng.flat_params).all()
+
+
+def test_where_scale_sample_is_kept_off_zero_by_the_guard(gpu_device):
+    """cell.py:130-133 can sample an exact zero scale (where = loc + scale * eps cancels to the last bit; seed 9 of round 4 died of
+    it at update 1320): with the guard the sampled scale components keep |s| >= guard_eps (sign kept, +guard for +0), the shift
+    components are untouched, and without it the sample is the reference's."""
+    from attend_infer_repeat_amd import hip as H
+    pre = torch.zeros(6, 8)
+    pre[:, 4:] = 0.5413                                                   # softplus(raw) ~ 1
+    eps = torch.zeros(6, 4)
+    sig = torch.sigmoid(torch.zeros(())).item()                           # loc of a scale component = 0.5
+    sc = torch.nn.functional.softplus(torch.tensor(0.5413)).item()
+    eps[0, 0] = -sig / sc                                                 # cancels (to rounding)
+    eps[1, 2] = -sig / sc
+    eps[2, 1] = 0.0                                                       # a shift component at tanh(0) = 0 stays 0
+    loc, scale, samp, _ = H.gauss_sample_fwd(pre.cuda(), eps.cuda(), 0.0, 1, (0., 1., 0., 1.), want_kl=False, guard_eps=1e-3)
+    ref_loc, ref_scale, ref_samp, _ = H.gauss_sample_fwd(pre.cuda(), eps.cuda(), 0.0, 1, (0., 1., 0., 1.), want_kl=False)
+    samp, ref_samp = samp.cpu(), ref_samp.cpu()
+    assert ref_samp[0, 0].abs().item() < 1e-6 and ref_samp[1, 2].abs().item() < 1e-6
+    assert samp[0, 0].abs().item() == pytest.approx(1e-3) and samp[1, 2].abs().item() == pytest.approx(1e-3)
+    assert samp[2, 1].item() == 0.0 and samp[:, 1::2].equal(ref_samp[:, 1::2])
+    keep = ref_samp.abs() >= 1e-3
+    assert samp[keep].equal(ref_samp[keep])
+
+
 # sampled scales of the inverse warp that break 1/s, 1/s^2 or s^2 in fp32 (SURVEY appendix B-11: sx, sy are unbounded samples; the
 # reference divides by them, modules.py:101-102).  An exact 0.0 is not exotic: where = loc + scale * eps cancels to the last bit with
 # probability ~1e-8 per draw while the scale is O(1) -- profiles/r04_blowup_seed9_legacy.json is such an update (update 1320).
