@@ -54,11 +54,11 @@ SIGNATURES = {
     "air_canvas_unroll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_float, c_float, P]),
     "air_canvas_unroll_bwd_nvil": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                           c_float, c_float, P, c_int, P, P, P, P, P, P, P]),
+                                           c_float, c_float, P, c_int, P, P, P, P, P, P, P, P]),
     "air_canvas_unroll_bands": (c_int, [c_int, c_int]),
     "air_canvas_unroll_fwd_banded": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                              c_float, c_float, P]),
-    "air_nvil_parts": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P]),
+    "air_nvil_parts": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, P]),
     "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
                          c_float, P, P, c_size_t, P]),
     "air_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
@@ -94,7 +94,7 @@ SIGNATURES = {
     "air_gauss_sample_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
                                      P, c_float, P, c_int, c_int, c_int, c_float, P]),
     "air_gauss_sample_bwd_nvil": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                          P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P]),
+                                          P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P, P]),
     "air_canvas_unroll_fwd_bwd_fits": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "air_canvas_unroll_fwd_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_float, c_float, c_float, P]),
@@ -128,7 +128,8 @@ SIGNATURES = {
     "air_steps_prior": (c_int, [P, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_double, P, c_int, P]),
     "air_counter_add": (c_int, [P, ctypes.c_int64, P]),
-    "air_nvil": (c_int, [P, P, P, P, P, P, c_int, P]),
+    "air_nvil": (c_int, [P, P, P, P, P, P, c_int, P, P]),
+    "air_l2_grad_add": (c_int, [P, P, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t), c_int, c_float, P]),
     "air_baseline_pack": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "air_rmsprop_centered": (c_int, [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, P]),
     "air_rmsprop": (c_int, [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_int, c_float, P]),

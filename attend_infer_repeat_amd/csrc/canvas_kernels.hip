@@ -580,6 +580,254 @@ __global__ __launch_bounds__(1024) void st_write_bwd_kernel(WriteBwdArgs a, Nvil
     extern __shared__ __align__(16) float smem[];
     st_write_bwd_body<RC>(a, nv, smem, (int)blockIdx.x, (int)gridDim.x);
 }
+// ---- image-major backward for the throughput regime (round 5) ------------------------------------------------------------
+// The unit-major kernel above is bound by vector-instruction issue once the chip is full (879 vector instructions per wave and
+// unit at 65536 images; 5 waves per SIMD waiting for the pipe, profiles/r04_canvas_pmc.txt), and two thirds of a unit are fixed
+// work that the T units of one image repeat: staging and forming dcanvas (it does not depend on t), the linspace tables, three
+// barriers.  Here one workgroup owns an IMAGE and runs its T units side by side:
+//   * dcanvas = coef * (mult * final - obs) is formed ONCE into LDS and never copied: the column contraction reads it directly and
+//     the unit's presence multiplies the finished dglimpse element (dG is linear in it) -- no per-unit `go` image;
+//   * the contraction weights of a glimpse column / row (<= 4 canvas columns / rows touch it at the scales AIR trains at; longer
+//     ranges take the general loop) are formed once per (t, j) / (t, i) next to the exact ranges, so a contraction element is
+//     4 LDS reads + 4 FMAs instead of 4 x (table read, two compares, two selects, FMA);
+//   * 4 barriers per IMAGE (operands | footprint pass + ranges | column contraction | row contraction) instead of 4 per unit.
+// Same tables, taps, ranges and dwhere chain as the unit-major kernel (degenerate scales give the same NaN / inf placement); the
+// summation orders differ, so results agree to rounding, not bit for bit.  Stored-canvas form only (final_canvas given).
+struct CarveImg {
+    float *gimg, *src, *t1, *X, *Y, *scratch, *pres;
+    float2 *xe, *ye;
+    int2 *jr, *ir, *rows;
+    float4 *wx4, *wy4;
+    int hwp;
+};
+__device__ __forceinline__ CarveImg carve_img(float *smem, int T, int H, int W, int h, int w) {
+    CarveImg c;
+    float *p = smem;
+    c.hwp = pad_count(h, w);
+    c.gimg = p; p += (H * W + 3) & ~3;
+    c.wx4 = reinterpret_cast<float4 *>(p); p += 4 * T * w;
+    c.wy4 = reinterpret_cast<float4 *>(p); p += 4 * T * h;
+    c.src = p; p += T * c.hwp;
+    c.t1 = p; p += T * ((H * w + 3) & ~3);
+    c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
+    c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * H;
+    c.jr = reinterpret_cast<int2 *>(p); p += 2 * T * w;
+    c.ir = reinterpret_cast<int2 *>(p); p += 2 * T * h;
+    c.X = p; p += W;
+    c.Y = p; p += H;
+    c.pres = p; p += (T + 3) & ~3;
+    c.rows = reinterpret_cast<int2 *>(p); p += 2 * ((T + 1) & ~1);       // per unit: first valid canvas row, number of valid rows
+    c.scratch = p;                                       // [waves][T][8]
+    return c;
+}
+static inline size_t carve_img_bytes(int T, int H, int W, int h, int w, int waves) {
+    return sizeof(float) * (size_t)(((H * W + 3) & ~3) + 4 * T * (w + h) + T * pad_count_host(h, w) + T * ((H * w + 3) & ~3) +
+                                    2 * T * (W + H) + 2 * T * (w + h) + W + H + ((T + 3) & ~3) + 2 * ((T + 1) & ~1) + waves * T * 8 + 16);
+}
+// the (up to) four contraction weights of source index j from canvas index lo on: weight of canvas index J for source index j is
+// d_J if floor_J == j, 1 - d_J if floor_J + 1 == j (the transpose of the bilinear taps), 0 past the range
+__device__ __forceinline__ float4 touch_weights(const float2 *tab, int2 r, int j) {
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int J = r.x + u;
+        const bool in = J <= r.y;
+        const float2 e = tab[in ? J : (r.x <= r.y ? r.x : 0)];
+        const int f = __float_as_int(e.x);
+        const float wgt = (f == j ? e.y : 0.f) + (f + 1 == j ? 1.f - e.y : 0.f);
+        wv[u] = in ? wgt : 0.f;
+    }
+    return make_float4(wv[0], wv[1], wv[2], wv[3]);
+}
+__global__ __launch_bounds__(512) void st_write_bwd_img_kernel(WriteBwdArgs a, NvilArgs nv) {
+    extern __shared__ __align__(16) float smem[];
+    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
+    const float *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
+    float *__restrict__ dglimpse = a.dglimpse, *__restrict__ dwhere = a.dwhere, *__restrict__ dpresence = a.dpresence;
+    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w;
+    const int grid_st = nv.imp ? (int)gridDim.x - 1 : (int)gridDim.x;
+    const int bid0 = nv.imp ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (bid0 < 0) { nvil_body(nv); return; }
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+    CarveImg c = carve_img(smem, T, H, W, h, w);
+    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
+    const float coef = a.loss_scale * a.mult / (a.std * a.std), mult = a.mult;
+    const int pitch = w + 2, nQ = HW >> 2, nq = hw >> 2, t1s = (H * w + 3) & ~3;
+    const float inv_w = 1.0f / (float)w;
+    // once per workgroup: the linspace tables (they depend on the shapes only) and the zero borders of the T glimpse copies
+    for (int e = tid; e < W + H; e += nt) {
+        if (e < W) c.X[e] = lin_m11(e, W, a.stepX); else c.Y[e - W] = lin_m11(e - W, H, a.stepY);
+    }
+    for (int e = tid; e < T * pad_border(h, w); e += nt) {
+        const int tt = e / pad_border(h, w);
+        c.src[(size_t)tt * c.hwp + pad_border_index(e - tt * pad_border(h, w), h, w)] = 0.f;
+    }
+    __syncthreads();
+    for (int b = bid0; b < B; b += grid_st) {
+        if (b != bid0) __syncthreads();                       // the previous image's readers are done with the carve
+        // ---- operands: dcanvas of the image (once), the T glimpses, the T pairs of axis tables
+        {
+            const float4 *fc4 = reinterpret_cast<const float4 *>(final_canvas + (size_t)b * HW);
+            const float4 *ob4 = reinterpret_cast<const float4 *>(obs + (size_t)b * HW);
+            for (int q = tid; q < nQ; q += nt) {
+                const float4 f = fc4[q], o = ob4[q];
+                float4 gv;
+                gv.x = dcanvas_of(coef, mult, f.x, o.x); gv.y = dcanvas_of(coef, mult, f.y, o.y);
+                gv.z = dcanvas_of(coef, mult, f.z, o.z); gv.w = dcanvas_of(coef, mult, f.w, o.w);
+                reinterpret_cast<float4 *>(c.gimg)[q] = gv;
+            }
+        }
+        if (a.vec4_glimpse) {
+            for (int q = tid; q < T * nq; q += nt) {
+                const int tt = q / nq;
+                const float4 v = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[q - tt * nq];
+                float *d = c.src + (size_t)tt * c.hwp + pad_index(4 * (q - tt * nq), w, inv_w);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int q = tid; q < T * hw; q += nt) {
+                const int tt = q / hw;
+                c.src[(size_t)tt * c.hwp + pad_index(q - tt * hw, w, inv_w)] = glimpse[((size_t)tt * B + b) * hw + (q - tt * hw)];
+            }
+        }
+        for (int a0 = tid; a0 < T * (W + H); a0 += nt) {
+            const int tt = a0 / (W + H), r = a0 - tt * (W + H);
+            const float *wk = where + 4 * ((size_t)tt * B + b);
+            if (r < W) {
+                const float s_ = wk[0], t_ = wk[1];
+                c.xe[tt * W + r] = axis_entry2(grid_coord(1.0f / s_, c.X[r], -t_ / s_, cxs), w);
+            } else {
+                const float s_ = wk[2], t_ = wk[3];
+                c.ye[tt * H + (r - W)] = axis_entry2(grid_coord(1.0f / s_, c.Y[r - W], -t_ / s_, cys), h);
+            }
+        }
+        if (tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
+        __syncthreads();                                       // (1)
+        // ---- exact contraction ranges + weights of every glimpse column / row (they only need the tables)
+        for (int e = tid; e < T * (w + h); e += nt) {
+            const int tt = e / (w + h), r = e - tt * (w + h);
+            const float *wk = where + 4 * ((size_t)tt * B + b);
+            if (r < w) {
+                const float s_ = wk[0], t_ = wk[1];
+                const int2 rg = touch_range(c.xe + tt * W, -t_ / s_, s_, inv_cxs, r, W);
+                c.jr[tt * w + r] = rg;
+                c.wx4[tt * w + r] = touch_weights(c.xe + tt * W, rg, r);
+            } else {
+                const float s_ = wk[2], t_ = wk[3];
+                const int i = r - w;
+                const int2 rg = touch_range(c.ye + tt * H, -t_ / s_, s_, inv_cys, i, H);
+                c.ir[tt * h + i] = rg;
+                c.wy4[tt * h + i] = touch_weights(c.ye + tt * H, rg, i);
+            }
+        }
+        // ---- footprint pass per unit: the dwhere / dpresence sums (dglimpse needs no pixel pass here)
+        for (int tt = 0; tt < T; ++tt) {
+            const float2 *xe = c.xe + tt * W, *ye = c.ye + tt * H;
+            const int2 vx = valid_span(xe, W), vy = valid_span(ye, H);
+            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
+            const float pres = c.pres[tt];
+            // an ABSENT step (presence exactly 0 -- the sampled z_pres of cell.py:147-148) has dglimpse = 0 and zero dwhere sums: its
+            // pixel pass and both contractions are skipped (the dwhere chain below still runs on the zero sums, so a degenerate
+            // scale gives the same NaN as before); only a caller that wants dpresence needs the pass
+            const bool absent = pres == 0.f && !dpresence;
+            const int npx = (fw > 0 && fh > 0 && !absent) ? fw * fh : 0;
+            if (tid == 0) c.rows[tt] = make_int2(I0, absent ? -1 : (fh > 0 ? fh : 0));   // (every valid row gets its T1 row, even under an empty column span)
+            const float inv_fw = 1.0f / (float)(fw > 0 ? fw : 1);
+            const float *src = c.src + (size_t)tt * c.hwp;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int idx = tid; idx < npx; idx += nt) {
+                const int Ir = div_small(idx, fw, inv_fw), I = I0 + Ir, J = J0 + (idx - Ir * fw);
+                const float2 ex = xe[J], ey = ye[I];
+                const Taps tp = load_taps_pad(src, pitch, __float_as_int(ey.x), __float_as_int(ex.x));
+                const float v = bilerp(tp, ex.y, ey.y);
+                const float dc = c.gimg[I * W + J];
+                where_grad_accum(acc, tp, ex.y, ey.y, pres * dc, dc, v, cxs, cys, c.X[J], c.Y[I], true);
+            }
+            const float r = wave_reduce8(acc);
+            if ((lane & 7) == 0) c.scratch[(wid * T + tt) * 8 + wave_reduce8_slot()] = r;
+        }
+        __syncthreads();                                       // (2)
+        // ---- pass 1: T1[t][I, j] = sum_J dcanvas[I, J] * wx[J, j] on the unit's valid rows
+        for (int tt = 0; tt < T; ++tt) {
+            const int2 rw = c.rows[tt];
+            const int I0 = rw.x, fh = rw.y;
+            float *t1 = c.t1 + (size_t)tt * t1s;
+            for (int e = tid; e < fh * w; e += nt) {
+                const int Ir = div_small(e, w, inv_w), I = I0 + Ir, j = e - Ir * w;
+                const int2 r = c.jr[tt * w + j];
+                const float4 wv = c.wx4[tt * w + j];
+                const float *grow = c.gimg + I * W;
+                float s = 0.f;
+                if (r.x <= r.y) {                              // (an empty range contributes exactly zero, whatever dcanvas holds)
+                    const int Jb = r.x;
+                    const int j1 = Jb + 1 <= r.y ? Jb + 1 : Jb, j2 = Jb + 2 <= r.y ? Jb + 2 : Jb, j3 = Jb + 3 <= r.y ? Jb + 3 : Jb;
+                    s = grow[Jb] * wv.x;
+                    s = __builtin_fmaf(grow[j1], wv.y, s);
+                    s = __builtin_fmaf(grow[j2], wv.z, s);
+                    s = __builtin_fmaf(grow[j3], wv.w, s);
+                    for (int J = r.x + 4; J <= r.y; ++J) {     // wide ranges (scales towards 1 and beyond): the general form
+                        const float2 ex = c.xe[tt * W + J];
+                        const int fx = __float_as_int(ex.x);
+                        s = __builtin_fmaf(grow[J], (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f), s);
+                    }
+                }
+                t1[I * w + j] = s;
+            }
+        }
+        __syncthreads();                                       // (3)
+        // ---- pass 2: dG[t][i, j] = presence_t * sum_I wy[I, i] * T1[t][I, j]
+        for (int tt = 0; tt < T; ++tt) {
+            const float *t1 = c.t1 + (size_t)tt * t1s;
+            const float pres = c.pres[tt];
+            float *dg = dglimpse + ((size_t)tt * B + b) * hw;
+            if (c.rows[tt].y < 0) {                            // absent step
+                for (int e = tid; e < hw; e += nt) dg[e] = 0.f;
+                continue;
+            }
+            for (int e = tid; e < hw; e += nt) {
+                const int i = div_small(e, w, inv_w), j = e - i * w;
+                const int2 r = c.ir[tt * h + i];
+                const float4 wv = c.wy4[tt * h + i];
+                float s = 0.f;
+                if (r.x <= r.y) {                              // (rows outside the footprint were never written: weight 0 is not enough)
+                    const int i1 = r.x + 1 <= r.y ? r.x + 1 : r.x, i2 = r.x + 2 <= r.y ? r.x + 2 : r.x, i3 = r.x + 3 <= r.y ? r.x + 3 : r.x;
+                    s = t1[r.x * w + j] * wv.x;
+                    s = __builtin_fmaf(t1[i1 * w + j], wv.y, s);
+                    s = __builtin_fmaf(t1[i2 * w + j], wv.z, s);
+                    s = __builtin_fmaf(t1[i3 * w + j], wv.w, s);
+                    for (int I = r.x + 4; I <= r.y; ++I) {
+                        const float2 ey = c.ye[tt * H + I];
+                        const int fy = __float_as_int(ey.x);
+                        s = __builtin_fmaf(t1[I * w + j], (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f), s);
+                    }
+                }
+                dg[e] = pres * s;
+            }
+        }
+        // ---- dwhere / dpresence of the T units: the per-wave partials (visible since barrier 2), fixed order, one wave per unit
+        for (int tt = wid; tt < T; tt += nw) {
+            float part[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[(lane * T + tt) * 8 + q] : 0.f;
+            const float tot = wave_reduce8(part);
+            const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64),
+                        r4 = __shfl(tot, 32, 64);
+            if (lane == 0) {
+                const size_t k = (size_t)tt * B + b;
+                const float sx = where[4 * k], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
+                const float ax = 1.0f / sx, bx = -tx / sx, ay = 1.0f / sy, by = -ty / sy;
+                float *d = dwhere + 4 * k;                     // (the chain through 1/s, (-t)/s as the unit-major kernel writes it)
+                d[0] = -(r0 * (ax / sx)) - r1 * (bx / sx);
+                d[1] = -(r1 / sx);
+                d[2] = -(r2 * (ay / sy)) - r3 * (by / sy);
+                d[3] = -(r3 / sy);
+                if (dpresence) dpresence[k] = r4;
+            }
+        }
+    }
+}
+
 // Canvas forward and backward of a train step in ONE launch (latency regime).  The recompute form of the backward reads nothing
 // the forward writes, so the two are independent roles of one grid: workgroups [0, n_fwd) run st_write_fwd_body (image x row
 // band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_body<true> (one per glimpse).  One
@@ -590,7 +838,7 @@ __global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, Writ
     extern __shared__ __align__(16) float smem[];
     if ((int)blockIdx.x < n_fwd) st_write_fwd_body(f, smem, (int)blockIdx.x, n_fwd);
     else {
-        const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
+        const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr};
         st_write_bwd_body<true, SPLIT>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
     }
 }
@@ -706,7 +954,7 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
                             float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
     const bool rc = !dcanvas && !final_canvas;                // recompute form: the canvas is re-formed on the unit's footprint
     const size_t lds = carve_bwd_bytes(H, W, h, w, rc ? T : 1);
-    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
+    NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr};
     if (nvil) nv = *nvil;
     AIR_REQUIRE(lds <= CV_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);   // 16-byte groups that never straddle a glimpse row
@@ -717,6 +965,22 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     const int wr_threads = bwd_threads((long)B * T);
     const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, 1};
+    {   // throughput regime, stored-canvas form: one workgroup per IMAGE runs its T units side by side (st_write_bwd_img_kernel)
+        // (read at every call, not cached: tests and A/B runs switch forms inside one process; a captured graph keeps what it captured)
+        const char *env_img = getenv("AIR_CANVAS_BWD_IMG");
+        const int img_major = env_img ? atoi(env_img) : 1;
+        const char *env_thr = getenv("AIR_CANVAS_IMG_THREADS");
+        const int thr_i = env_thr ? atoi(env_thr) : 256;
+        const size_t lds_i = carve_img_bytes(T, H, W, h, w, thr_i / 64);
+        if (img_major && !dcanvas && final_canvas && (long)T * B > 256 * 8 && T <= 8 && vec4c && lds_i <= 64 * 1024 && H * W >= 16 &&
+            (thr_i == 256 || thr_i == 512 || thr_i == 128)) {
+            const int cap_i = cv_resident_cap(st_write_bwd_img_kernel, thr_i, lds_i, 256 * 4);
+            const int grid_i = cv_grid(B, cap_i) + (nvil ? 1 : 0);
+            hipLaunchKernelGGL(st_write_bwd_img_kernel, dim3(grid_i), dim3(thr_i), lds_i, air_stream(stream), a, nv);
+            AIR_LAUNCH_CHECK();
+            return AIR_OK;
+        }
+    }
     int cap = 256 * 8;
     // (the recompute form -- 118 VGPRs, four workgroups per CU -- measured 1-2 % SLOWER with the resident cap: it keeps 2048)
     if ((long)T * B > cap && !rc) cap = cv_resident_cap(st_write_bwd_kernel<false>, wr_threads, lds, cap);
@@ -756,13 +1020,13 @@ extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *whe
                                           int T, int B, int H, int W, int h, int w, float mult, float std,
                                           float loss_scale, const float *imp_parts, int n_parts, float *imp_sum,
                                           const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                                          float *dbaseline, void *stream) {
+                                          float *dbaseline, float *ema_dev, void *stream) {
     AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere, AIR_E_NULL);      // final_canvas == NULL: the recompute form
     AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
     AIR_REQUIRE(T > 0 && n_parts > 0, AIR_E_SHAPE);
     int st = cv_check_dims(B, H, W, h, w);
     if (st) return st;
-    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
+    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum, ema_dev};
     return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, nullptr, T, B, H, W,
                             h, w, mult, std, loss_scale, stream, &nv);
 }

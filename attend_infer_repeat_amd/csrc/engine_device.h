@@ -14,9 +14,12 @@
 // starts with a cold instruction cache (36 different kernels per step share 64 KB per CU pair), so code size is latency
 __device__ __noinline__ double air_log_f64(double x) { return log(x); }
 
+// pm = NaN: the prior is centred on the posterior's own mean (a where-shift prior given without `loc`, model.py:203-207): the
+// (mu - pm)^2 term and its gradient vanish
+__device__ __forceinline__ float kl_mean_diff(float mu, float pm) { return pm == pm ? mu - pm : 0.f; }
 __device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps) {
     const float ratio = (s * s) / (ps * ps);
-    const float d = mu - pm;
+    const float d = kl_mean_diff(mu, pm);
     return d * d / (2.f * ps * ps) + 0.5f * (ratio - 1.f - logf(ratio));
 }
 // d KL / d scale, evaluated in the order the reference's automatic differentiation walks the expression above (TF 1.1
@@ -95,7 +98,7 @@ __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const floa
         const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
         const float ds = (dsample ? dsample[e] : 0.f) + (dsample2 ? dsample2[e] : 0.f);
         const float dk = dkl_row ? dkl_row[m] * dkl_scale : 0.f;
-        float dmu = ds + dk * (mu - pm) / (ps * ps);
+        float dmu = ds + dk * kl_mean_diff(mu, pm) / (ps * ps);
         const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + normal_kl_dscale(dk, s, ps);
         if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
         const float raw = pre[m * ld_pre + D + d] + raw_offset.v;

@@ -233,19 +233,20 @@ extern "C" int air_counter_add(int64_t *counter_dev, int64_t increment, void *st
 //   reinforce_loss = mean_j (imp_j - mean_i b_i) * logp_j ;  baseline_loss = 0.5 * mean_ij (imp_j - b_i)^2.
 __global__ __launch_bounds__(256) void nvil_kernel(NvilArgs a) { nvil_body(a); }
 extern "C" int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
-                        float *dbaseline, int B, void *stream) {
+                        float *dbaseline, int B, float *ema_dev, void *stream) {
     AIR_REQUIRE(imp && baseline && logp && out, AIR_E_NULL);
     AIR_REQUIRE(B > 0, AIR_E_SHAPE);
-    NvilArgs a = {imp, baseline, logp, out, dlogp, dbaseline, B, 1, nullptr};
+    NvilArgs a = {imp, baseline, logp, out, dlogp, dbaseline, B, 1, nullptr, ema_dev};
     hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
 extern "C" int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline,
-                              const float *logp, float *out, float *dlogp, float *dbaseline, int B, void *stream) {
+                              const float *logp, float *out, float *dlogp, float *dbaseline, int B, float *ema_dev,
+                              void *stream) {
     AIR_REQUIRE(imp_parts && baseline && logp && out, AIR_E_NULL);
     AIR_REQUIRE(B > 0 && n_parts > 0, AIR_E_SHAPE);
-    NvilArgs a = {imp_parts, baseline, logp, out, dlogp, dbaseline, B, n_parts, imp_sum};
+    NvilArgs a = {imp_parts, baseline, logp, out, dlogp, dbaseline, B, n_parts, imp_sum, ema_dev};
     hipLaunchKernelGGL(nvil_kernel, dim3(1), dim3(256), 0, air_stream(stream), a);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

@@ -12,6 +12,12 @@ struct NvilArgs {
     // imp_sum (the complete rec_loss_per_sample) when that pointer is given
     int imp_parts;
     float *imp_sum;
+    // optional EMA normalisation of the importance weight (decay_rate of model.py:232-239, ops.py:46-64), a DEVICE block of four
+    // floats {moving_mean, moving_var, decay_rate, update}: the [B,B] weight is shifted by the moving mean and divided by
+    // max(sqrt(moving_var), 1) -- the values the variables hold BEFORE this step's update, as the reference's graph reads them --
+    // and, when update != 0 (train steps; evaluation passes only read), the two averages then move towards this batch's mean /
+    // variance of the [B,B] weight.  NULL = the script's decay_rate=None.
+    float *ema;
 };
 __device__ __forceinline__ float nvil_imp(const NvilArgs &g, int i) {
     float r = g.imp[i];
@@ -25,7 +31,7 @@ __device__ __forceinline__ float nvil_imp(const NvilArgs &g, int i) {
 // then ONE multi-value wave reduction), so there is a single barrier -- the broadcast of the two means -- and no serial
 // cross-wave stage; fixed order => bitwise reproducible.
 __device__ __forceinline__ void nvil_body(const NvilArgs &g) {
-    __shared__ double tot[2];
+    __shared__ double tot[4];
     const int nt = blockDim.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (wid == 0) {
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // sum imp, imp^2, b, b^2, imp*logp, logp, (unused x2)
@@ -43,17 +49,28 @@ __device__ __forceinline__ void nvil_body(const NvilArgs &g) {
             const double n = (double)g.B;
             const double mi = t[0] / n, mb = t[2] / n;
             const double vi = t[1] / n - mi * mi, vb = t[3] / n - mb * mb;
-            g.out[0] = (float)((t[4] - mb * t[5]) / n);                                // reinforce_loss
-            g.out[1] = (float)(0.5 * (vi + vb + (mi - mb) * (mi - mb)));              // baseline_loss
-            g.out[2] = (float)(mi - mb);                                               // imp_weight_mean over [B,B]
-            g.out[3] = (float)(vi + vb);                                               // imp_weight_var  over [B,B]
-            tot[0] = mi; tot[1] = mb;
+            double shift = 0.0, inv_f = 1.0;
+            if (g.ema) {
+                const float mm = g.ema[0], mv = g.ema[1], d = g.ema[2];
+                shift = (double)mm;
+                const float f = sqrtf(mv);
+                inv_f = 1.0 / (double)(f > 1.f ? f : 1.f);
+                if (g.ema[3] != 0.f) {                                                 // assign_moving_average, zero_debias=False
+                    g.ema[0] = d * mm + (1.f - d) * (float)(mi - mb);
+                    g.ema[1] = d * mv + (1.f - d) * (float)(vi + vb);
+                }
+            }
+            g.out[0] = (float)(((t[4] - mb * t[5]) - shift * t[5]) * inv_f / n);      // reinforce_loss
+            g.out[1] = (float)(0.5 * (vi + vb + (mi - mb) * (mi - mb)));              // baseline_loss (not normalised, model.py:253-256)
+            g.out[2] = (float)((mi - mb - shift) * inv_f);                             // imp_weight_mean over [B,B]
+            g.out[3] = (float)((vi + vb) * inv_f * inv_f);                             // imp_weight_var  over [B,B]
+            tot[0] = mi; tot[1] = mb; tot[2] = shift; tot[3] = inv_f;
         }
     }
     __syncthreads();
-    const double mi = tot[0], mb = tot[1];
+    const double mi = tot[0], mb = tot[1], shift = tot[2], inv_f = tot[3];
     for (int i = threadIdx.x; i < g.B; i += nt) {
-        if (g.dlogp) g.dlogp[i] = (float)(((double)nvil_imp(g, i) - mb) / (double)g.B);
+        if (g.dlogp) g.dlogp[i] = (float)((((double)nvil_imp(g, i) - mb) - shift) * inv_f / (double)g.B);
         if (g.dbase) g.dbase[i] = (float)(-(mi - (double)g.base[i]) / (double)g.B);
     }
 }

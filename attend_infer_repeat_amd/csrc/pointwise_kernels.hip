@@ -197,13 +197,13 @@ extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const flo
                                          const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
                                          int ld_dpre, int M, int D, const float *imp_parts, int n_parts, float *imp_sum,
                                          const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                                         float *dbaseline, int B, float guard_eps, void *stream) {
+                                         float *dbaseline, int B, float guard_eps, float *ema_dev, void *stream) {
     AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
     AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
     AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
     AIR_REQUIRE(B > 0 && n_parts > 0, AIR_E_SHAPE);
-    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum};
+    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum, ema_dev};
     hipLaunchKernelGGL(gauss_bwd_nvil_kernel, dim3(pw_blocks((size_t)M * D) + 1), dim3(PW_THREADS), 0, air_stream(stream), pre,
                        ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
                        dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, nv);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(PW_THREADS) void normal_kl_bwd_kernel(const float *
         const int d = (int)(e - m * D);
         const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
         const float g = dkl[m], s = scale[e];
-        dloc[e] = g * (loc[e] - pm) / (ps * ps);
+        dloc[e] = g * kl_mean_diff(loc[e], pm) / (ps * ps);
         dscale[e] = normal_kl_dscale(g, s, ps);
     }
 }
@@ -640,6 +640,35 @@ extern "C" int air_f32_to_bf16(const float *x, void *out_bf16, size_t n, void *s
     else
         hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(pw_blocks(n)), dim3(PW_THREADS), 0, air_stream(stream), x,
                            (unsigned short *)out_bf16, n);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// ---- L2 weight decay of the objective (model.py:346-353): g += l2 * w over the 2-D model weights ------------------------------
+// The reference adds l2_weight * sum(w^2) / 2 over every model variable with a 2-D shape to the loss; its gradient is one axpy per
+// such tensor.  One launch over up to AIR_L2_MAX_RANGES [lo, hi) slices of the flat buffers (biases and baseline variables lie
+// between the slices and are left alone).
+struct L2Ranges { size_t lo[AIR_L2_MAX_RANGES], hi[AIR_L2_MAX_RANGES]; int n; };
+__global__ __launch_bounds__(PW_THREADS) void l2_grad_kernel(float *__restrict__ g, const float *__restrict__ p, L2Ranges r, float l2) {
+    for (int k = 0; k < r.n; ++k) {
+        const size_t lo = r.lo[k], hi = r.hi[k];
+        for (size_t i = lo + (size_t)blockIdx.x * PW_THREADS + threadIdx.x; i < hi; i += (size_t)gridDim.x * PW_THREADS)
+            g[i] = __builtin_fmaf(l2, p[i], g[i]);
+    }
+}
+extern "C" int air_l2_grad_add(float *g, const float *p, const size_t *range_lo, const size_t *range_hi, int n_ranges, float l2_weight,
+                               void *stream) {
+    AIR_REQUIRE(g && p && range_lo && range_hi, AIR_E_NULL);
+    AIR_REQUIRE(n_ranges > 0 && n_ranges <= AIR_L2_MAX_RANGES, AIR_E_SHAPE);
+    L2Ranges r;
+    size_t longest = 0;
+    for (int k = 0; k < AIR_L2_MAX_RANGES; ++k) {
+        r.lo[k] = k < n_ranges ? range_lo[k] : 0; r.hi[k] = k < n_ranges ? range_hi[k] : 0;
+        AIR_REQUIRE(r.lo[k] <= r.hi[k], AIR_E_SHAPE);
+        if (r.hi[k] - r.lo[k] > longest) longest = r.hi[k] - r.lo[k];
+    }
+    r.n = n_ranges;
+    hipLaunchKernelGGL(l2_grad_kernel, dim3(pw_blocks(longest ? longest : 1)), dim3(PW_THREADS), 0, air_stream(stream), g, p, r, l2_weight);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
                 g.dwhere_r[4 * k + d_] = accd;
                 const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
                 const float ds = s_dw + accd;
-                float dmu = ds + s_dk * (mu - pm) / (ps * ps);
+                float dmu = ds + s_dk * kl_mean_diff(mu, pm) / (ps * ps);
                 const float dsc = ds * s_eps + normal_kl_dscale(s_dk, sc, ps);
                 dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
                 float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
             const float mu = s_mu, sc = s_sc;
             const float pm = (d_ & 1) ? g.pl1 : g.pl0, ps = (d_ & 1) ? g.ps1 : g.ps0;
             const float ds = s_dw + accd;
-            float dmu = ds + s_dk * (mu - pm) / (ps * ps);
+            float dmu = ds + s_dk * kl_mean_diff(mu, pm) / (ps * ps);
             const float dsc = ds * s_eps + normal_kl_dscale(s_dk, sc, ps);
             dmu *= (d_ & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
             float dsp = s_raw > 20.f ? 1.f : sigmoid_acc(s_raw);

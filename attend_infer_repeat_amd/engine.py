@@ -61,6 +61,11 @@ class EngineConfig:
     rms_decay: float = 0.9
     rms_momentum: float = 0.9
     rms_eps: float = 1e-10
+    rms_centered: bool = True             # opt_kwargs of model.py:265 (centered=False: tf.train.RMSPropOptimizer's own default)
+    # the rest of train_step's arguments (model.py:261-353), all off in the script:
+    l2_weight: float = 0.0                # l2_weight * sum(w^2) / 2 over the 2-D model variables (model.py:346-353)
+    decay_rate: Optional[float] = None    # EMA normalisation of the importance weight (model.py:232-239, ops.py:46-64)
+    nsp_weight: float = 1.0               # num_steps_prior.weight (model.py:339-340)
     # "f32": exact fp32 MFMA everywhere.  "bf16": every dense product (MLPs, LSTM gates, their dX / dW) rounds its operands
     # to bf16 in registers and multiplies on the bf16 MFMA with fp32 accumulate; parameters, activations, gradients and the
     # optimiser stay fp32 (BASELINE.json configs[4], "bf16 MFMA MLP path").
@@ -593,6 +598,8 @@ class AIREngine:
                         "air_lstm_pointwise_fwd"))
         h_all = self.h_seq[1:]                                                              # [T,B,Hd] contiguous
         sp, shp = cfg.where_scale_prior, cfg.where_shift_prior
+        if shp[0] is None:                  # a shift prior without `loc` is centred on the posterior's own mean (model.py:203-207):
+            shp = (float("nan"), shp[1])    # the kernels' NaN convention (include/air_hip.h, air_gauss_sample_fwd)
         eps = -1.0 if cfg.explore_eps is None else float(cfg.explore_eps)
         # "attend" fusion: output layers of the transform / steps MLPs + where sampling + presence / num-steps + the glimpse
         # read in ONE launch (three dependent launches otherwise).  Needs a 16-byte addressable image that fits the
@@ -658,8 +665,19 @@ class AIREngine:
         nvil_args = (p(self.rec_parts), NB, p(self.rec), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out),
                      p(self.dlogp), p(self.dbase))
         self._nvil_args = nvil_args
+        # decay_rate: the two moving averages + the rate + the update switch as one device block (air_nvil's `ema_dev`); evaluation
+        # passes (forward() alone) read the averages without moving them
+        ema_p = None
+        if cfg.decay_rate is not None and cfg.use_reinforce:
+            if getattr(self, "ema_dev", None) is None:
+                self.ema_dev = torch.tensor([0.0, 1.0, float(cfg.decay_rate), 1.0], dtype=torch.float32, device=self.device)
+            self._fill_in(self.ema_dev[2:3], float(cfg.decay_rate))
+            ema_p = p(self.ema_dev)
         rec_sum = (L.air_sum_leading, (p(self.rec_parts), p(self.rec), NB, ctypes.c_size_t(B)), "air_sum_leading")
-        fwd_tail = [(L.air_nvil_parts, nvil_args + (B,), "air_nvil_parts")] if cfg.use_reinforce else [rec_sum]
+        fwd_tail = [(L.air_nvil_parts, nvil_args + (B, ema_p), "air_nvil_parts")] if cfg.use_reinforce else [rec_sum]
+        if ema_p is not None:               # (forward() is an evaluation pass: the update switch is off around its NVIL launch)
+            sw = ctypes.c_void_p(self.ema_dev.data_ptr() + 12)
+            fwd_tail = [(L.air_fill, (sw, ctypes.c_size_t(1), 0.0), "air_fill")] + fwd_tail + [(L.air_fill, (sw, ctypes.c_size_t(1), 1.0), "air_fill")]
 
         # ---- backward of opt_loss = mean(rec) + pw*(mean kl_n + mean sum_t w*(kl_what+kl_where)) + reinforce -------
         pw = 1.0 if cfg.use_prior else 0.0
@@ -715,7 +733,7 @@ class AIREngine:
                                                       cfg.output_multiplier, cfg.output_std, inv_b),
                         "air_canvas_unroll_fwd_bwd"))
         elif cfg.use_reinforce:
-            bwd.append((L.air_canvas_unroll_bwd_nvil, cu_args + nvil_args, "air_canvas_unroll_bwd_nvil"))
+            bwd.append((L.air_canvas_unroll_bwd_nvil, cu_args + nvil_args + (ema_p,), "air_canvas_unroll_bwd_nvil"))
         else:
             bwd.append(rec_sum)          # nobody consumes rec in the step itself; keeps outputs() complete after train_step
             bwd.append((L.air_canvas_unroll_bwd, cu_args, "air_canvas_unroll_bwd"))
@@ -727,7 +745,7 @@ class AIREngine:
         gb_args = (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0], wp[1], wp[0], wp[1], p(self.what_loc),
                    p(self.what_scale), p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M, A)
         if fuse_canvas:
-            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B, float(cfg.guard_eps)), "air_gauss_sample_bwd_nvil"))
+            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B, float(cfg.guard_eps), ema_p), "air_gauss_sample_bwd_nvil"))
         else:
             bwd.append((L.air_gauss_sample_bwd, gb_args + (float(cfg.guard_eps),), "air_gauss_sample_bwd"))
         launch(bwd, [desc(1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
@@ -751,7 +769,7 @@ class AIREngine:
                                               p(self.tr.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
                                               shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w), n_split,
                                               p(self.step_w), pw * inv_b, p(self.tr.g[-1]),
-                                              p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                              p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b * float(cfg.nsp_weight),
                                               p(self.kl_what_row), p(self.kl_where_row), pw * inv_b, dlogp_p,
                                               p(self.st.out[-1]), cfg.step_bias, eps, p(self.st.g[-1]), T, B, Hi, Wi, hc, wc,
                                               p(self.tr.w[-1]), p(tr_y) if tr_y is not None else None, p(tr_dx), tr_kk, tr_ld,
@@ -764,7 +782,7 @@ class AIREngine:
                                           sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
                                           p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
                                           p(self.tr.g[-1]), 8, M, 4,
-                                          p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b,
+                                          p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b * float(cfg.nsp_weight),
                                           p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
                                           dlogp_p, p(self.st.out[-1]), cfg.step_bias,
                                           eps, p(self.st.g[-1]), T, B, float(cfg.guard_eps)), "air_heads_bwd"))
@@ -879,6 +897,26 @@ class AIREngine:
                 bwd.append((L.air_gemm_grouped, (arr, len(grp)), "air_gemm_grouped"))
             marks = []                            # no gradient slice is final before the end of the backward
 
+        # ---- L2 term (model.py:346-353): g += l2 * w on the 2-D model variables, the last launch of the backward (so every protocol
+        #      -- single GPU, data parallel: the all-reduced sum of `world` identical terms is scaled back by 1/world -- sees it).
+        #      Rare switch (0 in the script): the riders / folded update, which consume gradients before the end, are then off.
+        if cfg.l2_weight and cfg.l2_weight > 0.0:
+            spans = []
+            for k, shape in self.param_shapes.items():
+                if len(shape) == 2 and not k.startswith("baseline/"):
+                    lo = self.param_offsets[k]
+                    if spans and spans[-1][1] == lo:
+                        spans[-1][1] = lo + self.param_sizes[k]
+                    else:
+                        spans.append([lo, lo + self.param_sizes[k]])
+            if len(spans) > 32:
+                raise _lib.AirHipError("more than 32 separate 2-D model tensors: the L2 launch takes 32 slices")
+            lo_arr = (ctypes.c_size_t * len(spans))(*[a for a, _ in spans])
+            hi_arr = (ctypes.c_size_t * len(spans))(*[b_ for _, b_ in spans])
+            self._keep += [lo_arr, hi_arr]
+            bwd.append((L.air_l2_grad_add, (p(self.flat_grads), p(self.flat_params), lo_arr, hi_arr, len(spans), float(cfg.l2_weight)),
+                        "air_l2_grad_add"))
+            marks, rider_hosts = [], []
         # ---- optimiser: both centred-RMSProp updates + device counters in one launch ---------------------------------
         tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
         pre_fwd = []
@@ -898,6 +936,21 @@ class AIREngine:
                                        p(self.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, gscale,
                                        p(self.step_dev), p(self.rng_state), ctypes.c_uint64(self._rng_inc)),
                  "air_step_epilogue")]
+        if not cfg.rms_centered:
+            # tf.train.RMSPropOptimizer(centered=False) (model.py:265 with other opt_kwargs): the generic update kernel on the two
+            # segments + the counters; no riders (the BPTT riders and the fold are the centred form)
+            if use16:
+                raise _lib.AirHipError("the bf16 data path keeps its parameter shadow in the centred update launch: centered=False is not available with it")
+            seg = lambda lo, hi, mult, gscale: (L.air_rmsprop, (
+                ctypes.c_void_p(self.flat_params.data_ptr() + 4 * lo), ctypes.c_void_p(self.flat_grads.data_ptr() + 4 * lo),
+                ctypes.c_void_p(self.flat_ms.data_ptr() + 4 * lo), ctypes.c_void_p(self.flat_mg.data_ptr() + 4 * lo),
+                ctypes.c_void_p(self.flat_mom.data_ptr() + 4 * lo), ctypes.c_size_t(hi - lo), p(self.lr_dev), mult, cfg.rms_decay,
+                cfg.rms_momentum, cfg.rms_eps, 0, gscale), "air_rmsprop")
+            self._opt_calls_factory = lambda gscale: (
+                [seg(0, self.n_model, 1.0, gscale)] + ([seg(self.n_model, self.n_total, tail_mult, gscale)] if self.n_total > self.n_model and tail_mult else [])
+                + [(L.air_counter_add, (p(self.step_dev), ctypes.c_int64(1)), "air_counter_add"),
+                   (L.air_rng_advance, (p(self.rng_state), ctypes.c_uint64(self._rng_inc)), "air_rng_advance")])
+            rider_hosts = []
         self._plan_rng = rng
         def fwd_plan(with_noise):
             """the forward list with its prologue: a launch of its own, or -- with the fused LSTM steps -- extra workgroups
@@ -1470,6 +1523,7 @@ class AIREngine:
                 "flat_mg": self.flat_mg.cpu().clone(), "flat_mom": self.flat_mom.cpu().clone(),
                 "global_step": int(self.step_dev.item()), "rng_state": self.rng_state.cpu().clone(),
                 "learning_rate": float(self.lr_dev.item()),
+                **({"ema": self.ema_dev.cpu().clone()} if getattr(self, "ema_dev", None) is not None else {}),
                 "param_offsets": dict(self.param_offsets), "param_shapes": {k: tuple(v) for k, v in self.param_shapes.items()}}
 
     def load_state_dict(self, sd):
@@ -1480,6 +1534,8 @@ class AIREngine:
             self._copy_in(dst, sd[key])
         self.set_learning_rate(float(sd["learning_rate"]))
         self.set_global_step(int(sd["global_step"]))
+        if "ema" in sd and getattr(self, "ema_dev", None) is not None:
+            self._copy_in(self.ema_dev, sd["ema"])
         self._sync_param_shadow()
         self.synchronize()
 
@@ -1510,7 +1566,7 @@ class AIREngine:
         o["kl_what"] = o["kl_what_per_sample"].mean()
         o["kl_where"] = o["kl_where_per_sample"].mean()
         pw = 1.0 if cfg.use_prior else 0.0
-        o["prior_loss"] = o["kl_num_steps"] + o["kl_what"] + o["kl_where"]
+        o["prior_loss"] = float(cfg.nsp_weight) * o["kl_num_steps"] + o["kl_what"] + o["kl_where"]
         o["loss"] = o["rec_loss"] + pw * o["prior_loss"]
         o["num_step_per_sample"] = self.presence.sum(0)
         o["num_steps_log_prob"] = self.logp
@@ -1522,6 +1578,12 @@ class AIREngine:
             o["imp_weight_mean"] = self.nvil_out[2]
             o["imp_weight_var"] = self.nvil_out[3]
             o["opt_loss"] = o["loss"] + o["reinforce_loss"]
+        if cfg.l2_weight and cfg.l2_weight > 0.0:                  # model.py:346-353; evaluated on the CURRENT parameters (a read-out)
+            sq = sum((v * v).sum() for k, v in self.params.items() if v.dim() == 2 and not k.startswith("baseline/"))
+            o["l2_loss"] = float(cfg.l2_weight) * sq / 2
+            o["opt_loss"] = o["opt_loss"] + o["l2_loss"]
+        if getattr(self, "ema_dev", None) is not None:
+            o["imp_weight_moving_mean"], o["imp_weight_moving_var"] = self.ema_dev[0], self.ema_dev[1]
         return o
 
     def named_grads(self) -> Dict[str, torch.Tensor]:

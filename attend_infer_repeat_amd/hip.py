@@ -426,13 +426,13 @@ def numsteps_bwd(presence_prob, presence, prior_f64, kl_scale, dstep_weight=None
     return dprob
 
 
-def nvil(imp, baseline, logp):
+def nvil(imp, baseline, logp, ema=None):
     imp = _f32(imp, "imp", 1); baseline = _f32(baseline, "baseline", 1); logp = _f32(logp, "logp", 1)
     B = imp.shape[0]
     dev = imp.device
     out = torch.empty((4,), dtype=torch.float32, device=dev)
     dlogp = torch.empty((B,), dtype=torch.float32, device=dev); dbase = torch.empty((B,), dtype=torch.float32, device=dev)
-    _lib.check(lib().air_nvil(_p(imp), _p(baseline), _p(logp), _p(out), _p(dlogp), _p(dbase), B, _stream()), "air_nvil")
+    _lib.check(lib().air_nvil(_p(imp), _p(baseline), _p(logp), _p(out), _p(dlogp), _p(dbase), B, _p(ema), _stream()), "air_nvil")
     return out, dlogp, dbase
 
 

@@ -77,20 +77,23 @@ class AIRonMNIST(AIRModel):
 
     def _engine_eligible(self, use_engine, l2_weight, what_prior, where_scale_prior, where_shift_prior, num_steps_prior,
                          decay_rate):
-        """The fused engine implements the configuration of the reference script (scripts/multi_mnist.py:24-94) and its
-        plain switches.  Anything else the reference's train_step accepts (model.py:261-265) -- priors left at None, a shift
-        prior without `loc`, a weighted / non-analytic num-steps prior, EMA-normalised importance weights, L2, continuous
-        steps, a non-MLP baseline -- trains through the generic autograd path over the same kernels."""
+        """The fused engine takes the reference script's configuration (scripts/multi_mnist.py:24-94) and, since round 5, the rest
+        of train_step's plain arguments (model.py:261-353): l2_weight, decay_rate (EMA-normalised importance weights), a weighted
+        num-steps prior, a where-shift prior without `loc`, and the RMSProp keyword set (decay / momentum / epsilon / centered).
+        What still trains through the generic autograd path over the same kernels: a custom optimizer CLASS, a non-MLP baseline,
+        priors left at None, continuous steps (discrete_steps=False: the presence then carries a gradient into the canvas write
+        and the baseline input) and a non-analytic num-steps prior (sampled step weights, the prior inside the importance weight)."""
         nsp = num_steps_prior
         has = lambda p, *keys: p is not None and all(k in p for k in keys)
-        if not (use_engine and self.discrete_steps and decay_rate is None and not l2_weight):
+        if not (use_engine and self.discrete_steps):
             return False
-        if getattr(self, "_custom_optimizer", None) is not None or not getattr(self, "_default_rms", True):
-            return False       # (the engine's fused update is the script's RMSProp(momentum=.9, centered=True))
-        if nsp is None or not getattr(nsp, 'analytic', True) or float(getattr(nsp, 'weight', 1.)) != 1.:
+        if getattr(self, "_custom_optimizer", None) is not None:
             return False
-        if not (has(what_prior, 'loc', 'scale') and has(where_scale_prior, 'loc', 'scale')
-                and has(where_shift_prior, 'loc', 'scale')):
+        if nsp is None or not getattr(nsp, 'analytic', True):
+            return False
+        if not (has(what_prior, 'loc', 'scale') and has(where_scale_prior, 'loc', 'scale') and has(where_shift_prior, 'scale')):
+            return False
+        if decay_rate is not None and not self.use_reinforce:
             return False
         if self.use_reinforce:
             bm = getattr(self, "baseline_module", None)
@@ -98,8 +101,10 @@ class AIRonMNIST(AIRModel):
                 return False
         return True
 
-    def engine_config(self, learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior):
+    def engine_config(self, learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior, l2_weight=0.,
+                      decay_rate=None):
         nsp = num_steps_prior
+        rms = getattr(self, "_rms_kwargs", None) or dict(decay=0.9, momentum=0.9, epsilon=1e-10, centered=True)
         return EngineConfig(
             img_size=tuple(self.img_size), crop_size=tuple(self.glimpse_size), n_appearance=self.n_appearance,
             n_hidden=256, max_steps=self.max_steps,
@@ -108,12 +113,15 @@ class AIRonMNIST(AIRModel):
             explore_eps=None if self.explore_eps is None else float(self.explore_eps),
             what_prior=(what_prior.loc, what_prior.scale),
             where_scale_prior=(where_scale_prior.loc, where_scale_prior.scale),
-            where_shift_prior=(where_shift_prior.loc, where_shift_prior.scale),
+            where_shift_prior=(where_shift_prior.loc if 'loc' in where_shift_prior else None, where_shift_prior.scale),
             nsp_anneal=getattr(nsp, 'anneal', None), nsp_init=nsp.init, nsp_final=getattr(nsp, 'final', nsp.init),
             nsp_steps_div=getattr(nsp, 'steps_div', 1.), nsp_steps=getattr(nsp, 'steps', 1.),
             nsp_hold_init=getattr(nsp, 'hold_init', 0.),
             use_prior=self.use_prior, use_reinforce=self.use_reinforce, learning_rate=float(learning_rate),
-            guard_eps=float(getattr(self, 'guard_degenerate', 0.0)), **self._hyper)
+            guard_eps=float(getattr(self, 'guard_degenerate', 0.0)),
+            l2_weight=float(l2_weight or 0.), decay_rate=None if decay_rate is None else float(decay_rate),
+            nsp_weight=float(getattr(nsp, 'weight', 1.)), rms_decay=float(rms["decay"]), rms_momentum=float(rms["momentum"]),
+            rms_eps=float(rms["epsilon"]), rms_centered=bool(rms["centered"]), **self._hyper)
 
     def train_step(self, learning_rate, l2_weight=0., what_prior=None, where_scale_prior=None,
                    where_shift_prior=None, num_steps_prior=None, use_prior=True, use_reinforce=True, baseline=None,
@@ -128,7 +136,8 @@ class AIRonMNIST(AIRModel):
                                      num_steps_prior, decay_rate):
             return fn, gs
         self._hyper["mfma_dtype"] = mfma_dtype
-        cfg = self.engine_config(learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior)
+        cfg = self.engine_config(learning_rate, num_steps_prior, what_prior, where_scale_prior, where_shift_prior, l2_weight,
+                                 decay_rate)
         eng = AIREngine(cfg, self.batch_size, device=self.obs.device)
         named = self._named_module_params()
         eng.load_parameters({k: v.detach() for k, v in named.items()})
@@ -218,8 +227,11 @@ class AIRonMNIST(AIRModel):
         self.num_step = self.num_step_per_sample.mean()
         from .ops import Loss
         from .prior import NumStepsDistribution
-        self.prior_loss = Loss(); self.prior_loss.add(o["prior_loss"], o["kl_num_steps_per_sample"]
+        self.prior_loss = Loss(); self.prior_loss.add(o["prior_loss"], float(eng.cfg.nsp_weight) * o["kl_num_steps_per_sample"]
                                                       + o["kl_what_per_sample"] + o["kl_where_per_sample"])
+        for k in ("l2_loss", "imp_weight_moving_mean", "imp_weight_moving_var"):
+            if k in o:
+                setattr(self, k, o[k])
         self.loss = Loss(); self.loss.add(o["loss"], o["rec_loss_per_sample"]
                                           + self.prior_weight * self.prior_loss.per_sample)
         if "baseline" in o:

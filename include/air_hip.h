@@ -103,7 +103,7 @@ int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const f
                                const float *final_canvas, float *dglimpse, float *dwhere,
                                int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                                const float *imp_parts, int n_parts, float *imp_sum, const float *baseline,
-                               const float *logp, float *nvil_out, float *dlogp, float *dbaseline, void *stream);
+                               const float *logp, float *nvil_out, float *dlogp, float *dbaseline, float *ema_dev, void *stream);
 /* Canvas forward (banded, as air_canvas_unroll_fwd_banded) and backward (as air_canvas_unroll_bwd with final_canvas = NULL: every
  * (t, b) unit re-forms the canvas on its own footprint, bit-identically to the forward, so it reads nothing the forward writes) as
  * the two roles of ONE launch: one dependent launch less on the train step's chain at small batch.  The NVIL objective, which
@@ -278,7 +278,9 @@ int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const
  *   (sign kept, straight-through) so that the inverse warp's 1/s (modules.py:101-102) never meets an exact zero -- the
  *   documented stability switch of SURVEY section 7 / App. B-11 (model.py:188-214, cell.py:130-133).
  *   kl_row[M] (optional) = sum_d KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])); prior4 = {loc_even, scale_even,
- *   loc_odd, scale_odd} passed by value (where: even dims = scale prior, odd = shift prior; what: both equal).     */
+ *   loc_odd, scale_odd} passed by value (where: even dims = scale prior, odd = shift prior; what: both equal).
+ *   A prior location of NaN means "centred on the posterior's own mean" -- the where-shift prior given without `loc`,
+ *   model.py:203-207: the (mu - p_loc)^2 term of the KL and its gradient vanish (every KL entry point honours it).  */
 int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          float *loc, float *scale, float *sample, float *kl_row, int M, int D, float guard_eps, void *stream);
@@ -295,7 +297,7 @@ int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, fl
                               const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
                               float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *imp_parts, int n_parts,
                               float *imp_sum, const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                              float *dbaseline, int B, float guard_eps, void *stream);
+                              float *dbaseline, int B, float guard_eps, float *ema_dev, void *stream);
 
 /* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
  * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
@@ -379,13 +381,18 @@ int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
 /* NVIL / REINFORCE with the reference's [B]-[B,1]->[B,B] broadcast (model.py:218-259).
  *   imp[B] (= rec_loss_per_sample), baseline[B], logp[B].
  *   out[4] = {reinforce_loss, baseline_loss, imp_weight_mean, imp_weight_var};
- *   dlogp[B] = d reinforce_loss / d logp; dbaseline[B] = d baseline_loss / d baseline.                              */
+ *   dlogp[B] = d reinforce_loss / d logp; dbaseline[B] = d baseline_loss / d baseline.
+ *   ema_dev (every entry point that evaluates NVIL takes it; NULL = decay_rate=None, the script's setting): a DEVICE block of four
+ *   floats {moving_mean, moving_var, decay_rate, update} -- the EMA normalisation of model.py:232-239 / ops.py:46-64: the [B,B]
+ *   weight is shifted by the moving mean and divided by max(sqrt(moving_var), 1) as the variables stand BEFORE this step, then --
+ *   when update != 0 (train steps; evaluation passes read only) -- both move towards this batch's mean / variance (zero_debias
+ *   off).  Kept on the device so that a captured graph carries the state from replay to replay.                        */
 int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
-             float *dbaseline, int B, void *stream);
+             float *dbaseline, int B, float *ema_dev, void *stream);
 /* air_nvil with the importance weight given as n_parts shares per sample (imp_parts[n_parts, B], added in share order in
  * fp32); the sum is also written to imp_sum[B] when given (the complete rec_loss_per_sample).                          */
 int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline, const float *logp,
-                   float *out, float *dlogp, float *dbaseline, int B, void *stream);
+                   float *out, float *dlogp, float *dbaseline, int B, float *ema_dev, void *stream);
 
 
 /* Baseline input assembly, modules.py:131-139: out[B, HW + T*A + T*4 + T + S] =
@@ -442,6 +449,13 @@ int air_attend_bwd_dx(const float *img, const float *where, const float *dglimps
                    float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
                       const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision, float guard_eps,
                       void *stream);
+
+/* L2 term of the objective (model.py:346-353: l2_weight * sum(w^2) / 2 over the 2-D model variables): g += l2_weight * p on up
+ * to AIR_L2_MAX_RANGES slices [range_lo[k], range_hi[k]) of the flat buffers (host arrays; biases and baseline variables are not
+ * in any slice).  Runs between the backward and the update.                                                            */
+#define AIR_L2_MAX_RANGES 32
+int air_l2_grad_add(float *g, const float *p, const size_t *range_lo, const size_t *range_hi, int n_ranges, float l2_weight,
+                    void *stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------------
  * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;

@@ -78,6 +78,7 @@ class AIRConfig:
     nsp_steps: float = 1e5
     nsp_hold_init: float = 1e3
     nsp_analytic: bool = True
+    nsp_weight: float = 1.0                     # num_steps_prior.weight (model.py:339-340: prior_loss.add(kl, weight=...))
     use_prior: bool = True
     use_reinforce: bool = True
     decay_rate: Optional[float] = None          # model.py:232-239 (None in the script)
@@ -92,6 +93,7 @@ class AIRConfig:
     rms_decay: float = 0.9
     rms_momentum: float = 0.9
     rms_eps: float = 1e-10
+    rms_centered: bool = True                   # opt_kwargs of model.py:265 (tf.train.RMSPropOptimizer's own default: False)
 
     @property
     def n_pix(self) -> int:
@@ -655,8 +657,8 @@ def objective(params, cfg: AIRConfig, obs: Tensor, noise, global_step=0) -> Dict
     where_kl = (scale_kl + shift_kl).sum(-1) * w
     kl_where_ps = where_kl.sum(0)
     kl_where = kl_where_ps.mean()
-    prior_loss = kl_n + kl_what + kl_where
-    prior_ps = kl_n_ps + kl_what_ps + kl_where_ps
+    prior_loss = cfg.nsp_weight * kl_n + kl_what + kl_where
+    prior_ps = cfg.nsp_weight * kl_n_ps + kl_what_ps + kl_where_ps
     prior_weight = 1.0 if cfg.use_prior else 0.0
     loss = rec + prior_weight * prior_loss
     loss_ps = rec_ps + prior_weight * prior_ps
@@ -731,7 +733,8 @@ def rmsprop_centered_step(params, grads, slots, cfg: AIRConfig):
         g, s = grads[k], slots[k]
         s["ms"].mul_(d).add_(g * g, alpha=1 - d)
         s["mg"].mul_(d).add_(g, alpha=1 - d)
-        s["mom"].mul_(m).add_(lr * g / torch.sqrt(s["ms"] - s["mg"] * s["mg"] + eps))
+        denom = s["ms"] - s["mg"] * s["mg"] + eps if cfg.rms_centered else s["ms"] + eps
+        s["mom"].mul_(m).add_(lr * g / torch.sqrt(denom))
         p.sub_(s["mom"])
 
 

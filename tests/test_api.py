@@ -423,18 +423,31 @@ def test_aironmnist_argument_combinations_the_reference_accepts(amd):
     assert air._engine is None
     ts()
     assert int(gs) == 1 and np.isfinite(float(air.opt_loss))
-    # shift prior without loc -> generic path
+    # shift prior without loc -> on the engine since round 5 (the kernels' NaN-location convention)
     air = _mnist_model(amd)
     ts, gs = air.train_step(1e-4, 0., N01(), N01(), AD(scale=1.), nsp())
-    assert air._engine is None
+    assert air._engine is not None and air._engine.cfg.where_shift_prior[0] is None
     ts()
     assert np.isfinite(float(air.kl_where))
-    # weighted num-steps KL -> generic path, and the weight is honoured
+    # weighted num-steps KL -> engine, and the weight is honoured
     air = _mnist_model(amd)
     ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp(weight=3.))
-    assert air._engine is None
+    assert air._engine is not None and air._engine.cfg.nsp_weight == 3.
+    ts()
     expect = 3. * float(air.kl_num_steps) + float(air.kl_what) + float(air.kl_where)
     assert abs(float(air.prior_loss.value) - expect) < 1e-4 * (abs(expect) + 1)
+    # l2_weight + decay_rate + the RMSProp keyword set (model.py:261-265) -> engine; what stays generic: a non-analytic prior,
+    # continuous steps, a custom optimizer class (test below), priors at None (above)
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-4, 1e-3, N01(), N01(), N01(), nsp(), decay_rate=0.9, opt_kwargs=dict(momentum=.5, centered=True, decay=.95))
+    eng = air._engine
+    assert eng is not None and eng.cfg.l2_weight == 1e-3 and eng.cfg.decay_rate == 0.9 and eng.cfg.rms_momentum == 0.5 and eng.cfg.rms_decay == 0.95
+    ts(); ts()
+    assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(eng.flat_params).all()
+    assert float(air.l2_loss) > 0 and float(air.imp_weight_moving_var) != 1.0
+    air = _mnist_model(amd)
+    ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp(analytic=False))
+    assert air._engine is None
 
 
 def test_debug_flag_validates_distribution_parameters(amd):
@@ -491,11 +504,12 @@ def test_custom_optimizer_runs_on_the_generic_path(amd):
     air2 = _mnist_model(amd)
     ts2, gs2 = air2.train_step(1e-3, 0., AD(loc=0., scale=1.), AD(loc=0., scale=1.), AD(loc=0., scale=1.),
                                AD(anneal=None, init=0.5), opt_kwargs=dict(momentum=0.5))
-    assert air2._engine is None and air2._custom_optimizer is None
+    assert air2._engine is not None and air2._custom_optimizer is None          # (round 5: the keyword set runs on the engine)
+    assert air2._engine.cfg.rms_centered is False and air2._engine.cfg.rms_momentum == 0.5
     w = air2.cell._input_encoder.mlp.layers[1].w
     w0 = w.detach().clone()
     ts2()
-    g = w.grad.double()
+    g = air2._engine.named_grads()["input_encoder/1/w"].double()
     expect = w0.double() - 1e-3 * g / torch.sqrt(0.9 * 1.0 + 0.1 * g * g + 1e-10)        # slots start at ms = 1, mom = 0
     assert torch.allclose(w.detach().double(), expect, rtol=0, atol=2e-7 * float(expect.abs().max()) + 1e-9)
     ts2()

@@ -290,6 +290,84 @@ def test_graph_captured_train_steps_at_batch_64_match_oracle(gpu_device):
     assert eng.global_step == 6 and eng.step_dev.item() == 6
 
 
+SWITCHES = {
+    # the rest of train_step's arguments (model.py:261-353), each on the fused engine since round 5
+    "l2_weight": dict(l2_weight=3e-3),
+    "decay_rate": dict(decay_rate=0.9),
+    "nsp_weight": dict(nsp_weight=2.5),
+    "shift_prior_without_loc": dict(where_shift_prior=(None, 0.7)),
+    "rms_kwargs": dict(rms_decay=0.95, rms_momentum=0.5, rms_eps=1e-7),
+    "rms_not_centered": dict(rms_centered=False, rms_momentum=0.0),
+    "all_together": dict(l2_weight=1e-3, decay_rate=0.8, nsp_weight=0.5, where_shift_prior=(None, 1.3), rms_momentum=0.7),
+}
+
+
+@pytest.mark.parametrize("B", [8, 64])
+@pytest.mark.parametrize("switch", list(SWITCHES))
+def test_train_step_switches_on_the_engine_match_oracle(gpu_device, switch, B):
+    """Every further argument of the reference's train_step (model.py:261-353) on the fused, graph-captured engine: L2 on the 2-D
+    model variables, EMA-normalised importance weights (the moving averages live on the device and move inside the replayed graph),
+    a weighted num-steps prior, a where-shift prior without `loc`, the RMSProp keyword set incl. centered=False.  Three
+    hipGraph-replayed updates against O.train_step in float64 fed the noise each replay drew; outputs, losses and the EMA state
+    too."""
+    ocfg = O.AIRConfig(**SWITCHES[switch])
+    eng, params, obs, noise = make_pair(ocfg, B, gstep=3)
+    for k, v in SWITCHES[switch].items():
+        assert getattr(eng.cfg, k) == v or k == "where_shift_prior"
+    assert eng.cfg.where_shift_prior == ocfg.where_shift_prior
+    p64 = f64(params)
+    slots = O.rmsprop_init(p64)
+    ema_noise_state = {}
+    eng.capture()
+    prev = {k: v.clone() for k, v in p64.items()}
+    for it in range(3):
+        eng.train_step()
+        eng.synchronize()
+        used = {"eps_where": eng.eps_where.cpu().double(), "eps_what": eng.eps_what.cpu().double(),
+                "u_pres": eng.u_pres.cpu().double().reshape(ocfg.max_steps, B, 1)}
+        used = {k: v.reshape(noise[k].shape) for k, v in used.items()}
+        used.update(ema_noise_state)                       # (the oracle keeps its moving averages in the noise dict: "_ema")
+        res, _ = O.train_step(p64, slots, ocfg, obs.double(), used, global_step=3 + it)
+        if "_ema" in used:
+            ema_noise_state = {"_ema": used["_ema"]}
+        out = eng.outputs()
+        for k in ("opt_loss", "loss", "prior_loss", "kl_where", "reinforce_loss", "baseline_loss", "imp_weight_mean", "imp_weight_var"):
+            assert abs(out[k].item() - res[k].item()) < 3e-4 * (abs(res[k].item()) + 1.0), (it, k, out[k].item(), res[k].item())
+        if ocfg.l2_weight > 0:
+            # (a read-out over the CURRENT parameters -- after the update the replay ended with; the L2 gradient inside the step
+            #  is what the parameter deltas below check)
+            l2_now = ocfg.l2_weight * sum((v * v).sum() / 2 for k, v in p64.items() if v.dim() == 2 and not O.is_baseline_param(k))
+            assert abs(out["l2_loss"].item() - l2_now.item()) < 1e-5 * l2_now.item()
+        if ocfg.decay_rate is not None:
+            assert abs(eng.ema_dev[0].item() - used["_ema"]["mean"].item()) < 1e-4 * (abs(used["_ema"]["mean"].item()) + 1.0)
+            assert abs(eng.ema_dev[1].item() - used["_ema"]["var"].item()) < 1e-4 * (abs(used["_ema"]["var"].item()) + 1.0)
+        for k, ref in p64.items():
+            d_ref, d_got = ref - prev[k], eng.params[k].cpu().double() - prev[k]
+            assert rel_err(d_got, d_ref) < 1e-3, (switch, it, k, rel_err(d_got, d_ref))
+        for k in p64:
+            p64[k] = eng.params[k].cpu().double().clone()
+            prev[k] = p64[k].clone()
+        for sk, flat in {"ms": eng.flat_ms, "mg": eng.flat_mg, "mom": eng.flat_mom}.items():
+            for k in p64:
+                o, n = eng.param_offsets[k], eng.param_sizes[k]
+                slots[k][sk] = flat[o:o + n].view(eng.param_shapes[k]).cpu().double().clone()
+        if "_ema" in ema_noise_state:                      # ... and from the engine's fp32 moving averages
+            ema_noise_state["_ema"] = {"mean": eng.ema_dev[0].cpu().double().clone(), "var": eng.ema_dev[1].cpu().double().clone()}
+    assert eng.step_dev.item() == 6
+    if ocfg.decay_rate is not None:
+        # an evaluation pass reads the moving averages without moving them (UPDATE_OPS run with the train step only, ops.py:46-64)
+        before = eng.ema_dev.clone()
+        eng.forward(); eng.synchronize()
+        assert torch.equal(eng.ema_dev, before)
+    # gradients of the plain forward / backward against the oracle (the L2 term is part of flat_grads)
+    eng2, params2, obs2, noise2 = make_pair(ocfg, B)
+    eng2.forward(sample_noise=False); eng2.backward()
+    res, ref = O.forward_backward(f64(params2), ocfg, obs2.double(), f64(noise2), global_step=20000)
+    grads = eng2.named_grads()
+    for k, r in ref.items():
+        check_tensor("switches", switch, "grad", k, grads[k], r, GRAD_TOL, GRAD_L2)
+
+
 def test_bf16_graph_train_step_runs_and_learns(gpu_device):
     ocfg, B = O.AIRConfig(), 32
     eng, params, obs, noise = make_pair(ocfg, B, bias_std=0.0, mfma_dtype="bf16")

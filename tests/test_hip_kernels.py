@@ -238,10 +238,61 @@ def test_canvas_kernels_in_every_workgroup_shape_match_the_oracle(hip, T, B, H, 
     st2, final2, rec2 = hip.canvas_unroll_fwd(sl(glm), sl(where), sl(pres), (H, W), obs=g(obs[:nb2]), mult=mult, std=std)
     assert torch.equal(st2, st[:, :nb2]) and torch.equal(final2, final[:nb2])
     assert_close(rec2, rec[:nb2], 1e-5, 1e-3, "rec")
+    # (beyond 2048 units the stored-canvas backward runs image-major -- st_write_bwd_img_kernel, round 5: one workgroup per image,
+    #  dcanvas formed once, presence applied to the finished element -- which agrees with the unit-major form to rounding)
+    img_major = T * B > 2048 and T <= 8
     for fc in (final2, None):
         dg2, dwhere2 = hip.canvas_unroll_bwd(sl(glm), sl(where), sl(pres), g(obs[:nb2]), fc, mult, std, 1.0 / B)
-        assert torch.equal(dg2, dg[:, :nb2])
+        if img_major:
+            assert_close(dg2, dg[:, :nb2], 2e-5, 2e-6 * float(dg.abs().max()), "dglimpse")
+        else:
+            assert torch.equal(dg2, dg[:, :nb2])
         assert_close(dwhere2, dwhere[:, :nb2], 2e-4, 1e-5 * float(dwhere.abs().max()) + 1e-7, "dwhere")
+
+
+@pytest.mark.parametrize("T,B,H,W,h,w", [(3, 704, 50, 50, 20, 20), (5, 420, 40, 60, 12, 16), (1, 2100, 17, 13, 5, 7), (2, 1100, 50, 50, 21, 19)])
+def test_canvas_backward_image_major_equals_unit_major(hip, monkeypatch, T, B, H, W, h, w):
+    """Round 5: beyond 2048 units the stored-canvas backward runs one workgroup per IMAGE (st_write_bwd_img_kernel: dcanvas formed
+    once per image, contraction weights once per glimpse column / row, 4 barriers per image) instead of one per (t, b) unit.  Same
+    tables, taps, exact ranges and dwhere chain: dglimpse / dwhere agree with the unit-major kernel to rounding on ordinary,
+    mirrored, tiny, oversized (ranges wider than four canvas columns: the general loop) and off-canvas transforms, and are NaN /
+    inf exactly where it is on degenerate scales (the reference's inverse warp has no guard: tests/test_extreme_scales.py)."""
+    rng = np.random.default_rng(T * 1000 + B)
+    glm = rng.standard_normal((T, B, h, w)).astype(np.float32)
+    where = rand_where(T * B, rng, wide=True).reshape(T, B, 4)
+    where[0, 0] = [-0.7, 0.2, 0.9, -0.13]
+    where[-1, 1] = [3.0, 0.0, 3.0, 0.0]
+    where[0, 2] = [0.3, 5.0, 0.3, 0.0]
+    where[-1, 3] = [1.3, 0.05, 0.95, -0.02]           # every glimpse column touched by 6-7 canvas columns
+    where[0, 4] = [0.04, 0.1, 0.05, -0.3]             # a glimpse smaller than two canvas pixels
+    for i, v in enumerate([0.0, -0.0, 1e-40, 1e-30, 1e-20, -1e-20, 1e19, 3e38]):
+        where[i % T, 8 + i] = [v, 0.3, 0.7, -0.2]
+        where[(i + 1) % T, 20 + i] = [0.6, -0.1, v, 0.25]
+    pres = np.cumprod(rng.integers(0, 2, (T, B)), 0).astype(np.float32); pres[:, :40] = 1.0
+    obs = rng.random((B, H, W)).astype(np.float32)
+    mult, std = 0.5, 0.3
+    _, final, _ = hip.canvas_unroll_fwd(g(glm), g(where), g(pres), (H, W), obs=g(obs), mult=mult, std=std)
+    monkeypatch.setenv("AIR_CANVAS_BWD_IMG", "0")
+    dg_u, dw_u = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, mult, std, 1.0 / B)
+    monkeypatch.setenv("AIR_CANVAS_BWD_IMG", "1")
+    dg_i, dw_i = hip.canvas_unroll_bwd(g(glm), g(where), g(pres), g(obs), final, mult, std, 1.0 / B)
+    torch.cuda.synchronize()
+    for name, a, b in (("dglimpse", dg_i, dg_u), ("dwhere", dw_i, dw_u)):
+        a, b = a.cpu(), b.cpu()
+        cls = lambda t: torch.isnan(t) * 3 + torch.isposinf(t) * 1 + torch.isneginf(t) * 2
+        assert torch.equal(cls(a), cls(b)), name + ": non-finite placement differs"
+        fin = torch.isfinite(b)
+        if name == "dglimpse":
+            err = ((a - b)[fin].abs().max() / b[fin].abs().max()).item()
+            assert err < 5e-6, (name, err)
+        else:
+            # rows: relative to the row's largest component (the four components share their partial sums)
+            af, bf = torch.where(fin, a, torch.zeros_like(a)), torch.where(fin, b, torch.zeros_like(b))
+            scale = bf.abs().amax(-1, keepdim=True) + 1e-6 * bf.abs().max() + 1e-30
+            err = ((af - bf).abs() / scale).max().item()
+            assert err < 2e-3, (name, err)
+    # (with a binary presence the two forms' dglimpse is the same FMA chain -- they differ in the sign of the zeros an absent step
+    #  leaves, which is how one can tell that the switch took effect)
 
 
 # ---------------------------------------------------------------------------------------------------------------
