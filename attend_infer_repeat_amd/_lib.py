@@ -84,6 +84,9 @@ SIGNATURES = {
     "air_lstm_step_fwd_prologue": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int,
                                            P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P]),
+    "air_lstm_first_step_fwd": (c_int, [P, c_int, c_int, P, P, P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int,
+                                        P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P]),
     "air_lstm_step_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "air_lstm_step_bwd_opt": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
     "air_lstm_pointwise_bwd_opt": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
@@ -92,9 +95,12 @@ SIGNATURES = {
     "air_gauss_sample_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
                                      c_int, c_int, c_float, P]),
     "air_gauss_sample_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                     P, c_float, P, c_int, c_int, c_int, c_float, P]),
+                                     P, c_float, P, c_int, c_int, c_int, c_float, P, c_int, P, P]),
+    "air_what_head_parts": (c_int, [c_int]),
+    "air_what_head_fwd": (c_int, [P, c_int, c_int, P, P, P, c_float, c_float, c_float, P, P, P, P, P, c_int, P, P, P, P, P,
+                                  c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "air_gauss_sample_bwd_nvil": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P,
-                                          P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P, P]),
+                                          P, c_float, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P, P, c_int, P, P]),
     "air_canvas_unroll_fwd_bwd_fits": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "air_canvas_unroll_fwd_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_float, c_float, c_float, P]),

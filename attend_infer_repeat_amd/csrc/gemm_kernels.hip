@@ -16,6 +16,7 @@
 #include "air_common.h"
 #include "prologue_device.h"
 #include "optimizer_device.h"
+#include "engine_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // explicit global address space: descriptors that travel through memory (grouped launch) would otherwise make every
@@ -1627,6 +1628,56 @@ __device__ __forceinline__ void tile16_kloop(f32x4 (&acc)[1][1], gcf gA, int lda
     }
 }
 
+// Two independent contractions of one tile position with the loads of BOTH issued before the first MFMA (the first LSTM step with
+// the folded input product: x . W_x and h0 . W_h): one memory round trip instead of two per group of U chunks.  Chunk c of segment s
+// goes to the wave tile16_kloop gives it to, and each segment accumulates its chunks in tile16_kloop's order: same bits.
+template <int KW, bool BF>
+__device__ __forceinline__ void tile16_kloop2(f32x4 (&acc0)[1][1], f32x4 (&acc1)[1][1], gcf gA0, int lda0, bool vecA0, gcf gB0, int K0,
+                                              gcf gA1, int lda1, bool vecA1, gcf gB1, int K1, int ldb, int rowA, bool okA, int colB,
+                                              bool okB, int limA, int limB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane >> 4;
+    constexpr int U = 4;
+    const int full0 = K0 >> 4, full1 = K1 >> 4;
+    const int rowAc = okA ? rowA : limA - 1, colBc = okB ? colB : limB;
+    const int fmax = full0 > full1 ? full0 : full1;
+#pragma nounroll
+    for (int c = wave; c < fmax; c += U * KW) {
+        f32x4 fa0[U][1], fb0[U][1], fa1[U][1], fb1[U][1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = c + u * KW;
+            const int k = (cu << 4) + 4 * lg;
+            if (cu < full0) { fa0[u][0] = ld_kcontig_full(gA0, lda0, rowAc, k, vecA0); fb0[u][0] = ld_kstrided_full(gB0, ldb, colBc, k); }
+            else { fa0[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; fb0[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if (cu < full1) { fa1[u][0] = ld_kcontig_full(gA1, lda1, rowAc, k, vecA1); fb1[u][0] = ld_kstrided_full(gB1, ldb, colBc, k); }
+            else { fa1[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; fb1[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW < full0) mfma_chunk<1, 1, BF>(acc0, fa0[u], fb0[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u * KW < full1) mfma_chunk<1, 1, BF>(acc1, fa1[u], fb1[u]);
+        }
+    }
+    const int pc0 = K0 >> 4, pc1 = K1 >> 4;
+    if ((K0 & 15) && (pc0 % KW) == wave) {
+        const int k = (pc0 << 4) + 4 * lg;
+        f32x4 fa[1], fb[1];
+        fa[0] = ld_kcontig(gA0, lda0, rowA, okA, k, K0, vecA0);
+        fb[0] = ld_kstrided(gB0, ldb, colB, okB, k, K0);
+        mfma_chunk<1, 1, BF>(acc0, fa, fb);
+    }
+    if ((K1 & 15) && (pc1 % KW) == wave) {
+        const int k = (pc1 << 4) + 4 * lg;
+        f32x4 fa[1], fb[1];
+        fa[0] = ld_kcontig(gA1, lda1, rowA, okA, k, K1, vecA1);
+        fb[0] = ld_kstrided(gB1, ldb, colB, okB, k, K1);
+        mfma_chunk<1, 1, BF>(acc1, fa, fb);
+    }
+}
+
 struct LstmFwdArgs {
     const float *h_prev, *w_h, *gx, *c_prev;
     float *h, *c, *gate_act;
@@ -1689,6 +1740,167 @@ __global__ __launch_bounds__(256) void lstm_fwd_fused_kernel(LstmFwdArgs g, Prol
         const gf_t ar = (gf_t)g.gate_act + (size_t)em * 4 * g.Hd + eu;
         ar[0] = gi; ar[g.Hd] = gj; ar[2 * (size_t)g.Hd] = gf; ar[3 * (size_t)g.Hd] = go;
     }
+}
+
+// The FIRST step of the unroll with the hoisted input product folded in (round 5: one dependent launch fewer on the forward chain).
+// gx = x . W_x + b does not depend on t (the image never changes, cell.py:121-125), so it used to be a launch of its own in front of
+// the recurrence; but step 0's recurrent operand is the trainable initial state -- ONE row for the whole batch -- so its product
+// h0 . W_h costs nothing to add here: the tile accumulates BOTH contractions (x[M,E] . W_x[E,4Hd] and h0[1,Hd] . W_h[Hd,4Hd]) into
+// two accumulators, writes gx = (x . W_x) + b for the later steps and finishes step 0's gate math on gx + h0 . W_h -- the same
+// sums in the same order as the two launches it replaces (bit-identical h_1, c_1, gate_act_0, gx).
+struct LstmFirstArgs { const float *x, *w_x, *b; float *gx_out; int E, ldx, vecX; };
+template <bool BF>
+__global__ __launch_bounds__(256) void lstm_fwd_first_kernel(LstmFwdArgs g, LstmFirstArgs f, PrologueArgs pro) {
+    constexpr int KW = 4, LDT = 20;
+    __shared__ float s_x[KW][16 * LDT], s_h[KW][16 * LDT];
+    if ((int)blockIdx.x >= g.tiles) {
+        step_prologue_body(pro, (int)blockIdx.x - g.tiles, (int)gridDim.x - g.tiles);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_u = (g.Hd + 3) >> 2;
+    const int tm = blockIdx.x / tiles_u, tu = blockIdx.x - tm * tiles_u;
+    const int m0 = tm * 16, u0 = tu * 4;
+    const int ub = u0 + (li & 3);
+    const bool okB = ub < g.Hd;
+    const int colB = (li >> 2) * g.Hd + ub;
+    const int rowA = m0 + li;
+    const bool okA = rowA < g.M;
+    const int er = threadIdx.x >> 2, eu = u0 + (threadIdx.x & 3), em = m0 + er;
+    const bool e_ok = threadIdx.x < 64 && em < g.M && eu < g.Hd;
+    float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_c = 0.f;
+    if (e_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_b[q] = ((gcf)f.b)[(size_t)q * g.Hd + eu];
+        e_c = ((gcf)g.c_prev)[(size_t)em * g.ldc + eu];
+    }
+    f32x4 ax[1][1], ah[1][1];
+    ax[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ah[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int limB = (li >> 2) * g.Hd + g.Hd - 1;
+    tile16_kloop2<KW, BF>(ax, ah, (gcf)f.x, f.ldx, f.vecX != 0, (gcf)f.w_x, f.E, (gcf)g.h_prev, g.ldh, g.vecA != 0, (gcf)g.w_h, g.Hd,
+                          g.ldw, rowA, okA, colB, okB, g.M, limB);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s_x[wave][(4 * lg + r) * LDT + li] = ax[0][0][r];
+        s_h[wave][(4 * lg + r) * LDT + li] = ah[0][0][r];
+    }
+    __syncthreads();
+    if (e_ok) {
+        float pre[4];
+        const gf_t gxo = (gf_t)f.gx_out + (size_t)em * g.ldgx + eu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = er * LDT + 4 * q + (threadIdx.x & 3);
+            const float gxv = ((s_x[0][off] + s_x[1][off]) + (s_x[2][off] + s_x[3][off])) + e_b[q];      // the BIAS epilogue of the gx product
+            gxo[(size_t)q * g.Hd] = gxv;
+            pre[q] = ((s_h[0][off] + s_h[1][off]) + (s_h[2][off] + s_h[3][off])) + gxv;
+        }
+        const float gi = sigmoid_acc(pre[0]);
+        const float gj = tanhf(pre[1]);
+        const float gf = sigmoid_acc(pre[2] + g.fb);
+        const float go = sigmoid_acc(pre[3]);
+        const float cn = gf * e_c + gi * gj;
+        const size_t e = (size_t)em * g.Hd + eu;
+        ((gf_t)g.c)[e] = cn;
+        ((gf_t)g.h)[e] = tanhf(cn) * go;
+        const gf_t ar = (gf_t)g.gate_act + (size_t)em * 4 * g.Hd + eu;
+        ar[0] = gi; ar[g.Hd] = gj; ar[2 * (size_t)g.Hd] = gf; ar[3 * (size_t)g.Hd] = go;
+    }
+}
+
+// ---- the `what` head in ONE launch (round 5): q = x . W + b (modules.py:20-21), what ~ N(loc, softplus(raw + offset)) with its KL
+// terms (cell.py:154-156, model.py:174-186) and the latent columns of the baseline input (modules.py:131-139) -- three things the
+// step used to spend two dependent launches on (the product, then air_what_sample_pack).  A tile is 16 rows x 8 LATENT DIMS: its 16
+// accumulator columns are the loc pre-activations of those dims AND their raw scales (gathered W columns a and A + a, the trick of the
+// fused LSTM step), so after the in-workgroup K reduction a thread holds both halves of its (row, dim) and samples right there.  The
+// KL row sum spans the ceil(A / 8) tiles of a row: each tile writes its 8-dim share to kl_parts[tile][M] (summed in the tile by three
+// lane exchanges) and a later launch of the step adds the shares in tile order (air_gauss_sample_bwd*: kl_parts / kl_row_out).
+struct WhatHeadArgs {
+    const float *x, *w, *b, *eps;
+    float *q, *loc, *scale, *what, *kl_parts, *pack;
+    const float *where, *presence, *s0, *s1;
+    int M, K, A, ldx, vecX, T, B, S0, S1, tiles;
+    float raw_offset, pl, ps, guard;
+};
+template <bool BF>
+__global__ __launch_bounds__(256) void what_head_kernel(WhatHeadArgs g) {
+    constexpr int KW = 4, LDT = 20;
+    __shared__ float s_tile[KW][16 * LDT];
+    const int width = g.T * g.A + g.T * 4 + g.T + g.S0 + g.S1;
+    if ((int)blockIdx.x >= g.tiles) {       // independent role: the where / presence / state columns of the baseline input
+        baseline_pack_body((int)blockIdx.x - g.tiles, (int)gridDim.x - g.tiles, nullptr, g.what, g.where, g.presence, g.s0, g.s1,
+                           g.pack, g.T, g.B, 0, g.A, g.S0, g.S1, g.T * g.A);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_n = (g.A + 7) >> 3;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 16, a0 = tn * 8;
+    const int ab = a0 + (li & 7);
+    const bool okB = ab < g.A;
+    const int colB = (li >> 3) * g.A + ab;
+    const int rowA = m0 + li;
+    const bool okA = rowA < g.M;
+    const int er = threadIdx.x >> 3, ed = threadIdx.x & 7, em = m0 + er, ea = a0 + ed;
+    const bool e_ok = threadIdx.x < 128 && em < g.M && ea < g.A;
+    float e_bl = 0.f, e_br = 0.f, e_eps = 0.f;
+    if (e_ok) {
+        e_bl = ((gcf)g.b)[ea]; e_br = ((gcf)g.b)[g.A + ea];
+        e_eps = ((gcf)g.eps)[(size_t)em * g.A + ea];
+    }
+    f32x4 acc[1][1];
+    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile16_kloop<KW, BF, false>(acc, (gcf)g.x, g.ldx, rowA, okA, g.vecX != 0, (gcf)g.w, 2 * g.A, colB, okB, false, g.K, g.M, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_tile[wave][(4 * lg + r) * LDT + li] = acc[0][0][r];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float kl = 0.f;
+        if (e_ok) {
+            const int o0 = er * LDT + ed, o1 = o0 + 8;
+            const float locp = ((s_tile[0][o0] + s_tile[1][o0]) + (s_tile[2][o0] + s_tile[3][o0])) + e_bl;   // the BIAS epilogue
+            const float raw = ((s_tile[0][o1] + s_tile[1][o1]) + (s_tile[2][o1] + s_tile[3][o1])) + e_br;
+            const gf_t qr = (gf_t)g.q + (size_t)em * 2 * g.A;
+            qr[ea] = locp; qr[g.A + ea] = raw;
+            const float s = guard_scale(softplus_acc(raw + g.raw_offset), g.guard);
+            const float v = locp + s * e_eps;
+            const size_t o = (size_t)em * g.A + ea;
+            ((gf_t)g.loc)[o] = locp; ((gf_t)g.scale)[o] = s; ((gf_t)g.what)[o] = v;
+            const int t = em / g.B, bb = em - t * g.B;
+            ((gf_t)g.pack)[(size_t)bb * width + t * g.A + ea] = v;
+            kl = normal_kl(locp, s, g.pl, g.ps);
+        }
+        kl += __shfl_xor(kl, 1, 64);
+        kl += __shfl_xor(kl, 2, 64);
+        kl += __shfl_xor(kl, 4, 64);
+        if (ed == 0 && em < g.M) ((gf_t)g.kl_parts)[(size_t)tn * g.M + em] = kl;
+    }
+}
+extern "C" int air_what_head_parts(int A) { return (A + 7) / 8; }
+extern "C" int air_what_head_fwd(const float *x, int ldx, int K, const float *w, const float *b, const float *eps, float raw_offset,
+                                 float p_loc, float p_scale, float *q, float *loc, float *scale, float *sample, float *kl_parts,
+                                 int A, const float *where, const float *presence, const float *state0, const float *state1,
+                                 float *pack_out, int T, int B, int S0, int S1, float guard_eps, int precision, void *stream) {
+    AIR_REQUIRE(x && w && b && eps && q && loc && scale && sample && kl_parts && where && presence && pack_out, AIR_E_NULL);
+    AIR_REQUIRE((S0 == 0 || state0) && (S1 == 0 || state1), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && A > 0 && K > 0 && ldx >= K && S0 >= 0 && S1 >= 0, AIR_E_SHAPE);
+    AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+    WhatHeadArgs g;
+    g.x = x; g.w = w; g.b = b; g.eps = eps; g.q = q; g.loc = loc; g.scale = scale; g.what = sample; g.kl_parts = kl_parts; g.pack = pack_out;
+    g.where = where; g.presence = presence; g.s0 = state0; g.s1 = state1;
+    g.M = T * B; g.K = K; g.A = A; g.ldx = ldx; g.vecX = ((ldx % 4) == 0 && air_aligned16(x)) ? 1 : 0;
+    g.T = T; g.B = B; g.S0 = S0; g.S1 = S1;
+    g.tiles = air_cdiv(g.M, 16) * air_cdiv(A, 8);
+    g.raw_offset = raw_offset; g.pl = p_loc; g.ps = p_scale; g.guard = guard_eps;
+    const size_t n_pack = (size_t)B * (T * 5 + S0 + S1);
+    int pb = (int)((n_pack + PW_THREADS - 1) / PW_THREADS);
+    if (pb > 256) pb = 256;
+    if (pb < 1) pb = 1;
+    if (precision == AIR_PREC_BF16) hipLaunchKernelGGL((what_head_kernel<true>), dim3(g.tiles + pb), dim3(256), 0, air_stream(stream), g);
+    else hipLaunchKernelGGL((what_head_kernel<false>), dim3(g.tiles + pb), dim3(256), 0, air_stream(stream), g);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 // ---- throughput regime (more than 512 tiles of 16 x 16): the same fusion on the wide-tile scheme ---------------------------
@@ -2261,6 +2473,38 @@ extern "C" int air_lstm_step_fwd_prologue(const float *h0, const float *c0, cons
     const int extra = prologue_blocks(pro);
     return precision == AIR_PREC_BF16 ? lstm_fwd_launch<true>(g, pro, extra, air_stream(stream))
                                       : lstm_fwd_launch<false>(g, pro, extra, air_stream(stream));
+}
+
+// air_lstm_step_fwd_prologue with the hoisted input product x . W_x + b folded in (lstm_fwd_first_kernel): latency regime only --
+// AIR_E_UNSUPPORTED beyond 512 tiles of (batch, hidden), where the caller keeps the gx launch and the wide-tile first step.
+extern "C" int air_lstm_first_step_fwd(const float *x, int ldx, int E, const float *w_x, const float *b_gates, const float *h0,
+                                       const float *c0, const float *w_h, int ldw, float *gx_out, int ldgx, float *h, float *c,
+                                       float *gate_act, int M, int Hd, float forget_bias, int precision, float *normal,
+                                       size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
+                                       const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+                                       double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
+                                       float *h_tiled, float *c_tiled, void *stream) {
+    AIR_REQUIRE(x && w_x && b_gates && gx_out, AIR_E_NULL);
+    AIR_REQUIRE(rng_state_dev && global_step_dev && prior_out_f64 && h_tiled && c_tiled, AIR_E_NULL);
+    AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && anneal_type >= 0 && anneal_type <= 2 && E > 0 && ldx >= E, AIR_E_SHAPE);
+    AIR_REQUIRE(air_cdiv(M, 16) * air_cdiv(Hd, 16) <= 512, AIR_E_UNSUPPORTED);
+    LstmFwdArgs g;
+    int st = lstm_fwd_fill(g, h0, 0, c0, 0, w_h, ldw, gx_out, ldgx, h, c, gate_act, M, Hd, forget_bias, precision);
+    if (st) return st;
+    LstmFirstArgs f;
+    f.x = x; f.w_x = w_x; f.b = b_gates; f.gx_out = gx_out; f.E = E; f.ldx = ldx;
+    f.vecX = ((ldx % 4) == 0 && air_aligned16(x)) ? 1 : 0;
+    const PrologueArgs pro = make_prologue_args(normal, n_normal, uniform, n_uniform, rng_state_dev, global_step_dev,
+                                                anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
+                                                prior_out_f64, T, h0, c0, h_tiled, c_tiled, M, Hd);
+    const int extra = prologue_blocks(pro);
+    if (precision == AIR_PREC_BF16)
+        hipLaunchKernelGGL((lstm_fwd_first_kernel<true>), dim3(g.tiles + extra), dim3(256), 0, air_stream(stream), g, f, pro);
+    else
+        hipLaunchKernelGGL((lstm_fwd_first_kernel<false>), dim3(g.tiles + extra), dim3(256), 0, air_stream(stream), g, f, pro);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 template <bool BF>

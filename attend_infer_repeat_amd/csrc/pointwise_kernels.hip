@@ -154,6 +154,17 @@ extern "C" int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_
 // ---- reparameterised Gaussian + KL (cell.py:130-133,154-156; modules.py:17-24,41-46,58-63; model.py:174-209) ----
 #include "engine_device.h"
 #include "nvil_device.h"
+// The KL rows of a head whose forward left them as per-tile shares (air_what_head_fwd: kl_parts[n_parts][M]): the backward launch of
+// the same head adds the shares in tile order into kl_row_out[M] with ONE extra workgroup (the row sums are only consumed further down
+// the backward chain and by the read-outs).
+struct KlParts { const float *parts; float *out; int n_parts; };
+__device__ __forceinline__ void kl_parts_sum(const KlParts &kp, int M) {
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        float s = kp.parts[m];
+        for (int p = 1; p < kp.n_parts; ++p) s += kp.parts[(size_t)p * M + m];
+        kp.out[m] = s;
+    }
+}
 __global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
@@ -171,8 +182,10 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_kernel(const float *__re
                                                                const float *__restrict__ dsample,
                                                                const float *__restrict__ dsample2,
                                                                const float *__restrict__ dkl_row, float dkl_scale,
-                                                               float *__restrict__ dpre, int ld_dpre, int M, int D) {
-    gauss_bwd_body(blockIdx.x, gridDim.x, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
+                                                               float *__restrict__ dpre, int ld_dpre, int M, int D, KlParts kp) {
+    if (kp.n_parts > 0 && blockIdx.x == gridDim.x - 1) { kl_parts_sum(kp, M); return; }
+    const int vg = kp.n_parts > 0 ? gridDim.x - 1 : gridDim.x;
+    gauss_bwd_body(blockIdx.x, vg, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
                    dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
 }
 // the same launch with ONE extra workgroup (the first of the grid) that evaluates the NVIL objective (nvil_body): the two are
@@ -186,9 +199,12 @@ __global__ __launch_bounds__(PW_THREADS) void gauss_bwd_nvil_kernel(const float 
                                                                     const float *__restrict__ dsample,
                                                                     const float *__restrict__ dsample2,
                                                                     const float *__restrict__ dkl_row, float dkl_scale,
-                                                                    float *__restrict__ dpre, int ld_dpre, int M, int D, NvilArgs nv) {
+                                                                    float *__restrict__ dpre, int ld_dpre, int M, int D, NvilArgs nv,
+                                                                    KlParts kp) {
     if (blockIdx.x == 0) { nvil_body(nv); return; }
-    gauss_bwd_body(blockIdx.x - 1, gridDim.x - 1, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
+    if (kp.n_parts > 0 && blockIdx.x == gridDim.x - 1) { kl_parts_sum(kp, M); return; }
+    const int vg = (kp.n_parts > 0 ? gridDim.x - 1 : gridDim.x) - 1;
+    gauss_bwd_body(blockIdx.x - 1, vg, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale, dsample,
                    dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
 }
 extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
@@ -197,16 +213,19 @@ extern "C" int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const flo
                                          const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
                                          int ld_dpre, int M, int D, const float *imp_parts, int n_parts, float *imp_sum,
                                          const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                                         float *dbaseline, int B, float guard_eps, float *ema_dev, void *stream) {
+                                         float *dbaseline, int B, float guard_eps, float *ema_dev, const float *kl_parts, int n_kl_parts,
+                                         float *kl_row_out, void *stream) {
     AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
+    AIR_REQUIRE(n_kl_parts >= 0 && (n_kl_parts == 0 || (kl_parts && kl_row_out)), AIR_E_NULL);
     AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
     AIR_REQUIRE(imp_parts && baseline && logp && nvil_out, AIR_E_NULL);
     AIR_REQUIRE(B > 0 && n_parts > 0, AIR_E_SHAPE);
     const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts, imp_sum, ema_dev};
-    hipLaunchKernelGGL(gauss_bwd_nvil_kernel, dim3(pw_blocks((size_t)M * D) + 1), dim3(PW_THREADS), 0, air_stream(stream), pre,
-                       ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
-                       dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, nv);
+    const KlParts kp = {kl_parts, kl_row_out, n_kl_parts};
+    hipLaunchKernelGGL(gauss_bwd_nvil_kernel, dim3(pw_blocks((size_t)M * D) + 1 + (n_kl_parts > 0 ? 1 : 0)), dim3(PW_THREADS), 0,
+                       air_stream(stream), pre, ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even,
+                       p_loc_odd, p_scale_odd, loc, scale, dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, nv, kp);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -228,13 +247,16 @@ extern "C" int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *e
                                     float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                                     const float *loc, const float *scale, const float *dsample,
                                     const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
-                                    int ld_dpre, int M, int D, float guard_eps, void *stream) {
+                                    int ld_dpre, int M, int D, float guard_eps, const float *kl_parts, int n_kl_parts,
+                                    float *kl_row_out, void *stream) {
     AIR_REQUIRE(pre && loc && scale && dpre, AIR_E_NULL);
+    AIR_REQUIRE(n_kl_parts >= 0 && (n_kl_parts == 0 || (kl_parts && kl_row_out)), AIR_E_NULL);
     AIR_REQUIRE(!(dsample || dsample2) || eps, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && ld_dpre >= 2 * D, AIR_E_SHAPE);
-    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(pw_blocks((size_t)M * D)), dim3(PW_THREADS), 0, air_stream(stream), pre,
-                       ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale,
-                       dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
+    const KlParts kp = {kl_parts, kl_row_out, n_kl_parts};
+    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(pw_blocks((size_t)M * D) + (n_kl_parts > 0 ? 1 : 0)), dim3(PW_THREADS), 0,
+                       air_stream(stream), pre, ld_pre, eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even,
+                       p_loc_odd, p_scale_odd, loc, scale, dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, kp);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

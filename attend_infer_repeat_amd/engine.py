@@ -559,7 +559,16 @@ class AIREngine:
         enc_out, E = self.enc.out[-1], self.enc.shapes[-1][1]
         wg, bg = self.params["lstm/w_gates"], self.params["lstm/b_gates"]
         w_x, w_h = wg[:E], wg[E:]
-        if self.enc.n == 1:
+        # Round 5: in the latency regime the hoisted product gx = enc_out . W_x + b has no launch of its own -- the first LSTM step,
+        # whose recurrent operand is the one-row initial state, accumulates it next to h0 . W_h and writes gx for the later steps
+        # (air_lstm_first_step_fwd: same sums, same order, one dependent launch fewer).  Not when the first encoder layer is the
+        # only one (its K-split halves are reduced by the gx product's A-prologue) and not beyond the fused-step tile count.
+        fold_gx = (self.enc.n > 1 and ((B + 15) // 16) * ((Hd + 15) // 16) <= int(os.environ.get("AIR_FUSE_LSTM_TILES", "512"))
+                   and os.environ.get("AIR_FOLD_GX", "1") == "1")
+        self._fold_gx = fold_gx
+        if fold_gx:
+            pass
+        elif self.enc.n == 1:
             launch(fwd, [after_enc0(E, 4 * Hd, w_x, 4 * Hd, self.gx, bg, BIAS)])
         else:
             launch(fwd, [desc(0, 0, B, 4 * Hd, E, enc_out, E, w_x, 4 * Hd, self.gx, 4 * Hd, bias=bg, epi=BIAS)])
@@ -630,16 +639,37 @@ class AIREngine:
                         "air_st_read_fwd"))                                                 # cell.py:135
         mlp_fwd_multi(fwd, [(self.ge, self.glimpse_in, hw)])                                # cell.py:153
         ge_out, G = self.ge.out[-1], self.ge.shapes[-1][1]
-        launch(fwd, [desc(0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
-                          bias=self.params["what/b"], epi=BIAS)])                           # modules.py:20-21
         wp = cfg.what_prior
+        # Round 5, latency regime with REINFORCE: the whole `what` head -- the product q = ge_out . W + b, the sampling with its KL
+        # terms and the latent columns of the baseline input -- is ONE launch (air_what_head_fwd: a tile holds both halves of its
+        # (row, latent dim) pairs) instead of a GEMM launch + air_what_sample_pack.  The KL row of a sample spans several tiles: the
+        # tiles leave shares, the backward launch of the same head (air_gauss_sample_bwd*) adds them; a forward() on its own -- an
+        # evaluation pass -- adds them with a small launch of its own, which the train step drops.
+        what_head = (cfg.use_reinforce and not throughput and os.environ.get("AIR_FUSE_WHAT_HEAD", "1") == "1")
+        self._what_head = what_head
+        self._kl_parts_args = (None, 0, None)
+        if what_head:
+            n_kl = int(L.air_what_head_parts(A))
+            self.kl_what_parts = self._buf("kl_what_parts", (n_kl, M))
+            self._kl_parts_args = (p(self.kl_what_parts), n_kl, p(self.kl_what_row))
+            fwd.append((L.air_what_head_fwd, (p(ge_out), G, G, p(self.params["what/w"]), p(self.params["what/b"]), p(self.eps_what),
+                                              cfg.what_scale_offset, wp[0], wp[1], p(self.q), p(self.what_loc), p(self.what_scale),
+                                              p(self.what), p(self.kl_what_parts), A, p(self.where), p(self.presence),
+                                              p(self.h_seq[T]), p(self.c_seq[T]), p(self.base_lat), T, B, Hd, Hd,
+                                              float(cfg.guard_eps), prec), "air_what_head_fwd"))        # modules.py:20-21, cell.py:154-156
+            fwd.append((L.air_sum_leading, (p(self.kl_what_parts), p(self.kl_what_row), n_kl, ctypes.c_size_t(M)),
+                        "air_sum_leading:kl_what"))
+        else:
+            launch(fwd, [desc(0, 0, M, 2 * A, G, ge_out, G, self.params["what/w"], 2 * A, self.q, 2 * A,
+                              bias=self.params["what/b"], epi=BIAS)])                       # modules.py:20-21
         if cfg.use_reinforce:                                                               # model.py:218-259
             # sample `what` + assemble the latent columns of the baseline input in one launch
             KL = cfg.baseline_in - P
-            fwd.append((L.air_what_sample_pack, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, wp[0], wp[1],
-                                                 p(self.what_loc), p(self.what_scale), p(self.what), p(self.kl_what_row),
-                                                 A, p(self.where), p(self.presence), p(self.h_seq[T]), p(self.c_seq[T]),
-                                                 p(self.base_lat), T, B, Hd, Hd, float(cfg.guard_eps)), "air_what_sample_pack"))
+            if not what_head:
+                fwd.append((L.air_what_sample_pack, (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, wp[0], wp[1],
+                                                     p(self.what_loc), p(self.what_scale), p(self.what), p(self.kl_what_row),
+                                                     A, p(self.where), p(self.presence), p(self.h_seq[T]), p(self.c_seq[T]),
+                                                     p(self.base_lat), T, B, Hd, Hd, float(cfg.guard_eps)), "air_what_sample_pack"))
             n0 = self.bl.shapes[0][1]
             launch(fwd, [desc(0, 0, B, n0, KL, self.base_lat, KL, self.bl.w[0][P:], n0, self.bl.out[0], n0,
                               epi=ADDAUX_ELU if self.bl.n > 1 or not self.bl.last_linear else ADDAUX,
@@ -745,9 +775,9 @@ class AIREngine:
         gb_args = (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0], wp[1], wp[0], wp[1], p(self.what_loc),
                    p(self.what_scale), p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M, A)
         if fuse_canvas:
-            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B, float(cfg.guard_eps), ema_p), "air_gauss_sample_bwd_nvil"))
+            bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B, float(cfg.guard_eps), ema_p) + self._kl_parts_args, "air_gauss_sample_bwd_nvil"))
         else:
-            bwd.append((L.air_gauss_sample_bwd, gb_args + (float(cfg.guard_eps),), "air_gauss_sample_bwd"))
+            bwd.append((L.air_gauss_sample_bwd, gb_args + (float(cfg.guard_eps),) + self._kl_parts_args, "air_gauss_sample_bwd"))
         launch(bwd, [desc(1, 0, G, 2 * A, M, ge_out, G, self.dq, 2 * A, self.grads["what/w"], 2 * A,
                           colsum=self.grads["what/b"]),
                      desc(0, 1, M, G, 2 * A, self.dq, 2 * A, self.params["what/w"], 2 * A, self.ge.g[-1], G, epi=MDELU,
@@ -957,6 +987,16 @@ class AIREngine:
             of the first LSTM step, which then reads h0 / c0 with a broadcast row stride"""
             if not prologue_rides:
                 return [prologue(with_noise)] + fwd
+            pro_tail = (p(self.noise_normal), ctypes.c_size_t(n_norm if with_noise else 0), p(self.u_pres),
+                        ctypes.c_size_t(n_uni if with_noise else 0), p(self.rng_state), p(self.step_dev), anneal,
+                        float(cfg.nsp_init), float(cfg.nsp_final), float(cfg.nsp_steps), float(cfg.nsp_hold_init),
+                        float(cfg.nsp_steps_div), p(self.prior_dev), T, p(self.h_seq[0]), p(self.c_seq[0]))
+            if fold_gx:
+                lstm0 = (L.air_lstm_first_step_fwd,
+                         (p(enc_out), E, E, p(w_x), p(bg), p(self.params["lstm/h0"]), p(self.params["lstm/c0"]), p(w_h), 4 * Hd,
+                          p(self.gx), 4 * Hd, p(self.h_seq[1]), p(self.c_seq[1]), p(self.gate_act[0]), B, Hd, 1.0, prec) + pro_tail,
+                         "air_lstm_first_step_fwd")
+                return fwd[:lstm0_index] + [lstm0] + fwd[lstm0_index + 1:]
             lstm0 = (L.air_lstm_step_fwd_prologue,
                      (p(self.params["lstm/h0"]), p(self.params["lstm/c0"]), p(w_h), 4 * Hd, p(self.gx), 4 * Hd,
                       p(self.h_seq[1]), p(self.c_seq[1]), p(self.gate_act[0]), B, Hd, 1.0, prec,
@@ -969,7 +1009,8 @@ class AIREngine:
 
         self._plan_fwd_noise = pre_fwd + fwd_plan(True) + fwd_tail    # forward(): complete outputs
         self._plan_fwd = pre_fwd + fwd_plan(False) + fwd_tail
-        self._plan_fwd_train = pre_fwd + fwd_plan(True)               # train step: NVIL rides in the first backward launch
+        # train step: NVIL rides in the first backward launch, the `what` KL shares are added by the backward of that head
+        self._plan_fwd_train = [e for e in pre_fwd + fwd_plan(True) if e[2] != "air_sum_leading:kl_what"]
         if fuse_canvas:                                               # ... and the canvas forward IS the first backward launch
             assert self._plan_fwd_train[-1][2] == "air_canvas_unroll_fwd_banded"
             self._plan_fwd_train = self._plan_fwd_train[:-1]

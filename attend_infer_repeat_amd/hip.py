@@ -336,7 +336,7 @@ def gauss_sample_bwd(pre, eps, raw_offset, loc_mode, prior4, loc, scale, dsample
     a, b, c, d = (float(v) for v in prior4)
     _lib.check(lib().air_gauss_sample_bwd(_p(pre), ld, _p(eps), float(raw_offset), int(loc_mode), a, b, c, d, _p(loc),
                                           _p(scale), _p(_f32(dsample, "dsample")), None, _p(_f32(dkl_row, "dkl_row")),
-                                          1.0, _p(dpre), 2 * D, M, D, float(guard_eps), _stream()), "air_gauss_sample_bwd")
+                                          1.0, _p(dpre), 2 * D, M, D, float(guard_eps), None, 0, None, _stream()), "air_gauss_sample_bwd")
     return dpre
 
 

@@ -325,6 +325,10 @@ def gemm_roofline(eng, reps=50):
                 f = sum(2.0 * d.M * d.N * d.K for d in a[0])
             elif name in ("air_lstm_step_fwd", "air_lstm_step_fwd_prologue"):   # h[M,Hd] . W_h[Hd,4Hd], gate math fused
                 f = 2.0 * a[9] * a[10] * 4 * a[10]
+            elif name == "air_what_head_fwd":                      # ge_out[T*B,K] . W[K,2A], sampling fused
+                f = 2.0 * a[20] * a[21] * 2 * a[14] * a[2]
+            elif name == "air_lstm_first_step_fwd":                # x[M,E] . W_x[E,4Hd] + h0 . W_h, gate math fused
+                f = 2.0 * a[14] * 4 * a[15] * (a[2] + a[15])
             elif name == "air_lstm_step_bwd":                      # dgates[M,4Hd] . W_h^T
                 f = 2.0 * a[12] * a[13] * 4 * a[13]
             else:

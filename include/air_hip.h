@@ -206,6 +206,17 @@ int air_lstm_step_fwd_prologue(const float *h0, const float *c0, const float *w_
                                const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
                                double init, double final_value, double anneal_steps, double hold_for, double steps_div,
                                double *prior_out_f64, int T, float *h_tiled, float *c_tiled, void *stream);
+/* air_lstm_step_fwd_prologue with the hoisted input product folded in (cell.py:121-127: the image never changes, so gx = x . W_x + b
+ * is computed once): step 0's recurrent operand is the trainable initial state -- one row for the whole batch -- so this launch
+ * accumulates x[M,E](ldx) . w_x[E,4Hd](ldw) and h0[1,Hd] . w_h[Hd,4Hd](ldw) side by side, writes gx_out[M,4Hd](ldgx) = x . w_x +
+ * b_gates for the later steps and finishes step 0 on gx + h0 . w_h: the results of the gx launch + air_lstm_step_fwd_prologue it
+ * replaces, bit for bit.  Latency regime only: AIR_E_UNSUPPORTED beyond 512 tiles of 16 x 16 over (M, Hd).                    */
+int air_lstm_first_step_fwd(const float *x, int ldx, int E, const float *w_x, const float *b_gates, const float *h0,
+                            const float *c0, const float *w_h, int ldw, float *gx_out, int ldgx, float *h, float *c,
+                            float *gate_act, int M, int Hd, float forget_bias, int precision, float *normal, size_t n_normal,
+                            float *uniform, size_t n_uniform, const uint64_t *rng_state_dev, const int64_t *global_step_dev,
+                            int anneal_type, double init, double final_value, double anneal_steps, double hold_for,
+                            double steps_div, double *prior_out_f64, int T, float *h_tiled, float *c_tiled, void *stream);
 /* One BPTT link: dh = dgates_next[M,4Hd] . w_h[Hd,4Hd]^T + dh_a + dh_b (either may be NULL), then
  * air_lstm_pointwise_bwd of the step that gate_act / c_prev / c belong to -> dgates[M,4Hd], dc_prev[M,Hd]; and, if
  * dgx_out != NULL, dgx_out = dgx_in + dgates (the running sum over time that the hoisted x.W_x product receives;
@@ -290,6 +301,7 @@ int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float r
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          const float *loc, const float *scale, const float *dsample, const float *dsample2,
                          const float *dkl_row, float dkl_scale, float *dpre, int ld_dpre, int M, int D, float guard_eps,
+                         const float *kl_parts, int n_kl_parts, float *kl_row_out /* air_what_head_fwd's shares -> rows; 0: off */,
                          void *stream);
 /* air_gauss_sample_bwd with air_nvil_parts riding as one extra workgroup (arguments of both, in that order; B = batch).  */
 int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
@@ -297,7 +309,8 @@ int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, fl
                               const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
                               float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *imp_parts, int n_parts,
                               float *imp_sum, const float *baseline, const float *logp, float *nvil_out, float *dlogp,
-                              float *dbaseline, int B, float guard_eps, float *ema_dev, void *stream);
+                              float *dbaseline, int B, float guard_eps, float *ema_dev, const float *kl_parts, int n_kl_parts,
+                              float *kl_row_out, void *stream);
 
 /* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
  * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
@@ -409,6 +422,18 @@ int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float r
                          float *loc, float *scale, float *sample, float *kl_row, int D, const float *where,
                          const float *presence, const float *state0, const float *state1, float *pack_out,
                          int T, int B, int S0, int S1, float guard_eps, void *stream);
+
+/* The whole `what` head in ONE launch (modules.py:20-21 + cell.py:154-156 + the latent columns of modules.py:131-139): the
+ * product q[T*B, 2A] = x[T*B, K](ldx) . w[K, 2A] + b, then -- in the tile that formed both halves of a (row, latent dim) pair --
+ * loc, scale = softplus(raw + raw_offset), sample = loc + scale * eps (time-major [T*B, A] and batch-major into pack_out, as
+ * air_what_sample_pack), while extra workgroups copy the where / presence / state columns of pack_out.  The KL row of a sample spans
+ * air_what_head_parts(A) = ceil(A / 8) tiles: each writes its share to kl_parts[parts][T*B]; air_gauss_sample_bwd[_nvil] of the same
+ * head adds them in tile order (kl_parts / n_kl_parts / kl_row_out).  Replaces a GEMM launch + air_what_sample_pack.            */
+int air_what_head_parts(int A);
+int air_what_head_fwd(const float *x, int ldx, int K, const float *w, const float *b, const float *eps, float raw_offset,
+                      float p_loc, float p_scale, float *q, float *loc, float *scale, float *sample, float *kl_parts, int A,
+                      const float *where, const float *presence, const float *state0, const float *state1, float *pack_out,
+                      int T, int B, int S0, int S1, float guard_eps, int precision, void *stream);
 
 /* ---- "attend": fused engine launches around the glimpse read (cell.py:129-151, modules.py:104-109) ------------------
  * Forward, one launch: the output layers of the transform MLP (tr_h[T*B,tr_k] . tr_w[tr_k,8] + tr_b -> pre[T*B,8]) and of the

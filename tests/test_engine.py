@@ -678,6 +678,71 @@ def test_folded_closing_update_equals_closing_launch(gpu_device, monkeypatch, na
         assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
 
 
+@pytest.mark.parametrize("name", ["mnist_b8", "mnist_b64", "c4_b64", "enc512_b32", "tiny", "rect_t5", "t1_b5", "mnist_b17"])
+def test_first_step_with_folded_input_product_equals_two_launches(gpu_device, monkeypatch, name):
+    """Round 5: in the latency regime the hoisted product gx = enc_out . W_x + b rides in the FIRST LSTM step
+    (air_lstm_first_step_fwd: step 0's recurrent operand is the one-row initial state, so the tile accumulates both contractions
+    side by side) instead of a launch of its own: one dependent launch fewer, and -- same sums in the same order -- every buffer of
+    the step bit-identical to the plan with the separate gx launch (AIR_FOLD_GX=0), over graph-replayed updates."""
+    ocfg, B = CONFIGS[name]
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    monkeypatch.setenv("AIR_FOLD_GX", "0")
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert not eng_b._fold_gx
+    if len(ocfg.inpt_encoder_hidden) > 1:
+        assert eng_a._fold_gx and len(eng_a._plan_fwd_train) == len(eng_b._plan_fwd_train) - 1
+        assert any(n == "air_lstm_first_step_fwd" for _, _, n in eng_a._plan_fwd_train)
+    else:
+        assert not eng_a._fold_gx                            # (a single encoder layer: its K-split halves are reduced by the gx product)
+    for e in (eng_a, eng_b):
+        e.forward(sample_noise=False); e.backward(); e.synchronize()
+    for k in ("gx", "gate_act", "h_seq", "c_seq", "flat_grads", "final_canvas", "kl_what_row"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    eng_a.capture(); eng_b.capture()
+    for _ in range(3):
+        eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads", "noise_normal", "h_seq"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+
+
+@pytest.mark.parametrize("name", ["mnist_b8", "mnist_b64", "c4_b64", "tiny", "rect_t5", "t1_b5", "mnist_b17", "b1"])
+def test_what_head_in_one_launch_equals_product_plus_sampling(gpu_device, monkeypatch, name):
+    """Round 5: the `what` head of a latency-regime step -- q = ge_out . W + b, the reparameterised sample with its KL terms, the
+    latent columns of the baseline input -- is one launch (air_what_head_fwd) instead of a GEMM launch + air_what_sample_pack.
+    q, loc, scale, the sample and the baseline input are bit-identical to the two launches (same K split, same order); the KL rows
+    are the tiles' shares added in tile order instead of one 64-lane tree, so they -- and what depends on them -- agree to rounding.
+    A forward() on its own still leaves complete KL rows; three graph-replayed updates end within rounding of each other."""
+    ocfg, B = CONFIGS[name]
+    eng_a, params, obs, noise = make_pair(ocfg, B, seed=3, gstep=0)
+    monkeypatch.setenv("AIR_FUSE_WHAT_HEAD", "0")
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert eng_a._what_head and not eng_b._what_head
+    assert len(eng_a._plan_fwd_train) == len(eng_b._plan_fwd_train) - 1
+    for e in (eng_a, eng_b):
+        e.forward(sample_noise=False); e.synchronize()
+    for k in ("q", "what", "what_loc", "what_scale", "base_lat"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    assert l2_err(eng_a.kl_what_row, eng_b.kl_what_row) < 1e-6          # complete after forward() alone
+    oa, ob = eng_a.outputs(), eng_b.outputs()
+    for k in ("kl_what", "loss", "opt_loss", "final_canvas", "reinforce_loss"):
+        assert rel_err(oa[k], ob[k]) < 1e-6, k
+    for e in (eng_a, eng_b):
+        e.backward(); e.synchronize()
+    assert l2_err(eng_a.kl_what_row, eng_b.kl_what_row) < 1e-6          # ... and after the backward re-added the shares
+    for k in eng_a.grads:
+        assert l2_err(eng_a.grads[k], eng_b.grads[k]) < 2e-6, k
+    res, ref = O.forward_backward(f64(params), ocfg, obs.double(), f64(noise), global_step=0)
+    check_tensor("what_head", name, "out", "kl_what_per_sample", oa["kl_what_per_sample"], res["kl_what_per_sample"], OUT_TOL, OUT_L2)
+    eng_a.capture(); eng_b.capture()
+    for _ in range(3):
+        eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    assert torch.equal(eng_a.noise_normal, eng_b.noise_normal)
+    assert l2_err(eng_a.flat_params, eng_b.flat_params) < 1e-5
+    assert l2_err(eng_a.kl_what_row, eng_b.kl_what_row) < 1e-4          # (inside the train step only the backward adds the shares)
+
+
 @pytest.mark.parametrize("name", ["mnist_b8", "t1_b5"])
 def test_multi_step_replay_equals_single_steps(gpu_device, name):
     """capture(steps_per_replay=K): K consecutive updates in one graph replay, step j reading its batch from slot j of the
