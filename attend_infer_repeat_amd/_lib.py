@@ -40,6 +40,11 @@ class AirOptFold(ctypes.Structure):
                 ("global_step_dev", c_void_p), ("rng_state_dev", c_void_p), ("rng_increment", c_uint64)]
 
 
+class AirIpcPeers(ctypes.Structure):
+    """mirror of `struct AirIpcPeers` (include/air_hip.h)"""
+    _fields_ = [("world", c_int), ("rank", c_int), ("grads", c_void_p * 8), ("params", c_void_p * 8), ("flags", c_void_p * 8)]
+
+
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
 SIGNATURES = {
     "air_abi_version": (c_int, []),
@@ -153,6 +158,9 @@ SIGNATURES = {
     "air_comm_destroy": (c_int, [P]),
     "air_allreduce_sum": (c_int, [P, c_size_t, P, P]),
     "air_comm_last_error": (ctypes.c_char_p, []),
+    "air_dp_ipc_barrier": (c_int, [ctypes.POINTER(AirIpcPeers), c_int, P, P, P]),
+    "air_dp_ipc_rs_update_ag": (c_int, [ctypes.POINTER(AirIpcPeers), P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float,
+                                        P, P, c_uint64, P]),
     "air_stream_wait_event": (c_int, [P, P]),
     "air_graph_begin_capture": (c_int, [P]),
     "air_graph_end_capture": (c_int, [P, ctypes.POINTER(c_void_p)]),

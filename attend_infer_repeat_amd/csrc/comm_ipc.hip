@@ -1,0 +1,166 @@
+// Data-parallel step WITHOUT a library collective: reduce-scatter by direct peer reads, sharded centred RMSProp, all-gather by
+// direct peer writes -- three kernel nodes of the step's hipGraph over buffers the ranks of one node map into each other's
+// address space (hipIpc handles; point-to-point xGMI links between the eight GPUs of an MI355X node).
+//
+// Why: the 10.5 MB gradient bucket is small enough that an RCCL all-reduce is bound by its latency
+// floor and by a ring's per-link bandwidth, and it cannot start before the END of the backward for the 54 % of the bucket that
+// the BPTT chain finishes last.  Here rank r reads ITS 1/world shard of every peer's gradient buffer straight over the seven
+// links (every link carries 1/world of the bucket, all at once), sums the `world` values in RANK ORDER -- one rank computes each
+// element, so every replica receives bit-identical parameters by construction --, runs centred RMSProp on its shard only
+// (optimiser traffic per GPU / world: 94 MB -> 12 MB at 8 ranks) and writes the updated shard into every peer's parameter buffer.
+//
+// Ordering between ranks: a barrier kernel in front (every rank's gradients final and written back) and behind (every pushed
+// parameter landed).  A barrier is one workgroup per XCD: each performs a SYSTEM-scope release fence (writes its XCD's L2 back),
+// workgroup 0 exchanges monotone epochs with the peers through flag words in their memory, then every workgroup performs a
+// system-scope acquire fence (invalidates its XCD's L2: peer-written parameters / peer gradients read a step ago must not be
+// served stale).  Spins are BOUNDED: a peer that never arrives sets err_dev instead of hanging the GPU.
+//
+// Validated with two processes sharing one GPU (tests/test_engine.py::test_data_parallel_two_ranks_on_two_gpus[ipc-rsag]); no
+// multi-GPU node has been available.  RCCL protocols stay the default (distributed.py).
+#include "air_common.h"
+#include "optimizer_device.h"
+
+#define AIR_IPC_MAX_WORLD 8
+#define AIR_IPC_XCDS 8
+#define AIR_IPC_SPIN_LIMIT (1 << 24)
+
+struct IpcPeers {
+    int world, rank;
+    const float *grads[AIR_IPC_MAX_WORLD];
+    float *params[AIR_IPC_MAX_WORLD];
+    unsigned long long *flags[AIR_IPC_MAX_WORLD];         // flags[q]: rank q's flag block [2 barriers][AIR_IPC_MAX_WORLD]
+};
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// local[0..3]: {completed barriers of kind 0, of kind 1, arrivals of local workgroups (monotone), last released instance};
+// err[0] != 0 after a timeout.  Instance k (1-based, both kinds counted) of this rank's barriers waits for k * gridDim.x arrivals.
+__global__ __launch_bounds__(64) void ipc_barrier_kernel(IpcPeers pr, int which, unsigned long long *local, unsigned long long *err) {
+    const int tid = threadIdx.x;
+    __shared__ unsigned long long s_epoch, s_inst;
+    // every XCD: write back what its L2 holds (the kernels in front of this node ran on all of them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (tid == 0) {
+        // (read BEFORE this workgroup's arrival is counted: workgroup 0 advances them only after every workgroup has arrived)
+        const unsigned long long e0 = ld_sys(&local[0]), e1 = ld_sys(&local[1]);
+        s_epoch = (which ? e1 : e0) + 1;
+        s_inst = e0 + e1 + 1;
+        __hip_atomic_fetch_add(&local[2], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned long long epoch = s_epoch, inst = s_inst;
+    if (blockIdx.x == 0) {
+        bool ok = true;
+        if (tid == 0) {                                      // all local workgroups have released
+            int spin = 0;
+            while (__hip_atomic_load(&local[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < inst * gridDim.x && ++spin < AIR_IPC_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(2);
+            ok = spin < AIR_IPC_SPIN_LIMIT;
+        }
+        __syncthreads();
+        if (tid < pr.world) {
+            st_sys(&pr.flags[tid][which * AIR_IPC_MAX_WORLD + pr.rank], epoch);                 // tell every rank (incl. this one)
+            int spin = 0;
+            while (ld_sys(&pr.flags[pr.rank][which * AIR_IPC_MAX_WORLD + tid]) < epoch && ++spin < AIR_IPC_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
+            if (spin >= AIR_IPC_SPIN_LIMIT) ok = false;
+        }
+        if (!ok) st_sys(&err[0], 1ull);
+        __syncthreads();
+        if (tid == 0) {
+            st_sys(&local[which], epoch);
+            __hip_atomic_store(&local[3], inst, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // go
+        }
+    } else if (tid == 0) {
+        int spin = 0;
+        while (__hip_atomic_load(&local[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < inst && ++spin < AIR_IPC_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    // every XCD: drop what its L2 caches of memory another rank has written since
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// Rank r's shard of the flat buffers: float4 indices [q_lo, q_hi).  g = (sum over ranks, in rank order, of their gradient) * 1/world;
+// centred RMSProp on the local parameter / slots (optimizer_device.h: the same element function as every other update path);
+// the new parameter goes to EVERY rank's parameter buffer.  The step counter and the Philox offset advance here (every rank runs
+// this kernel once per step).
+struct IpcUpdateArgs {
+    float *ms, *mg, *mom;
+    size_t n_total, n_model;
+    const float *lr_dev;
+    float lr_mult_tail, decay, momentum, eps;
+    int64_t *gstep; uint64_t *rng_state; uint64_t rng_inc;
+};
+__global__ __launch_bounds__(256) void ipc_rs_update_ag_kernel(IpcPeers pr, IpcUpdateArgs u) {
+    const size_t nq = u.n_total >> 2;
+    const size_t per = (nq + pr.world - 1) / pr.world;
+    const size_t q_lo = per * pr.rank, q_hi = q_lo + per < nq ? q_lo + per : nq;
+    const float lr0 = u.lr_dev[0], gscale = 1.0f / (float)pr.world;
+    float4 *ms4 = reinterpret_cast<float4 *>(u.ms), *mg4 = reinterpret_cast<float4 *>(u.mg), *mom4 = reinterpret_cast<float4 *>(u.mom);
+    const float4 *p4 = reinterpret_cast<const float4 *>(pr.params[pr.rank]);
+    for (size_t q = q_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_hi; q += (size_t)gridDim.x * blockDim.x) {
+        float4 g = reinterpret_cast<const float4 *>(pr.grads[0])[q];
+        for (int s = 1; s < pr.world; ++s) {
+            const float4 o = reinterpret_cast<const float4 *>(pr.grads[s])[q];
+            g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+        }
+        const float lr = (q << 2) < u.n_model ? lr0 : lr0 * u.lr_mult_tail;
+        float4 pv = p4[q], a = ms4[q], b = mg4[q], c = mom4[q];
+        rmsprop_elem(pv.x, g.x, a.x, b.x, c.x, lr, u.decay, u.momentum, u.eps, gscale);
+        rmsprop_elem(pv.y, g.y, a.y, b.y, c.y, lr, u.decay, u.momentum, u.eps, gscale);
+        rmsprop_elem(pv.z, g.z, a.z, b.z, c.z, lr, u.decay, u.momentum, u.eps, gscale);
+        rmsprop_elem(pv.w, g.w, a.w, b.w, c.w, lr, u.decay, u.momentum, u.eps, gscale);
+        ms4[q] = a; mg4[q] = b; mom4[q] = c;
+        for (int s = 0; s < pr.world; ++s) reinterpret_cast<float4 *>(pr.params[s])[q] = pv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (u.gstep) u.gstep[0] += 1;
+        if (u.rng_state) u.rng_state[1] += u.rng_inc;
+    }
+}
+
+static int ipc_fill(IpcPeers &pr, const AirIpcPeers *p) {
+    AIR_REQUIRE(p, AIR_E_NULL);
+    AIR_REQUIRE(p->world >= 1 && p->world <= AIR_IPC_MAX_WORLD && p->rank >= 0 && p->rank < p->world, AIR_E_SHAPE);
+    pr.world = p->world; pr.rank = p->rank;
+    for (int s = 0; s < AIR_IPC_MAX_WORLD; ++s) {
+        const int j = s < p->world ? s : 0;
+        AIR_REQUIRE(p->grads[j] && p->params[j] && p->flags[j], AIR_E_NULL);
+        AIR_REQUIRE(air_aligned16(p->grads[j]) && air_aligned16(p->params[j]), AIR_E_ALIGN);
+        pr.grads[s] = p->grads[j]; pr.params[s] = p->params[j]; pr.flags[s] = (unsigned long long *)p->flags[j];
+    }
+    return AIR_OK;
+}
+extern "C" int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream) {
+    AIR_REQUIRE(local_dev && err_dev, AIR_E_NULL);
+    AIR_REQUIRE(which == 0 || which == 1, AIR_E_SHAPE);
+    IpcPeers pr;
+    int st = ipc_fill(pr, peers);
+    if (st) return st;
+    hipLaunchKernelGGL(ipc_barrier_kernel, dim3(AIR_IPC_XCDS), dim3(64), 0, air_stream(stream), pr, which,
+                       (unsigned long long *)local_dev, (unsigned long long *)err_dev);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+extern "C" int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+                                       const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps,
+                                       int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream) {
+    AIR_REQUIRE(ms && mg && mom && lr_dev, AIR_E_NULL);
+    AIR_REQUIRE(n_total > 0 && n_total % 4 == 0 && n_model % 4 == 0 && n_model <= n_total, AIR_E_SHAPE);
+    AIR_REQUIRE(air_aligned16(ms) && air_aligned16(mg) && air_aligned16(mom), AIR_E_ALIGN);
+    IpcPeers pr;
+    int st = ipc_fill(pr, peers);
+    if (st) return st;
+    IpcUpdateArgs u = {ms, mg, mom, n_total, n_model, lr_dev, lr_mult_tail, decay, momentum, eps, global_step_dev, rng_state_dev, rng_increment};
+    const size_t per = ((n_total >> 2) + pr.world - 1) / pr.world;
+    size_t blocks = (per + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ipc_rs_update_ag_kernel, dim3((int)blocks), dim3(256), 0, air_stream(stream), pr, u);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}

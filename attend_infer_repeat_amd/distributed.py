@@ -20,6 +20,13 @@ Where the collective runs (AIR_DP_COLLECTIVE / the `collective` argument):
                   round trip (+ AIR_DP_OVERLAP=1: the tail of the gradient buffer is reduced on a forked captured stream, on
                   a second communicator, while the backward finishes).  Opt-in: bit-equal to the single-GPU graph with one
                   rank on the GPU, but no multi-GPU node has been available to validate it on more than one.
+  "ipc-rsag"      (round 5, opt-in): NO library collective.  The ranks of one node map each other's flat gradient / parameter
+                  buffers (hipIpc, exchanged through torch.distributed) and the step's graph ends with three kernel nodes
+                  (csrc/comm_ipc.hip): barrier | rank r sums ITS 1/world shard of all ranks' gradients in rank order, runs centred
+                  RMSProp on that shard and writes the new parameters into every rank's buffer | barrier.  Replicas are
+                  bit-identical by construction (one rank computes each element), every xGMI link carries 1/world of the bucket
+                  at once, optimiser traffic per GPU drops by the world size, and the step stays ONE graph replay.  Validated
+                  with two processes on one GPU only -- hence not a default.  flat_grads keeps the rank's LOCAL gradient.
 The own communicator is created once from a unique id that rank 0 broadcasts through torch.distributed, after every rank has
 AGREED that RCCL can be bound (a rank that failed early would otherwise leave the others blocked inside ncclCommInitRank); the
 first use is an eager all-reduce of a small known buffer checked against the analytic sum, and any failure -- on any rank --
@@ -154,6 +161,59 @@ def selftest_comm(comm, device, stream, group=None) -> bool:
     return _agree(ok, device, group)
 
 
+class IpcPeerBuffers(object):
+    """The peer mapping of the "ipc-rsag" protocol: every rank exports its flat gradient buffer, its flat parameter buffer and a
+    block of flag words (torch's CUDA-IPC reductions: hipIpcGetMemHandle on the sender, hipIpcOpenMemHandle on the receiver; the
+    handles travel through torch.distributed), and keeps the opened peer tensors alive for as long as the captured graph holds
+    their addresses.  Collective over `group`; raises on the calling rank only -- the caller agrees on the outcome."""
+
+    def __init__(self, engine, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import _lib
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > 8:
+            raise _lib.AirHipError("ipc-rsag maps the ranks of ONE node: at most 8")
+        dev = engine.device
+        self.flags = torch.zeros(16, dtype=torch.int64, device=dev)           # [2 barriers][8 ranks]
+        self.local = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.err = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        mine = tuple(reduce_tensor(t) for t in (engine.flat_grads, engine.flat_params, self.flags))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=group)
+        self._keep = []
+        self.struct = _lib.AirIpcPeers()
+        self.struct.world, self.struct.rank = self.world, self.rank
+        for q in range(self.world):
+            if q == self.rank:
+                g, p_, f = engine.flat_grads, engine.flat_params, self.flags
+            else:
+                g, p_, f = (fn(*args) for fn, args in everyone[q])
+                if g.device != dev:                                             # another GPU of the node: peer access both ways
+                    if not torch.cuda.can_device_access_peer(dev.index, g.device.index):
+                        raise _lib.AirHipError("GPU %d cannot map GPU %d's memory" % (dev.index, g.device.index))
+                    _ = f[:1].to(dev)                                           # (torch enables peer access on the first P2P copy)
+                self._keep += [g, p_, f]
+            self.struct.grads[q], self.struct.params[q], self.struct.flags[q] = g.data_ptr(), p_.data_ptr(), f.data_ptr()
+        torch.cuda.synchronize(dev)
+
+    def plan(self, engine):
+        """the three launches that follow the backward in the step's graph"""
+        from . import hip as H
+        L, p, cfg = H.lib(), H._p, engine.cfg
+        peers = ctypes.byref(self.struct)
+        tail_mult = cfg.baseline_lr_mult if cfg.use_reinforce else 0.0
+        upd = (peers, p(engine.flat_ms), p(engine.flat_mg), p(engine.flat_mom), ctypes.c_size_t(engine.n_model),
+               ctypes.c_size_t(engine.n_total), p(engine.lr_dev), tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps,
+               p(engine.step_dev), p(engine.rng_state), ctypes.c_uint64(engine._rng_inc))
+        return [(L.air_dp_ipc_barrier, (peers, 0, p(self.local), p(self.err)), "air_dp_ipc_barrier"),
+                (L.air_dp_ipc_rs_update_ag, upd, "air_dp_ipc_rs_update_ag"),
+                (L.air_dp_ipc_barrier, (peers, 1, p(self.local), p(self.err)), "air_dp_ipc_barrier")]
+
+    def timed_out(self) -> bool:
+        return bool(self.err.item() != 0)
+
+
 class DataParallelEngine(object):
     """Wraps an AIREngine for multi-GPU data parallelism (one instance per process / GPU).
 
@@ -178,17 +238,46 @@ class DataParallelEngine(object):
         want = (collective or os.environ.get("AIR_DP_COLLECTIVE", "").strip().lower() or "torch-overlap")
         want = {"captured": "rccl-captured", "split": "torch-split", "torch": "torch-split", "rccl": "rccl-split",
                 "overlap": "torch-overlap"}.get(want, want)
-        if want not in ("torch-overlap", "torch-split", "rccl-split", "rccl-captured"):
-            raise ValueError("AIR_DP_COLLECTIVE / collective must be torch-overlap, torch-split, rccl-split or rccl-captured, "
-                             "got %r" % want)
+        want = {"ipc": "ipc-rsag"}.get(want, want)
+        if want not in ("torch-overlap", "torch-split", "rccl-split", "rccl-captured", "ipc-rsag"):
+            raise ValueError("AIR_DP_COLLECTIVE / collective must be torch-overlap, torch-split, rccl-split, rccl-captured or "
+                             "ipc-rsag, got %r" % want)
         if overlap is None:
             overlap = os.environ.get("AIR_DP_OVERLAP", "0") == "1"
         on_gpu = getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
         self.collective = "none"
         self.rccl_nranks = None
         self._comm_side = None
+        self._ipc = self._ipc_plan = None
         if self.world > 1:
             self.collective = "torch-split"
+            if on_gpu and want == "ipc-rsag":
+                # peer mapping + capture, each followed by an agreement: every rank ends up in the same protocol
+                ok = (getattr(engine, "_use16", False) is False and getattr(engine.cfg, "rms_centered", True)
+                      and engine.n_total % 4 == 0 and engine.n_model % 4 == 0)
+                try:
+                    if ok:
+                        self._ipc = IpcPeerBuffers(engine, group)
+                except Exception as e:                              # noqa: BLE001
+                    ok, self._ipc_error = False, repr(e)
+                if _agree(ok, engine.device, group):
+                    self._ipc_plan = self._ipc.plan(engine)
+                    good = True
+                    if capture_graph:
+                        try:
+                            engine.release_graphs()
+                            engine.synchronize()
+                            engine._graph = engine._capture_plans([engine._plan_fwd_train, engine._plan_bwd, self._ipc_plan])
+                            engine._graph_has_opt, engine._graph_b2, engine._steps_per_replay = True, None, 1
+                        except Exception as e:                      # noqa: BLE001
+                            good, self._ipc_error = False, repr(e)
+                    if _agree(good, engine.device, group):
+                        dist.barrier(group=group)                   # every rank's flags are mapped everywhere before anyone replays
+                        self.collective = "ipc-rsag"
+                        return
+                    engine.release_graphs()
+                self._ipc = self._ipc_plan = None
+                want = "torch-split"
             if on_gpu and want in ("rccl-split", "rccl-captured"):
                 # Every step below is collective and ends in an agreement, so all ranks leave it in the same protocol.
                 try:
@@ -246,6 +335,17 @@ class DataParallelEngine(object):
         return dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def train_step(self, obs=None):
+        if self.collective == "ipc-rsag":
+            eng = self.engine
+            if eng._graph is not None:
+                eng.train_step(obs)                         # ONE replay: forward, backward, barrier, shard update + push, barrier
+            else:
+                if obs is not None:
+                    eng.set_obs(obs)
+                for pl in (eng._plan_fwd_train, eng._plan_bwd, self._ipc_plan):
+                    eng._run(pl, eng._sp())
+                eng.global_step += 1
+            return
         host_collective = self.world > 1 and not self.collective.startswith("rccl-captured")
         if self.collective == "torch-overlap":
             self.engine.train_step(obs, allreduce=self._allreduce, allreduce_async=self._allreduce_async)
@@ -259,6 +359,10 @@ class DataParallelEngine(object):
         if self.world == 1:
             return True
         self.engine.synchronize()
+        if self._ipc is not None and self._ipc.timed_out():            # a peer never arrived at a barrier: nothing after it is valid
+            ok = False
+        else:
+            ok = True
         p = self.engine.flat_params
         # two order-independent 64-bit digests of the raw bits, compared through MIN / MAX over the ranks
         bits = p.view(torch.int32).to(torch.int64)
@@ -267,9 +371,14 @@ class DataParallelEngine(object):
         lo, hi = dig.clone(), dig.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-        return bool(torch.equal(lo, hi))
+        return bool(torch.equal(lo, hi)) and _agree(ok, self.engine.device, self.group)
 
     def close(self):
+        if self._ipc is not None:
+            self.engine.synchronize()
+            self.engine.release_graphs()
+            dist.barrier(group=self.group)                  # nobody unmaps while a peer may still be pushing
+            self._ipc = self._ipc_plan = None
         if self.comm is not None:
             from . import hip as H
             self.engine.synchronize()

@@ -767,6 +767,7 @@ def main():
                        # N > 1: every protocol timed in this invocation (the headline is the fastest one whose replicas ended bit-identical
                        # and finite), and the step's one collective on its own
                        "protocol_ab": ab, "protocol_note": note,
+                       "protocols_opt_in": None if world == 1 else "ipc-rsag (AIR_BENCH_PROTOCOLS=torch-overlap,ipc-rsag): validated with two processes on one GPU only",
                        "allreduce_us": ar["us"] if ar else None, "allreduce_bytes": ar["bytes"] if ar else None,
                        "allreduce_busbw_GBs": ar["busbw_GBs"] if ar else None,
                        # ranks as the communication layer itself reports them: ncclCommCount of the engine's own communicator
@@ -786,7 +787,12 @@ def main():
         state["line_holder"]["make"] = make_line
         ar = guarded("the bare gradient all-reduce", bare_allreduce, later_limit)
         state["allreduce"] = ar
-        extra = [x for x in os.environ.get("AIR_BENCH_PROTOCOLS", "torch-overlap").split(",") if x and x != "torch-split"]
+        # Protocols timed after the safe one.  "ipc-rsag" (round 5: barrier | shard sum + sharded RMSProp + parameter push | barrier as
+        # kernel nodes over hipIpc-mapped peer buffers, no library collective) has only ever run with two processes on ONE GPU; a
+        # wrong peer mapping on real multi-GPU hardware would be a GPU fault, which no watchdog survives -- so on real GPUs it is
+        # opt-in (AIR_BENCH_PROTOCOLS=torch-overlap,ipc-rsag) and the default run cannot lose its line to it.
+        default_protocols = "torch-overlap,ipc-rsag" if share_gpu else "torch-overlap"
+        extra = [x for x in os.environ.get("AIR_BENCH_PROTOCOLS", default_protocols).split(",") if x and x != "torch-split"]
         notes = []
         for proto in extra:
             rec = guarded(proto, lambda: run_protocol(proto), later_limit)

@@ -554,6 +554,27 @@ int air_comm_count(void *comm, int *count_out);   /* ncclCommCount: the number o
 int air_comm_destroy(void *comm);
 int air_allreduce_sum(float *buf, size_t n, void *comm, void *stream);
 const char *air_comm_last_error(void);
+
+/* Data-parallel update WITHOUT a library collective (csrc/comm_ipc.hip): the ranks of one node map each other's
+ * flat gradient / parameter buffers and a block of flag words (hipIpc; the caller exchanges the handles) and every step runs
+ *   air_dp_ipc_barrier(.., 0)  -- every rank's gradients final and written back --
+ *   air_dp_ipc_rs_update_ag    -- rank r sums ITS 1/world shard of all ranks' gradients in rank order, scales by 1/world, runs
+ *                                 centred RMSProp on that shard of its own p / ms / mg / mom (model.py:265,355-367) and writes the
+ *                                 new parameters into EVERY rank's parameter buffer; the step counter / Philox offset advance --
+ *   air_dp_ipc_barrier(.., 1)  -- every pushed parameter landed --
+ * as kernel nodes of the step's graph.  One rank computes each element: replicas are bit-identical by construction.
+ * flags[q]: rank q's block of 2 x 8 uint64 (zero-initialised); local_dev: 4 uint64 of this rank (zero-initialised); err_dev[0]
+ * becomes 1 when a peer did not arrive within the (bounded) spin.                                                              */
+typedef struct AirIpcPeers {
+    int world, rank;                   /* world <= 8 */
+    const float *grads[8];
+    float *params[8];
+    uint64_t *flags[8];
+} AirIpcPeers;
+int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream);
+int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+                            const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps,
+                            int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
 int air_stream_wait_event(void *stream, void *event);
 
 int air_graph_begin_capture(void *stream);

@@ -41,7 +41,8 @@ def test_bench_two_ranks_sharing_one_gpu(gpu_device, launcher):
     assert c["dist_world_size"] == 2
     # one invocation times the safe protocol, the bare collective and the overlapped protocol; the headline is the fastest VALIDATED one
     ab = c["protocol_ab"]
-    assert set(ab) == {"torch-split", "torch-overlap"}, ab
+    # (round 5: with the ranks sharing a GPU the hipIpc protocol -- no library collective -- is timed too; on real GPUs it is opt-in)
+    assert set(ab) == {"torch-split", "torch-overlap", "ipc-rsag"}, ab
     for name, r in ab.items():
         assert r["replicas_in_sync_after_run"] is True and r["params_finite_after_run"] is True and r["images_per_sec"] > 0, (name, r)
     assert c["collective"] in ab and d["value"] == max(r["images_per_sec"] for r in ab.values())

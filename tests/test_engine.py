@@ -928,17 +928,21 @@ def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
     dp = D.DataParallelEngine(eng, collective=collective)
     start = eng.flat_params.cpu().clone()
     # one step with the gradient read back before the update: split protocols expose it between the two graphs
-    for _ in range(3):
+    for _ in range(20 if collective in ("ipc-rsag",) or os.environ.get("AIR_TEST_DP_STEPS") else 3):
         dp.train_step()
     eng.synchronize()
+    in_sync = dp.replicas_in_sync()
+    assert in_sync, "replicas diverged under %s" % dp.collective
     torch.save(dict(start=start, params=eng.flat_params.cpu(), grads=eng.flat_grads.cpu(), collective=dp.collective,
-                    nranks=dp.rccl_nranks, noise=eng.eps_what.cpu()), os.path.join(out_dir, f"{collective}_{rank}.pt"))
+                    nranks=dp.rccl_nranks, noise=eng.eps_what.cpu(), steps=int(eng.step_dev.item()),
+                    timed_out=bool(dp._ipc.timed_out()) if dp._ipc is not None else False),
+               os.path.join(out_dir, f"{collective}_{rank}.pt"))
     dp.close()
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("collective", ["torch-overlap", "torch-split", "rccl-split", "rccl-captured"])
+@pytest.mark.parametrize("collective", ["torch-overlap", "torch-split", "rccl-split", "rccl-captured", "ipc-rsag"])
 def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     """The real thing where the box has it: min(device_count, 2) = 2 ranks, one process per GPU, each protocol of
     DataParallelEngine.  After three steps both replicas must hold IDENTICAL parameters (they started from rank 0's, every
@@ -948,7 +952,7 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     import socket
     import torch.multiprocessing as mp
     share_gpu = torch.cuda.device_count() < 2
-    if share_gpu and not collective.startswith("torch-"):
+    if share_gpu and collective.startswith("rccl-"):
         pytest.skip("the own-communicator protocols need two GPUs (RCCL refuses two ranks on one device)")
     # one GPU only: the host-issued protocol is still run for real -- two processes, two engines on GPU 0, gradients summed over
     # gloo -- so the data-parallel step (broadcast, split graphs, all-reduce in between, 1/world scaling) is exercised end to end
@@ -956,6 +960,25 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     mp.spawn(_dp_rank_main, args=(2, port, str(tmp_path), collective, share_gpu), nprocs=2, join=True)
     r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(2)]
     assert r[0]["collective"] == r[1]["collective"] == collective
+    if collective == "ipc-rsag":
+        # Round 5: no library collective -- the ranks map each other's buffers (hipIpc works between two
+        # processes on ONE device too) and the step's graph ends with barrier | shard sum + sharded RMSProp + parameter push | barrier.
+        # A two-rank sum has one order, so the parameters must be bit-equal to the plain two-graph protocol's; the replicas are
+        # identical by construction; flat_grads keeps each rank's LOCAL gradient (they differ, and sum to torch-split's).
+        port2 = port + 1 if port < 65000 else port - 1
+        os.environ["AIR_TEST_DP_STEPS"] = "20"                       # (the reference run takes the same twenty updates)
+        try:
+            mp.spawn(_dp_rank_main, args=(2, port2, str(tmp_path), "torch-split", share_gpu), nprocs=2, join=True)
+        finally:
+            del os.environ["AIR_TEST_DP_STEPS"]
+        ref = torch.load(os.path.join(tmp_path, "torch-split_0.pt"))
+        assert torch.equal(r[0]["start"], r[1]["start"]) and torch.equal(r[0]["start"], ref["start"])
+        assert torch.equal(r[0]["params"], r[1]["params"]) and torch.equal(r[0]["params"], ref["params"])
+        assert not torch.equal(r[0]["grads"], r[1]["grads"])
+        assert torch.equal(r[0]["grads"] + r[1]["grads"], ref["grads"])
+        assert r[0]["steps"] == r[1]["steps"] == ref["steps"] and not r[0]["timed_out"] and not r[1]["timed_out"]
+        assert not torch.equal(r[0]["noise"], r[1]["noise"])
+        return
     if collective == "torch-overlap":
         # the bucketed protocol (tail bucket reduced underneath the rest of the backward) must produce exactly what the plain
         # two-graph protocol produces: same launches, same sums (a two-rank sum has one order)
