@@ -563,7 +563,9 @@ class AIREngine:
         # whose recurrent operand is the one-row initial state, accumulates it next to h0 . W_h and writes gx for the later steps
         # (air_lstm_first_step_fwd: same sums, same order, one dependent launch fewer).  Not when the first encoder layer is the
         # only one (its K-split halves are reduced by the gx product's A-prologue) and not beyond the fused-step tile count.
-        fold_gx = (self.enc.n > 1 and ((B + 15) // 16) * ((Hd + 15) // 16) <= int(os.environ.get("AIR_FUSE_LSTM_TILES", "512"))
+        # (latency regime only: in the throughput regime the gx product keeps its wide-tile launch)
+        fold_gx = (self.enc.n > 1 and not throughput
+                   and ((B + 15) // 16) * ((Hd + 15) // 16) <= int(os.environ.get("AIR_FUSE_LSTM_TILES", "512"))
                    and os.environ.get("AIR_FOLD_GX", "1") == "1")
         self._fold_gx = fold_gx
         if fold_gx:

@@ -102,9 +102,11 @@ def test_engine_and_oracle_learning_curves_agree(gpu_device):
             late = [i for i, cp in enumerate(report["checkpoints"]) if cp >= 1000]
             mid, spread = 0.5 * (a[k] + b[k]), max(abs(e1[i][k] - e2[i][k]) for i in late)
             # ... capped: 4x the largest late spread alone could reach ~4.8 in kl_where and hide a real drift; the band
-            # never exceeds 2.5x the metric's floor, and never 4x the spread of the compared checkpoint's own neighbourhood (+-1)
+            # never exceeds 5x the metric's floor (3.0 for kl_where at values of 18-24: the oracle is a THIRD noise seed, and round 5
+            # measured it 2.2 from the mean of two engine seeds that sat 1.4 apart), and never 4x the spread of the compared
+            # checkpoint's own neighbourhood (+-1)
             near = max(abs(e1[i][k] - e2[i][k]) for i in range(max(c - 1, 0), min(c + 2, len(e1))))
-            band = max(floors[k], min(4.0 * spread, 2.5 * floors[k], max(floors[k], 4.0 * near)))
+            band = max(floors[k], min(4.0 * spread, 5.0 * floors[k], max(floors[k], 4.0 * near)))
             assert abs(o[k] - mid) <= band, (report["checkpoints"][c], k, o[k], a[k], b[k], band)
     # the annealed num-steps prior enters both identically: once it moves, the KL of the step count follows it to the digit
     assert abs(orc[-1]["kl_num_steps"] - e1[-1]["kl_num_steps"]) < 0.15
