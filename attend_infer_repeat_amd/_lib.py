@@ -45,6 +45,13 @@ class AirIpcPeers(ctypes.Structure):
     _fields_ = [("world", c_int), ("rank", c_int), ("grads", c_void_p * 8), ("params", c_void_p * 8), ("flags", c_void_p * 8)]
 
 
+class AirGaussBwdEpi(ctypes.Structure):
+    """mirror of `struct AirGaussBwdEpi` (include/air_hip.h)"""
+    _fields_ = [("problem", c_int), ("pre", c_void_p), ("ld_pre", c_int), ("eps", c_void_p), ("raw_offset", c_float),
+                ("p_loc", c_float), ("p_scale", c_float), ("loc", c_void_p), ("scale", c_void_p), ("dkl_row", c_void_p),
+                ("dkl_scale", c_float), ("dpre", c_void_p), ("ld_dpre", c_int), ("D", c_int), ("guard_eps", c_float)]
+
+
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
 SIGNATURES = {
     "air_abi_version": (c_int, []),
@@ -70,6 +77,8 @@ SIGNATURES = {
                               c_float, P, P, c_size_t, P]),
     "air_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "air_gemm_grouped": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, P]),
+    "air_gemm_grouped_gauss_bwd": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, ctypes.POINTER(AirGaussBwdEpi), P, c_int, P, P, P, P, P, P,
+                                           c_int, P, P, c_int, P, c_int, P]),
     "air_gemm_grouped_opt": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, ctypes.POINTER(AirOptFold), P]),
     "air_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "air_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),

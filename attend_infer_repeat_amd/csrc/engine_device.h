@@ -29,6 +29,7 @@ __device__ __forceinline__ float normal_kl(float mu, float s, float pm, float ps
 // is: -inf once s^2 underflows (s < 3.7e-23: the KL row itself is +inf there), NaN for s == 0.  The closed form would stay
 // finite down to s = 1e-38 and hide the blow-up the reference's arithmetic has (match, don't clamp).
 __device__ __forceinline__ float normal_kl_dscale(float dk, float s, float ps) {
+#pragma clang fp contract(off)
     const float ps2 = ps * ps;
     const float ratio = (s * s) / ps2;
     const float gr = 0.5f * dk - (0.5f * dk) / ratio;
@@ -81,6 +82,31 @@ __device__ __forceinline__ void gauss_fwd_body(int vblock, int vgrid, const floa
         if (kl_row && lane == 0) kl_row[m] = kl;
     }
 }
+// One (row, dim) element of a Gaussian head's backward: d pre_loc, d pre_raw from the sample gradient `ds` (has_ds), the row's KL
+// weight `dk`, the stored loc / scale and the raw scale (+ offset).  ONE function with contraction off, so that the stand-alone
+// launch (gauss_bwd_body) and the GEMM epilogue that folds it (gemm_kernels.hip, air_gemm_grouped_gauss_bwd) give the same bits.
+__device__ __forceinline__ void gauss_bwd_elem(float ds, bool has_ds, float eps, float mu, float s, float pm, float ps, float dk,
+                                               float raw, int loc_mode, int d, float guard, float &dloc, float &draw) {
+#pragma clang fp contract(off)
+    float dmu = ds + dk * kl_mean_diff(mu, pm) / (ps * ps);
+    const float dsc = (has_ds ? ds * eps : 0.f) + normal_kl_dscale(dk, s, ps);
+    if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
+    float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);                // d softplus
+    if (guard > 0.f && s <= guard) dsp = 0.f;                       // a floored scale passes no gradient
+    dloc = dmu;
+    draw = dsc * dsp;
+}
+// The KL rows of a head whose forward left them as per-tile shares (air_what_head_fwd: kl_parts[n_parts][M]): a later launch of the
+// same head adds the shares in tile order into kl_row_out[M] with ONE extra workgroup (the row sums are only consumed further down
+// the backward chain and by the read-outs).
+struct KlParts { const float *parts; float *out; int n_parts; };
+__device__ __forceinline__ void kl_parts_sum(const KlParts &kp, int M) {
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        float s = kp.parts[m];
+        for (int p = 1; p < kp.n_parts; ++p) s += kp.parts[(size_t)p * M + m];
+        kp.out[m] = s;
+    }
+}
 __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,
@@ -98,14 +124,11 @@ __device__ __forceinline__ void gauss_bwd_body(int vblock, int vgrid, const floa
         const float pm = (d & 1) ? pl1 : pl0, ps = (d & 1) ? ps1 : ps0;
         const float ds = (dsample ? dsample[e] : 0.f) + (dsample2 ? dsample2[e] : 0.f);
         const float dk = dkl_row ? dkl_row[m] * dkl_scale : 0.f;
-        float dmu = ds + dk * kl_mean_diff(mu, pm) / (ps * ps);
-        const float dsc = ((dsample || dsample2) ? ds * eps[e] : 0.f) + normal_kl_dscale(dk, s, ps);
-        if (loc_mode == 1) dmu *= (d & 1) ? (1.f - mu * mu) : mu * (1.f - mu);
-        const float raw = pre[m * ld_pre + D + d] + raw_offset.v;
-        float dsp = raw > 20.f ? 1.f : sigmoid_acc(raw);                // d softplus
-        if (raw_offset.guard > 0.f && s <= raw_offset.guard) dsp = 0.f; // a floored scale passes no gradient
-        dpre[m * ld_dpre + d] = dmu;
-        dpre[m * ld_dpre + D + d] = dsc * dsp;
+        float dloc, draw;
+        gauss_bwd_elem(ds, dsample || dsample2, (dsample || dsample2) ? eps[e] : 0.f, mu, s, pm, ps, dk,
+                       pre[m * ld_pre + D + d] + raw_offset.v, loc_mode, d, raw_offset.guard, dloc, draw);
+        dpre[m * ld_dpre + d] = dloc;
+        dpre[m * ld_dpre + D + d] = draw;
     }
 }
 

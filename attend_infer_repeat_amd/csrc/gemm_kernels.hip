@@ -17,6 +17,7 @@
 #include "prologue_device.h"
 #include "optimizer_device.h"
 #include "engine_device.h"
+#include "nvil_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // explicit global address space: descriptors that travel through memory (grouped launch) would otherwise make every
@@ -98,6 +99,16 @@ struct OptFold {
     size_t lo[AIR_OPT_MAX_RANGES], hi[AIR_OPT_MAX_RANGES];
     int64_t *gstep; uint64_t *rng_state; uint64_t rng_inc;
 };
+// the backward of a Gaussian head (loc_mode 0: the `what` head) folded into the epilogue of the product that forms its sample
+// gradient (the decoder's first-layer dX, d_what[T*B, D]): the tile's element (m, d) IS dsample[m, d], and the thread that finished it
+// writes dpre[m, d] and dpre[m, D + d] (engine_device.h gauss_bwd_elem) instead of storing it for a pointwise launch to re-read.
+struct GaussEpi {
+    const float *pre, *eps, *loc, *scale, *dkl_row;
+    float *dpre;
+    int ld_pre, ld_dpre, D;
+    float raw_offset, pl, ps, dkl_scale, guard;
+    unsigned mask;                                          // bit i: problem i carries the epilogue
+};
 struct GemmArgs {
     const float *A, *B, *bias, *aux;
     float *C, *colsum, *ws;
@@ -177,9 +188,10 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // MT x NT 16x16 MFMA tiles per wave.  KW = 4 / 16: the workgroup's KW waves split K for ONE tile (LDS reduce; 16
 // waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
-template <int MT, int NT, int KW, bool BF, bool APRO = false, bool OPT = false>
+template <int MT, int NT, int KW, bool BF, bool APRO = false, bool OPT = false, bool GBW = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split, const AproArgs pro = AproArgs(),
-                                          void *c16 = nullptr, const OptFold *opt = nullptr, const bool fold = false) {
+                                          void *c16 = nullptr, const OptFold *opt = nullptr, const bool fold = false,
+                                          const GaussEpi *gb = nullptr) {
     const gh_t hC = (gh_t)c16;             // bf16 mirror of C (bf16 data path: the next product reads it instead of the fp32 value)
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
@@ -234,6 +246,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
             e_bias[i] = (ok && g.bias != nullptr) ? gBias[n] : 0.f;
             e_aux[i] = (ok && g.epi >= AIR_EPI_MUL_DELU) ? gAux[(size_t)m * g.ldaux + n] : 0.f;
             e_c[i] = (ok && g.beta != 0.f) ? gC[(size_t)m * g.ldc + n] : 0.f;
+        }
+    }
+    // Gaussian-head backward in the epilogue: its operands are requested NOW as well
+    float b_loc[GBW ? EPT : 1], b_scale[GBW ? EPT : 1], b_eps[GBW ? EPT : 1], b_raw[GBW ? EPT : 1], b_dk[GBW ? EPT : 1];
+    if (GBW && KW > 1 && fold) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = threadIdx.x + NTH * i;
+            const int r = e / TN, cidx = e - r * TN;
+            const int m = m0 + r, n = n0 + cidx;
+            const bool ok = (e < TM * TN) && m < g.M && n < g.N;
+            const size_t o = ok ? (size_t)m * gb->D + n : 0;
+            b_loc[i] = ok ? ((gcf)gb->loc)[o] : 0.f;
+            b_scale[i] = ok ? ((gcf)gb->scale)[o] : 1.f;
+            b_eps[i] = ok ? ((gcf)gb->eps)[o] : 0.f;
+            b_raw[i] = ok ? ((gcf)gb->pre)[(size_t)m * gb->ld_pre + gb->D + n] : 0.f;
+            b_dk[i] = (ok && gb->dkl_row) ? ((gcf)gb->dkl_row)[m] : 0.f;
         }
     }
     // folded update: the element's parameter and RMSProp slots are requested NOW, with the operands (same flat offset as its gradient)
@@ -384,6 +413,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                 }
                 gC[(size_t)m * g.ldc + n] = v;
                 if (BF && hC) hC[(size_t)m * g.ldc + n] = bf16_bits(v);
+                if (GBW && fold) {                          // v = dsample[m, n] of the head: its pre-activation gradients, here
+                    float dloc, draw;
+                    gauss_bwd_elem(v, true, b_eps[i], b_loc[i], b_scale[i], gb->pl, gb->ps, b_dk[i] * gb->dkl_scale,
+                                   b_raw[i] + gb->raw_offset, 0, n, gb->guard, dloc, draw);
+                    const gf dp_ = (gf)gb->dpre + (size_t)m * gb->ld_dpre;
+                    dp_[n] = dloc; dp_[gb->D + n] = draw;
+                }
                 if (OPT && fold) {
                     const size_t idx = (size_t)((gC + (size_t)m * g.ldc + n) - (gf)opt->g0);
                     const float lr = idx < opt->n_model ? o_lr0 : o_lr0 * opt->lr_mult_tail;
@@ -1006,6 +1042,39 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_opt_kern
 #undef AIR_OPT_CASE
 }
 
+// gemm_grouped_kernel whose problem(s) of `gb.mask` finish a Gaussian head's backward in their epilogue, with up to two rider
+// workgroups behind the tiles: the NVIL objective (nvil_device.h; nv.imp == NULL: none) and the sum of the head's KL shares
+// (engine_device.h kl_parts_sum; kp.n_parts == 0: none) -- what air_gauss_sample_bwd_nvil did as a launch of its own
+template <int MT, int NT, int KW, bool BF>
+__global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_gb_kernel(GroupArgs ga, GaussEpi gb, NvilArgs nv, KlParts kp, int tiles,
+                                                                                  int kl_rows) {
+    if ((int)blockIdx.x >= tiles) {
+        const int r = (int)blockIdx.x - tiles;
+        if (r == 0 && nv.imp) nvil_body(nv);
+        else kl_parts_sum(kp, kl_rows);
+        return;
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+#define AIR_GB_CASE(I_)                                                                                                                  \
+    gemm_body<MT, NT, KW, BF, false, false, true>(ga.g[I_], (int)blockIdx.x - ga.tile_start[I_], blockIdx.y, AproArgs(), nullptr, nullptr,  \
+                                                  ((gb.mask >> I_) & 1u) != 0, &gb)
+    switch (p) {
+        case 0: AIR_GB_CASE(0); break;
+        case 1: AIR_GB_CASE(1); break;
+        case 2: AIR_GB_CASE(2); break;
+        case 3: AIR_GB_CASE(3); break;
+        case 4: AIR_GB_CASE(4); break;
+        case 5: AIR_GB_CASE(5); break;
+        case 6: AIR_GB_CASE(6); break;
+        default: AIR_GB_CASE(7); break;
+    }
+#undef AIR_GB_CASE
+}
+
 struct C16Ptrs { void *p[AIR_GEMM_GROUP_MAX]; };
 template <int MT, int NT, int KW>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_c16_kernel(GroupArgs ga, C16Ptrs c16) {
@@ -1507,6 +1576,62 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     }
 #undef AIR_SINGLE_LAUNCH
 #undef AIR_GROUP_LAUNCH
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// air_gemm_grouped with the backward of a Gaussian head (loc_mode 0) in the epilogue of problem `gb->problem` + NVIL / KL-share riders
+// (include/air_hip.h).  Latency-regime tile kernels only.
+extern "C" int air_gemm_grouped_gauss_bwd(const AirGemmDesc *descs, int count, const AirGaussBwdEpi *e, const float *imp_parts,
+                                          int n_parts, float *imp_sum, const float *baseline, const float *logp, float *nvil_out,
+                                          float *dlogp, float *dbaseline, int B, float *ema_dev, const float *kl_parts,
+                                          int n_kl_parts, float *kl_row_out, int kl_rows, void *stream) {
+    AIR_REQUIRE(descs && e, AIR_E_NULL);
+    AIR_REQUIRE(count > 0 && count <= AIR_GEMM_GROUP_MAX && e->problem >= 0 && e->problem < count, AIR_E_SHAPE);
+    AIR_REQUIRE(e->pre && e->eps && e->loc && e->scale && e->dpre && e->D > 0 && e->ld_pre >= 2 * e->D && e->ld_dpre >= 2 * e->D, AIR_E_NULL);
+    AIR_REQUIRE(!imp_parts || (baseline && logp && nvil_out && B > 0 && n_parts > 0), AIR_E_NULL);
+    AIR_REQUIRE(n_kl_parts >= 0 && (n_kl_parts == 0 || (kl_parts && kl_row_out && kl_rows > 0)), AIR_E_NULL);
+    {
+        const AirGemmDesc &d = descs[e->problem];          // the product that forms dsample[M, D]
+        AIR_REQUIRE(d.N == e->D && d.beta == 0.f && d.epilogue == AIR_EPI_NONE && !d.colsum, AIR_E_UNSUPPORTED);
+    }
+    GroupArgs ga;
+    long tiles16 = 0;
+    for (int i = 0; i < count; ++i) tiles16 += (long)air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+    AIR_REQUIRE(tiles16 <= 1000, AIR_E_UNSUPPORTED);         // (beyond: the 32x32 / wide-tile dispatch of air_gemm_grouped -- no fold there)
+    int tiles = 0;
+    const bool bf = descs[0].precision == AIR_PREC_BF16;
+    bool long_k = true;
+    for (int i = 0; i < count; ++i) {
+        const AirGemmDesc &d = descs[i];
+        AIR_REQUIRE(d.precision == AIR_PREC_F32 || d.precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
+        AIR_REQUIRE((d.precision == AIR_PREC_BF16) == bf && !d.A2 && !d.C16, AIR_E_UNSUPPORTED);
+        int st = fill_gemm_args(ga.g[i], d);
+        if (st) return st;
+        ga.tile_start[i] = tiles;
+        tiles += air_cdiv(d.M, 16) * air_cdiv(d.N, 16);
+        long_k = long_k && d.K >= 512 && d.K >= 8 * (d.M < d.N ? d.M : d.N);
+    }
+    for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
+    for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
+    ga.count = count;
+    ga.xcd_map = 0;
+    GaussEpi gb;
+    gb.pre = e->pre; gb.eps = e->eps; gb.loc = e->loc; gb.scale = e->scale; gb.dkl_row = e->dkl_row; gb.dpre = e->dpre;
+    gb.ld_pre = e->ld_pre; gb.ld_dpre = e->ld_dpre; gb.D = e->D; gb.raw_offset = e->raw_offset; gb.pl = e->p_loc; gb.ps = e->p_scale;
+    gb.dkl_scale = e->dkl_scale; gb.guard = e->guard_eps; gb.mask = 1u << e->problem;
+    const NvilArgs nv = {imp_parts, baseline, logp, nvil_out, dlogp, dbaseline, B, n_parts > 0 ? n_parts : 1, imp_sum, ema_dev};
+    const KlParts kp = {kl_parts, kl_row_out, n_kl_parts};
+    const int riders = (imp_parts ? 1 : 0) + (n_kl_parts > 0 ? 1 : 0);
+    // (rider 0 is NVIL when there is one; the KL-share sum is the other -- or the only -- rider)
+    hipStream_t st = air_stream(stream);
+#define AIR_GB_LAUNCH(KW_, NTH_)                                                                                                   \
+    do {                                                                                                                           \
+        if (bf) hipLaunchKernelGGL((gemm_grouped_gb_kernel<1, 1, KW_, true>), dim3(tiles + riders), dim3(NTH_), 0, st, ga, gb, nv, kp, tiles, kl_rows);  \
+        else hipLaunchKernelGGL((gemm_grouped_gb_kernel<1, 1, KW_, false>), dim3(tiles + riders), dim3(NTH_), 0, st, ga, gb, nv, kp, tiles, kl_rows);   \
+    } while (0)
+    if (long_k) AIR_GB_LAUNCH(16, 1024); else AIR_GB_LAUNCH(4, 256);
+#undef AIR_GB_LAUNCH
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

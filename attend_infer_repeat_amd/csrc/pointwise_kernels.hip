@@ -154,17 +154,6 @@ extern "C" int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_
 // ---- reparameterised Gaussian + KL (cell.py:130-133,154-156; modules.py:17-24,41-46,58-63; model.py:174-209) ----
 #include "engine_device.h"
 #include "nvil_device.h"
-// The KL rows of a head whose forward left them as per-tile shares (air_what_head_fwd: kl_parts[n_parts][M]): the backward launch of
-// the same head adds the shares in tile order into kl_row_out[M] with ONE extra workgroup (the row sums are only consumed further down
-// the backward chain and by the read-outs).
-struct KlParts { const float *parts; float *out; int n_parts; };
-__device__ __forceinline__ void kl_parts_sum(const KlParts &kp, int M) {
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        float s = kp.parts[m];
-        for (int p = 1; p < kp.n_parts; ++p) s += kp.parts[(size_t)p * M + m];
-        kp.out[m] = s;
-    }
-}
 __global__ __launch_bounds__(PW_THREADS) void gauss_fwd_kernel(const float *__restrict__ pre, int ld_pre,
                                                                const float *__restrict__ eps, RawOffset raw_offset,
                                                                int loc_mode, float pl0, float ps0, float pl1, float ps1,

@@ -776,7 +776,28 @@ class AIREngine:
         marks = [] if fuse_canvas else [(len(bwd), "glimpse_decoder/0/w")]   # gradients of [glimpse_decoder .. baseline] are final here
         gb_args = (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0], wp[1], wp[0], wp[1], p(self.what_loc),
                    p(self.what_scale), p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M, A)
-        if fuse_canvas:
+        # Round 5, latency regime: the backward of the `what` head needs no launch of its own -- the decoder's first-layer dX IS its
+        # sample gradient, so the thread that finishes d_what[m, a] writes dq[m, a] and dq[m, A + a] in the same epilogue
+        # (air_gemm_grouped_gauss_bwd), and NVIL / the sum of the head's KL shares ride behind the tiles of that launch.
+        self._fold_gauss_bwd = False
+        last = bwd[-1]
+        if (not throughput and os.environ.get("AIR_FUSE_GAUSS_BWD", "1") == "1" and last[2] == "air_gemm_grouped"
+                and sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in last[1][0]) <= 1000):
+            arr, n_d = last[1]
+            which = [i for i in range(n_d) if arr[i].C == self.d_what.data_ptr() and not arr[i].ta and arr[i].N == A
+                     and arr[i].epilogue == NONE and arr[i].beta == 0.0 and not arr[i].colsum]
+            if len(which) == 1:
+                epi = _lib.AirGaussBwdEpi(which[0], dp(self.q), 2 * A, dp(self.eps_what), cfg.what_scale_offset, wp[0], wp[1],
+                                          dp(self.what_loc), dp(self.what_scale), dp(self.step_w), pw * inv_b, dp(self.dq), 2 * A, A,
+                                          float(cfg.guard_eps))
+                self._keep.append(epi)
+                nv = (nvil_args + (B, ema_p)) if fuse_canvas else (None, 0, None, None, None, None, None, None, 0, None)
+                bwd[-1] = (L.air_gemm_grouped_gauss_bwd, (arr, n_d, ctypes.byref(epi)) + nv + self._kl_parts_args + (M,),
+                           "air_gemm_grouped_gauss_bwd")
+                self._fold_gauss_bwd = True
+        if self._fold_gauss_bwd:
+            pass
+        elif fuse_canvas:
             bwd.append((L.air_gauss_sample_bwd_nvil, gb_args + nvil_args + (B, float(cfg.guard_eps), ema_p) + self._kl_parts_args, "air_gauss_sample_bwd_nvil"))
         else:
             bwd.append((L.air_gauss_sample_bwd, gb_args + (float(cfg.guard_eps),) + self._kl_parts_args, "air_gauss_sample_bwd"))

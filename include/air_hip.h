@@ -235,6 +235,27 @@ typedef struct AirRmspropSlice {
     const float *lr_dev;
     float lr_mult_tail, decay, momentum, eps, grad_scale;
 } AirRmspropSlice;
+/* air_gemm_grouped with the backward of a Gaussian head folded into the product that forms its sample gradient (latency regime):
+ * problem `problem` of the group is dsample[M, D] = g . W^T (the decoder's first-layer dX for the `what` head, cell.py:154-158); the
+ * thread that finishes element (m, d) writes dpre[m, d] and dpre[m, D + d] exactly as air_gauss_sample_bwd (loc_mode 0, one prior)
+ * would from the stored value.  Two optional riders behind the tiles: air_nvil_parts (imp_parts == NULL: none) and the sum of the
+ * head's KL shares (n_kl_parts == 0: none; kl_rows = T*B) -- together what the launch air_gauss_sample_bwd_nvil did.  Groups beyond
+ * ~1000 16x16 tiles are declined (AIR_E_UNSUPPORTED).                                                                       */
+typedef struct AirGaussBwdEpi {
+    int problem;
+    const float *pre; int ld_pre;
+    const float *eps;
+    float raw_offset, p_loc, p_scale;
+    const float *loc, *scale, *dkl_row;
+    float dkl_scale;
+    float *dpre; int ld_dpre;
+    int D;
+    float guard_eps;
+} AirGaussBwdEpi;
+int air_gemm_grouped_gauss_bwd(const AirGemmDesc *descs, int count, const AirGaussBwdEpi *epi, const float *imp_parts, int n_parts,
+                               float *imp_sum, const float *baseline, const float *logp, float *nvil_out, float *dlogp,
+                               float *dbaseline, int B, float *ema_dev, const float *kl_parts, int n_kl_parts, float *kl_row_out,
+                               int kl_rows, void *stream);
 /* air_gemm_grouped with the closing update of the train step folded in (single GPU, latency regime; model.py:355-367 + the weight
  * gradients of the first layers): the problems of `fold_mask` are plain weight gradients (ta = 1, beta = 0, no epilogue) whose C /
  * colsum point INTO the flat gradient buffer `g`; every element they finish is written to `g` as before and, in the same epilogue,

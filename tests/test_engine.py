@@ -743,6 +743,37 @@ def test_what_head_in_one_launch_equals_product_plus_sampling(gpu_device, monkey
     assert l2_err(eng_a.kl_what_row, eng_b.kl_what_row) < 1e-4          # (inside the train step only the backward adds the shares)
 
 
+@pytest.mark.parametrize("name", ["mnist_b8", "mnist_b64", "tiny", "rect_t5", "t1_b5", "mnist_b17", "b1"])
+def test_what_head_backward_in_the_decoder_epilogue_equals_its_own_launch(gpu_device, monkeypatch, name):
+    """Round 5: the backward of the `what` head (air_gauss_sample_bwd_nvil: d q from d what, the KL weights and the stored loc / scale,
+    with NVIL and the KL-share sum riding) is folded into the launch that forms d what -- the decoder's first-layer dX writes dq from
+    its epilogue, NVIL and the share sum ride behind its tiles (air_gemm_grouped_gauss_bwd).  One element function serves both forms:
+    every gradient, the NVIL scalars and the KL rows are BIT-identical to the plan with the separate launch, eagerly and over
+    graph-replayed updates; one launch fewer."""
+    ocfg, B = CONFIGS[name]
+    eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    monkeypatch.setenv("AIR_FUSE_GAUSS_BWD", "0")
+    eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+    assert not eng_b._fold_gauss_bwd
+    if name.startswith("mnist"):
+        assert eng_a._fold_gauss_bwd
+    if eng_a._fold_gauss_bwd:
+        assert len(eng_a._plan_bwd) == len(eng_b._plan_bwd) - 1
+        assert not any(n.startswith("air_gauss_sample_bwd") for _, _, n in eng_a._plan_bwd)
+    # (plans whose last decoder launch also carries the baseline's first-layer weight gradients -- no fused canvas launch -- or that
+    #  exceed the 16x16-tile dispatch keep the launch of their own: the comparison below then checks two identical plans)
+    for e in (eng_a, eng_b):
+        e.forward(sample_noise=False); e.backward(); e.synchronize()
+    for k in ("dq", "flat_grads", "nvil_out", "dlogp", "dbase", "kl_what_row", "rec"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+    eng_a.capture(); eng_b.capture()
+    for _ in range(3):
+        eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    for k in ("flat_params", "flat_ms", "flat_mg", "flat_mom", "flat_grads", "nvil_out", "kl_what_row"):
+        assert torch.equal(getattr(eng_a, k), getattr(eng_b, k)), k
+
+
 @pytest.mark.parametrize("name", ["mnist_b8", "t1_b5"])
 def test_multi_step_replay_equals_single_steps(gpu_device, name):
     """capture(steps_per_replay=K): K consecutive updates in one graph replay, step j reading its batch from slot j of the
