@@ -97,16 +97,12 @@ def test_engine_and_oracle_learning_curves_agree(gpu_device):
                 assert o["rec_loss"] < orc[c - 1]["rec_loss"] and a["rec_loss"] < e1[c - 1]["rec_loss"]
             continue
         for k in KEYS:
-            # seed-to-seed spread: the largest over the late checkpoints (two curves can cross: at one checkpoint of the round-4 run
-            # the two engine seeds sat 0.006 apart in kl_where while they were 1.2 apart 250 and 500 updates earlier)
-            late = [i for i, cp in enumerate(report["checkpoints"]) if cp >= 1000]
-            mid, spread = 0.5 * (a[k] + b[k]), max(abs(e1[i][k] - e2[i][k]) for i in late)
-            # ... capped: 4x the largest late spread alone could reach ~4.8 in kl_where and hide a real drift; the band
-            # never exceeds 5x the metric's floor (3.0 for kl_where at values of 18-24: the oracle is a THIRD noise seed, and round 5
-            # measured it 2.2 from the mean of two engine seeds that sat 1.4 apart), and never 4x the spread of the compared
-            # checkpoint's own neighbourhood (+-1)
-            near = max(abs(e1[i][k] - e2[i][k]) for i in range(max(c - 1, 0), min(c + 2, len(e1))))
-            band = max(floors[k], min(4.0 * spread, 5.0 * floors[k], max(floors[k], 4.0 * near)))
-            assert abs(o[k] - mid) <= band, (report["checkpoints"][c], k, o[k], a[k], b[k], band)
+            # The oracle (a THIRD noise seed) must lie inside the band the engine's own two seeds span, widened by 3x the metric's
+            # floor on either side.  (Rounds 3-4 compared it with the MIDPOINT of the two seeds under a band of 4x their largest late
+            # spread -- ADVICE r04: up to 4.8 in kl_where, a real drift could hide in it; a midpoint is also meaningless when the two
+            # REINFORCE trajectories part ways: round 5 saw rec_loss -528 / -380 at update 1000 with the oracle at -532.)
+            lo, hi = min(a[k], b[k]), max(a[k], b[k])
+            dist = max(0.0, lo - o[k], o[k] - hi)
+            assert dist <= 3.0 * floors[k], (report["checkpoints"][c], k, o[k], a[k], b[k], 3.0 * floors[k])
     # the annealed num-steps prior enters both identically: once it moves, the KL of the step count follows it to the digit
     assert abs(orc[-1]["kl_num_steps"] - e1[-1]["kl_num_steps"]) < 0.15
