@@ -136,6 +136,9 @@ SIGNATURES = {
     "air_step_prologue": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
                                   c_int, P]),
+    "air_step_prologue_cvt": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
+                                      c_int, P, P, c_size_t, P]),
     "air_batch_gather": (c_int, [P, ctypes.c_longlong, c_int, P, P, c_int, P, c_int, P, P]),
     "air_step_epilogue": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
                                   P, P, c_uint64, P]),

@@ -549,6 +549,38 @@ extern "C" int air_step_prologue(float *normal, size_t n_normal, float *uniform,
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
+// the prologue with the bf16 conversion of the observation batch riding as extra workgroups (bf16 data path, round 5: the two
+// independent tiny launches that opened the batch-1024 step are one)
+__global__ __launch_bounds__(PW_THREADS) void step_prologue_cvt_kernel(PrologueArgs a, int pro_blocks, const float4 *__restrict__ x,
+                                                                       uint2 *__restrict__ out, size_t nq) {
+    if ((int)blockIdx.x < pro_blocks) { step_prologue_body(a, blockIdx.x, pro_blocks); return; }
+    const size_t vb = blockIdx.x - pro_blocks, vg = gridDim.x - pro_blocks;
+    for (size_t q = vb * PW_THREADS + threadIdx.x; q < nq; q += vg * PW_THREADS) {
+        const float4 v = x[q];
+        const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.y) << 16);
+        const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.z) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.w) << 16);
+        out[q] = make_uint2(lo, hi);
+    }
+}
+extern "C" int air_step_prologue_cvt(float *normal, size_t n_normal, float *uniform, size_t n_uniform,
+                                     const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
+                                     double init, double final_value, double anneal_steps, double hold_for,
+                                     double steps_div, double *prior_out_f64, int T, const float *h0, const float *c0,
+                                     float *h_tiled, float *c_tiled, int B, int Hd, const float *x, void *x_bf16, size_t n_x,
+                                     void *stream) {
+    AIR_REQUIRE(rng_state_dev && global_step_dev && prior_out_f64 && h0 && c0 && h_tiled && c_tiled && x && x_bf16, AIR_E_NULL);
+    AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && Hd > 0 && anneal_type >= 0 && anneal_type <= 2 && n_x > 0 && n_x % 4 == 0, AIR_E_SHAPE);
+    AIR_REQUIRE(air_aligned16(x) && ((uintptr_t)x_bf16 % 8 == 0), AIR_E_ALIGN);
+    const PrologueArgs a = make_prologue_args(normal, n_normal, uniform, n_uniform, rng_state_dev, global_step_dev,
+                                              anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
+                                              prior_out_f64, T, h0, c0, h_tiled, c_tiled, B, Hd);
+    const int pb = prologue_blocks(a);
+    hipLaunchKernelGGL(step_prologue_cvt_kernel, dim3(pb + pw_blocks(n_x >> 2)), dim3(PW_THREADS), 0, air_stream(stream), a, pb,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<uint2 *>(x_bf16), n_x >> 2);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
 
 // epilogue: both centred-RMSProp updates (model segment [0, n_model) at lr, baseline segment at lr * lr_mult_tail) in
 //           one pass over the flat buffers, then the device counters (global step, Philox offset) advance.

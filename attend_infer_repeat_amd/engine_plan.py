@@ -717,6 +717,17 @@ class PlanMixin:
                      "air_lstm_step_fwd_prologue")
             return fwd[:lstm0_index] + [lstm0] + fwd[lstm0_index + 1:]
 
+        if pre_fwd and not prologue_rides and os.environ.get("AIR_FUSE_PROLOGUE_CVT", "1") == "1" and self.obs.numel() % 4 == 0:
+            # bf16 data path (round 5): the conversion of the observation batch rides in the step prologue -- the two independent tiny
+            # launches that opened the step are one (air_step_prologue_cvt)
+            cvt_tail = (p(self.obs), ctypes.c_void_p(self.obs16.data_ptr()), ctypes.c_size_t(self.obs.numel()))
+            plain_fwd_plan = fwd_plan
+
+            def fwd_plan(with_noise):                      # noqa: F811
+                pl = plain_fwd_plan(with_noise)
+                assert pl[0][2] == "air_step_prologue"
+                return [(L.air_step_prologue_cvt, pl[0][1] + cvt_tail, "air_step_prologue_cvt")] + pl[1:]
+            pre_fwd = []
         self._plan_fwd_noise = pre_fwd + fwd_plan(True) + fwd_tail    # forward(): complete outputs
         self._plan_fwd = pre_fwd + fwd_plan(False) + fwd_tail
         # train step: NVIL rides in the first backward launch, the `what` KL shares are added by the backward of that head

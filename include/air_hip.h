@@ -523,6 +523,13 @@ int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_u
                       const int64_t *global_step_dev, int anneal_type, double init, double final_value,
                       double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
                       const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, void *stream);
+/* air_step_prologue with air_f32_to_bf16(x -> x_bf16, n_x elements, n_x % 4 == 0) riding as extra workgroups (bf16 data path: the
+ * observation batch's mirror is refreshed at the start of every step).                                                        */
+int air_step_prologue_cvt(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
+                          const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+                          double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
+                          const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, const float *x,
+                          void *x_bf16, size_t n_x, void *stream);
 int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                       const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
                       int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
