@@ -816,6 +816,12 @@ class PlanMixin:
                 covered.append((coff, coff + d.N))
         if not mask:
             return
+        # the library declines (AIR_E_UNSUPPORTED) a group its wide-tile dispatch would take -- all weight gradients, K >= 256, more than
+        # AIR_GEMM_WIDE_MIN_TILES 16x16 tiles (a long batch at T = 1): such a plan keeps its closing launch
+        tiles16 = sum(((arr[i].M + 15) // 16) * ((arr[i].N + 15) // 16) for i in range(n))
+        if (tiles16 > int(os.environ.get("AIR_GEMM_WIDE_MIN_TILES", "1000")) and all(arr[i].ta and not arr[i].tb for i in range(n))
+                and min(arr[i].K for i in range(n)) >= 256):
+            return
         # any other problem of the launch must leave the head of the gradient buffer alone (and none reads parameters: the
         # operands of weight gradients are activations / gradients; a dX problem would read its layer's weights)
         p0, p1 = self.flat_params.data_ptr(), self.flat_params.data_ptr() + 4 * self.n_total
@@ -844,7 +850,6 @@ class PlanMixin:
         for j, (lo, hi) in enumerate(ranges):
             fold.range_lo[j], fold.range_hi[j] = lo, hi
         fold.global_step_dev, fold.rng_state_dev, fold.rng_increment = dp(self.step_dev), dp(self.rng_state), self._rng_inc
-        # (a dry run of the argument checks: a group the library's wide-tile dispatch would take is declined there)
         self._keep.append(fold)
         self._fold = fold
         riders = list(riders)

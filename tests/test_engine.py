@@ -98,6 +98,9 @@ CONFIGS = {
     # configs[3] (100x100 canvas, 28x28 glimpse, T=5) at the same batch
     "mnist_b64": (O.AIRConfig(), 64),
     "c4_b64": (O.AIRConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5), 64),
+    # one step at batch 512: 512 rows keep the LATENCY plan while the closing weight-gradient group (K = 512, thousands of tiles) is one
+    # the library's wide-tile dispatch takes -- the folded closing update must step aside instead of failing at the first launch
+    "t1_b512": (O.AIRConfig(max_steps=1), 512),
 }
 
 
@@ -622,7 +625,7 @@ def test_optimizer_riders_equal_closing_update(gpu_device, monkeypatch, name):
     assert eng_a.step_dev.item() == eng_b.step_dev.item() == 3
 
 
-@pytest.mark.parametrize("name", ["mnist_b8", "mnist_b64", "c4_b64", "enc512_b32", "tiny", "rect_t5", "t1_b5"])
+@pytest.mark.parametrize("name", ["mnist_b8", "mnist_b64", "c4_b64", "enc512_b32", "tiny", "rect_t5", "t1_b5", "t1_b512"])
 def test_folded_closing_update_equals_closing_launch(gpu_device, monkeypatch, name):
     """Round 5: the closing air_step_epilogue of the single-GPU latency-regime step is folded into the LAST
     backward launch -- its weight-gradient tiles apply centred RMSProp to the elements they finish (air_gemm_grouped_opt), rider
