@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 7  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 8  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -65,11 +65,14 @@ SIGNATURES = {
                                       c_float, P]),
     "air_canvas_unroll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_float, c_float, P]),
+    "air_canvas_unroll_bwd_dpresence": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                                c_float, c_float, P]),
     "air_canvas_unroll_bwd_nvil": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                            c_float, c_float, P, c_int, P, P, P, P, P, P, P, P]),
     "air_canvas_unroll_bands": (c_int, [c_int, c_int]),
     "air_canvas_unroll_fwd_banded": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                              c_float, c_float, P]),
+    "air_imp_weight": (c_int, [P, c_int, P, P, c_float, P, P, P, c_int, c_int, P, P, c_float, P]),
     "air_nvil_parts": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, P]),
     "air_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P, c_int,
                          c_float, P, P, c_size_t, P]),
@@ -88,10 +91,10 @@ SIGNATURES = {
                                P, P, P, P, P, c_float, c_float, P, P, P, P, P, P, P, P, P,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "air_attend_bwd": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, c_int, P, c_float, P,
-                               P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
+                               P, P, P, c_float, P, P, c_float, P, P, P, c_float, c_float, P,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "air_attend_bwd_dx": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P, c_int, P, c_float, P,
-                                  P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
+                                  P, P, P, c_float, P, P, c_float, P, P, P, c_float, c_float, P,
                                   c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, c_int, c_int,
                                   c_int, c_float, P]),
     "air_lstm_step_fwd": (c_int, [P, P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_float, c_int, P]),
@@ -127,11 +130,11 @@ SIGNATURES = {
     "air_numsteps_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "air_numsteps_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
     "air_presence_numsteps_fwd": (c_int, [P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, P]),
-    "air_numsteps_presence_bwd": (c_int, [P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P, c_int, c_int, P]),
+    "air_numsteps_presence_bwd": (c_int, [P, P, P, c_float, P, P, c_float, P, P, P, c_float, c_float, P, c_int, c_int, P]),
     "air_heads_fwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P, c_int, c_int,
                               P, P, c_float, c_float, P, P, P, P, P, P, P, c_int, c_int, c_float, P]),
     "air_heads_bwd": (c_int, [P, c_int, P, c_float, c_int, c_float, c_float, c_float, c_float, P, P, P, P, P, c_float,
-                              P, c_int, c_int, c_int, P, P, P, c_float, P, P, c_float, P, P, c_float, c_float, P,
+                              P, c_int, c_int, c_int, P, P, P, c_float, P, P, c_float, P, P, P, c_float, c_float, P,
                               c_int, c_int, c_float, P]),
     "air_step_prologue": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,

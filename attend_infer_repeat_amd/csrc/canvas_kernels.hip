@@ -1015,6 +1015,20 @@ extern "C" int air_canvas_unroll_bwd(const float *glimpse, const float *where, c
                             h, w, mult, std, loss_scale, stream);
 }
 
+// air_canvas_unroll_bwd + dpresence[T,B] = sum_pix dL/dcanvas * (the step's write): what a CONTINUOUS presence (discrete_steps=False,
+// cell.py:150-151, 163) receives from the canvas write
+extern "C" int air_canvas_unroll_bwd_dpresence(const float *glimpse, const float *where, const float *presence,
+                                               const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
+                                               float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
+                                               float loss_scale, void *stream) {
+    AIR_REQUIRE(glimpse && where && obs && dglimpse && dwhere && dpresence, AIR_E_NULL);
+    AIR_REQUIRE(T > 0, AIR_E_SHAPE);
+    int st = cv_check_dims(B, H, W, h, w);
+    if (st) return st;
+    return launch_write_bwd(glimpse, where, presence, nullptr, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W,
+                            h, w, mult, std, loss_scale, stream);
+}
+
 extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence,
                                           const float *obs, const float *final_canvas, float *dglimpse, float *dwhere,
                                           int T, int B, int H, int W, int h, int w, float mult, float std,

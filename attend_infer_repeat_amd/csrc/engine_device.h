@@ -195,7 +195,8 @@ __device__ __forceinline__ void posterior_r(const float *__restrict__ prob, int 
 template <int MT>
 __device__ __forceinline__ void presence_numsteps_col(int b, const float (&lg)[MT], const float (&uu)[MT],
     const double (&pri)[MT + 1], float step_bias, float eps, float *__restrict__ prob, float *__restrict__ pres,
-    float *__restrict__ q, float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B) {
+    float *__restrict__ q, float *__restrict__ kl_ps, float *__restrict__ logp, float *__restrict__ step_w, int T, int B,
+    bool discrete = true) {
     float run = 1.0f, nsteps = 0.f, p32[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -206,7 +207,8 @@ __device__ __forceinline__ void presence_numsteps_col(int b, const float (&lg)[M
             if (eps >= 0.f) p = eps / 2 + (1 - eps) * p;
             p32[t] = p;
             prob[k] = p;
-            run *= (uu[t] < p) ? 1.0f : 0.0f;
+            // cell.py:147-151: the Bernoulli chain, or (discrete_steps=False; the callers pass no uniform variates) the probability itself
+            run = discrete ? run * ((uu[t] < p) ? 1.0f : 0.0f) : p;
             pres[k] = run;
             nsteps += run;
         }
@@ -245,11 +247,11 @@ __device__ __forceinline__ void presence_numsteps_fwd_body(int vblock, int vgrid
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             lg[t] = t < T ? logit[(size_t)t * B + b] : 0.f;
-            uu[t] = t < T ? u[(size_t)t * B + b] : 0.f;
+            uu[t] = (t < T && u) ? u[(size_t)t * B + b] : 0.f;
         }
 #pragma unroll
         for (int n = 0; n <= MT; ++n) pri[n] = n <= T ? prior[n] : 1.0;
-        presence_numsteps_col<MT>(b, lg, uu, pri, step_bias, eps, prob, pres, q, kl_ps, logp, step_w, T, B);
+        presence_numsteps_col<MT>(b, lg, uu, pri, step_bias, eps, prob, pres, q, kl_ps, logp, step_w, T, B, u != nullptr);
     }
 }
 
@@ -261,7 +263,7 @@ __device__ __forceinline__ void numsteps_presence_bwd_col(int b,
     const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
     float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
     const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
-    float (&dl)[MT], int T, int B) {
+    float (&dl)[MT], int T, int B, const float *__restrict__ dpres = nullptr) {
     NumStepsR<MT> s;
     posterior_r<MT>(prob, T, B, b, s);
     int nstar = -1;
@@ -307,6 +309,8 @@ __device__ __forceinline__ void numsteps_presence_bwd_col(int b,
             const size_t idx = (size_t)k * B + b;
             const float sg = 1.0f / (1.0f + expf(-(logit[idx] + step_bias)));
             float gg = (float)g;
+            // discrete_steps=False (cell.py:150-151): presence IS the probability, so what the canvas write's backward holds for it joins here
+            if (dpres) gg += dpres[idx];
             if (eps >= 0.f) gg *= (1 - eps);
             dl[k] = gg * sg * (1.f - sg);
         }
@@ -317,12 +321,12 @@ __device__ __forceinline__ void numsteps_presence_bwd_body(int vblock, int vgrid
     const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
     float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
     const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
-    float *__restrict__ dlogit, int T, int B) {
+    float *__restrict__ dlogit, int T, int B, const float *__restrict__ dpres = nullptr) {
     for (int b = vblock * 64 + (int)threadIdx.x; b < B; b += vgrid * 64) {
         if (threadIdx.x >= 64) break;
         float dl[MT];
         numsteps_presence_bwd_col<MT>(b, prob, presence, prior, kl_scale, kl_a, kl_b, w_scale, dlogp, logit, step_bias, eps, dl,
-                                      T, B);
+                                      T, B, dpres);
 #pragma unroll
         for (int k = 0; k < MT; ++k) if (k < T) dlogit[(size_t)k * B + b] = dl[k];
     }

@@ -32,13 +32,14 @@ __global__ __launch_bounds__(PW_THREADS) void heads_bwd_kernel(
     float dkl_scale, float *__restrict__ dpre, int ld_dpre, int M, int D,
     const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior, float kl_scale,
     const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale, const float *__restrict__ dlogp,
-    const float *__restrict__ logit, float step_bias, float explore_eps, float *__restrict__ dlogit, int T, int B) {
+    const float *__restrict__ dpres, const float *__restrict__ logit, float step_bias, float explore_eps, float *__restrict__ dlogit,
+    int T, int B) {
     if ((int)blockIdx.x < gauss_blocks)
         gauss_bwd_body(blockIdx.x, gauss_blocks, pre, ld_pre, eps, raw_offset, loc_mode, pl0, ps0, pl1, ps1, loc, scale,
                        dsample, dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D);
     else
         numsteps_presence_bwd_body<MT>(blockIdx.x - gauss_blocks, gridDim.x - gauss_blocks, prob, presence, prior,
-                                       kl_scale, kl_a, kl_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
+                                       kl_scale, kl_a, kl_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B, dpres);
 }
 
 static inline int blocks_for(size_t n) {
@@ -52,7 +53,7 @@ extern "C" int air_heads_fwd(const float *pre, int ld_pre, const float *eps, flo
                              const float *u, float step_bias, float explore_eps, const double *prior_f64,
                              float *presence_prob, float *presence, float *q, float *kl_per_sample, float *logp,
                              float *step_weight, int T, int B, float guard_eps, void *stream) {
-    AIR_REQUIRE(pre && eps && loc && scale && sample && kl_row && logit && u && prior_f64 && presence_prob && presence &&
+    AIR_REQUIRE(pre && eps && loc && scale && sample && kl_row && logit && prior_f64 && presence_prob && presence &&   /* u NULL: continuous steps */
                     q && kl_per_sample && logp && step_weight, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && D > 0 && ld_pre >= 2 * D && T > 0 && T <= 32 && B > 0, AIR_E_SHAPE);
     const int gb = blocks_for((size_t)M * 64), nb = air_cdiv(B, 64);
@@ -75,7 +76,7 @@ extern "C" int air_heads_bwd(const float *pre, int ld_pre, const float *eps, flo
                              const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
                              float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *presence_prob,
                              const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
-                             const float *kl_row_b, float w_scale, const float *dlogp, const float *logit,
+                             const float *kl_row_b, float w_scale, const float *dlogp, const float *dpresence, const float *logit,
                              float step_bias, float explore_eps, float *dlogit, int T, int B, float guard_eps, void *stream) {
     AIR_REQUIRE(pre && eps && loc && scale && dpre && presence_prob && prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
@@ -85,12 +86,12 @@ extern "C" int air_heads_bwd(const float *pre, int ld_pre, const float *eps, flo
         hipLaunchKernelGGL(heads_bwd_kernel<8>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
                            eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
                            dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, presence_prob, presence, prior_f64, kl_scale,
-                           kl_row_a, kl_row_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
+                           kl_row_a, kl_row_b, w_scale, dlogp, dpresence, logit, step_bias, explore_eps, dlogit, T, B);
     else
         hipLaunchKernelGGL(heads_bwd_kernel<32>, dim3(gb + nb), dim3(PW_THREADS), 0, air_stream(stream), gb, pre, ld_pre,
                            eps, RawOffset(raw_offset, guard_eps), loc_mode, p_loc_even, p_scale_even, p_loc_odd, p_scale_odd, loc, scale, dsample,
                            dsample2, dkl_row, dkl_scale, dpre, ld_dpre, M, D, presence_prob, presence, prior_f64, kl_scale,
-                           kl_row_a, kl_row_b, w_scale, dlogp, logit, step_bias, explore_eps, dlogit, T, B);
+                           kl_row_a, kl_row_b, w_scale, dlogp, dpresence, logit, step_bias, explore_eps, dlogit, T, B);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

@@ -143,8 +143,8 @@ extern "C" int air_presence_numsteps_fwd(const float *logit, const float *u, flo
                                          const double *prior_f64, float *presence_prob, float *presence, float *q,
                                          float *kl_per_sample, float *logp, float *step_weight, int T, int B,
                                          void *stream) {
-    AIR_REQUIRE(logit && u && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight,
-                AIR_E_NULL);
+    AIR_REQUIRE(logit && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight,
+                AIR_E_NULL);                                   // u == NULL: continuous steps (presence = presence_prob, cell.py:150-151)
     AIR_REQUIRE(T > 0 && T <= NS_MAXT && B > 0, AIR_E_SHAPE);
     if (T <= 8)
         hipLaunchKernelGGL(presence_numsteps_fwd_kernel<8>, dim3(air_cdiv(B, 64)), dim3(64), 0, air_stream(stream), logit,
@@ -162,25 +162,25 @@ template <int MT>
 __global__ __launch_bounds__(64) void numsteps_presence_bwd_kernel(
     const float *__restrict__ prob, const float *__restrict__ presence, const double *__restrict__ prior,
     float kl_scale, const float *__restrict__ kl_a, const float *__restrict__ kl_b, float w_scale,
-    const float *__restrict__ dlogp, const float *__restrict__ logit, float step_bias, float eps,
+    const float *__restrict__ dlogp, const float *__restrict__ dpres, const float *__restrict__ logit, float step_bias, float eps,
     float *__restrict__ dlogit, int T, int B) {
     numsteps_presence_bwd_body<MT>(blockIdx.x, gridDim.x, prob, presence, prior, kl_scale, kl_a, kl_b, w_scale, dlogp,
-                                   logit, step_bias, eps, dlogit, T, B);
+                                   logit, step_bias, eps, dlogit, T, B, dpres);
 }
 extern "C" int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
                                          float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
-                                         const float *dlogp, const float *logit, float step_bias, float explore_eps,
-                                         float *dlogit, int T, int B, void *stream) {
+                                         const float *dlogp, const float *dpresence, const float *logit, float step_bias,
+                                         float explore_eps, float *dlogit, int T, int B, void *stream) {
     AIR_REQUIRE(presence_prob && prior_f64 && logit && dlogit, AIR_E_NULL);
     AIR_REQUIRE(!dlogp || presence, AIR_E_NULL);
     AIR_REQUIRE(T > 0 && T <= NS_MAXT && B > 0, AIR_E_SHAPE);
     if (T <= 8)
         hipLaunchKernelGGL(numsteps_presence_bwd_kernel<8>, dim3(air_cdiv(B, 64)), dim3(64), 0, air_stream(stream),
-                           presence_prob, presence, prior_f64, kl_scale, kl_row_a, kl_row_b, w_scale, dlogp, logit,
+                           presence_prob, presence, prior_f64, kl_scale, kl_row_a, kl_row_b, w_scale, dlogp, dpresence, logit,
                            step_bias, explore_eps, dlogit, T, B);
     else
         hipLaunchKernelGGL(numsteps_presence_bwd_kernel<NS_MAXT>, dim3(air_cdiv(B, 64)), dim3(64), 0, air_stream(stream),
-                           presence_prob, presence, prior_f64, kl_scale, kl_row_a, kl_row_b, w_scale, dlogp, logit,
+                           presence_prob, presence, prior_f64, kl_scale, kl_row_a, kl_row_b, w_scale, dlogp, dpresence, logit,
                            step_bias, explore_eps, dlogit, T, B);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
@@ -232,6 +232,37 @@ extern "C" int air_counter_add(int64_t *counter_dev, int64_t increment, void *st
 // importance_weight[i,j] = imp[j] - baseline[i]  ([B]-[B,1] broadcast), so
 //   reinforce_loss = mean_j (imp_j - mean_i b_i) * logp_j ;  baseline_loss = 0.5 * mean_ij (imp_j - b_i)^2.
 __global__ __launch_bounds__(256) void nvil_kernel(NvilArgs a) { nvil_body(a); }
+// REINFORCE importance weight of a NON-analytic num-steps prior (model.py:339-340: reinforce_imp_weight += prior_loss.per_sample):
+//   rec[b] = sum of the reconstruction shares (in share order); imp[b] = rec[b] + nsp_weight * kl_n[b] + sum_t w[t,b] (kl_a[t,b] + kl_b[t,b])
+__global__ __launch_bounds__(256) void imp_weight_kernel(const float *__restrict__ parts, int n_parts, float *__restrict__ rec,
+                                                         const float *__restrict__ kl_n, float nsp_w, const float *__restrict__ kl_a,
+                                                         const float *__restrict__ kl_b, const float *__restrict__ w, int T, int B,
+                                                         float *__restrict__ imp, float *__restrict__ dpres, float dkl_scale) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        float r = parts[b];
+        for (int p = 1; p < n_parts; ++p) r += parts[(size_t)p * B + b];
+        if (rec) rec[b] = r;
+        float pr = kl_n ? nsp_w * kl_n[b] : 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            const float kl = (kl_a ? kl_a[k] : 0.f) + (kl_b ? kl_b[k] : 0.f);
+            pr += w[k] * kl;
+            // continuous steps (cell.py:150-151): the step weight IS the presence probability, so the weighted KL rows reach it directly
+            if (dpres) dpres[k] += dkl_scale * kl;
+        }
+        if (imp) imp[b] = r + pr;
+    }
+}
+extern "C" int air_imp_weight(const float *rec_parts, int n_parts, float *rec_out, const float *kl_n, float nsp_weight,
+                              const float *kl_row_a, const float *kl_row_b, const float *step_weight, int T, int B, float *imp_out,
+                              float *dpresence_inout, float dkl_scale, void *stream) {
+    AIR_REQUIRE(rec_parts && step_weight && (imp_out || dpresence_inout), AIR_E_NULL);
+    AIR_REQUIRE(n_parts > 0 && T > 0 && B > 0, AIR_E_SHAPE);
+    hipLaunchKernelGGL(imp_weight_kernel, dim3(air_cdiv(B, 256)), dim3(256), 0, air_stream(stream), rec_parts, n_parts, rec_out, kl_n,
+                       nsp_weight, kl_row_a, kl_row_b, step_weight, T, B, imp_out, dpresence_inout, dkl_scale);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
 extern "C" int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
                         float *dbaseline, int B, float *ema_dev, void *stream) {
     AIR_REQUIRE(imp && baseline && logp && out, AIR_E_NULL);

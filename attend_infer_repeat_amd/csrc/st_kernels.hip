@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
             float uu[MT], lg[MT];
             double pri[MT + 1];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) uu[t] = (t < T && live) ? g.u[(size_t)t * B + b] : 0.f;
+            for (int t = 0; t < MT; ++t) uu[t] = (t < T && live && g.u) ? g.u[(size_t)t * B + b] : 0.f;
 #pragma unroll
             for (int q = 0; q <= MT; ++q) pri[q] = q <= T ? g.prior[q + z0] : 1.0;
 #pragma unroll
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
 #pragma unroll
                 for (int t = 0; t < MT; ++t) if (t < T) g.logit[(size_t)t * B + b] = lg[t];
                 presence_numsteps_col<MT>(b, lg, uu, pri, g.step_bias, g.explore_eps, g.prob, g.pres, g.q, g.kl_ps, g.logp,
-                                          g.step_w, T, B);
+                                          g.step_w, T, B, g.u != nullptr);
             }
         }
         AIR_TR(6);
@@ -598,8 +598,8 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
                               float guard_eps, void *stream) {
     AIR_REQUIRE(precision == AIR_PREC_F32 || precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
     AIR_REQUIRE(tr_h && tr_w && tr_b && st_h && st_w && st_b && pre && logit && eps && loc && scale && where && kl_row &&
-                    u && prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight && img &&
-                    glimpse, AIR_E_NULL);
+                    prior_f64 && presence_prob && presence && q && kl_per_sample && logp && step_weight && img &&
+                    glimpse, AIR_E_NULL);                      // u == NULL: discrete_steps=False (presence = presence_prob, cell.py:150-151)
     AIR_REQUIRE(T > 0 && T <= 32 && tr_k > 0 && st_k > 0, AIR_E_SHAPE);
     int st = st_check_dims(B, H, W, h, w);
     if (st) return st;
@@ -653,7 +653,7 @@ struct AttendBwdArgs {
     const float *loc, *scale, *dwhere_w, *dkl_row; float dkl_scale; float *dpre;
     int dwhere_w_slabs;   // dwhere_w[slabs][T*B][4]: the canvas backward may write its dwhere as several partial slabs (their sum, in order)
     const float *prob, *presence; const double *prior; float kl_scale; const float *kl_a, *kl_b; float w_scale;
-    const float *dlogp, *logit; float step_bias, explore_eps; float *dlogit;
+    const float *dlogp, *dpres, *logit; float step_bias, explore_eps; float *dlogit;
     int T, B, H, W, h, w, vec4;
     double stepx, stepy;
     // optional: dX of the output layers of the transform / steps MLPs in the same launch (the two 8- and 1-deep products that
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
         if (g.st_dx == nullptr) {
             numsteps_presence_bwd_body<MT>((int)blockIdx.x, nb_, g.prob, g.presence, g.prior, g.kl_scale,
                                            g.kl_a, g.kl_b, g.w_scale, g.dlogp, g.logit, g.step_bias, g.explore_eps, g.dlogit,
-                                           T, B);
+                                           T, B, g.dpres);
         } else {
             // 16 batch columns per workgroup: threads 0..15 run the float64 chain of their column, then all threads form
             // st_dx for the 16 x T rows (their input activations were requested before the chain started)
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
                 if (tid < 16 && base + tid < B) {
                     float dl[MT];
                     numsteps_presence_bwd_col<MT>(base + tid, g.prob, g.presence, g.prior, g.kl_scale, g.kl_a, g.kl_b, g.w_scale,
-                                                  g.dlogp, g.logit, g.step_bias, g.explore_eps, dl, T, B);
+                                                  g.dlogp, g.logit, g.step_bias, g.explore_eps, dl, T, B, g.dpres);
 #pragma unroll
                     for (int t = 0; t < MT; ++t) if (t < T) { g.dlogit[(size_t)t * B + base + tid] = dl[t]; s_dl[t][tid] = dl[t]; }
                 }
@@ -970,7 +970,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
                               const float *dwhere_w, int dwhere_w_slabs, const float *dkl_row, float dkl_scale, float *dpre,
                               const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
                               const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
-                              const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
+                              const float *dpresence, const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
                               int W, int h, int w, float guard_eps, void *stream) {
     AIR_REQUIRE(img && where && dglimpse && dwhere_r && pre && eps && loc && scale && dwhere_w && dpre && presence_prob &&
                     prior_f64 && logit && dlogit, AIR_E_NULL);
@@ -985,7 +985,7 @@ extern "C" int air_attend_bwd(const float *img, const float *where, const float 
     g.raw_offset = raw_offset; g.guard_eps = guard_eps; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
     g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dwhere_w_slabs = dwhere_w_slabs; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
     g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
-    g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
+    g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.dpres = dpresence; g.logit = logit; g.step_bias = step_bias;
     g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;
     g.vec4 = (((H * W) % 4 == 0) && air_aligned16(img)) ? 1 : 0;
     g.stepx = lin_step(w); g.stepy = lin_step(h);
@@ -1001,7 +1001,7 @@ extern "C" int air_attend_bwd_dx(const float *img, const float *where, const flo
                               const float *dwhere_w, int dwhere_w_slabs, const float *dkl_row, float dkl_scale, float *dpre,
                               const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
                               const float *kl_row_a, const float *kl_row_b, float w_scale, const float *dlogp,
-                              const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
+                              const float *dpresence, const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B, int H,
                               int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
                                  const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision,
                                  float guard_eps, void *stream) {
@@ -1018,7 +1018,7 @@ extern "C" int air_attend_bwd_dx(const float *img, const float *where, const flo
     g.raw_offset = raw_offset; g.guard_eps = guard_eps; g.pl0 = p_loc_even; g.ps0 = p_scale_even; g.pl1 = p_loc_odd; g.ps1 = p_scale_odd;
     g.loc = loc; g.scale = scale; g.dwhere_w = dwhere_w; g.dwhere_w_slabs = dwhere_w_slabs; g.dkl_row = dkl_row; g.dkl_scale = dkl_scale; g.dpre = dpre;
     g.prob = presence_prob; g.presence = presence; g.prior = prior_f64; g.kl_scale = kl_scale; g.kl_a = kl_row_a;
-    g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.logit = logit; g.step_bias = step_bias;
+    g.kl_b = kl_row_b; g.w_scale = w_scale; g.dlogp = dlogp; g.dpres = dpresence; g.logit = logit; g.step_bias = step_bias;
     g.explore_eps = explore_eps; g.dlogit = dlogit; g.T = T; g.B = B; g.H = H; g.W = W; g.h = h; g.w = w;
     g.vec4 = (((H * W) % 4 == 0) && air_aligned16(img)) ? 1 : 0;
     g.stepx = lin_step(w); g.stepy = lin_step(h);

@@ -578,9 +578,12 @@ class AIREngine(PlanMixin):
         o["num_steps_posterior"] = self.q_n
         o["kl_num_steps_per_sample"] = self.kl_n
         o["kl_num_steps"] = self.kl_n.mean()
-        o["prior_step_weight"] = self.step_w
-        o["kl_what_per_sample"] = (self.kl_what_row * self.step_w).sum(0)
-        o["kl_where_per_sample"] = (self.kl_where_row * self.step_w).sum(0)
+        wts = self._kl_weights                                  # q(n > t) (analytic) or the sampled presences (model.py:157-163)
+        o["prior_step_weight"] = wts
+        # (a prior left at None: its KL term is not part of the loss -- model.py:174-209 -- and reads as zero here)
+        o["kl_what_per_sample"] = (self.kl_what_row * wts).sum(0) if cfg.what_prior is not None else torch.zeros_like(self.kl_n)
+        o["kl_where_per_sample"] = ((self.kl_where_row * wts).sum(0) if cfg.where_scale_prior is not None and cfg.where_shift_prior is not None
+                                    else torch.zeros_like(self.kl_n))
         o["kl_what"] = o["kl_what_per_sample"].mean()
         o["kl_where"] = o["kl_where_per_sample"].mean()
         pw = 1.0 if cfg.use_prior else 0.0

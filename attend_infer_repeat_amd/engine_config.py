@@ -24,9 +24,9 @@ class EngineConfig:
     output_std: float = 0.3
     explore_eps: Optional[float] = 1e-3
     what_scale_offset: float = 0.5
-    what_prior: Tuple[float, float] = (0.0, 1.0)
-    where_scale_prior: Tuple[float, float] = (0.0, 1.0)
-    where_shift_prior: Tuple[float, float] = (0.0, 1.0)
+    what_prior: Optional[Tuple[float, float]] = (0.0, 1.0)              # None: the term is not added (model.py:174)
+    where_scale_prior: Optional[Tuple[float, float]] = (0.0, 1.0)       # either of the two at None: no where term (model.py:187)
+    where_shift_prior: Optional[Tuple[Optional[float], float]] = (0.0, 1.0)   # loc None: centred on the posterior's own mean
     nsp_anneal: Optional[str] = "exp"
     nsp_init: float = 1.0 - 1e-15
     nsp_final: float = 1e-7
@@ -45,6 +45,9 @@ class EngineConfig:
     l2_weight: float = 0.0                # l2_weight * sum(w^2) / 2 over the 2-D model variables (model.py:346-353)
     decay_rate: Optional[float] = None    # EMA normalisation of the importance weight (model.py:232-239, ops.py:46-64)
     nsp_weight: float = 1.0               # num_steps_prior.weight (model.py:339-340)
+    discrete_steps: bool = True         # False (cell.py:150-151): presence = presence_prob, with a gradient through the canvas write
+    nsp_analytic: bool = True             # False: step weights = the sampled presences, the prior joins the importance weight (model.py:157-163,339-340)
+    # what_prior / where_scale_prior + where_shift_prior may be None: that KL term is then left out of the loss (model.py:174-209)
     # "f32": exact fp32 MFMA everywhere.  "bf16": every dense product (MLPs, LSTM gates, their dX / dW) rounds its operands
     # to bf16 in registers and multiplies on the bf16 MFMA with fp32 accumulate; parameters, activations, gradients and the
     # optimiser stay fp32 (BASELINE.json configs[4], "bf16 MFMA MLP path").

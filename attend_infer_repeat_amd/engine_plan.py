@@ -295,7 +295,19 @@ class PlanMixin:
                                                    p(self.c_seq[t + 1]), p(self.gate_act[t]), B, Hd, 1.0),
                         "air_lstm_pointwise_fwd"))
         h_all = self.h_seq[1:]                                                              # [T,B,Hd] contiguous
-        sp, shp = cfg.where_scale_prior, cfg.where_shift_prior
+        # priors left at None (model.py:174-209: that KL term is simply not added): the kernels still evaluate the rows against a
+        # standard normal, but they enter neither the loss nor any gradient (weights 0 / pointers NULL below)
+        has_what = cfg.what_prior is not None
+        has_where = cfg.where_scale_prior is not None and cfg.where_shift_prior is not None
+        analytic = bool(cfg.nsp_analytic)
+        # continuous steps (cell.py:150-151): the entry points that draw the presence take no uniform variates and write the probability
+        # itself; the canvas write's backward returns d/d presence, which joins d/d presence_prob in the steps-logit backward
+        discrete = bool(cfg.discrete_steps)
+        u_p = p(self.u_pres) if discrete else None
+        self.dpres = None if discrete else self._buf("dpres", (T, B))
+        dpres_p = None if discrete else p(self.dpres)
+        self._kl_weights = self.step_w if analytic else self.presence       # model.py:157-163
+        sp, shp = (cfg.where_scale_prior, cfg.where_shift_prior) if has_where else ((0.0, 1.0), (0.0, 1.0))
         if shp[0] is None:                  # a shift prior without `loc` is centred on the posterior's own mean (model.py:203-207):
             shp = (float("nan"), shp[1])    # the kernels' NaN convention (include/air_hip.h, air_gauss_sample_fwd)
         eps = -1.0 if cfg.explore_eps is None else float(cfg.explore_eps)
@@ -312,7 +324,7 @@ class PlanMixin:
                                            p(self.st.w[-1]), p(self.st.b[-1]), st_k, p(self.tr.out[-1]),
                                            p(self.st.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
                                            shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.where),
-                                           p(self.kl_where_row), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
+                                           p(self.kl_where_row), u_p, cfg.step_bias, eps, p(self.prior_dev),
                                            p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n),
                                            p(self.logp), p(self.step_w), p(self.obs), p(self.glimpse_in), T, B, Hi, Wi,
                                            hc, wc, prec, float(cfg.guard_eps)), "air_attend_fwd"))                      # cell.py:129-151
@@ -321,20 +333,20 @@ class PlanMixin:
             fwd.append((L.air_heads_fwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
                                           sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
                                           p(self.where), p(self.kl_where_row), M, 4,             # cell.py:129-133
-                                          p(self.st.out[-1]), p(self.u_pres), cfg.step_bias, eps, p(self.prior_dev),
+                                          p(self.st.out[-1]), u_p, cfg.step_bias, eps, p(self.prior_dev),
                                           p(self.presence_prob), p(self.presence), p(self.q_n), p(self.kl_n), p(self.logp),
                                           p(self.step_w), T, B, float(cfg.guard_eps)), "air_heads_fwd"))               # cell.py:137-151, prior.py
             fwd.append((L.air_st_read_fwd, (p(self.obs), p(self.where), p(self.glimpse_in), M, B, Hi, Wi, hc, wc),
                         "air_st_read_fwd"))                                                 # cell.py:135
         mlp_fwd_multi(fwd, [(self.ge, self.glimpse_in, hw)])                                # cell.py:153
         ge_out, G = self.ge.out[-1], self.ge.shapes[-1][1]
-        wp = cfg.what_prior
+        wp = cfg.what_prior if has_what else (0.0, 1.0)
         # Round 5, latency regime with REINFORCE: the whole `what` head -- the product q = ge_out . W + b, the sampling with its KL
         # terms and the latent columns of the baseline input -- is ONE launch (air_what_head_fwd: a tile holds both halves of its
         # (row, latent dim) pairs) instead of a GEMM launch + air_what_sample_pack.  The KL row of a sample spans several tiles: the
         # tiles leave shares, the backward launch of the same head (air_gauss_sample_bwd*) adds them; a forward() on its own -- an
         # evaluation pass -- adds them with a small launch of its own, which the train step drops.
-        what_head = (cfg.use_reinforce and not throughput and os.environ.get("AIR_FUSE_WHAT_HEAD", "1") == "1")
+        what_head = (cfg.use_reinforce and analytic and discrete and not throughput and os.environ.get("AIR_FUSE_WHAT_HEAD", "1") == "1")
         self._what_head = what_head
         self._kl_parts_args = (None, 0, None)
         if what_head:
@@ -394,6 +406,17 @@ class PlanMixin:
             ema_p = p(self.ema_dev)
         rec_sum = (L.air_sum_leading, (p(self.rec_parts), p(self.rec), NB, ctypes.c_size_t(B)), "air_sum_leading")
         fwd_tail = [(L.air_nvil_parts, nvil_args + (B, ema_p), "air_nvil_parts")] if cfg.use_reinforce else [rec_sum]
+        nvil_direct = None
+        if cfg.use_reinforce and not analytic:
+            # a non-analytic num-steps prior (model.py:157-163, 339-340): the step weights are the sampled presences and the prior's
+            # per-sample value joins the importance weight -- formed by a small launch of its own, NVIL as the plain launch behind it
+            self.imp = self._buf("imp", (B,))
+            nvil_direct = [(L.air_imp_weight, (p(self.rec_parts), NB, p(self.rec), p(self.kl_n), float(cfg.nsp_weight),
+                                               p(self.kl_what_row) if has_what else None, p(self.kl_where_row) if has_where else None,
+                                               p(self.presence), T, B, p(self.imp), None, 0.0), "air_imp_weight"),
+                           (L.air_nvil, (p(self.imp), p(self.bl.out[-1]), p(self.logp), p(self.nvil_out), p(self.dlogp), p(self.dbase),
+                                         B, ema_p), "air_nvil")]
+            fwd_tail = list(nvil_direct)
         if ema_p is not None:               # (forward() is an evaluation pass: the update switch is off around its NVIL launch)
             sw = ctypes.c_void_p(self.ema_dev.data_ptr() + 12)
             fwd_tail = [(L.air_fill, (sw, ctypes.c_size_t(1), 0.0), "air_fill")] + fwd_tail + [(L.air_fill, (sw, ctypes.c_size_t(1), 1.0), "air_fill")]
@@ -416,7 +439,7 @@ class PlanMixin:
         n_split = int(os.environ.get("AIR_CANVAS_SPLIT", "2" if M <= 128 else "1")) if (fuse_attend and M * 2 + B * NB <= 1024) else 1
         n_split = max(1, min(4, n_split))
         self._canvas_split = n_split
-        fuse_canvas = (cfg.use_reinforce and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
+        fuse_canvas = (cfg.use_reinforce and analytic and discrete and (not throughput or os.environ.get("AIR_FUSE_CANVAS_THROUGHPUT", "0") == "1")
                        # (the fused launch's backward re-forms the canvas from ALL T glimpses on each unit's footprint -- T^2 taps:
                        #  measured 0.2095 against 0.2111 ms per step at T = 3 (50x50 / 20x20), 0.3231 against 0.3194 ms at T = 5
                        #  (100x100 / 28x28; tools/runs/r04_x.sh): by default only up to T = 3; "1" / "0" force it on / off)
@@ -451,6 +474,24 @@ class PlanMixin:
                                                       p(self.gd.g[-1]), p(self.dwhere_w), n_split, T, B, Hi, Wi, hc, wc,
                                                       cfg.output_multiplier, cfg.output_std, inv_b),
                         "air_canvas_unroll_fwd_bwd"))
+        elif not discrete:
+            # continuous steps: the canvas backward also returns d/d presence; a non-analytic prior weighs the KL rows with the presence
+            # ITSELF (model.py:162-163), whose gradient -- the weighted rows -- is added behind it by the importance-weight launch
+            bwd.append((L.air_canvas_unroll_bwd_dpresence, cu_args[:7] + (dpres_p,) + cu_args[7:], "air_canvas_unroll_bwd_dpresence"))
+            if not analytic:
+                bwd.append((L.air_imp_weight, (p(self.rec_parts), NB, p(self.rec), p(self.kl_n), float(cfg.nsp_weight),
+                                               p(self.kl_what_row) if has_what else None, p(self.kl_where_row) if has_where else None,
+                                               p(self.presence), T, B, p(self.imp) if cfg.use_reinforce else None, dpres_p,
+                                               (1.0 if cfg.use_prior else 0.0) * inv_b), "air_imp_weight"))
+                if cfg.use_reinforce:
+                    bwd.append(nvil_direct[1])
+            elif cfg.use_reinforce:
+                bwd.append((L.air_nvil_parts, nvil_args + (B, ema_p), "air_nvil_parts"))
+            else:
+                bwd.append(rec_sum)
+        elif cfg.use_reinforce and nvil_direct is not None:
+            bwd.extend(nvil_direct)
+            bwd.append((L.air_canvas_unroll_bwd, cu_args, "air_canvas_unroll_bwd"))
         elif cfg.use_reinforce:
             bwd.append((L.air_canvas_unroll_bwd_nvil, cu_args + nvil_args + (ema_p,), "air_canvas_unroll_bwd_nvil"))
         else:
@@ -462,20 +503,20 @@ class PlanMixin:
         mlp_bwd_multi(bwd, chains)
         marks = [] if fuse_canvas else [(len(bwd), "glimpse_decoder/0/w")]   # gradients of [glimpse_decoder .. baseline] are final here
         gb_args = (p(self.q), 2 * A, p(self.eps_what), cfg.what_scale_offset, 0, wp[0], wp[1], wp[0], wp[1], p(self.what_loc),
-                   p(self.what_scale), p(self.d_what), None, p(self.step_w), pw * inv_b, p(self.dq), 2 * A, M, A)
+                   p(self.what_scale), p(self.d_what), None, p(self._kl_weights), pw * inv_b if has_what else 0.0, p(self.dq), 2 * A, M, A)
         # Round 5, latency regime: the backward of the `what` head needs no launch of its own -- the decoder's first-layer dX IS its
         # sample gradient, so the thread that finishes d_what[m, a] writes dq[m, a] and dq[m, A + a] in the same epilogue
         # (air_gemm_grouped_gauss_bwd), and NVIL / the sum of the head's KL shares ride behind the tiles of that launch.
         self._fold_gauss_bwd = False
         last = bwd[-1]
-        if (not throughput and os.environ.get("AIR_FUSE_GAUSS_BWD", "1") == "1" and last[2] == "air_gemm_grouped"
+        if (not throughput and analytic and discrete and os.environ.get("AIR_FUSE_GAUSS_BWD", "1") == "1" and last[2] == "air_gemm_grouped"
                 and sum(((d.M + 15) // 16) * ((d.N + 15) // 16) for d in last[1][0]) <= 1000):
             arr, n_d = last[1]
             which = [i for i in range(n_d) if arr[i].C == self.d_what.data_ptr() and not arr[i].ta and arr[i].N == A
                      and arr[i].epilogue == NONE and arr[i].beta == 0.0 and not arr[i].colsum]
             if len(which) == 1:
                 epi = _lib.AirGaussBwdEpi(which[0], dp(self.q), 2 * A, dp(self.eps_what), cfg.what_scale_offset, wp[0], wp[1],
-                                          dp(self.what_loc), dp(self.what_scale), dp(self.step_w), pw * inv_b, dp(self.dq), 2 * A, A,
+                                          dp(self.what_loc), dp(self.what_scale), dp(self._kl_weights), pw * inv_b if has_what else 0.0, dp(self.dq), 2 * A, A,
                                           float(cfg.guard_eps))
                 self._keep.append(epi)
                 nv = (nvil_args + (B, ema_p)) if fuse_canvas else (None, 0, None, None, None, None, None, None, 0, None)
@@ -508,9 +549,10 @@ class PlanMixin:
             bwd.append((L.air_attend_bwd_dx, (p(self.obs), p(self.where), p(self.d_glimpse_in), p(self.dwhere_r),
                                               p(self.tr.out[-1]), p(self.eps_where), cfg.transform_var_bias, sp[0], sp[1],
                                               shp[0], shp[1], p(self.where_loc), p(self.where_scale), p(self.dwhere_w), n_split,
-                                              p(self.step_w), pw * inv_b, p(self.tr.g[-1]),
+                                              p(self._kl_weights), pw * inv_b if has_where else 0.0, p(self.tr.g[-1]),
                                               p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b * float(cfg.nsp_weight),
-                                              p(self.kl_what_row), p(self.kl_where_row), pw * inv_b, dlogp_p,
+                                              p(self.kl_what_row) if has_what else None, p(self.kl_where_row) if has_where else None,
+                                              pw * inv_b if analytic else 0.0, dlogp_p, dpres_p,
                                               p(self.st.out[-1]), cfg.step_bias, eps, p(self.st.g[-1]), T, B, Hi, Wi, hc, wc,
                                               p(self.tr.w[-1]), p(tr_y) if tr_y is not None else None, p(tr_dx), tr_kk, tr_ld,
                                               p(self.st.w[-1]), p(st_y) if st_y is not None else None, p(st_dx), st_kk, st_ld,
@@ -520,11 +562,12 @@ class PlanMixin:
                                             B, Hi, Wi, hc, wc), "air_st_read_bwd"))
             bwd.append((L.air_heads_bwd, (p(self.tr.out[-1]), 8, p(self.eps_where), cfg.transform_var_bias, 1,
                                           sp[0], sp[1], shp[0], shp[1], p(self.where_loc), p(self.where_scale),
-                                          p(self.dwhere_w), p(self.dwhere_r), p(self.step_w), pw * inv_b,
+                                          p(self.dwhere_w), p(self.dwhere_r), p(self._kl_weights), pw * inv_b if has_where else 0.0,
                                           p(self.tr.g[-1]), 8, M, 4,
                                           p(self.presence_prob), p(self.presence), p(self.prior_dev), pw * inv_b * float(cfg.nsp_weight),
-                                          p(self.kl_what_row), p(self.kl_where_row), pw * inv_b,
-                                          dlogp_p, p(self.st.out[-1]), cfg.step_bias,
+                                          p(self.kl_what_row) if has_what else None, p(self.kl_where_row) if has_where else None,
+                                          pw * inv_b if analytic else 0.0,
+                                          dlogp_p, dpres_p, p(self.st.out[-1]), cfg.step_bias,
                                           eps, p(self.st.g[-1]), T, B, float(cfg.guard_eps)), "air_heads_bwd"))
         mlp_bwd_multi(bwd, [dict(m=self.tr, x=h_all, ldx=Hd, g_last=self.tr.g[-1], dx_out=self.dH),
                             dict(m=self.st, x=h_all, ldx=Hd, g_last=self.st.g[-1], dx_out=self.dH_b)],

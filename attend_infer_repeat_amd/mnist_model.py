@@ -79,19 +79,25 @@ class AIRonMNIST(AIRModel):
                          decay_rate):
         """The fused engine takes the reference script's configuration (scripts/multi_mnist.py:24-94) and, since round 5, the rest
         of train_step's plain arguments (model.py:261-353): l2_weight, decay_rate (EMA-normalised importance weights), a weighted
-        num-steps prior, a where-shift prior without `loc`, and the RMSProp keyword set (decay / momentum / epsilon / centered).
-        What still trains through the generic autograd path over the same kernels: a custom optimizer CLASS, a non-MLP baseline,
-        priors left at None, continuous steps (discrete_steps=False: the presence then carries a gradient into the canvas write
-        and the baseline input) and a non-analytic num-steps prior (sampled step weights, the prior inside the importance weight)."""
+        num-steps prior, a where-shift prior without `loc`, the RMSProp keyword set (decay / momentum / epsilon / centered), a
+        what / where prior left at None (model.py:174, 187: the term is not added) and a non-analytic num-steps prior (sampled step
+        weights, the prior inside the importance weight: model.py:157-163, 339-340).
+        Continuous steps (discrete_steps=False, cell.py:150-151: the presence is the probability itself and carries a gradient
+        through the canvas write) run on the engine too.  What still trains through the generic autograd path over the same kernels:
+        a custom optimizer CLASS and a non-MLP baseline.  num_steps_prior=None is an error in the reference too (model.py:157 reads
+        its `analytic`)."""
         nsp = num_steps_prior
         has = lambda p, *keys: p is not None and all(k in p for k in keys)
-        if not (use_engine and self.discrete_steps):
+        if not use_engine:
             return False
         if getattr(self, "_custom_optimizer", None) is not None:
             return False
-        if nsp is None or not getattr(nsp, 'analytic', True):
+        if nsp is None:
             return False
-        if not (has(what_prior, 'loc', 'scale') and has(where_scale_prior, 'loc', 'scale') and has(where_shift_prior, 'scale')):
+        if what_prior is not None and not has(what_prior, 'loc', 'scale'):
+            return False
+        if where_scale_prior is not None and where_shift_prior is not None and not (
+                has(where_scale_prior, 'loc', 'scale') and has(where_shift_prior, 'scale')):
             return False
         if decay_rate is not None and not self.use_reinforce:
             return False
@@ -105,15 +111,18 @@ class AIRonMNIST(AIRModel):
                       decay_rate=None):
         nsp = num_steps_prior
         rms = getattr(self, "_rms_kwargs", None) or dict(decay=0.9, momentum=0.9, epsilon=1e-10, centered=True)
+        has_where = where_scale_prior is not None and where_shift_prior is not None
         return EngineConfig(
             img_size=tuple(self.img_size), crop_size=tuple(self.glimpse_size), n_appearance=self.n_appearance,
             n_hidden=256, max_steps=self.max_steps,
             transform_var_bias=float(self.transform_var_bias), step_bias=float(self.step_bias),
             output_multiplier=float(self.output_multiplier), output_std=float(self.output_std),
             explore_eps=None if self.explore_eps is None else float(self.explore_eps),
-            what_prior=(what_prior.loc, what_prior.scale),
-            where_scale_prior=(where_scale_prior.loc, where_scale_prior.scale),
-            where_shift_prior=(where_shift_prior.loc if 'loc' in where_shift_prior else None, where_shift_prior.scale),
+            what_prior=None if what_prior is None else (what_prior.loc, what_prior.scale),
+            where_scale_prior=None if not has_where else (where_scale_prior.loc, where_scale_prior.scale),
+            where_shift_prior=None if not has_where else (where_shift_prior.loc if 'loc' in where_shift_prior else None,
+                                                          where_shift_prior.scale),
+            nsp_analytic=bool(getattr(nsp, 'analytic', True)), discrete_steps=bool(self.discrete_steps),
             nsp_anneal=getattr(nsp, 'anneal', None), nsp_init=nsp.init, nsp_final=getattr(nsp, 'final', nsp.init),
             nsp_steps_div=getattr(nsp, 'steps_div', 1.), nsp_steps=getattr(nsp, 'steps', 1.),
             nsp_hold_init=getattr(nsp, 'hold_init', 0.),
@@ -222,6 +231,8 @@ class AIRonMNIST(AIRModel):
                   "glimpse", "canvas", "final_canvas", "final_state", "rec_loss_per_sample", "rec_loss",
                   "kl_num_steps_per_sample", "kl_num_steps", "kl_what", "kl_where", "prior_step_weight",
                   "num_step_per_sample", "opt_loss", "reinforce_loss", "baseline_loss", "baseline"):
+            if k == "kl_what" and eng.cfg.what_prior is None or k == "kl_where" and eng.cfg.where_scale_prior is None:
+                continue                                   # model.py:174, 187: a prior left at None defines no such tensor
             if k in o:
                 setattr(self, k, o[k])
         self.num_step = self.num_step_per_sample.mean()
@@ -235,7 +246,9 @@ class AIRonMNIST(AIRModel):
         self.loss = Loss(); self.loss.add(o["loss"], o["rec_loss_per_sample"]
                                           + self.prior_weight * self.prior_loss.per_sample)
         if "baseline" in o:
-            self.importance_weight = o["rec_loss_per_sample"][None, :] - o["baseline"]       # [B,B] quirk, model.py:230
+            imp = o["rec_loss_per_sample"] if eng.cfg.nsp_analytic else o["rec_loss_per_sample"] + self.prior_loss.per_sample
+            self.reinforce_imp_weight = imp                                                   # model.py:337-340
+            self.importance_weight = imp[None, :] - o["baseline"]                             # [B,B] quirk, model.py:230
         self.num_steps_distrib = NumStepsDistribution(o["presence_prob"].reshape(T, B).t())
         self.steps_prior_success_prob = eng.steps_prior_success_prob(max(eng.global_step - 1, 0))
         if self.nums is not None:

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 7
+#define AIR_ABI_VERSION 8
 
 enum {
     AIR_OK = 0,
@@ -97,6 +97,12 @@ int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float 
                           const float *final_canvas, float *dglimpse, float *dwhere,
                           int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                           void *stream);
+/* air_canvas_unroll_bwd that also returns dpresence[T,B] = sum_pix dL/dcanvas * (the step's write) -- what a continuous presence
+ * (discrete_steps=False: cell.py:150-151, 163) receives from the canvas write.                                           */
+int air_canvas_unroll_bwd_dpresence(const float *glimpse, const float *where, const float *presence, const float *obs,
+                                    const float *final_canvas, float *dglimpse, float *dwhere, float *dpresence,
+                                    int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
+                                    void *stream);
 /* The same launch with one extra workgroup that evaluates air_nvil(imp, baseline, logp, nvil_out, dlogp, dbaseline, B)
  * (the two are independent; the step is bound by the number of dependent launches).                                  */
 int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence, const float *obs,
@@ -375,14 +381,17 @@ int air_numsteps_bwd(const float *presence_prob, const float *presence, const do
 /* Engine fusions of the two above with presence (the step is launch bound at batch 64):
  *   air_presence_numsteps_fwd  = air_presence_fwd (discrete) + air_numsteps_fwd;
  *   air_numsteps_presence_bwd  = [dstep_weight = w_scale*(kl_row_a + kl_row_b)] + air_numsteps_bwd + air_presence_bwd,
- *                                producing d loss / d logit directly.                                               */
+ *                                producing d loss / d logit directly.
+ * Continuous steps (AIRCell(discrete_steps=False), cell.py:150-151): every *_fwd entry that draws the presence takes u == NULL and
+ * then writes presence = presence_prob (no Bernoulli chain); every *_bwd entry that forms dlogit takes `dpresence[T,B]` -- what the
+ * canvas write's backward (air_canvas_unroll_bwd_dpresence) holds for the presence -- and adds it to d/d presence_prob (NULL: discrete). */
 int air_presence_numsteps_fwd(const float *logit, const float *u, float step_bias, float explore_eps,
                               const double *prior_f64, float *presence_prob, float *presence, float *q,
                               float *kl_per_sample, float *logp, float *step_weight, int T, int B, void *stream);
 int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
                               float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
-                              const float *dlogp, const float *logit, float step_bias, float explore_eps,
-                              float *dlogit, int T, int B, void *stream);
+                              const float *dlogp, const float *dpresence, const float *logit, float step_bias,
+                              float explore_eps, float *dlogit, int T, int B, void *stream);
 
 /* "Heads" launches: two independent small ops in ONE dispatch (blocks split by role).
  *   air_heads_fwd = air_gauss_sample_fwd (the where sample)  ||  air_presence_numsteps_fwd
@@ -398,8 +407,8 @@ int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offs
                   const float *dsample, const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
                   int ld_dpre, int M, int D, const float *presence_prob, const float *presence,
                   const double *prior_f64, float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
-                  const float *dlogp, const float *logit, float step_bias, float explore_eps, float *dlogit, int T, int B,
-                  float guard_eps, void *stream);
+                  const float *dlogp, const float *dpresence, const float *logit, float step_bias, float explore_eps, float *dlogit,
+                  int T, int B, float guard_eps, void *stream);
 
 /* Annealed geometric prior over the number of steps, entirely on device (model.py:106-124,139-146; prior.py:26-32):
  *   step' = max(*global_step_dev - hold_for, 0);  anneal_type 0: s = init; 1 ("exp"): s = max(final, init *
@@ -423,6 +432,14 @@ int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
  *   off).  Kept on the device so that a captured graph carries the state from replay to replay.                        */
 int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
              float *dbaseline, int B, float *ema_dev, void *stream);
+/* The importance weight of a NON-analytic num-steps prior (model.py:157-163, 339-340: the step weights are the sampled presences
+ * and reinforce_imp_weight += prior_loss.per_sample): rec_out[B] (optional) = sum of rec_parts[n_parts, B] in share order;
+ * imp_out[b] = rec[b] + nsp_weight * kl_n[b] + sum_t step_weight[t,b] * (kl_row_a[t,b] + kl_row_b[t,b])   (kl_n / kl_row_* may be NULL).
+ * dpresence_inout[T,B] (optional; continuous steps, where the step weight is the presence probability itself and carries a gradient):
+ * += dkl_scale * (kl_row_a + kl_row_b).  One of imp_out / dpresence_inout may be NULL.                                       */
+int air_imp_weight(const float *rec_parts, int n_parts, float *rec_out, const float *kl_n, float nsp_weight, const float *kl_row_a,
+                   const float *kl_row_b, const float *step_weight, int T, int B, float *imp_out, float *dpresence_inout,
+                   float dkl_scale, void *stream);
 /* air_nvil with the importance weight given as n_parts shares per sample (imp_parts[n_parts, B], added in share order in
  * fp32); the sum is also written to imp_sum[B] when given (the complete rec_loss_per_sample).                          */
 int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline, const float *logp,
@@ -479,7 +496,7 @@ int air_attend_bwd(const float *img, const float *where, const float *dglimpse, 
                    float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w, int dwhere_w_slabs,
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
-                   const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
+                   const float *kl_row_b, float w_scale, const float *dlogp, const float *dpresence, const float *logit, float step_bias,
                    float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, float guard_eps, void *stream);
 /* The same launch plus the dX of the two MLP OUTPUT layers (transform: [.., 8], steps: [.., 1]) whose dpre / dlogit it has just
  * formed -- the 8- and 1-deep products that otherwise need a launch of their own on the backward chain:
@@ -491,7 +508,7 @@ int air_attend_bwd_dx(const float *img, const float *where, const float *dglimps
                    float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w, int dwhere_w_slabs,
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
                    const float *presence, const double *prior_f64, float kl_scale, const float *kl_row_a,
-                   const float *kl_row_b, float w_scale, const float *dlogp, const float *logit, float step_bias,
+                   const float *kl_row_b, float w_scale, const float *dlogp, const float *dpresence, const float *logit, float step_bias,
                    float explore_eps, float *dlogit, int T, int B, int H, int W, int h, int w, const float *tr_w, const float *tr_y, float *tr_dx, int tr_k, int tr_ld,
                       const float *st_w, const float *st_y, float *st_dx, int st_k, int st_ld, int precision, float guard_eps,
                       void *stream);

@@ -642,20 +642,27 @@ def objective(params, cfg: AIRConfig, obs: Tensor, noise, global_step=0) -> Dict
         w = torch.flip(torch.cumsum(torch.flip(q[:, 1:].t(), [0]), 0), [0]).to(dt)   # model.py:157-161  [T,B]
     else:
         w = o["presence"].reshape(T, B)
-    what_kl = normal_kl(o["what_loc"], o["what_scale"], cfg.what_prior[0] * torch.ones((), dtype=dt),
-                        cfg.what_prior[1] * torch.ones((), dtype=dt)).sum(-1) * w
-    kl_what_ps = what_kl.sum(0)
+    # a prior left at None: that term is not added (model.py:174, 187)
+    if cfg.what_prior is not None:
+        what_kl = normal_kl(o["what_loc"], o["what_scale"], cfg.what_prior[0] * torch.ones((), dtype=dt),
+                            cfg.what_prior[1] * torch.ones((), dtype=dt)).sum(-1) * w
+        kl_what_ps = what_kl.sum(0)
+    else:
+        kl_what_ps = torch.zeros(B, dtype=dt)
     kl_what = kl_what_ps.mean()
     wl, ws = o["where_loc"], o["where_scale"]
     us, ss = wl[..., [0, 2]], ws[..., [0, 2]]                                   # model.py:190-194
     ut, st = wl[..., [1, 3]], ws[..., [1, 3]]
     one = torch.ones((), dtype=dt)
-    scale_kl = normal_kl(us, ss, cfg.where_scale_prior[0] * one, cfg.where_scale_prior[1] * one)
-    # model.py:203-207: a shift prior without `loc` (here: loc = None) is centred on the posterior's own mean `ut`
-    shift_mean = ut if cfg.where_shift_prior[0] is None else cfg.where_shift_prior[0] * one
-    shift_kl = normal_kl(ut, st, shift_mean, cfg.where_shift_prior[1] * one)
-    where_kl = (scale_kl + shift_kl).sum(-1) * w
-    kl_where_ps = where_kl.sum(0)
+    if cfg.where_scale_prior is not None and cfg.where_shift_prior is not None:
+        scale_kl = normal_kl(us, ss, cfg.where_scale_prior[0] * one, cfg.where_scale_prior[1] * one)
+        # model.py:203-207: a shift prior without `loc` (here: loc = None) is centred on the posterior's own mean `ut`
+        shift_mean = ut if cfg.where_shift_prior[0] is None else cfg.where_shift_prior[0] * one
+        shift_kl = normal_kl(ut, st, shift_mean, cfg.where_shift_prior[1] * one)
+        where_kl = (scale_kl + shift_kl).sum(-1) * w
+        kl_where_ps = where_kl.sum(0)
+    else:
+        kl_where_ps = torch.zeros(B, dtype=dt)
     kl_where = kl_where_ps.mean()
     prior_loss = cfg.nsp_weight * kl_n + kl_what + kl_where
     prior_ps = cfg.nsp_weight * kl_n_ps + kl_what_ps + kl_where_ps

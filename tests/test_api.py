@@ -417,12 +417,13 @@ def test_aironmnist_argument_combinations_the_reference_accepts(amd):
     ts(); ts()
     assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(air._engine.flat_params).all()
     assert abs(air.opt_loss.item() - air.loss.value.item()) < 1e-6 * abs(air.loss.value.item())
-    # priors left at None (the reference's defaults: the KL term is skipped) -> generic path
+    # priors left at None (the reference's defaults: the KL term is skipped) -> on the engine since round 5
     air = _mnist_model(amd)
     ts, gs = air.train_step(1e-4, num_steps_prior=nsp())
-    assert air._engine is None
+    assert air._engine is not None and air._engine.cfg.what_prior is None and air._engine.cfg.where_scale_prior is None
     ts()
-    assert int(gs) == 1 and np.isfinite(float(air.opt_loss))
+    assert int(gs) == 1 and np.isfinite(float(air.opt_loss)) and not hasattr(air, "kl_what")
+    assert abs(float(air.prior_loss.value) - float(air.kl_num_steps)) < 1e-5 * (abs(float(air.kl_num_steps)) + 1)
     # shift prior without loc -> on the engine since round 5 (the kernels' NaN-location convention)
     air = _mnist_model(amd)
     ts, gs = air.train_step(1e-4, 0., N01(), N01(), AD(scale=1.), nsp())
@@ -436,8 +437,8 @@ def test_aironmnist_argument_combinations_the_reference_accepts(amd):
     ts()
     expect = 3. * float(air.kl_num_steps) + float(air.kl_what) + float(air.kl_where)
     assert abs(float(air.prior_loss.value) - expect) < 1e-4 * (abs(expect) + 1)
-    # l2_weight + decay_rate + the RMSProp keyword set (model.py:261-265) -> engine; what stays generic: a non-analytic prior,
-    # continuous steps, a custom optimizer class (test below), priors at None (above)
+    # l2_weight + decay_rate + the RMSProp keyword set (model.py:261-265) -> engine; what stays generic: continuous steps and a
+    # custom optimizer class (test below)
     air = _mnist_model(amd)
     ts, gs = air.train_step(1e-4, 1e-3, N01(), N01(), N01(), nsp(), decay_rate=0.9, opt_kwargs=dict(momentum=.5, centered=True, decay=.95))
     eng = air._engine
@@ -446,7 +447,16 @@ def test_aironmnist_argument_combinations_the_reference_accepts(amd):
     assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(eng.flat_params).all()
     assert float(air.l2_loss) > 0 and float(air.imp_weight_moving_var) != 1.0
     air = _mnist_model(amd)
+    # a non-analytic num-steps prior: sampled step weights, the prior inside the importance weight (model.py:157-163, 339-340)
     ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp(analytic=False))
+    assert air._engine is not None and air._engine.cfg.nsp_analytic is False
+    ts(); ts()
+    assert torch.equal(air.prior_step_weight.reshape(-1), air.presence.reshape(-1))
+    assert torch.allclose(air.reinforce_imp_weight, air.rec_loss_per_sample + air.prior_loss.per_sample)
+    assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(air._engine.flat_params).all()
+    # discrete_steps=False stays on the generic autograd path
+    air = _mnist_model(amd, discrete_steps=False)
+    ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp())
     assert air._engine is None
 
 

@@ -302,6 +302,17 @@ SWITCHES = {
     "rms_kwargs": dict(rms_decay=0.95, rms_momentum=0.5, rms_eps=1e-7),
     "rms_not_centered": dict(rms_centered=False, rms_momentum=0.0),
     "all_together": dict(l2_weight=1e-3, decay_rate=0.8, nsp_weight=0.5, where_shift_prior=(None, 1.3), rms_momentum=0.7),
+    # a non-analytic num-steps prior (model.py:157-163, 339-340) and priors left at None (model.py:174, 187)
+    "nsp_not_analytic": dict(nsp_analytic=False),
+    "what_prior_none": dict(what_prior=None),
+    "where_priors_none": dict(where_scale_prior=None, where_shift_prior=None),
+    "not_analytic_and_more": dict(nsp_analytic=False, what_prior=None, nsp_weight=2.0, decay_rate=0.9, l2_weight=1e-3),
+    # continuous steps (cell.py:150-151): presence = presence_prob, with a gradient through the canvas write (and, under a non-analytic
+    # prior, through the step weights of the KL rows)
+    "continuous_steps": dict(discrete_steps=False),
+    "continuous_not_analytic": dict(discrete_steps=False, nsp_analytic=False, nsp_weight=1.5),
+    "continuous_no_reinforce": dict(discrete_steps=False, use_reinforce=False),
+    "continuous_not_analytic_no_reinforce": dict(discrete_steps=False, nsp_analytic=False, use_reinforce=False, what_prior=None),
 }
 
 
@@ -318,6 +329,10 @@ def test_train_step_switches_on_the_engine_match_oracle(gpu_device, switch, B):
     for k, v in SWITCHES[switch].items():
         assert getattr(eng.cfg, k) == v or k == "where_shift_prior"
     assert eng.cfg.where_shift_prior == ocfg.where_shift_prior
+    if not ocfg.nsp_analytic and (ocfg.use_reinforce or not ocfg.discrete_steps):
+        assert "air_imp_weight" in [e[2] for e in eng._plan_bwd]
+    if not ocfg.discrete_steps:
+        assert "air_canvas_unroll_bwd_dpresence" in [e[2] for e in eng._plan_bwd]
     p64 = f64(params)
     slots = O.rmsprop_init(p64)
     ema_noise_state = {}
@@ -334,7 +349,10 @@ def test_train_step_switches_on_the_engine_match_oracle(gpu_device, switch, B):
         if "_ema" in used:
             ema_noise_state = {"_ema": used["_ema"]}
         out = eng.outputs()
-        for k in ("opt_loss", "loss", "prior_loss", "kl_where", "reinforce_loss", "baseline_loss", "imp_weight_mean", "imp_weight_var"):
+        assert rel_err(out["prior_step_weight"], res["prior_step_weight"]) < 1e-4
+        assert rel_err(out["presence"].reshape(-1), res["presence"].reshape(-1)) < 1e-5
+        for k in ("opt_loss", "loss", "prior_loss", "kl_where", "kl_what") + (
+                ("reinforce_loss", "baseline_loss", "imp_weight_mean", "imp_weight_var") if ocfg.use_reinforce else ()):
             assert abs(out[k].item() - res[k].item()) < 3e-4 * (abs(res[k].item()) + 1.0), (it, k, out[k].item(), res[k].item())
         if ocfg.l2_weight > 0:
             # (a read-out over the CURRENT parameters -- after the update the replay ended with; the L2 gradient inside the step
