@@ -627,8 +627,16 @@ class PlanMixin:
                    desc(1, 0, E, 4 * Hd, B, enc_out, E, dgx, 4 * Hd, gw[:E], 4 * Hd)]        # dW_x
         self._lstm_tail = [desc(1, 0, 1, Hd, B, self.ones_b, 1, self.dh_init, Hd, self.grads["lstm/h0"], Hd),   # dh0
                            desc(1, 0, 1, Hd, B, self.ones_b, 1, dc_in, Hd, self.grads["lstm/c0"], Hd)]          # dc0
-        mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail,
-                      extra_last=lstm_dw)
+        # Round 5 (late): in the latency regime the LSTM's weight gradients leave the LAST launch for the one in front of it (they
+        # have been ready since the BPTT closed): the closing launch -- 19 us with the folded update of input encoder + LSTM --
+        # then holds the input encoder's first layer only, and the LSTM's half of that update runs in the epilogue of a launch
+        # that left most of the chip idle.  AIR_LSTM_DW_EARLY=0: the previous placement (A/B).
+        self._lstm_dw_early = (not throughput and not use16 and self.enc.n >= 2 and os.environ.get("AIR_LSTM_DW_EARLY", "1") == "1")
+        if self._lstm_dw_early:
+            mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail + lstm_dw)
+        else:
+            mlp_bwd_multi(bwd, [dict(m=self.enc, x=self.obs, ldx=P, g_last=self.enc.g[-1])], extra_first=self._lstm_tail,
+                          extra_last=lstm_dw)
 
         if deferred_dw:
             # wide-tile eligible problems (16-byte loads along M and N: both multiples of 4, aligned) together, longest K first
@@ -836,46 +844,79 @@ class PlanMixin:
         if os.environ.get("AIR_OPT_FOLD", "1") != "1" or self._use16:
             return
         L, dp = H.lib(), (lambda t: t.data_ptr())
-        last = riders[-1]
-        if last[2] != "air_gemm_grouped":
-            return
-        arr, n = last[1]
         g0 = self.flat_grads.data_ptr()
+        p0, p1 = self.flat_params.data_ptr(), self.flat_params.data_ptr() + 4 * self.n_total
         head = [(self.param_offsets[k], self.param_sizes[k]) for k in self.param_shapes if self.param_offsets[k] < r_lo]
         if any(sz % 4 for _, sz in head) or sum(sz for _, sz in head) != r_lo:
             return                                   # padding inside the head: the closing launch stays
-        covered, mask = [], 0
-        for i in range(n):
-            d = arr[i]
-            if not (d.ta and not d.tb):
-                continue
-            off = (int(d.C) - g0) // 4
-            if not (0 <= off < r_lo) or d.ldc != d.N or d.beta != 0.0 or d.epilogue != H.EPI_NONE:
-                continue
-            mask |= 1 << i
-            covered.append((off, off + d.M * d.N))
-            if d.colsum:
-                coff = (int(d.colsum) - g0) // 4
-                covered.append((coff, coff + d.N))
-        if not mask:
+        spans = sorted((self.param_offsets[k], self.param_offsets[k] + self.param_sizes[k]) for k in self.param_shapes)
+
+        def tensors_read(entry):
+            """flat-buffer spans of the parameter tensors the problems of a grouped launch read (a dX problem reads its layer's
+            weights; weight gradients read activations / gradients only)"""
+            arr, n = entry[1]
+            out = []
+            for i in range(n):
+                for x in (arr[i].A, arr[i].B, arr[i].aux, arr[i].bias, arr[i].A2):
+                    if p0 <= int(x or 0) < p1:
+                        off = (int(x) - p0) // 4
+                        out += [sp for sp in spans if sp[0] <= off < sp[1]]
+            return out
+
+        def foldable(entry, barred):
+            """(mask, covered spans) of the launch's weight-gradient problems whose parameters nothing in `barred` reads"""
+            arr, n = entry[1]
+            mask, cov = 0, []
+            for i in range(n):
+                d = arr[i]
+                if not (d.ta and not d.tb):
+                    continue
+                off = (int(d.C) - g0) // 4
+                if not (0 <= off < r_lo) or d.ldc != d.N or d.beta != 0.0 or d.epilogue != H.EPI_NONE:
+                    continue
+                mine = [(off, off + d.M * d.N)]
+                if d.colsum:
+                    coff = (int(d.colsum) - g0) // 4
+                    mine.append((coff, coff + d.N))
+                if any(a0 < b1 and b0 < a1 for a0, a1 in mine for b0, b1 in barred):
+                    continue
+                mask |= 1 << i
+                cov += mine
+            return mask, cov
+
+        def wide_form(entry):
+            # the library declines (AIR_E_UNSUPPORTED) a group its wide-tile dispatch would take -- all weight gradients, K >= 256, more
+            # than AIR_GEMM_WIDE_MIN_TILES 16x16 tiles (a long batch at T = 1): such a plan keeps its closing launch
+            arr, n = entry[1]
+            tiles16 = sum(((arr[i].M + 15) // 16) * ((arr[i].N + 15) // 16) for i in range(n))
+            return (tiles16 > int(os.environ.get("AIR_GEMM_WIDE_MIN_TILES", "1000")) and all(arr[i].ta and not arr[i].tb for i in range(n))
+                    and min(arr[i].K for i in range(n)) >= 256)
+
+        def disjoint(cov):
+            cov = sorted(cov)
+            return all(b0 >= a1 for (a0, a1), (b0, b1) in zip(cov, cov[1:]))
+
+        last = riders[-1]
+        if last[2] != "air_gemm_grouped" or wide_form(last):
             return
-        # the library declines (AIR_E_UNSUPPORTED) a group its wide-tile dispatch would take -- all weight gradients, K >= 256, more than
-        # AIR_GEMM_WIDE_MIN_TILES 16x16 tiles (a long batch at T = 1): such a plan keeps its closing launch
-        tiles16 = sum(((arr[i].M + 15) // 16) * ((arr[i].N + 15) // 16) for i in range(n))
-        if (tiles16 > int(os.environ.get("AIR_GEMM_WIDE_MIN_TILES", "1000")) and all(arr[i].ta and not arr[i].tb for i in range(n))
-                and min(arr[i].K for i in range(n)) >= 256):
+        # the closing launch folds what it forms; nothing in it may read a parameter at all (the rider workgroups behind its tiles
+        # update the rest of the head, whatever it is)
+        if tensors_read(last):
             return
-        # any other problem of the launch must leave the head of the gradient buffer alone (and none reads parameters: the
-        # operands of weight gradients are activations / gradients; a dX problem would read its layer's weights)
-        p0, p1 = self.flat_params.data_ptr(), self.flat_params.data_ptr() + 4 * self.n_total
-        for i in range(n):
-            d = arr[i]
-            if any(p0 <= int(x or 0) < p1 for x in (d.A, d.B, d.aux, d.bias, d.A2)):
-                return
-        covered.sort()
-        for (a0, a1), (b0, b1) in zip(covered, covered[1:]):
-            if b0 < a1:
-                return                               # overlapping outputs: not a layout this fold understands
+        mask_b, cov_b = foldable(last, [])
+        if not mask_b:
+            return
+        # the launch in front of it (round 5, late: it holds the LSTM's weight gradients): folds the problems whose parameters neither
+        # it nor the closing launch reads (its dX problem reads ITS layer's weights -- that layer's update stays with the closing launch)
+        prev, mask_a, cov_a = None, 0, []
+        if getattr(self, "_lstm_dw_early", False) and len(riders) >= 2 and riders[-2][2] == "air_gemm_grouped" and not wide_form(riders[-2]):
+            prev = riders[-2]
+            mask_a, cov_a = foldable(prev, tensors_read(prev))
+            if not mask_a or not disjoint(cov_a + cov_b):
+                prev, mask_a, cov_a = None, 0, []
+        covered = sorted(cov_a + cov_b)
+        if not disjoint(covered):
+            return                                   # overlapping outputs: not a layout this fold understands
         ranges, cur = [], 0
         for a0, a1 in covered + [(r_lo, r_lo)]:
             if a0 > cur:
@@ -884,19 +925,28 @@ class PlanMixin:
         if len(ranges) > 4 or any(lo % 4 or hi % 4 for lo, hi in ranges):
             return
         cfg = self.cfg
-        fold = _lib.AirOptFold()
-        fold.p, fold.g, fold.ms, fold.mg, fold.mom = (dp(self.flat_params), g0, dp(self.flat_ms), dp(self.flat_mg), dp(self.flat_mom))
-        fold.n_model = self.n_model
-        fold.lr_dev = dp(self.lr_dev)
-        fold.lr_mult_tail, fold.decay, fold.momentum, fold.eps, fold.grad_scale = (tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0)
-        fold.fold_mask, fold.n_ranges = mask, len(ranges)
-        for j, (lo, hi) in enumerate(ranges):
-            fold.range_lo[j], fold.range_hi[j] = lo, hi
-        fold.global_step_dev, fold.rng_state_dev, fold.rng_increment = dp(self.step_dev), dp(self.rng_state), self._rng_inc
-        self._keep.append(fold)
-        self._fold = fold
+
+        def make_fold(mask, rngs, counters):
+            fold = _lib.AirOptFold()
+            fold.p, fold.g, fold.ms, fold.mg, fold.mom = (dp(self.flat_params), g0, dp(self.flat_ms), dp(self.flat_mg), dp(self.flat_mom))
+            fold.n_model = self.n_model
+            fold.lr_dev = dp(self.lr_dev)
+            fold.lr_mult_tail, fold.decay, fold.momentum, fold.eps, fold.grad_scale = (tail_mult, cfg.rms_decay, cfg.rms_momentum, cfg.rms_eps, 1.0)
+            fold.fold_mask, fold.n_ranges = mask, len(rngs)
+            for j, (lo, hi) in enumerate(rngs):
+                fold.range_lo[j], fold.range_hi[j] = lo, hi
+            if counters:
+                fold.global_step_dev, fold.rng_state_dev, fold.rng_increment = dp(self.step_dev), dp(self.rng_state), self._rng_inc
+            self._keep.append(fold)
+            return fold
+
         riders = list(riders)
-        riders[-1] = (L.air_gemm_grouped_opt, (arr, n, ctypes.byref(fold)), "air_gemm_grouped_opt")
+        self._fold_early = None
+        if prev is not None:
+            self._fold_early = make_fold(mask_a, [], False)          # (no rider slices, the counters move in the closing launch)
+            riders[-2] = (L.air_gemm_grouped_opt, (prev[1][0], prev[1][1], ctypes.byref(self._fold_early)), "air_gemm_grouped_opt")
+        self._fold = make_fold(mask_b, ranges, True)
+        riders[-1] = (L.air_gemm_grouped_opt, (last[1][0], last[1][1], ctypes.byref(self._fold)), "air_gemm_grouped_opt")
         self._plan_bwd_riders = riders
         self._plan_opt_rest = []
 

@@ -193,7 +193,7 @@ def instep_durations(lib, shape, mfma_dtype, n_launches=None):
 PLAN_ENV = ("AIR_DEFER_DW_MIN_ROWS", "AIR_FUSE_ATTEND_M", "AIR_FUSE_LSTM_TILES", "AIR_FUSE_LSTM_WIDE", "AIR_SPLIT_K0", "AIR_OPT_RIDERS",
             "AIR_FUSE_CANVAS", "AIR_FUSE_CANVAS_THROUGHPUT", "AIR_CANVAS_SPLIT", "AIR_BF16_STORAGE", "AIR_BF16_LSTM", "AIR_OPT_FOLD",
             "AIR_GEMM_WIDE_MIN_TILES", "AIR_GEMM_WIDE_TN_BF16", "AIR_GEMM_WIDE_TN_F32", "AIR_GEMM_WIDE_NT_K", "AIR_GEMM_BIG_XCD",
-            "AIR_GEMM_BF16_STORAGE")
+            "AIR_GEMM_BF16_STORAGE", "AIR_LSTM_DW_EARLY", "AIR_FUSE_WHAT_HEAD", "AIR_FUSE_GAUSS_BWD", "AIR_FOLD_GX", "AIR_FUSE_PROLOGUE_CVT")
 
 
 def plan_env_overrides():

@@ -437,8 +437,8 @@ def test_aironmnist_argument_combinations_the_reference_accepts(amd):
     ts()
     expect = 3. * float(air.kl_num_steps) + float(air.kl_what) + float(air.kl_where)
     assert abs(float(air.prior_loss.value) - expect) < 1e-4 * (abs(expect) + 1)
-    # l2_weight + decay_rate + the RMSProp keyword set (model.py:261-265) -> engine; what stays generic: continuous steps and a
-    # custom optimizer class (test below)
+    # l2_weight + decay_rate + the RMSProp keyword set (model.py:261-265) -> engine; what stays generic: a custom optimizer class
+    # (test below) and a non-MLP baseline
     air = _mnist_model(amd)
     ts, gs = air.train_step(1e-4, 1e-3, N01(), N01(), N01(), nsp(), decay_rate=0.9, opt_kwargs=dict(momentum=.5, centered=True, decay=.95))
     eng = air._engine
@@ -454,10 +454,13 @@ def test_aironmnist_argument_combinations_the_reference_accepts(amd):
     assert torch.equal(air.prior_step_weight.reshape(-1), air.presence.reshape(-1))
     assert torch.allclose(air.reinforce_imp_weight, air.rec_loss_per_sample + air.prior_loss.per_sample)
     assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(air._engine.flat_params).all()
-    # discrete_steps=False stays on the generic autograd path
+    # discrete_steps=False (cell.py:150-151): presence = presence_prob, on the engine too
     air = _mnist_model(amd, discrete_steps=False)
     ts, gs = air.train_step(1e-4, 0., N01(), N01(), N01(), nsp())
-    assert air._engine is None
+    assert air._engine is not None and air._engine.cfg.discrete_steps is False
+    ts(); ts()
+    assert torch.equal(air.presence.reshape(-1), air.presence_prob.reshape(-1))
+    assert int(gs) == 2 and np.isfinite(air.opt_loss.item()) and torch.isfinite(air._engine.flat_params).all()
 
 
 def test_debug_flag_validates_distribution_parameters(amd):
