@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 8  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 9  # == AIR_ABI_VERSION in include/air_hip.h
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -106,6 +106,8 @@ SIGNATURES = {
                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P]),
     "air_lstm_step_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "air_lstm_step_bwd_opt": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
+    "air_lstm_step_bwd_entry_fits": (c_int, [c_int, c_int]),
+    "air_lstm_step_bwd_entry": (c_int, [P] * 16 + [c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
     "air_lstm_pointwise_bwd_opt": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, ctypes.POINTER(AirRmspropSlice), P]),
     "air_lstm_pointwise_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     "air_lstm_pointwise_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),

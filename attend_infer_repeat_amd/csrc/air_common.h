@@ -14,6 +14,15 @@ static inline hipStream_t air_stream(void *s) { return reinterpret_cast<hipStrea
 static inline bool air_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool air_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int air_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// rider workgroups of a launch that carries an optimiser slice of nq float4 (optimizer_device.h): AIR_RIDER_QPT float4 per rider
+// thread (the riders are bound by what ONE CU ingests -- nine arrays per element -- so fewer elements per workgroup on more of the
+// idle CUs shortens the launch until the riders outnumber them)
+static inline size_t air_rider_blocks(size_t nq, int nth, size_t cap) {
+    static const double qpt = getenv("AIR_RIDER_QPT") ? atof(getenv("AIR_RIDER_QPT")) : 2.0;
+    const double per_wg = (qpt > 0.05 ? qpt : 2.0) * nth;
+    size_t extra = (size_t)(((double)nq + per_wg - 1.0) / per_wg);
+    return extra > cap ? cap : extra;
+}
 // Grid of a grid-stride ("persistent") launch whose work items outnumber the workgroups the chip holds at once: exactly the resident
 // workgroups (CUs x what the kernel's registers and LDS allow per CU).  A cap that is not a multiple of that number runs in two
 // unequal phases -- the workgroups past the resident set only start when the first ones have finished ALL their items: canvas forward

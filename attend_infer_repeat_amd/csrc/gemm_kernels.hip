@@ -1691,8 +1691,7 @@ extern "C" int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const A
     }
     f.gstep = o->global_step_dev; f.rng_state = o->rng_state_dev; f.rng_inc = o->rng_increment;
     const int nth = long_k ? 1024 : 256;
-    size_t extra = (nq + 2 * nth - 1) / (2 * nth);                          // about two float4 per rider thread
-    if (extra > 512) extra = 512;
+    size_t extra = air_rider_blocks(nq, nth, 512);                          // about two float4 per rider thread
     if (extra < 1) extra = 1;                                               // (the counters live in rider workgroup 0)
     hipStream_t st = air_stream(stream);
 #define AIR_GROUP_OPT_LAUNCH(MT_, NT_, KW_)                                                                                                   \
@@ -2218,6 +2217,134 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_fused_kernel(LstmBwdArgs g, 
     }
 }
 
+// The ENTRY of the BPTT and its first link in ONE launch (latency regime, round 5): the pointwise backward of the last step T-1
+// has no product in front of it -- it was a launch of its own (air_lstm_pointwise_bwd) whose only consumer is the link of step
+// T-2.  Here every workgroup of that link forms its A operand dgates_{T-1}[16 rows, 4Hd] ON THE FLY from the saved gate activations,
+// cell states and the two direct dh terms of step T-1 (wave w owns the unit chunks w, w+16, ...: the four gates of a unit chunk are
+// four 16-deep chunks of K, so ONE set of loads yields four A fragments), multiplies it with W_h^T and finishes step T-2's gate
+// backward exactly as lstm_bwd_fused_kernel does; the (row, unit) pairs of the tile's epilogue re-form their own step T-1 values for
+// dc_in and the running sum over time.  The first column of tiles stores dgates_{T-1} / dc_{T-2 <- T-1} for the weight gradients.
+// One element function for both places: same bits wherever it is evaluated.
+struct LstmEntryArgs {
+    const float *gate_act1, *c_prev1, *c1, *dh_a1, *dh_b1;     // step T-1 (dh_a1 / dh_b1 may be NULL)
+    float *dgates1, *dc_prev1;
+};
+__device__ __forceinline__ void lstm_pw_bwd_elem(float gi, float gj, float gf, float go, float cp, float c, float dha, float dhb,
+                                                 float dci, float (&d)[4], float &dc_prev) {
+#pragma clang fp contract(off)
+    // tanh through one v_exp_f32 and one v_rcp_f32 (absolute error ~1e-7; exact limits +-1): every workgroup of a row tile repeats
+    // this for its 16 x Hd operand elements, and libm's tanhf is two thirds of that work (AIR_LSTM_ENTRY_TANHF: libm's, for A/B builds)
+#ifdef AIR_LSTM_ENTRY_TANHF
+    const float tc = tanhf(c);
+#else
+    const float tc = 1.f - __fdividef(2.f, __expf(2.f * c) + 1.f);
+#endif
+    const float dhe = dha + dhb;
+    const float dct = dci + dhe * go * (1.f - tc * tc);
+    d[0] = dct * gj * gi * (1.f - gi);
+    d[1] = dct * gi * (1.f - gj * gj);
+    d[2] = dct * cp * gf * (1.f - gf);
+    d[3] = dhe * tc * go * (1.f - go);
+    dc_prev = dct * gf;
+}
+__global__ __launch_bounds__(1024) void lstm_bwd_entry_kernel(LstmBwdArgs g, LstmEntryArgs en, RmspropSlice opt) {
+    constexpr int KW = 16, LDT = 20;
+    __shared__ float s_tile[KW][16 * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int tiles_n = g.Hd >> 4;
+    {
+        const int tiles = ((g.M + 15) >> 4) * tiles_n;
+        if ((int)blockIdx.x >= tiles) {
+            rmsprop_slice_body(opt, (int)blockIdx.x - tiles, (int)gridDim.x - tiles);
+            return;
+        }
+    }
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 16, n0 = tn * 16;
+    const int rowA = m0 + li, colB = n0 + li;                   // Hd % 16 == 0: every column of the tile exists
+    const bool okA = rowA < g.M;
+    const int rowAc = okA ? rowA : g.M - 1;
+    const int Hd = g.Hd, K = 4 * Hd;
+    // ---- epilogue operands of thread (er, ec): step T-2's, and step T-1's for dc_in and the running sum
+    const int er = threadIdx.x >> 4, ec = threadIdx.x & 15, em = m0 + er, eu = n0 + ec;
+    const bool e_ok = threadIdx.x < 256 && em < g.M;
+    float gi = 0.f, gj = 0.f, gff = 0.f, go = 0.f, cp = 0.f, cc = 0.f, dha = 0.f, dhb = 0.f;
+    float gi1 = 0.f, gj1 = 0.f, gf1 = 0.f, go1 = 0.f, cp1 = 0.f, cc1 = 0.f, dha1 = 0.f, dhb1 = 0.f;
+    if (e_ok) {
+        const size_t e = (size_t)em * Hd + eu;
+        const gcf ar = (gcf)g.gate_act + (size_t)em * K + eu;
+        gi = ar[0]; gj = ar[Hd]; gff = ar[2 * (size_t)Hd]; go = ar[3 * (size_t)Hd];
+        cp = ((gcf)g.c_prev)[e];
+        cc = ((gcf)g.c)[e];
+        if (g.dh_a) dha = ((gcf)g.dh_a)[e];
+        if (g.dh_b) dhb = ((gcf)g.dh_b)[e];
+        const gcf a1 = (gcf)en.gate_act1 + (size_t)em * K + eu;
+        gi1 = a1[0]; gj1 = a1[Hd]; gf1 = a1[2 * (size_t)Hd]; go1 = a1[3 * (size_t)Hd];
+        cp1 = ((gcf)en.c_prev1)[e];
+        cc1 = ((gcf)en.c1)[e];
+        if (en.dh_a1) dha1 = ((gcf)en.dh_a1)[e];
+        if (en.dh_b1) dhb1 = ((gcf)en.dh_b1)[e];
+    }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nuc = Hd >> 4;                                     // unit chunks (16 units each)
+    const gcf gW = (gcf)g.w_h + (size_t)colB * K;
+#pragma nounroll
+    for (int uc = wave; uc < nuc; uc += KW) {
+        const int u4 = (uc << 4) + 4 * lg;
+        const size_t eo = (size_t)rowAc * Hd + u4, ao = (size_t)rowAc * K + u4;
+        // all loads of the group first: 4 gate vectors, 2 cell states, 2 dh terms, 4 weight fragments
+        f32x4 a_g[4], fb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_g[q] = *(gcf4)((gcf)en.gate_act1 + ao + (size_t)q * Hd);
+        const f32x4 v_cp = *(gcf4)((gcf)en.c_prev1 + eo), v_c = *(gcf4)((gcf)en.c1 + eo);
+        f32x4 v_da = (f32x4){0.f, 0.f, 0.f, 0.f}, v_db = v_da;
+        if (en.dh_a1) v_da = *(gcf4)((gcf)en.dh_a1 + eo);
+        if (en.dh_b1) v_db = *(gcf4)((gcf)en.dh_b1 + eo);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fb[q] = *(gcf4)(gW + (size_t)q * Hd + u4);
+        f32x4 fa[4], v_dcp;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float d[4], dcp;
+            lstm_pw_bwd_elem(a_g[0][x], a_g[1][x], a_g[2][x], a_g[3][x], v_cp[x], v_c[x], v_da[x], v_db[x], 0.f, d, dcp);
+            fa[0][x] = d[0]; fa[1][x] = d[1]; fa[2][x] = d[2]; fa[3][x] = d[3];
+            v_dcp[x] = dcp;
+        }
+        if (tn == 0 && okA) {                                    // the entry's own outputs, once per row tile
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4 *)(en.dgates1 + ao + (size_t)q * Hd) = fa[q];
+            *(f32x4 *)(en.dc_prev1 + eo) = v_dcp;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q][j], fb[q][j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_tile[wave][(4 * lg + r) * LDT + li] = acc[r];
+    __syncthreads();
+    if (e_ok) {
+        const int off = er * LDT + ec;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KW; q += 4)
+            v += (s_tile[q][off] + s_tile[q + 1][off]) + (s_tile[q + 2][off] + s_tile[q + 3][off]);
+        float d1[4], dci;
+        lstm_pw_bwd_elem(gi1, gj1, gf1, go1, cp1, cc1, dha1, dhb1, 0.f, d1, dci);     // step T-1 at this (row, unit)
+        float d[4], dcp;
+        lstm_pw_bwd_elem(gi, gj, gff, go, cp, cc, v + dha, dhb, dci, d, dcp);          // dh = (product + dh_a) + dh_b, as the link
+        const gf_t dr = (gf_t)g.dgates + (size_t)em * K + eu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dr[(size_t)q * Hd] = d[q];
+        ((gf_t)g.dc_prev)[(size_t)em * Hd + eu] = dcp;
+        if (g.dgx_out) {
+            const gf_t so = (gf_t)g.dgx_out + (size_t)em * K + eu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) so[(size_t)q * Hd] = d1[q] + d[q];
+        }
+    }
+}
+
 // One BPTT link in the throughput regime: dh = dgates_{t+1}[M, 4Hd] . W_h[Hd, 4Hd]^T on the wide-tile scheme (both operands
 // k-contiguous: 16 rows x 64 units per workgroup, 8 waves split the 4Hd-deep contraction), then -- exactly as
 // lstm_bwd_fused_kernel -- the pointwise backward of step t for the (row, unit) pairs the tile owns.
@@ -2638,8 +2765,7 @@ static int lstm_bwd_launch(const LstmBwdArgs &g, const RmspropSlice &opt, size_t
     // few tiles (batch 64: 64 of them): 16 waves share the 4Hd-deep contraction of a tile; many tiles: 4 waves
     const bool wide = tiles > 512 && g.Hd % 64 == 0 && g.vecA && g.vecB;
     const int nth = tiles <= 512 ? 1024 : (wide ? 512 : 256);
-    size_t extra = (opt_nq + 2 * nth - 1) / (2 * nth);                     // about two float4 per thread of the riding slice
-    if (extra > 512) extra = 512;
+    size_t extra = air_rider_blocks(opt_nq, nth, 512);                     // about two float4 per thread of the riding slice
     if (wide) hipLaunchKernelGGL((lstm_bwd_wide_kernel<BF>), dim3(air_cdiv(g.M, 16) * (g.Hd / 64) + (int)extra), dim3(512), 0, st, g, opt);
     else if (tiles <= 512) hipLaunchKernelGGL((lstm_bwd_fused_kernel<16, BF>), dim3(tiles + (int)extra), dim3(1024), 0, st, g, opt);
     else hipLaunchKernelGGL((lstm_bwd_fused_kernel<4, BF>), dim3(tiles + (int)extra), dim3(256), 0, st, g, opt);
@@ -2670,6 +2796,36 @@ extern "C" int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h,
     g.vecB = air_aligned16(w_h) ? 1 : 0;
     return precision == AIR_PREC_BF16 ? lstm_bwd_launch<true>(g, os, onq, air_stream(stream))
                                       : lstm_bwd_launch<false>(g, os, onq, air_stream(stream));
+}
+
+extern "C" int air_lstm_step_bwd_entry_fits(int M, int Hd) {
+    return (M > 0 && Hd > 0 && Hd % 16 == 0 && air_cdiv(M, 16) * (Hd / 16) <= 512) ? 1 : 0;
+}
+extern "C" int air_lstm_step_bwd_entry(const float *gate_act1, const float *c_prev1, const float *c1, const float *dh_a1,
+                                       const float *dh_b1, float *dgates1, float *dc_prev1, const float *w_h, const float *dh_a,
+                                       const float *dh_b, const float *gate_act, const float *c_prev, const float *c, float *dgates,
+                                       float *dc_prev, float *dgx_out, int M, int Hd, const AirRmspropSlice *opt, void *stream) {
+    RmspropSlice os; size_t onq;
+    { int st_ = rmsprop_slice_from_abi(opt, os, &onq); if (st_) return st_; }
+    AIR_REQUIRE(gate_act1 && c_prev1 && c1 && dgates1 && dc_prev1 && w_h && gate_act && c_prev && c && dgates && dc_prev, AIR_E_NULL);
+    AIR_REQUIRE(dh_a1 || dh_b1, AIR_E_NULL);
+    AIR_REQUIRE(air_lstm_step_bwd_entry_fits(M, Hd) == 1, AIR_E_UNSUPPORTED);
+    // (Hd % 16 == 0: every row of every operand is a multiple of 64 bytes; the bases must be 16-byte aligned)
+    AIR_REQUIRE(air_aligned16(gate_act1) && air_aligned16(c_prev1) && air_aligned16(c1) && air_aligned16(dgates1) &&
+                air_aligned16(dc_prev1) && air_aligned16(w_h) && (!dh_a1 || air_aligned16(dh_a1)) && (!dh_b1 || air_aligned16(dh_b1)),
+                AIR_E_ALIGN);
+    LstmBwdArgs g;
+    g.dgates_next = dgates1; g.w_h = w_h; g.dh_a = dh_a; g.dh_b = dh_b; g.dc_in = nullptr; g.gate_act = gate_act;
+    g.c_prev = c_prev; g.c = c; g.dgx_in = nullptr; g.dgates = dgates; g.dc_prev = dc_prev; g.dgx_out = dgx_out;
+    g.M = M; g.Hd = Hd; g.vecA = 1; g.vecB = 1;
+    LstmEntryArgs en;
+    en.gate_act1 = gate_act1; en.c_prev1 = c_prev1; en.c1 = c1; en.dh_a1 = dh_a1; en.dh_b1 = dh_b1; en.dgates1 = dgates1;
+    en.dc_prev1 = dc_prev1;
+    const int tiles = air_cdiv(M, 16) * (Hd / 16);
+    size_t extra = air_rider_blocks(onq, 1024, 512);
+    hipLaunchKernelGGL(lstm_bwd_entry_kernel, dim3(tiles + (int)extra), dim3(1024), 0, air_stream(stream), g, en, os);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
 }
 
 // ---- linear layer wrappers (neural.py:56-60) ------------------------------------------------------------------

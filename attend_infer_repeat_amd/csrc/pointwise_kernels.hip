@@ -143,8 +143,7 @@ extern "C" int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_
     AIR_REQUIRE(dh || dc, AIR_E_NULL);
     AIR_REQUIRE(M > 0 && Hd > 0, AIR_E_SHAPE);
     const int main_blocks = pw_blocks((size_t)M * Hd);
-    size_t extra = (nq + 2 * PW_THREADS - 1) / (2 * PW_THREADS);           // about two float4 per thread
-    if (extra > 768) extra = 768;
+    size_t extra = air_rider_blocks(nq, PW_THREADS, 768);                  // about two float4 per thread
     hipLaunchKernelGGL(lstm_pw_bwd_opt_kernel, dim3(main_blocks + (int)extra), dim3(PW_THREADS), 0, air_stream(stream), gate_act,
                        c_prev, c, dh, dh2, dc, dgates, dc_prev, M, Hd, main_blocks, s);
     AIR_LAUNCH_CHECK();

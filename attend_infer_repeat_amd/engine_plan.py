@@ -580,7 +580,26 @@ class PlanMixin:
         rider_hosts = []                    # (index in bwd, entry with an optimiser slice): see _plan_bwd_riders below
         fuse_lstm_bwd = fuse_lstm_fwd            # (the library picks the 16-wave or the wide-tile form of the link by size)
         lstm16 = use16 and fuse_lstm_bwd and not fuse_lstm and self._lstm16_ok()
+        # Round 5 (session 3): in the latency regime the entry of the BPTT -- the pointwise backward of step T-1, a launch of its own
+        # whose only consumer is the link of step T-2 -- is formed inside that link (air_lstm_step_bwd_entry: every workgroup builds
+        # its A operand dgates_{T-1} from the saved activations; one dependent launch fewer).  AIR_LSTM_BWD_ENTRY=0: the two launches.
+        entry_fold = (fuse_lstm and fuse_lstm_bwd and not lstm16 and T >= 2 and prec == 0
+                      and L.air_lstm_step_bwd_entry_fits(B, Hd) == 1 and os.environ.get("AIR_LSTM_BWD_ENTRY", "1") == "1")
+        self._lstm_entry_fold = entry_fold
         for t in reversed(range(T)):
+            if entry_fold and t == T - 1:
+                # (step T-1's results go where the pointwise launch wrote them: dgates[T-1], dc_a)
+                entry_dc = dc_out
+                dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
+                continue
+            if entry_fold and t == T - 2:
+                ent_args = (p(self.gate_act[T - 1]), p(self.c_seq[T - 1]), p(self.c_seq[T]), p(self.dH[T - 1]), p(self.dH_b[T - 1]),
+                            p(self.dgates[T - 1]), p(entry_dc), p(w_h), p(self.dH[t]), p(self.dH_b[t]), p(self.gate_act[t]),
+                            p(self.c_seq[t]), p(self.c_seq[t + 1]), p(self.dgates[t]), p(dc_out), p(self.dgx), B, Hd)
+                rider_hosts.append((len(bwd), L.air_lstm_step_bwd_entry, ent_args, "air_lstm_step_bwd_entry"))
+                bwd.append((L.air_lstm_step_bwd_entry, ent_args + (None,), "air_lstm_step_bwd_entry"))
+                dc_in, dc_out = dc_out, (self.dc_b if dc_out is self.dc_a else self.dc_a)
+                continue
             if lstm16 and t == T - 1:
                 bwd.append((L.air_lstm_pointwise_bwd_bf16, (p(self.gate_act[t]), p(self.c_seq[t]), p(self.c_seq[t + 1]),
                                                             p(self.dH[t]), p(self.dH_b[t]), None, p(self.dgates[t]),

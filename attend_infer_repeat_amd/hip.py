@@ -309,6 +309,22 @@ def lstm_step_bwd_opt(dgates_next, w_h, dh_a, dh_b, dc_in, gate_act, c_prev, c, 
     return dgates, dc_prev
 
 
+def lstm_step_bwd_entry(gate_act1, c_prev1, c1, dh_a1, dh_b1, w_h, dh_a, dh_b, gate_act, c_prev, c, opt=None, want_dgx=True):
+    """air_lstm_step_bwd_entry: pointwise backward of the last step + the first BPTT link in one launch.
+    Returns (dgates1, dc_prev1, dgates, dc_prev, dgx)"""
+    gate_act1 = _f32(gate_act1, "gate_act1", 2); c_prev1 = _f32(c_prev1, "c_prev1", 2); c1 = _f32(c1, "c1", 2)
+    w_h = _f32(w_h, "w_h", 2); gate_act = _f32(gate_act, "gate_act", 2); c_prev = _f32(c_prev, "c_prev", 2); c = _f32(c, "c", 2)
+    M, Hd = c_prev.shape
+    dgates1 = torch.empty_like(gate_act1); dc_prev1 = torch.empty_like(c_prev1)
+    dgates = torch.empty_like(gate_act); dc_prev = torch.empty_like(c_prev)
+    dgx = torch.empty_like(gate_act) if want_dgx else None
+    _lib.check(lib().air_lstm_step_bwd_entry(_p(gate_act1), _p(c_prev1), _p(c1), _p(dh_a1), _p(dh_b1), _p(dgates1), _p(dc_prev1),
+                                             _p(w_h), _p(dh_a), _p(dh_b), _p(gate_act), _p(c_prev), _p(c), _p(dgates), _p(dc_prev),
+                                             _p(dgx), M, Hd, ctypes.byref(opt) if opt is not None else None, _stream()),
+               "air_lstm_step_bwd_entry")
+    return dgates1, dc_prev1, dgates, dc_prev, dgx
+
+
 # ---- stochastic nodes ----------------------------------------------------------------------------------------------
 def gauss_sample_fwd(pre, eps, raw_offset, loc_mode, prior4, want_kl=True, guard_eps=0.0):
     """pre[M, >=2D] (row stride allowed), eps[M,D] or None -> loc, scale, sample|None, kl_row|None

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 8
+#define AIR_ABI_VERSION 9
 
 enum {
     AIR_OK = 0,
@@ -286,6 +286,18 @@ int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const floa
                           const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                           const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
                           const AirRmspropSlice *opt, void *stream);
+/* The ENTRY of the BPTT and its first link in one launch (latency regime: at most 512 16x16 tiles of (batch, hidden), Hd % 16 == 0,
+ * fp32 products; cell.py:126-127 backward, replaces air_lstm_pointwise_bwd(step T-1) + air_lstm_step_bwd(step T-2)): every
+ * workgroup forms dgates_{T-1} -- the A operand of the link -- from the saved activations of step T-1 (gate_act1, c_prev1, c1 and
+ * the direct terms dh_a1 / dh_b1, no dc flowing in), multiplies it with W_h^T and finishes step T-2's gate backward (dh_a / dh_b,
+ * gate_act, c_prev, c -> dgates, dc_prev); dgates1 / dc_prev1 [M,4Hd] / [M,Hd] receive the entry's own results (the weight
+ * gradient reads dgates1), dgx_out (optional) = dgates1 + dgates, the running sum over time.  All operands 16-byte aligned.
+ * air_lstm_step_bwd_entry_fits(M, Hd) == 1 says whether the launch takes the shape.  opt: as air_lstm_step_bwd_opt.            */
+int air_lstm_step_bwd_entry_fits(int M, int Hd);
+int air_lstm_step_bwd_entry(const float *gate_act1, const float *c_prev1, const float *c1, const float *dh_a1,
+                            const float *dh_b1, float *dgates1, float *dc_prev1, const float *w_h, const float *dh_a,
+                            const float *dh_b, const float *gate_act, const float *c_prev, const float *c, float *dgates,
+                            float *dc_prev, float *dgx_out, int M, int Hd, const AirRmspropSlice *opt, void *stream);
 /* The recurrence on the bf16 DATA path (throughput regime: more than 512 16x16 tiles of (batch, hidden), Hd % 64 == 0): W_h is
  * read from the bf16 shadow of the parameters (w_h_bf16: same layout as w_h), h_prev / dgates_next from their bf16 mirrors when
  * given (NULL: the fp32 buffer, rounded in registers), products on v_mfma_f32_16x16x32_bf16; h_bf16 / dgates_bf16 / dgx_bf16

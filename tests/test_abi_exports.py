@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(libpath):
 def test_library_loads_and_reports_abi(libpath):
     from attend_infer_repeat_amd import _lib
     lib = _lib.load()
-    assert lib.air_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.air_abi_version() == _lib.ABI_VERSION == 9
     from attend_infer_repeat_amd import build
     assert lib.air_build_digest().decode() == build.source_digest()
     assert lib.air_status_string(-2).decode().startswith("AIR_E_SHAPE")

@@ -417,7 +417,7 @@ def test_large_batch_plan_matches_oracle(gpu_device, monkeypatch, variant):
     ocfg, B = O.AIRConfig(), (272 if variant == "mid" else 704)
     eng, params, obs, noise = make_pair(ocfg, B)
     names = [n for _, _, n in eng._plan_fwd_train + eng._plan_bwd]
-    assert "air_lstm_pointwise_bwd" in names
+    assert ("air_lstm_step_bwd_entry" if variant == "mid" else "air_lstm_pointwise_bwd") in names    # (mid: the BPTT entry folded into its first link)
     if variant == "mid":
         assert eng._defer_dw and "air_lstm_step_fwd_prologue" in names and "air_lstm_step_bwd" in names
         assert eng._plan_bwd_riders is None

@@ -454,6 +454,64 @@ def test_lstm_fused_step_matches_unfused_pair_and_fp64(hip, M, Hd):
     assert_close(dcp2, dh0 * go * (1 - tc * tc) * gf, 1e-4, 2e-5, "dc_prev (no dh/dc terms)")
 
 
+@pytest.mark.parametrize("M,Hd", [(64, 256), (37, 48), (130, 32), (272, 256), (5, 16), (64, 512)])
+def test_lstm_bwd_entry_matches_pointwise_plus_link_and_fp64(hip, M, Hd):
+    """air_lstm_step_bwd_entry = the pointwise backward of the last step (no dc flowing in) + the BPTT link of the step before it in
+    ONE launch (the link's A operand dgates_{T-1} is formed inside every workgroup); must equal the two launches and the fp64 formula,
+    with and without an optimiser slice riding along."""
+    gen = torch.Generator().manual_seed(M * 13 + Hd)
+    rn = lambda *sh: torch.randn(*sh, generator=gen)
+    w_h = (rn(Hd, 4 * Hd) / Hd ** 0.5).cuda()
+    act1 = torch.sigmoid(rn(M, 4 * Hd)).cuda(); act0 = torch.sigmoid(rn(M, 4 * Hd)).cuda()
+    act1[:, Hd:2 * Hd] = torch.tanh(rn(M, Hd)).cuda(); act0[:, Hd:2 * Hd] = torch.tanh(rn(M, Hd)).cuda()
+    c0, c1, c2 = rn(M, Hd).cuda(), rn(M, Hd).cuda(), rn(M, Hd).cuda()          # c_seq[T-2], c_seq[T-1], c_seq[T]
+    dh_a1, dh_b1, dh_a0, dh_b0 = (rn(M, Hd).cuda() for _ in range(4))
+    # the two launches
+    import ctypes
+    L = hip.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    dg1_ref = torch.empty_like(act1); dcp1_ref = torch.empty_like(c1)
+    assert L.air_lstm_pointwise_bwd(P(act1), P(c1), P(c2), P(dh_a1), P(dh_b1), None, P(dg1_ref), P(dcp1_ref), M, Hd, None) == 0
+    dg0_ref, dcp0_ref, dgx_ref = hip.lstm_step_bwd(dg1_ref, w_h, dh_a0, dh_b0, dcp1_ref, act0, c0, c1, dgx_in=dg1_ref, want_dgx=True)
+    # one launch
+    dg1, dcp1, dg0, dcp0, dgx = hip.lstm_step_bwd_entry(act1, c1, c2, dh_a1, dh_b1, w_h, dh_a0, dh_b0, act0, c0, c1)
+    assert_close(dg1, dg1_ref, 1e-6, 1e-6, "dgates of the last step"); assert_close(dcp1, dcp1_ref, 1e-6, 1e-6, "dc of the last step")
+    assert_close(dg0, dg0_ref, 1e-5, 1e-5, "dgates"); assert_close(dcp0, dcp0_ref, 1e-5, 1e-5, "dc_prev")
+    assert_close(dgx, dgx_ref, 1e-5, 1e-5, "dgx")
+    # fp64
+    a1 = act1.cpu().double(); gi, gj, gf, go = torch.chunk(a1, 4, -1)
+    tc = torch.tanh(c2.cpu().double()); dh1 = dh_a1.cpu().double() + dh_b1.cpu().double()
+    dct1 = dh1 * go * (1 - tc * tc)
+    d1 = torch.cat([dct1 * gj * gi * (1 - gi), dct1 * gi * (1 - gj * gj), dct1 * c1.cpu().double() * gf * (1 - gf), dh1 * tc * go * (1 - go)], -1)
+    dh0 = d1 @ w_h.cpu().double().t() + dh_a0.cpu().double() + dh_b0.cpu().double()
+    a0 = act0.cpu().double(); gi0, gj0, gf0, go0 = torch.chunk(a0, 4, -1)
+    tc0 = torch.tanh(c1.cpu().double())
+    dct0 = dct1 * gf + dh0 * go0 * (1 - tc0 * tc0)
+    d0 = torch.cat([dct0 * gj0 * gi0 * (1 - gi0), dct0 * gi0 * (1 - gj0 * gj0), dct0 * c0.cpu().double() * gf0 * (1 - gf0),
+                    dh0 * tc0 * go0 * (1 - go0)], -1)
+    assert_close(dg1, d1, 1e-4, 2e-5, "dgates of the last step vs fp64"); assert_close(dg0, d0, 1e-4, 2e-5, "dgates vs fp64")
+    assert_close(dcp0, dct0 * gf0, 1e-4, 2e-5, "dc_prev vs fp64"); assert_close(dgx, d1 + d0, 1e-4, 2e-5, "dgx vs fp64")
+    # one direct term only, no running sum; an optimiser slice riding along leaves the launch's own results unchanged
+    n, lo, hi = 8192, 1024, 6140
+    pbuf, g = rn(n).cuda(), rn(n).cuda()
+    ms, mg, mom = torch.rand(n, generator=gen).cuda() + 1.0, rn(n).cuda() * 0.1, rn(n).cuda() * 0.01
+    lr = torch.tensor([1e-3]).cuda()
+    orig = [t.clone() for t in (pbuf, ms, mg, mom)]
+    ref = [t.clone() for t in (pbuf, ms, mg, mom)]
+    hip.rmsprop_centered_(ref[0][lo:hi], g[lo:hi], ref[1][lo:hi], ref[2][lo:hi], ref[3][lo:hi], lr)
+    sl = hip.rmsprop_slice(pbuf, g, ms, mg, mom, lo, hi, n, lr)
+    r = hip.lstm_step_bwd_entry(act1, c1, c2, dh_a1, None, w_h, None, dh_b0, act0, c0, c1, opt=sl, want_dgx=False)
+    q = hip.lstm_step_bwd_entry(act1, c1, c2, dh_a1, None, w_h, None, dh_b0, act0, c0, c1, want_dgx=False)
+    torch.cuda.synchronize()
+    for a, b in zip(r[:4], q[:4]):
+        assert torch.equal(a, b)
+    assert r[4] is None
+    for b_, r_, o_ in zip((pbuf, ms, mg, mom), ref, orig):
+        assert torch.equal(b_[:lo], o_[:lo]) and torch.equal(b_[hi:], o_[hi:])
+        assert_close(b_[lo:hi], r_[lo:hi], 1e-6, 1e-7, "slice riding on the entry launch")
+        assert not torch.equal(b_[lo:hi], o_[lo:hi])
+
+
 @pytest.mark.parametrize("M,Hd", [(48, 64), (1045, 128)])          # the second: wide-tile form (> 512 tiles), ragged rows
 def test_lstm_fused_step_bf16(hip, M, Hd):
     gen = torch.Generator().manual_seed(3)
