@@ -15,8 +15,9 @@ static inline bool air_aligned16(const void *p) { return (reinterpret_cast<uintp
 __device__ __forceinline__ bool air_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int air_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // rider workgroups of a launch that carries an optimiser slice of nq float4 (optimizer_device.h): AIR_RIDER_QPT float4 per rider
-// thread (the riders are bound by what ONE CU ingests -- nine arrays per element -- so fewer elements per workgroup on more of the
-// idle CUs shortens the launch until the riders outnumber them)
+// thread, default 2.  Measured (profiles/r05_bptt_entry_fold_ab.txt): more, smaller rider workgroups are SLOWER -- 1 / 0.5 / 0.25
+// float4 per thread cost +1.0 ... +1.4 us per step at configs[1] against 2 -- the riders then compete with the tile workgroups they
+// ride beside.
 static inline size_t air_rider_blocks(size_t nq, int nth, size_t cap) {
     static const double qpt = getenv("AIR_RIDER_QPT") ? atof(getenv("AIR_RIDER_QPT")) : 2.0;
     const double per_wg = (qpt > 0.05 ? qpt : 2.0) * nth;
