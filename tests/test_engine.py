@@ -1106,3 +1106,20 @@ def test_checkpoint_resume_is_bit_exact(gpu_device, tmp_path):
     eng_a.synchronize(); eng_b.synchronize()
     assert eng_b.global_step == eng_a.global_step == 6
     assert torch.equal(eng_a.flat_params, eng_b.flat_params) and torch.equal(eng_a.flat_mom, eng_b.flat_mom)
+
+
+@pytest.mark.parametrize("name,kw,B,mfma,launches", [
+    ("configs[1]", {}, 64, "f32", 29),
+    ("configs[3]", dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5), 64, "f32", 35),
+    ("configs[4]", {}, 1024, "bf16", 39),
+])
+def test_launches_per_train_step_of_the_named_configurations(gpu_device, name, kw, B, mfma, launches):
+    """The dependent-launch count of the single-GPU train step is what the latency regime is optimised for (DESIGN section 3, round 5:
+    34 -> 29 at configs[1]); a plan change that adds a launch should be a decision, not an accident.  The entry of the BPTT rides in
+    its first link in the latency regime (air_lstm_step_bwd_entry), not in the throughput regime."""
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+    eng = AIREngine(EngineConfig(mfma_dtype=mfma, **kw), B, seed=1, keep_canvas_steps=True)
+    assert sum(eng.kernel_launch_count().values()) == launches, (name, eng.kernel_launch_count())
+    names = [n for plan in eng._single_gpu_step_plans() for _, _, n in plan]
+    assert ("air_lstm_step_bwd_entry" in names) == (B == 64), name
+    assert ("air_lstm_pointwise_bwd" in names or "air_lstm_pointwise_bwd_opt" in names or "air_lstm_pointwise_bwd_bf16" in names) == (B != 64), name
