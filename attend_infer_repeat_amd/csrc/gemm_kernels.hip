@@ -975,6 +975,7 @@ struct GroupArgs {
     int tile_start[AIR_GEMM_GROUP_MAX + 1];
     int count;
     int xcd_map;          // wide-tile launches: blockIdx -> tile through xcd_contiguous_tile
+    unsigned sk_mask;     // bit p: problem p is a short-K weight gradient on the streaming body (shortk_dw_body); its range = its workgroups
 };
 template <int MT, int NT, int KW, bool BF>
 __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(GroupArgs ga) {
@@ -1040,6 +1041,199 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_opt_kern
         default: AIR_OPT_CASE(7); break;
     }
 #undef AIR_OPT_CASE
+}
+
+// ---- short-K weight gradients of the wide first layers (latency regime: dW[M, N] = X^T . dY with K = batch rows <= 64, M = 2500 /
+// 10000 pixels, N <= 256): thousands of output tiles each fed by ONE 16-deep chunk per wave.  On the tile kernels every workgroup is
+// a chain of one cold operand round trip, an LDS reduction of four single-chunk partials, a barrier and the epilogue -- 2500 such
+// workgroups in three resident rounds: 10-17 us beside a 5 us critical path, 30 us where the update rides (configs[3]).  Here the
+// product STREAMS: a wave keeps the whole dY[K, 64 columns] operand of its column quarter in registers (K <= 64: sixteen float4) and
+// walks 16-row slabs of the output grid-stride -- four dword loads per chunk of X^T, sixteen MFMAs per chunk, the accumulators
+// stored (and, folded, updated) straight from the MFMA layout; the next slab's operand is requested before the current one is
+// multiplied.  No LDS, no barrier, no K split (one accumulation chain per element: a fixed order).
+template <bool OPT>
+__device__ __forceinline__ void shortk_dw_body(const GemmArgs &g, const int vb, const int vg, const OptFold *opt, const bool fold) {
+    const gcf gA = (gcf)g.A, gB = (gcf)g.B;
+    const gf gC = (gf)g.C, gCol = (gf)g.colsum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+    const int n_base = 64 * wave;
+    if (n_base >= g.N) return;                                   // (N % 64 == 0: whole quarters; no barrier anywhere below)
+    const int nch = g.K >> 4;                                    // K % 16 == 0, K <= 64
+    f32x4 fb[4][4];                                              // fb[c][t][j] = dY[16c + 4lg + j, n_base + 16t + li]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            fb[c][t] = c < nch ? ld_kstrided_full(gB, g.ldb, n_base + 16 * t + li, (c << 4) + 4 * lg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    float o_lr0 = 0.f;
+    if (OPT && fold) o_lr0 = ((gcf)opt->lr_dev)[0];
+    if (gCol != nullptr && vb == 0) {                            // the bias gradient: column sums of dY, by the first workgroup
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v += (fb[c][t].x + fb[c][t].y) + (fb[c][t].z + fb[c][t].w);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) {
+                const int n = n_base + 16 * t + li;
+                gCol[n] = v;
+                if (OPT && fold) {
+                    const size_t idx = (size_t)((gCol + n) - (gf)opt->g0);
+                    const float lr = idx < opt->n_model ? o_lr0 : o_lr0 * opt->lr_mult_tail;
+                    float pv = ((gf)opt->p)[idx], a = ((gf)opt->ms)[idx], b = ((gf)opt->mg)[idx], cmo = ((gf)opt->mom)[idx];
+                    rmsprop_elem(pv, v, a, b, cmo, lr, opt->decay, opt->momentum, opt->eps, opt->gscale);
+                    ((gf)opt->ms)[idx] = a; ((gf)opt->mg)[idx] = b; ((gf)opt->mom)[idx] = cmo; ((gf)opt->p)[idx] = pv;
+                }
+            }
+        }
+    }
+    const int tiles_m = (g.M + 15) >> 4;
+    int mt = vb;
+    if (mt >= tiles_m) return;
+    f32x4 fa[4];
+    {
+        int m = (mt << 4) + li; if (m > g.M - 1) m = g.M - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[c] = c < nch ? ld_kstrided_full(gA, g.lda, m, (c << 4) + 4 * lg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma nounroll
+    for (; mt < tiles_m; mt += vg) {
+        f32x4 fn[4];
+        {   // the next slab's operand, requested before this one is multiplied (clamped: a slab past the end is never used)
+            int mn = ((mt + vg) << 4) + li; if (mn > g.M - 1) mn = g.M - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fn[c] = c < nch ? ld_kstrided_full(gA, g.lda, mn, (c << 4) + 4 * lg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int mrow0 = (mt << 4) + 4 * lg;
+        // folded update: parameter and slots of this lane's 16 elements, requested before the product
+        f32x4 o_p[4], o_ms[4], o_mg[4], o_mom[4];               // [t][r]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o_p[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; o_ms[t] = o_p[t]; o_mg[t] = o_p[t]; o_mom[t] = o_p[t]; }
+        if (OPT && fold) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int mr = mrow0 + r; if (mr > g.M - 1) mr = g.M - 1;
+                const size_t idx0 = (size_t)((gC + (size_t)mr * g.ldc + n_base + li) - (gf)opt->g0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o_p[t][r] = ((gf)opt->p)[idx0 + 16 * t]; o_ms[t][r] = ((gf)opt->ms)[idx0 + 16 * t];
+                    o_mg[t][r] = ((gf)opt->mg)[idx0 + 16 * t]; o_mom[t][r] = ((gf)opt->mom)[idx0 + 16 * t];
+                }
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][j], fb[c][t][j], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mr = mrow0 + r;
+                if (mr < g.M) {
+                    const size_t off = (size_t)mr * g.ldc + n_base + 16 * t + li;
+                    const float v = acc[t][r];
+                    gC[off] = v;
+                    if (OPT && fold) {
+                        const size_t idx = (size_t)((gC + off) - (gf)opt->g0);
+                        const float lr = idx < opt->n_model ? o_lr0 : o_lr0 * opt->lr_mult_tail;
+                        float pv = o_p[t][r], a = o_ms[t][r], b = o_mg[t][r], cmo = o_mom[t][r];
+                        rmsprop_elem(pv, v, a, b, cmo, lr, opt->decay, opt->momentum, opt->eps, opt->gscale);
+                        ((gf)opt->ms)[idx] = a; ((gf)opt->mg)[idx] = b; ((gf)opt->mom)[idx] = cmo; ((gf)opt->p)[idx] = pv;
+                    }
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[c] = fn[c];
+    }
+}
+// what the streaming body takes (host side): an fp32 TN weight gradient with no epilogue, K in {16, 32, 48, 64}, N a multiple of 64 up
+// to 256, and at least AIR_GEMM_SHORTK_MIN_M (4096) output rows.  Measured (profiles/r05_shortk_dw_ab.txt): at 10000 rows (configs[3])
+// the launch beside the decoder's dX drops from 16.6 to 10.3 us and the closing launch with the folded update from 30.4 to 25.5 us;
+// at 2500 rows (configs[1]: 157 slabs, ONE per workgroup, so the register-resident dY operand is loaded for a single slab) the
+// closing launch is SLOWER (12.0 against 9.7 us) -- hence the row threshold.  The same rule in every entry point (a problem's
+// product must not depend on which launch carries it: the folded and the unfolded plan are bit-identical).  AIR_GEMM_SHORTK=0: never.
+static inline bool shortk_eligible(const AirGemmDesc &d) {
+    static const int on = getenv("AIR_GEMM_SHORTK") ? atoi(getenv("AIR_GEMM_SHORTK")) : 1;
+    static const int min_m = getenv("AIR_GEMM_SHORTK_MIN_M") ? atoi(getenv("AIR_GEMM_SHORTK_MIN_M")) : 4096;
+    return on && d.ta && !d.tb && d.precision == AIR_PREC_F32 && d.K >= 16 && d.K <= 64 && d.K % 16 == 0 && d.N >= 64 && d.N <= 256 &&
+           d.N % 64 == 0 && d.M >= min_m && d.epilogue == AIR_EPI_NONE && d.beta == 0.f && !d.A2 && !d.C16 && !d.bias;
+}
+static inline int shortk_workgroups(int M) {
+    static const int cap = getenv("AIR_GEMM_SHORTK_WGS") ? atoi(getenv("AIR_GEMM_SHORTK_WGS")) : 384;
+    const int t = air_cdiv(M, 16);
+    return t < cap ? t : (cap < 1 ? 1 : cap);
+}
+
+// gemm_grouped_kernel (4-wave tiles) with short-K weight gradients of ga.sk_mask on the streaming body
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_grouped_sk_kernel(GroupArgs ga) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+#define AIR_SK_CASE(I_)                                                                                                        \
+    do {                                                                                                                       \
+        if ((ga.sk_mask >> I_) & 1u)                                                                                           \
+            shortk_dw_body<false>(ga.g[I_], (int)blockIdx.x - ga.tile_start[I_], ga.tile_start[I_ + 1] - ga.tile_start[I_], nullptr, false); \
+        else gemm_body<MT, NT, 4, false>(ga.g[I_], (int)blockIdx.x - ga.tile_start[I_], blockIdx.y);                           \
+    } while (0)
+    switch (p) {
+        case 0: AIR_SK_CASE(0); break;
+        case 1: AIR_SK_CASE(1); break;
+        case 2: AIR_SK_CASE(2); break;
+        case 3: AIR_SK_CASE(3); break;
+        case 4: AIR_SK_CASE(4); break;
+        case 5: AIR_SK_CASE(5); break;
+        case 6: AIR_SK_CASE(6); break;
+        default: AIR_SK_CASE(7); break;
+    }
+#undef AIR_SK_CASE
+}
+// gemm_grouped_opt_kernel's counterpart for launches whose problems are ALL short-K weight gradients (the closing launch of the
+// latency-regime step: the first layer over the pixels of obs): a folded problem updates its elements from the MFMA layout
+__global__ __launch_bounds__(256) void gemm_grouped_opt_sk_kernel(GroupArgs ga, OptFold opt) {
+    if ((int)blockIdx.x >= opt.tiles) {
+        const int vb = (int)blockIdx.x - opt.tiles, vg = (int)gridDim.x - opt.tiles;
+        for (int r = 0; r < opt.n_ranges; ++r) {
+            RmspropSlice sl;
+            sl.p = opt.p; sl.g = opt.g0; sl.ms = opt.ms; sl.mg = opt.mg; sl.mom = opt.mom;
+            sl.lo = opt.lo[r]; sl.hi = opt.hi[r]; sl.n_model = opt.n_model; sl.lr_dev = opt.lr_dev;
+            sl.lr_mult_tail = opt.lr_mult_tail; sl.decay = opt.decay; sl.momentum = opt.momentum; sl.eps = opt.eps; sl.gscale = opt.gscale;
+            rmsprop_slice_body(sl, vb, vg);
+        }
+        if (vb == 0 && threadIdx.x == 0) {
+            if (opt.gstep) opt.gstep[0] += 1;
+            if (opt.rng_state) opt.rng_state[1] += opt.rng_inc;
+        }
+        return;
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+#define AIR_SK_CASE(I_)                                                                                                        \
+    shortk_dw_body<true>(ga.g[I_], (int)blockIdx.x - ga.tile_start[I_], ga.tile_start[I_ + 1] - ga.tile_start[I_], &opt,        \
+                         ((opt.fold_mask >> I_) & 1u) != 0)
+    switch (p) {
+        case 0: AIR_SK_CASE(0); break;
+        case 1: AIR_SK_CASE(1); break;
+        case 2: AIR_SK_CASE(2); break;
+        case 3: AIR_SK_CASE(3); break;
+        case 4: AIR_SK_CASE(4); break;
+        case 5: AIR_SK_CASE(5); break;
+        case 6: AIR_SK_CASE(6); break;
+        default: AIR_SK_CASE(7); break;
+    }
+#undef AIR_SK_CASE
 }
 
 // gemm_grouped_kernel whose problem(s) of `gb.mask` finish a Gaussian head's backward in their epilogue, with up to two rider
@@ -1398,10 +1592,44 @@ static int launch_big_tn_group(const AirGemmDesc *descs, int count, void *stream
     return AIR_OK;
 }
 
+// a latency-regime group with short-K weight gradients among its problems: those on the streaming body, the rest on the 4-wave
+// tile body (16x16 tiles, 32x32 once the REST holds more than 1536 of them), one launch
+static unsigned shortk_mask(const AirGemmDesc *descs, int count) {
+    unsigned m = 0;
+    for (int i = 0; i < count; ++i) {
+        if (descs[i].A2 || descs[i].C16 || descs[i].precision != AIR_PREC_F32) return 0;     // (the plain fp32 group only)
+        if (shortk_eligible(descs[i])) m |= 1u << i;
+    }
+    return m;
+}
+static int launch_grouped_sk(const AirGemmDesc *descs, int count, unsigned sk_mask, void *stream) {
+    GroupArgs ga;
+    long tiles16 = 0;
+    for (int i = 0; i < count; ++i)
+        if (!((sk_mask >> i) & 1u)) tiles16 += (long)air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+    const int T_ = tiles16 > 1536 ? 32 : 16;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        int st = fill_gemm_args(ga.g[i], descs[i]);
+        if (st) return st;
+        ga.tile_start[i] = tiles;
+        tiles += ((sk_mask >> i) & 1u) ? shortk_workgroups(descs[i].M) : air_cdiv(descs[i].M, T_) * air_cdiv(descs[i].N, T_);
+    }
+    for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
+    for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
+    ga.count = count; ga.xcd_map = 0; ga.sk_mask = sk_mask;
+    hipStream_t st = air_stream(stream);
+    if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_sk_kernel<1, 1>), dim3(tiles), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_grouped_sk_kernel<2, 2>), dim3(tiles), dim3(256), 0, st, ga);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
 extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream) {
     AIR_REQUIRE(descs, AIR_E_NULL);
     if (count > AIR_GEMM_GROUP_MAX) return launch_big_tn_group(descs, count, stream);
     AIR_REQUIRE(count > 0 && count <= AIR_GEMM_GROUP_MAX, AIR_E_SHAPE);
+    if (const unsigned skm = shortk_mask(descs, count)) return launch_grouped_sk(descs, count, skm, stream);
     GroupArgs ga;
     // tile shape for the whole group: 16x16 tiles (more, shorter-lived workgroups) while the group is far from filling
     // the chip, 32x32 tiles once it holds thousands of them (less operand re-read, fewer workgroup rounds)
@@ -1419,6 +1647,7 @@ extern "C" int air_gemm_grouped(const AirGemmDesc *descs, int count, void *strea
     for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
     ga.xcd_map = 0;
+    ga.sk_mask = 0;
     // long K on a handful of tiles (the BPTT products, 64x256x1024): 16 waves split K inside the workgroup, so every wave
     // still needs only one or two memory round trips and no second (split-K epilogue) launch is paid
     bool long_k = tiles16 <= 1024;
@@ -1616,6 +1845,7 @@ extern "C" int air_gemm_grouped_gauss_bwd(const AirGemmDesc *descs, int count, c
     for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
     ga.xcd_map = 0;
+    ga.sk_mask = 0;
     GaussEpi gb;
     gb.pre = e->pre; gb.eps = e->eps; gb.loc = e->loc; gb.scale = e->scale; gb.dkl_row = e->dkl_row; gb.dpre = e->dpre;
     gb.ld_pre = e->ld_pre; gb.ld_dpre = e->ld_dpre; gb.D = e->D; gb.raw_offset = e->raw_offset; gb.pl = e->p_loc; gb.ps = e->p_scale;
@@ -1646,12 +1876,18 @@ extern "C" int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const A
     AIR_REQUIRE(o->n_ranges >= 0 && o->n_ranges <= AIR_OPT_MAX_RANGES && o->n_model % 4 == 0, AIR_E_SHAPE);
     AIR_REQUIRE(air_aligned16(o->p) && air_aligned16(o->g) && air_aligned16(o->ms) && air_aligned16(o->mg) && air_aligned16(o->mom), AIR_E_ALIGN);
     GroupArgs ga;
+    // short-K weight gradients on the streaming body (their range = their workgroups).  A folded launch takes them when EVERY problem
+    // is one (the engine's closing launch); a folded launch that mixes one with tile problems is declined -- the caller keeps the
+    // unfolded launch + the closing update for it, so the product is the streaming body's in either plan
+    const unsigned sk_mask = shortk_mask(descs, count);
+    AIR_REQUIRE(sk_mask == 0 || sk_mask == (1u << count) - 1u, AIR_E_UNSUPPORTED);
     long tiles16 = 0;
-    for (int i = 0; i < count; ++i) tiles16 += (long)air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+    for (int i = 0; i < count; ++i)
+        if (!((sk_mask >> i) & 1u)) tiles16 += (long)air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
     const int T_ = tiles16 > 1536 ? 32 : 16;
     int tiles = 0;
     const bool bf = descs[0].precision == AIR_PREC_BF16;
-    bool long_k = tiles16 <= 1024;
+    bool long_k = tiles16 <= 1024 && sk_mask == 0;
     for (int i = 0; i < count; ++i) {
         const AirGemmDesc &d = descs[i];
         AIR_REQUIRE(d.precision == AIR_PREC_F32 || d.precision == AIR_PREC_BF16, AIR_E_UNSUPPORTED);
@@ -1659,7 +1895,7 @@ extern "C" int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const A
         int st = fill_gemm_args(ga.g[i], d);
         if (st) return st;
         ga.tile_start[i] = tiles;
-        tiles += air_cdiv(d.M, T_) * air_cdiv(d.N, T_);
+        tiles += ((sk_mask >> i) & 1u) ? shortk_workgroups(d.M) : air_cdiv(d.M, T_) * air_cdiv(d.N, T_);
         long_k = long_k && d.K >= 512 && d.K >= 8 * (d.M < d.N ? d.M : d.N);
         if ((o->fold_mask >> i) & 1u) {
             // a folded problem: a plain weight gradient written into the flat gradient buffer (its parameter sits at the same offset)
@@ -1678,6 +1914,7 @@ extern "C" int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const A
     for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
     ga.count = count;
     ga.xcd_map = 0;
+    ga.sk_mask = 0;
     OptFold f;
     f.p = o->p; f.g0 = o->g; f.ms = o->ms; f.mg = o->mg; f.mom = o->mom; f.n_model = o->n_model; f.lr_dev = o->lr_dev;
     f.lr_mult_tail = o->lr_mult_tail; f.decay = o->decay; f.momentum = o->momentum; f.eps = o->eps; f.gscale = o->grad_scale;
@@ -1699,7 +1936,9 @@ extern "C" int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const A
         if (bf) hipLaunchKernelGGL((gemm_grouped_opt_kernel<MT_, NT_, KW_, true>), dim3(tiles + (int)extra), dim3(nth), 0, st, ga, f);         \
         else hipLaunchKernelGGL((gemm_grouped_opt_kernel<MT_, NT_, KW_, false>), dim3(tiles + (int)extra), dim3(nth), 0, st, ga, f);           \
     } while (0)
-    if (long_k) AIR_GROUP_OPT_LAUNCH(1, 1, 16);
+    ga.sk_mask = sk_mask;
+    if (sk_mask) hipLaunchKernelGGL(gemm_grouped_opt_sk_kernel, dim3(tiles + (int)extra), dim3(256), 0, st, ga, f);
+    else if (long_k) AIR_GROUP_OPT_LAUNCH(1, 1, 16);
     else if (T_ == 16) AIR_GROUP_OPT_LAUNCH(1, 1, 4);
     else AIR_GROUP_OPT_LAUNCH(2, 2, 4);
 #undef AIR_GROUP_OPT_LAUNCH

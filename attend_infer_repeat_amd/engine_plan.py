@@ -911,12 +911,27 @@ class PlanMixin:
             return (tiles16 > int(os.environ.get("AIR_GEMM_WIDE_MIN_TILES", "1000")) and all(arr[i].ta and not arr[i].tb for i in range(n))
                     and min(arr[i].K for i in range(n)) >= 256)
 
+        def shortk_mixed(entry):
+            # ... and a group that MIXES a short-K streaming weight gradient (gemm_kernels.hip shortk_eligible: fp32 TN, K <= 64 in whole
+            # chunks, N a multiple of 64 up to 256, >= AIR_GEMM_SHORTK_MIN_M rows, no epilogue) with tile problems: such a problem keeps
+            # the product of the streaming body in every plan, and the folded launch takes it only when all its problems are of that kind
+            if os.environ.get("AIR_GEMM_SHORTK", "1") == "0":
+                return False
+            min_m = int(os.environ.get("AIR_GEMM_SHORTK_MIN_M", "4096"))
+            arr, n = entry[1]
+            if any(arr[i].A2 or arr[i].C16 or arr[i].precision != 0 for i in range(n)):
+                return False
+            el = [bool(arr[i].ta and not arr[i].tb and 16 <= arr[i].K <= 64 and arr[i].K % 16 == 0 and 64 <= arr[i].N <= 256
+                       and arr[i].N % 64 == 0 and arr[i].M >= min_m and arr[i].epilogue == 0 and arr[i].beta == 0.0 and not arr[i].bias)
+                  for i in range(n)]
+            return any(el) and not all(el)
+
         def disjoint(cov):
             cov = sorted(cov)
             return all(b0 >= a1 for (a0, a1), (b0, b1) in zip(cov, cov[1:]))
 
         last = riders[-1]
-        if last[2] != "air_gemm_grouped" or wide_form(last):
+        if last[2] != "air_gemm_grouped" or wide_form(last) or shortk_mixed(last):
             return
         # the closing launch folds what it forms; nothing in it may read a parameter at all (the rider workgroups behind its tiles
         # update the rest of the head, whatever it is)
@@ -928,7 +943,7 @@ class PlanMixin:
         # the launch in front of it (round 5, late: it holds the LSTM's weight gradients): folds the problems whose parameters neither
         # it nor the closing launch reads (its dX problem reads ITS layer's weights -- that layer's update stays with the closing launch)
         prev, mask_a, cov_a = None, 0, []
-        if getattr(self, "_lstm_dw_early", False) and len(riders) >= 2 and riders[-2][2] == "air_gemm_grouped" and not wide_form(riders[-2]):
+        if getattr(self, "_lstm_dw_early", False) and len(riders) >= 2 and riders[-2][2] == "air_gemm_grouped" and not wide_form(riders[-2]) and not shortk_mixed(riders[-2]):
             prev = riders[-2]
             mask_a, cov_a = foldable(prev, tensors_read(prev))
             if not mask_a or not disjoint(cov_a + cov_b):

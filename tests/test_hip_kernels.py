@@ -454,6 +454,38 @@ def test_lstm_fused_step_matches_unfused_pair_and_fp64(hip, M, Hd):
     assert_close(dcp2, dh0 * go * (1 - tc * tc) * gf, 1e-4, 2e-5, "dc_prev (no dh/dc terms)")
 
 
+@pytest.mark.parametrize("shapes", [
+    [(10000, 256, 64, True)],                                  # the closing launch's problem (configs[3])
+    [(5000, 128, 48, False), (4100, 256, 64, True)],            # two streaming problems, one with three chunks and half the columns
+    [(10000, 256, 64, True), (50, 256, 192, True), (787, 256, 64, False)],      # configs[3]'s pixels beside ordinary tile problems
+    [(4099, 64, 16, True), (192, 400, 256, False), (4203, 192, 32, False)],     # ragged rows, one chunk, mixed with a dX-shaped product
+    [(2500, 256, 64, True)],                                   # below the row threshold: the tile kernels (configs[1])
+])
+def test_short_k_weight_gradients_on_the_streaming_body(hip, shapes):
+    """air_gemm_grouped: TN weight gradients with K <= 64 rows and at least 4096 output rows run on the streaming body
+    (shortk_dw_body: the whole dY operand in registers, 16-row slabs grid-stride, no K split); every problem of the group -- streaming
+    or tiled -- must match the fp64 product and column sums, with offset row views as the engine passes them."""
+    gen = torch.Generator().manual_seed(sum(m + n + k for m, n, k, _ in shapes))
+    probs, refs = [], []
+    for i, (M, N, K, cs) in enumerate(shapes):
+        tn = (M, N, K) != (192, 400, 256)
+        if tn:
+            A = torch.randn(K, M + 8, generator=gen).cuda()[:, 4:4 + M]          # [K, M] view with a leading dimension
+            B = torch.randn(K, N, generator=gen).cuda()
+            out = torch.zeros(M + 3, N, device="cuda")[1:1 + M]
+            probs.append(dict(A=A, B=B, ta=True, out=out, colsum=cs))
+            refs.append((A.double().t() @ B.double(), B.double().sum(0) if cs else None))
+        else:
+            A = torch.randn(M, K, generator=gen).cuda(); B = torch.randn(N, K, generator=gen).cuda()
+            probs.append(dict(A=A, B=B, tb=True))
+            refs.append((A.double() @ B.double().t(), None))
+    outs = hip.gemm_grouped(probs)
+    for (C, cs), (rC, rcs), sh in zip(outs, refs, shapes):
+        assert_close(C, rC, 1e-5, 2e-5, "C %s" % (sh,))
+        if rcs is not None:
+            assert_close(cs, rcs, 1e-5, 2e-5, "colsum %s" % (sh,))
+
+
 @pytest.mark.parametrize("M,Hd", [(64, 256), (37, 48), (130, 32), (272, 256), (5, 16), (64, 512)])
 def test_lstm_bwd_entry_matches_pointwise_plus_link_and_fp64(hip, M, Hd):
     """air_lstm_step_bwd_entry = the pointwise backward of the last step (no dc flowing in) + the BPTT link of the step before it in

@@ -13,5 +13,5 @@ for n in ("c2_b64_unprofiled", "c2_b64_driver_command", "c4_b64", "c5_b1024_bf16
     except Exception as e:
         print(n, "FAILED", e)
 PY
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gpu_tests.log 2>&1
+timeout 1600 python -m pytest tests -x -q -m gpu > gpurun_out/$TAG/gpu_tests.log 2>&1
 grep -E "passed|failed|error" gpurun_out/$TAG/gpu_tests.log | tail -2
