@@ -1123,3 +1123,34 @@ def test_launches_per_train_step_of_the_named_configurations(gpu_device, name, k
     names = [n for plan in eng._single_gpu_step_plans() for _, _, n in plan]
     assert ("air_lstm_step_bwd_entry" in names) == (B == 64), name
     assert ("air_lstm_pointwise_bwd" in names or "air_lstm_pointwise_bwd_opt" in names or "air_lstm_pointwise_bwd_bf16" in names) == (B != 64), name
+
+
+@pytest.mark.gpu
+def test_tf_checkpoint_export_import_between_engines(gpu_device, tmp_path):
+    """an engine's parameters written as a TF-1 `model.ckpt` (TensorBundle, tf_checkpoint.write_bundle) under
+    reference-like variable names and imported into a differently initialised engine: same parameters bit for bit, and the next
+    train step (same batch, same noise state) leaves both on identical parameters."""
+    from attend_infer_repeat_amd import tf_checkpoint as TF
+    from test_tf_checkpoint import _reference_like_checkpoint
+    ocfg, B = CONFIGS["mnist_b8"]
+    eng_a, *_ = make_pair(ocfg, B, seed=5, gstep=0)
+    eng_b, *_ = make_pair(ocfg, B, seed=99, gstep=0)
+    eng_a.synchronize(); eng_b.synchronize()
+    assert not torch.equal(eng_a.flat_params, eng_b.flat_params)
+    names, _ = _reference_like_checkpoint(eng_a.cfg, np.random.default_rng(0))       # only the NAMES of this helper are used
+    tfmap = TF.default_name_map(eng_a.param_shapes, {k: v.shape for k, v in names.items()})
+    assert set(tfmap) == set(eng_a.param_shapes)
+    tensors = {tfmap[k]: eng_a.params[k].detach().cpu().numpy() for k in eng_a.param_shapes}
+    tensors["global_step"] = np.int64(0)
+    prefix = str(tmp_path / "model.ckpt-0")
+    TF.write_bundle(prefix, tensors)
+    named = TF.import_tf_checkpoint(prefix, eng_b.param_shapes)
+    eng_b.load_parameters({k: torch.from_numpy(v) for k, v in named.items()})
+    eng_b.reset_optimizer()
+    eng_b.set_obs(eng_a.obs.clone())
+    eng_b.rng_state.copy_(eng_a.rng_state)
+    eng_a.synchronize(); eng_b.synchronize()
+    assert torch.equal(eng_a.flat_params, eng_b.flat_params)
+    eng_a.train_step(); eng_b.train_step()
+    eng_a.synchronize(); eng_b.synchronize()
+    assert torch.equal(eng_a.flat_params, eng_b.flat_params)

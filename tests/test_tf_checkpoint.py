@@ -1,0 +1,190 @@
+"""TF-1 `model.ckpt` (TensorBundle) reader / writer and the importer into the engine's parameter names.
+No TensorFlow here: pinned are the checksum's published known answers, round trips, an independently built index file, and
+rejection of corrupted files; the reference's variable NAMES are an assumption (module docstring)."""
+import struct
+
+import numpy as np
+import pytest
+
+from attend_infer_repeat_amd import tf_checkpoint as T
+from attend_infer_repeat_amd.engine_config import EngineConfig, param_shapes
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 appendix B.4
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    # incremental == one shot, at lengths around the 8-byte stride
+    data = bytes(np.random.default_rng(0).integers(0, 256, 1000, dtype=np.uint8))
+    for cut in (0, 1, 7, 8, 9, 500, 999, 1000):
+        assert T.crc32c(data[cut:], T.crc32c(data[:cut])) == T.crc32c(data)
+    # LevelDB's mask (crc32c_test: the mask is not the identity, not an involution, and is undone by unmask)
+    c = T.crc32c(b"foo")
+    assert T.mask_crc(c) != c and T.mask_crc(T.mask_crc(c)) != c
+    assert T.unmask_crc(T.mask_crc(c)) == c and T.unmask_crc(T.unmask_crc(T.mask_crc(T.mask_crc(c)))) == c
+
+
+def _sample_tensors(rng):
+    return {
+        "AIRonMNIST/canvas_multiplier": np.float32(1.0),
+        "global_step": np.int64(175000),
+        "a/w": rng.standard_normal((7, 5)).astype(np.float32),
+        "a/b": rng.standard_normal((5,)).astype(np.float32),
+        "a/w/RMSProp": rng.standard_normal((7, 5)).astype(np.float32),
+        "z/empty": np.zeros((0, 3), np.float32),
+        "z/f64": rng.standard_normal((2, 3, 4)),
+        "z/i32": rng.integers(-5, 5, (9,), dtype=np.int32),
+        "z/flag": np.array([True, False]),
+        "z/h": rng.standard_normal((3,)).astype(np.float16),
+    }
+
+
+def test_round_trip_all_dtypes(tmp_path):
+    rng = np.random.default_rng(1)
+    t = _sample_tensors(rng)
+    p = str(tmp_path / "model.ckpt-175000")
+    T.write_bundle(p, t)
+    header, entries = T.read_index(p)
+    assert header["num_shards"] == 1 and set(entries) == set(t)
+    back = T.read_bundle(p)
+    for k, v in t.items():
+        assert back[k].dtype == np.asarray(v).dtype and back[k].shape == np.asarray(v).shape, k
+        np.testing.assert_array_equal(back[k], v)
+    assert T.global_step_of(p) == 175000
+    assert set(T.read_bundle(p, ["a/w"])) == {"a/w"}
+    with pytest.raises(KeyError):
+        T.read_bundle(p, ["nope"])
+
+
+def test_many_blocks_and_prefix_compression(tmp_path):
+    rng = np.random.default_rng(2)
+    t = {"scope/module_%03d/affine/w" % i: rng.standard_normal((3, 2)).astype(np.float32) for i in range(300)}
+    p = str(tmp_path / "m")
+    T.write_bundle(p, t, block_size=512)                 # dozens of data blocks behind a multi-entry index block
+    back = T.read_bundle(p)
+    assert list(back) == sorted(t) and all(np.array_equal(back[k], t[k]) for k in t)
+    # the keys really were stored prefix-compressed (the reader is exercising `shared` > 0)
+    raw = open(p + ".index", "rb").read()
+    assert raw.count(b"scope/module_") < 300 // 4
+
+
+def test_index_built_by_hand(tmp_path):
+    """An index file assembled here byte by byte from the format description (not by write_bundle): one data block with restart
+    interval 1 (no key sharing), an entry that spells out offset = 0, unknown extra fields in the messages."""
+    w = np.arange(6, dtype=np.float32).reshape(2, 3)
+    raw = w.tobytes()
+    p = str(tmp_path / "hand")
+    open(p + ".data-00000-of-00001", "wb").write(raw)
+    vi = lambda v: T._put_varint(v)
+    dim = lambda d: b"\x12" + vi(2) + b"\x08" + vi(d)                                   # TensorShapeProto.dim { size }
+    shape = dim(2) + dim(3)
+    entry = (b"\x08\x01" + b"\x12" + vi(len(shape)) + shape + b"\x18\x00" + b"\x20\x00" + b"\x28" + vi(len(raw)) +
+             b"\x35" + struct.pack("<I", T.mask_crc(T.crc32c(raw))) + b"\x78\x05")       # field 15: unknown, skipped
+    header = b"\x08\x01" + b"\x10\x00" + b"\x1a\x02\x08\x01"
+    ent = lambda k, v: vi(0) + vi(len(k)) + vi(len(v)) + k + v
+    body = ent(b"", header) + ent(b"enc/w", entry)
+    l1 = len(ent(b"", header))
+    block = body + struct.pack("<III", 0, l1, 2)
+    tr = lambda b: b + b"\x00" + struct.pack("<I", T.mask_crc(T.crc32c(b + b"\x00")))
+    out = tr(block)
+    meta = struct.pack("<II", 0, 1); meta_h = vi(len(out)) + vi(len(meta)); out += tr(meta)
+    idx = ent(b"enc/x", vi(0) + vi(len(block))) + struct.pack("<II", 0, 1); idx_h = vi(len(out)) + vi(len(idx)); out += tr(idx)
+    foot = meta_h + idx_h
+    out += foot + bytes(40 - len(foot)) + struct.pack("<Q", 0xdb4775248b80fb57)
+    open(p + ".index", "wb").write(out)
+    np.testing.assert_array_equal(T.read_bundle(p)["enc/w"], w)
+
+
+def test_corruption_is_rejected(tmp_path):
+    rng = np.random.default_rng(3)
+    p = str(tmp_path / "c")
+    T.write_bundle(p, {"a/w": rng.standard_normal((4, 4)).astype(np.float32)})
+    idx = bytearray(open(p + ".index", "rb").read())
+    data = bytearray(open(p + ".data-00000-of-00001", "rb").read())
+    bad = bytearray(idx); bad[5] ^= 0x40
+    open(p + ".index", "wb").write(bad)
+    with pytest.raises(T.TFCheckpointError, match="checksum"):
+        T.read_bundle(p)
+    bad = bytearray(idx); bad[-1] ^= 1
+    open(p + ".index", "wb").write(bad)
+    with pytest.raises(T.TFCheckpointError, match="magic"):
+        T.read_bundle(p)
+    open(p + ".index", "wb").write(idx)
+    flipped = bytearray(data); flipped[3] ^= 1
+    open(p + ".data-00000-of-00001", "wb").write(flipped)
+    with pytest.raises(T.TFCheckpointError, match="checksum mismatch in the data shard"):
+        T.read_bundle(p)
+    assert T.read_bundle(p, verify="index")["a/w"].shape == (4, 4)      # the caller may skip the data checksums
+    open(p + ".data-00000-of-00001", "wb").write(data[:-4])
+    with pytest.raises(T.TFCheckpointError, match="ends inside"):
+        T.read_bundle(p)
+
+
+def _reference_like_checkpoint(cfg, rng, with_baseline=True):
+    """A checkpoint under names of the kind Sonnet 1.1 would give the reference's graph (an ASSUMPTION: modules are scoped by
+    their snake-cased class names, repeated classes numbered in creation order, Affine layers `affine`, `affine_1`, ... inside
+    their MLP), with the optimiser slots and bookkeeping scalars a Saver also writes."""
+    shapes = param_shapes(cfg)
+    scope = {"input_encoder": "AIRonMNIST/air_cell/encoder/MLP", "glimpse_encoder": "AIRonMNIST/air_cell/encoder_1/MLP",
+             "transform": "AIRonMNIST/air_cell/stochastic_transform_param/MLP", "steps": "AIRonMNIST/air_cell/steps_predictor/MLP",
+             "glimpse_decoder": "AIRonMNIST/air_cell/decoder/MLP", "baseline": "AIRonMNIST/baseline_mlp/MLP"}
+    tensors, truth = {}, {}
+    for k, s in shapes.items():
+        g, rest = k.split("/", 1)
+        if g == "baseline" and not with_baseline:
+            continue
+        v = rng.standard_normal(s).astype(np.float32)
+        if g == "lstm":
+            tfn = {"w_gates": "AIRonMNIST/air_cell/lstm/w_gates", "b_gates": "AIRonMNIST/air_cell/lstm/b_gates",
+                   "h0": "AIRonMNIST/air_cell/initial_state_0", "c0": "AIRonMNIST/air_cell/initial_state_1"}[rest]
+        elif g == "what":
+            tfn = "AIRonMNIST/air_cell/parametrised_gaussian/affine/" + rest
+        else:
+            i, leaf = rest.split("/")
+            tfn = "%s/affine%s/%s" % (scope[g], "" if i == "0" else "_" + i, leaf)
+        tensors[tfn] = v; truth[k] = v
+        tensors[tfn + "/RMSProp"] = np.ones(s, np.float32); tensors[tfn + "/RMSProp_1"] = np.zeros(s, np.float32)
+    tensors["global_step"] = np.int64(5000)
+    tensors["AIRonMNIST/canvas_multiplier"] = np.float32(1.0)
+    tensors["AIRonMNIST/learning_rate"] = np.float32(1e-5)
+    return tensors, truth
+
+
+@pytest.mark.parametrize("with_baseline", [True, False])
+def test_import_into_engine_names(tmp_path, with_baseline):
+    cfg = EngineConfig(img_size=(12, 12), crop_size=(6, 6), n_appearance=5, n_hidden=16, max_steps=3, inpt_encoder_hidden=[16, 16],
+                       glimpse_encoder_hidden=[16, 16], glimpse_decoder_hidden=[12, 12], transform_estimator_hidden=[16, 16],
+                       steps_pred_hidden=[7], baseline_hidden=[16, 8])
+    rng = np.random.default_rng(4)
+    tensors, truth = _reference_like_checkpoint(cfg, rng, with_baseline)
+    p = str(tmp_path / "model.ckpt-5000")
+    T.write_bundle(p, tensors)
+    shapes = param_shapes(cfg)
+    got = T.import_tf_checkpoint(p, shapes)
+    assert set(got) == set(truth)                                           # every engine tensor the checkpoint can fill, no slot
+    for k in truth:
+        assert got[k].shape == tuple(shapes[k]) and got[k].dtype == np.float32
+        np.testing.assert_array_equal(got[k], truth[k])
+    # an explicit map (dict or callable) overrides the matcher and is shape-checked
+    one = T.import_tf_checkpoint(p, shapes, name_map={"what/w": "AIRonMNIST/air_cell/parametrised_gaussian/affine/w"})
+    np.testing.assert_array_equal(one["what/w"], truth["what/w"])
+    with pytest.raises(T.TFCheckpointError, match="engine shape"):
+        T.import_tf_checkpoint(p, shapes, name_map={"what/w": "AIRonMNIST/air_cell/lstm/w_gates"})
+    with pytest.raises(KeyError):
+        T.import_tf_checkpoint(p, shapes, name_map={"what/w": "missing"})
+    assert T.global_step_of(p) == 5000
+
+
+def test_import_at_the_reference_architecture(tmp_path):
+    """mnist_model.py:13-44's sizes: the (256, 256) layers of four different modules are told apart by their chains."""
+    cfg = EngineConfig()
+    rng = np.random.default_rng(5)
+    tensors, truth = _reference_like_checkpoint(cfg, rng)
+    tensors = {k: v for k, v in tensors.items() if "RMSProp" not in k}      # keep the file small
+    p = str(tmp_path / "model.ckpt-300000")
+    T.write_bundle(p, tensors)
+    got = T.import_tf_checkpoint(p, param_shapes(cfg), verify="index")
+    assert set(got) == set(truth) and all(np.array_equal(got[k], truth[k]) for k in truth)
