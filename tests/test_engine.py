@@ -1148,8 +1148,9 @@ def test_tf_checkpoint_export_import_between_engines(gpu_device, tmp_path):
     eng_b.load_parameters({k: torch.from_numpy(v) for k, v in named.items()})
     eng_b.reset_optimizer()
     eng_b.set_obs(eng_a.obs.clone())
-    eng_b.rng_state.copy_(eng_a.rng_state)
     eng_a.synchronize(); eng_b.synchronize()
+    eng_b.rng_state.copy_(eng_a.rng_state)
+    torch.cuda.synchronize()
     assert torch.equal(eng_a.flat_params, eng_b.flat_params)
     eng_a.train_step(); eng_b.train_step()
     eng_a.synchronize(); eng_b.synchronize()
