@@ -76,17 +76,44 @@ class AIREngine(PlanMixin):
             self.n_model = off
         self.n_total = off
         dev = self.device
-        self.flat_params = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        self.flat_grads = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        self.flat_ms = torch.ones(self.n_total, dtype=torch.float32, device=dev)
-        self.flat_mg = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        self.flat_mom = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        flat = self._alloc_flat(5, self.n_total, dev)
+        self.flat_params, self.flat_grads, self.flat_ms, self.flat_mg, self.flat_mom = flat
+        self.flat_ms.fill_(1.0)
         self.params = {k: self.flat_params[offs[k]:offs[k] + sizes[k]].view(shapes[k]) for k in shapes}
         self.grads = {k: self.flat_grads[offs[k]:offs[k] + sizes[k]].view(shapes[k]) for k in shapes}
         self.param_offsets, self.param_sizes, self.param_shapes = offs, sizes, shapes
         self.lr_dev = torch.tensor([cfg.learning_rate], dtype=torch.float32, device=dev)
         self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
         self.init_parameters(seed)
+
+    @staticmethod
+    def _alloc_flat(count, n, dev):
+        """The flat parameter / gradient / RMSProp-slot buffers.  AIR_FLAT_LAYOUT (developer switch, placement probe of round 5:
+        the same step ran 4-7 % faster or slower depending on WHERE the caching allocator happened to put these five arrays):
+          unset            one torch allocation each (what the allocator gives: 2 MB-aligned segments of their own in a fresh
+                           process once they exceed 10 MB, carved back to back out of a cached block otherwise)
+          packed           one arena, the arrays back to back (512-byte granules)
+          stagger:<bytes>  one arena, array k at a 2 MB-aligned slot + k * <bytes>"""
+        mode = os.environ.get("AIR_FLAT_LAYOUT", "")
+        if not mode:
+            return [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(count)]
+        nbytes = n * 4
+        if mode == "packed":
+            pitch, stagger = (nbytes + 511) // 512 * 512, 0
+        elif mode.startswith("stagger:"):
+            stagger = int(mode.split(":", 1)[1])
+            if stagger % 16:
+                raise ValueError("AIR_FLAT_LAYOUT=stagger:<bytes>: a multiple of 16 (vectorised operand loads)")
+            pitch = ((nbytes + count * stagger) + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        else:
+            raise ValueError(f"AIR_FLAT_LAYOUT={mode!r}: expected 'packed' or 'stagger:<bytes>'")
+        arena = torch.zeros(count * pitch + (2 << 20), dtype=torch.uint8, device=dev)
+        base = (-arena.data_ptr()) % (2 << 20)                # first 2 MB boundary inside the arena
+        out = []
+        for k in range(count):
+            lo = base + k * pitch + k * stagger
+            out.append(arena[lo:lo + nbytes].view(torch.float32))
+        return out
 
     def init_parameters(self, seed: int = 0):
         """Sonnet defaults: w ~ TruncNormal(0, 1/sqrt(fan_in)) (+-2 sigma), b = 0, LSTM initial state = 0."""
