@@ -41,6 +41,33 @@ import torch
 import torch.distributed as dist
 
 
+def free_rendezvous_port(lo: int = 20000, hi: int = 32000) -> int:
+    """A free TCP port for a local rendezvous, taken BELOW the kernel's ephemeral range (ip_local_port_range, 32768-60999 by default).
+    `bind(('127.0.0.1', 0))` hands out an ephemeral port; a rank that starts before rank 0 listens retries its connect from
+    ephemeral SOURCE ports, and when the kernel picks the destination port itself the connect succeeds against itself (TCP
+    simultaneous open) and rank 0's listen fails with EADDRINUSE -- seen once in ~140 spawned two-rank tests on a GPU box."""
+    import random
+    import socket
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            eph_lo = int(f.read().split()[0])
+        if eph_lo > lo + 1000:
+            hi = min(hi, eph_lo)
+    except (OSError, ValueError, IndexError):
+        pass
+    rng = random.SystemRandom()
+    for _ in range(200):
+        port = rng.randrange(lo, hi)
+        with socket.socket() as s:
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+        return port
+    raise RuntimeError("no free rendezvous port in [%d, %d)" % (lo, hi))
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun-style environment variables.  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

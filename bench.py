@@ -681,7 +681,8 @@ def self_launch(n):
     (exactly what the driver's own command line does), so that a plain invocation IS an N-rank run."""
     import socket
     import subprocess
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from attend_infer_repeat_amd.distributed import free_rendezvous_port
+    port = free_rendezvous_port()            # (not bind(0): an ephemeral port can be taken by a waiting rank's own connect attempt)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))

@@ -19,3 +19,26 @@ def test_all_cores_replica_leg_never_blocks_the_line():
     import bench
     # a limit no interpreter start-up can meet: the leg gives up, cleans up its children and reports nothing
     assert bench.cpu_all_cores_replicas({}, 8, max(1, (os.cpu_count() or 2) // 2), seconds=0.5, limit_s=0.05) is None
+
+
+def test_configs3_line_is_the_aggregate_over_engine_seeds(monkeypatch):
+    """other_configs.c4 = total images / total time over bench.C4_SEEDS with each seed's own figure beside it (its step time follows the
+    model state, profiles/r05_c4_seed_dependence.txt); configs[4] stays on one seed."""
+    import bench
+    ms = {1: 0.3225, 1000004: 0.3026, 7: 0.3075}
+    calls = []
+
+    def fake(name, device, steps=400, warmup=100, seed=1):
+        calls.append((name, seed))
+        return {"workload": name, "value": round(64 / (ms.get(seed, 0.4) * 1e-3), 1), "unit": "images/sec", "ms_per_step": ms.get(seed, 0.4),
+                "steps": steps, "warmup": warmup, "kernel_launches_per_step": 35, "params_finite_after_run": seed != 7,
+                "model_state_at_end": {"steps_present_per_image": float(seed % 3), "mean_abs_where": [1.0] * 4}, "roofline": {"frac": 0.1}}
+    monkeypatch.setattr(bench, "run_other_config", fake)
+    rec = bench.run_other_config_seeds("c4", None)
+    assert calls == [("c4", s) for s in bench.C4_SEEDS] and 1000004 in bench.C4_SEEDS     # the seed of `bench.py --config c4` is one of them
+    assert rec["steps"] == 1200 and abs(rec["ms_per_step"] - sum(ms.values()) / 3) < 1e-4
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 / 64 - 1.0) < 1e-3 and rec["params_finite_after_run"] is False
+    assert [p["engine_seed"] for p in rec["per_seed"]] == list(bench.C4_SEEDS) and all("model_state_at_end" in p for p in rec["per_seed"])
+    calls.clear()
+    one = bench.run_other_config_seeds("c5", None)
+    assert calls == [("c5", 1)] and "per_seed" not in one

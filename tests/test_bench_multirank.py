@@ -12,6 +12,8 @@ import sys
 
 import pytest
 
+from attend_infer_repeat_amd.distributed import free_rendezvous_port as D_free_port   # below the ephemeral range
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -20,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_two_ranks_sharing_one_gpu(gpu_device, launcher):
     """launcher = "driver": the command line the driver uses for N > 1; "self": a plain `python bench.py --gpus 2`, which must
     re-execute itself under torch.distributed.run with two ranks."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = D_free_port()
     env = dict(os.environ, AIR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -56,7 +58,7 @@ def test_bench_watchdog_prints_the_safe_protocols_line_when_a_later_protocol_han
     """A protocol that never returns (AIR_BENCH_FAKE_HANG: the overlapped one sleeps forever on every rank) must not cost the run its
     result: every rank's watchdog ends the process with exit code 0 and rank 0 prints the line of the torch-split measurement that
     had already finished -- what `bench.py --gpus N` does if the overlapped protocol deadlocks on its first contact with RCCL."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = D_free_port()
     env = dict(os.environ, AIR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AIR_BENCH_FAKE_HANG="torch-overlap",
                AIR_BENCH_PROTOCOL_TIMEOUT_S="25")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):

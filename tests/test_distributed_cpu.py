@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from attend_infer_repeat_amd.distributed import free_rendezvous_port as D_free_port   # below the ephemeral range
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -16,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    return D_free_port()
 
 
 def _worker(rank, world, port, out_dir):

@@ -14,6 +14,8 @@ import os
 
 import numpy as np
 import pytest
+
+from attend_infer_repeat_amd.distributed import free_rendezvous_port as D_free_port   # below the ephemeral range
 import torch
 
 from oracle import air_oracle as O
@@ -908,7 +910,7 @@ def test_data_parallel_path_on_one_gpu_rccl(gpu_device):
     import torch.distributed as dist
     from attend_infer_repeat_amd import distributed as D
     from attend_infer_repeat_amd import hip as H
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = D_free_port()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -1018,7 +1020,7 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
         pytest.skip("the own-communicator protocols need two GPUs (RCCL refuses two ranks on one device)")
     # one GPU only: the host-issued protocol is still run for real -- two processes, two engines on GPU 0, gradients summed over
     # gloo -- so the data-parallel step (broadcast, split graphs, all-reduce in between, 1/world scaling) is exercised end to end
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = D_free_port()
     mp.spawn(_dp_rank_main, args=(2, port, str(tmp_path), collective, share_gpu), nprocs=2, join=True)
     r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(2)]
     assert r[0]["collective"] == r[1]["collective"] == collective
@@ -1027,7 +1029,7 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
         # processes on ONE device too) and the step's graph ends with barrier | shard sum + sharded RMSProp + parameter push | barrier.
         # A two-rank sum has one order, so the parameters must be bit-equal to the plain two-graph protocol's; the replicas are
         # identical by construction; flat_grads keeps each rank's LOCAL gradient (they differ, and sum to torch-split's).
-        port2 = port + 1 if port < 65000 else port - 1
+        port2 = D_free_port()
         os.environ["AIR_TEST_DP_STEPS"] = "20"                       # (the reference run takes the same twenty updates)
         try:
             mp.spawn(_dp_rank_main, args=(2, port2, str(tmp_path), "torch-split", share_gpu), nprocs=2, join=True)
@@ -1044,7 +1046,7 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     if collective == "torch-overlap":
         # the bucketed protocol (tail bucket reduced underneath the rest of the backward) must produce exactly what the plain
         # two-graph protocol produces: same launches, same sums (a two-rank sum has one order)
-        port2 = port + 1 if port < 65000 else port - 1
+        port2 = D_free_port()
         mp.spawn(_dp_rank_main, args=(2, port2, str(tmp_path), "torch-split", share_gpu), nprocs=2, join=True)
         ref = torch.load(os.path.join(tmp_path, "torch-split_0.pt"))
         assert torch.equal(r[0]["params"], ref["params"]) and torch.equal(r[0]["grads"], ref["grads"])
