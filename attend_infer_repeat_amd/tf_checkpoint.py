@@ -286,9 +286,10 @@ def read_bundle(prefix: str, names: Optional[Iterable[str]] = None, verify: str 
         raw = shards[sid][e["offset"]:e["offset"] + e["size"]]
         if len(raw) != e["size"]:
             raise TFCheckpointError(f"{name}: data shard ends inside the tensor")
-        if verify == "all" and e["crc32c"] is not None and unmask_crc(e["crc32c"]) != crc32c(raw.tobytes()):
+        data = raw.tobytes()
+        if verify == "all" and e["crc32c"] is not None and unmask_crc(e["crc32c"]) != crc32c(data):
             raise TFCheckpointError(f"{name}: checksum mismatch in the data shard")
-        out[name] = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e["shape"]).copy()
+        out[name] = np.frombuffer(data, dtype=dt).reshape(e["shape"]).copy()
     return out
 
 

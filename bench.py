@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
                     help="c2: BASELINE configs[1], 50x50/20x20/T=3, batch 64, fp32 (headline); c4: configs[3], 100x100/28x28/T=5; "
                          "c5: configs[4], the c2 shapes at batch 1024 with the bf16 MFMA MLP path")
+    ap.add_argument("--step-bias", type=float, default=None,
+                    help="probe, not a headline: bias of the steps predictor's logit (mnist_model.py:26; the script's 0.75 by default).  +20 keeps "
+                         "every step present, -20 none -- measured: the step count is NOT what the state-dependent cost of the canvas kernels follows "
+                         "(profiles/r05_c4_seed_dependence.txt); the line says so in config.step_bias")
     args = ap.parse_args()
     if args.config == "c5":
         args.mfma = "bf16"
@@ -724,6 +728,8 @@ def main():
     from attend_infer_repeat_amd import hip as H, _lib
 
     cfg_kw = dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5) if args.config == "c4" else {}
+    if args.step_bias is not None:
+        cfg_kw = dict(cfg_kw, step_bias=float(args.step_bias))
     cfg = EngineConfig(mfma_dtype=args.mfma, **cfg_kw)
     B = args.batch
     # the engine exactly as AIRonMNIST.train_step builds it (mnist_model.py: per-step canvases kept, as model.py:86-95 exposes them)
@@ -770,7 +776,7 @@ def main():
             elapsed = t.item()
         finite = bool(torch.isfinite(eng.flat_params).all().item())
         eng.synchronize()
-        # the model state the last timed step ran in: the canvas kernels skip absent steps and cost what the glimpses cover
+        # the model state the last timed step ran in: the canvas kernels cost what the glimpses cover (the scales of `where`)
         mstate = {"steps_present_per_image": round(float(eng.presence.sum(0).mean().item()), 3),
                   "mean_abs_where": [round(float(v), 3) for v in eng.where.abs().mean(dim=(0, 1)).tolist()]}
         in_sync = dp.replicas_in_sync()      # (collective; outside the timed region) every rank ended with the same bits
@@ -896,7 +902,8 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "bf16 operands / f32 accumulate+storage",
             "data": "synthetic" if not share_gpu else "synthetic; NOT A MEASUREMENT: all ranks share one GPU (AIR_BENCH_SHARE_GPU)",
-            "config": {"workload": workload, "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
+            "config": {"workload": workload if args.step_bias is None else workload + " -- PROBE: --step-bias %g" % args.step_bias,
+                       "step_bias": cfg.step_bias, "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "steps_per_graph_replay": rec["spr"],
                        "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
                        "kernel_launches_by_lane": eng.kernel_launch_count(),
