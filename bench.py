@@ -320,10 +320,16 @@ def run_other_config(name, device, steps=400, warmup=100, seed=1):
     for _ in range(warmup):
         eng.train_step()
     torch.cuda.synchronize(device)
+    # timed as `blocks` consecutive blocks (a synchronize between them: ~10 us each): `ms_per_step` is the WHOLE region, the median block
+    # rides beside it -- a 400-step region of 130 ms caught a one-off +20 ms stall in about one run of fifteen (0.3577 against 0.3021-0.3030)
+    blocks, t_blocks = 4 if steps % 4 == 0 and steps >= 40 else 1, []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.train_step()
-    torch.cuda.synchronize(device)
+    for _ in range(blocks):
+        tb = time.perf_counter()
+        for _ in range(steps // blocks):
+            eng.train_step()
+        torch.cuda.synchronize(device)
+        t_blocks.append((time.perf_counter() - tb) / (steps // blocks) * 1e3)
     el = time.perf_counter() - t0
     finite = bool(torch.isfinite(eng.flat_params).all().item())
     # the model state the last timed step ran in (what the data-dependent canvas kernels saw): objects per image, |where| per component
@@ -337,7 +343,8 @@ def run_other_config(name, device, steps=400, warmup=100, seed=1):
                        f"{'bf16-operand MFMA MLP path' if name == 'c5' else 'fp32'}, hipGraph replay "
                        f"(BASELINE configs[{3 if name == 'c4' else 4}])",
            "value": round(B * steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
-           "warmup": warmup, "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
+           "warmup": warmup, "median_block_ms_per_step": round(sorted(t_blocks)[len(t_blocks) // 2], 4), "blocks": blocks,
+           "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
            "params_finite_after_run": finite, "model_state_at_end": state, "roofline": roof}
     del eng
     torch.cuda.empty_cache()
@@ -364,7 +371,9 @@ def run_other_config_seeds(name, device):
     rec["value"] = round(64 * total_steps / (total_ms * 1e-3), 1)
     rec["steps"] = total_steps
     rec["params_finite_after_run"] = all(r["params_finite_after_run"] for r in recs)
-    rec["per_seed"] = [{"engine_seed": s, "ms_per_step": r["ms_per_step"], "value": r["value"], "model_state_at_end": r["model_state_at_end"]}
+    rec["median_block_ms_per_step"] = round(sum(r.get("median_block_ms_per_step", r["ms_per_step"]) for r in recs) / len(recs), 4)
+    rec["per_seed"] = [{"engine_seed": s, "ms_per_step": r["ms_per_step"], "median_block_ms_per_step": r.get("median_block_ms_per_step"),
+                        "value": r["value"], "model_state_at_end": r["model_state_at_end"]}
                        for s, r in zip(C4_SEEDS, recs)]
     rec["note"] = ("aggregate over %d engine seeds x %d timed steps: the step time of this configuration depends on the model state "
                    "(canvas-write backward), see per_seed" % (len(recs), recs[0]["steps"]))
