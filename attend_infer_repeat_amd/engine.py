@@ -160,6 +160,14 @@ class AIREngine(PlanMixin):
             self._copy_in(self.params[k], torch.as_tensor(v).to(torch.float32))
         self._sync_param_shadow()
 
+    def load_optimizer_slots(self, ms=None, mg=None, mom=None):
+        """RMSProp slots by parameter name (tf_checkpoint.import_tf_optimizer_slots): mean square, mean gradient (centred form), momentum.
+        Parameters a dict does not name keep what they have."""
+        for flat, named in ((self.flat_ms, ms), (self.flat_mg, mg), (self.flat_mom, mom)):
+            for k, v in (named or {}).items():
+                off, n = self.param_offsets[k], self.param_sizes[k]
+                self._copy_in(flat[off:off + n], torch.as_tensor(v).to(torch.float32).reshape(-1))
+
     def reset_optimizer(self):
         self._fill_in(self.flat_ms, 1.0); self._fill_in(self.flat_mg, 0.0); self._fill_in(self.flat_mom, 0.0)
 

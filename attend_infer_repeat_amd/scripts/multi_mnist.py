@@ -57,8 +57,8 @@ def main(argv=None):
                          "the step counter, the learning rate, the Philox noise state and the feeders' positions")
     ap.add_argument("--init-from-tf-ckpt", default=None, metavar="PREFIX",
                     help="prefix of a checkpoint the reference's tf.train.Saver wrote (e.g. ../results/multi_mnist/model.ckpt-175000): "
-                         "the model / baseline variables become the initial parameters and its global_step the step counter; the "
-                         "RMSProp slots start fresh (tf_checkpoint.py: format and variable names unvalidated without TensorFlow)")
+                         "the model / baseline variables become the initial parameters, its RMSProp slots (where the file holds them) the "
+                         "optimiser state and its global_step the step counter (tf_checkpoint.py: format and names unvalidated without TensorFlow)")
     args = ap.parse_args(argv)
 
     learning_rate, n_steps, batch_size = args.learning_rate, 3, 64    # multi_mnist.py:24-25,37
@@ -97,14 +97,16 @@ def main(argv=None):
     train_step, global_step = air.train_step(learning_rate, l2_weight, appearance_prior, where_scale_prior,
                                              where_shift_prior, num_steps_prior)
     if args.init_from_tf_ckpt:
-        from attend_infer_repeat_amd.tf_checkpoint import global_step_of, import_tf_checkpoint
+        from attend_infer_repeat_amd.tf_checkpoint import global_step_of, import_tf_checkpoint, import_tf_optimizer_slots
         named = import_tf_checkpoint(args.init_from_tf_ckpt, air._engine.param_shapes)
         air._engine.load_parameters({k: torch.from_numpy(v) for k, v in named.items()})
         air._engine.reset_optimizer()
+        slots = import_tf_optimizer_slots(args.init_from_tf_ckpt, air._engine.param_shapes)
+        air._engine.load_optimizer_slots(**{k: {n: torch.from_numpy(v) for n, v in d.items()} for k, d in slots.items()})
         step0 = global_step_of(args.init_from_tf_ckpt)
         if step0 is not None:
             air._engine.set_global_step(step0); air.global_step.fill_(step0)
-        print('Initialised {} tensors from {} (global_step {})'.format(len(named), args.init_from_tf_ckpt, step0))
+        print('Initialised {} tensors (+ RMSProp slots of {}) from {} (global_step {})'.format(len(named), len(slots['ms']), args.init_from_tf_ckpt, step0))
         global_step = air.global_step
     if args.resume:
         # the reference only ever saves (tf.train.Saver over every variable incl. the optimiser slots and global_step,

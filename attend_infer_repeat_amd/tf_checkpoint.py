@@ -457,6 +457,35 @@ def import_tf_checkpoint(prefix: str, shapes: "Dict[str, Tuple[int, ...]]",
     return {k: raw[tfn].astype(np.float32) for k, tfn in m.items()}
 
 
+def import_tf_optimizer_slots(prefix: str, shapes: "Dict[str, Tuple[int, ...]]", name_map: "Optional[Dict[str, str]]" = None,
+                              verify: str = "all") -> "Dict[str, Dict[str, np.ndarray]]":
+    """The RMSProp slots a Saver wrote beside the variables (model.py:265: `tf.train.RMSPropOptimizer(momentum=.9, centered=True)` for the
+    model AND the baseline variables): TensorFlow names a slot `<variable>/<optimizer name>` and numbers repeats, and RMSProp creates its
+    slots in the order rms, mg (centred only), momentum -- `<var>/RMSProp`, `<var>/RMSProp_1`, `<var>/RMSProp_2` (uncentred:
+    `RMSProp` = rms, `RMSProp_1` = momentum).  Returns {"ms": {...}, "mg": {...}, "mom": {...}} under the engine's names for every
+    variable whose slots are ALL in the file (`AIREngine.load_optimizer_slots`); same caveat as the module: unvalidated against TensorFlow."""
+    _, entries = read_index(prefix, verify != "none")
+    m = dict(name_map) if name_map is not None else default_name_map(shapes, {n: e["shape"] for n, e in entries.items()})
+    out = {"ms": {}, "mg": {}, "mom": {}}
+    want = {}
+    for k, tfn in m.items():
+        have = [s for s in ("RMSProp", "RMSProp_1", "RMSProp_2") if tfn + "/" + s in entries]
+        if len(have) == 3:
+            want[k] = dict(ms=tfn + "/RMSProp", mg=tfn + "/RMSProp_1", mom=tfn + "/RMSProp_2")
+        elif len(have) == 2:
+            want[k] = dict(ms=tfn + "/RMSProp", mom=tfn + "/RMSProp_1")
+    names = sorted({n for d in want.values() for n in d.values()})
+    for n in names:
+        k = next(k for k, d in want.items() if n in d.values())
+        if tuple(entries[n]["shape"]) != tuple(shapes[k]):
+            raise TFCheckpointError(f"slot {n}: shape {tuple(entries[n]['shape'])}, variable {k} has {tuple(shapes[k])}")
+    raw = read_bundle(prefix, names, verify)
+    for k, d in want.items():
+        for slot, n in d.items():
+            out[slot][k] = raw[n].astype(np.float32)
+    return out
+
+
 def global_step_of(prefix: str) -> Optional[int]:
     """The Saver's `global_step` tensor if the checkpoint holds one (multi_mnist.py:128 would honour it)."""
     _, entries = read_index(prefix)

@@ -1130,8 +1130,9 @@ def test_launches_per_train_step_of_the_named_configurations(gpu_device, name, k
 @pytest.mark.gpu
 def test_tf_checkpoint_export_import_between_engines(gpu_device, tmp_path):
     """an engine's parameters written as a TF-1 `model.ckpt` (TensorBundle, tf_checkpoint.write_bundle) under
-    reference-like variable names and imported into a differently initialised engine: same parameters bit for bit, and the next
-    train step (same batch, same noise state) leaves both on identical parameters."""
+    reference-like variable names -- with the RMSProp slots and global_step a Saver writes beside them -- and imported into a differently
+    initialised engine: same parameters and optimiser state bit for bit, and the next train step (same batch, same noise state) leaves
+    both on identical parameters."""
     from attend_infer_repeat_amd import tf_checkpoint as TF
     from test_tf_checkpoint import _reference_like_checkpoint
     ocfg, B = CONFIGS["mnist_b8"]
@@ -1142,18 +1143,31 @@ def test_tf_checkpoint_export_import_between_engines(gpu_device, tmp_path):
     names, _ = _reference_like_checkpoint(eng_a.cfg, np.random.default_rng(0))       # only the NAMES of this helper are used
     tfmap = TF.default_name_map(eng_a.param_shapes, {k: v.shape for k, v in names.items()})
     assert set(tfmap) == set(eng_a.param_shapes)
+    eng_a.train_step(); eng_a.synchronize()                                           # (so that the slots are not their initial values)
     tensors = {tfmap[k]: eng_a.params[k].detach().cpu().numpy() for k in eng_a.param_shapes}
-    tensors["global_step"] = np.int64(0)
-    prefix = str(tmp_path / "model.ckpt-0")
+    for flat, suffix in ((eng_a.flat_ms, "RMSProp"), (eng_a.flat_mg, "RMSProp_1"), (eng_a.flat_mom, "RMSProp_2")):
+        for k in eng_a.param_shapes:
+            off, n = eng_a.param_offsets[k], eng_a.param_sizes[k]
+            tensors[tfmap[k] + "/" + suffix] = flat[off:off + n].cpu().numpy().reshape(eng_a.param_shapes[k])
+    tensors["global_step"] = np.int64(1)
+    prefix = str(tmp_path / "model.ckpt-1")
     TF.write_bundle(prefix, tensors)
     named = TF.import_tf_checkpoint(prefix, eng_b.param_shapes)
     eng_b.load_parameters({k: torch.from_numpy(v) for k, v in named.items()})
     eng_b.reset_optimizer()
+    slots = TF.import_tf_optimizer_slots(prefix, eng_b.param_shapes)
+    eng_b.load_optimizer_slots(**{s: {k: torch.from_numpy(v) for k, v in d.items()} for s, d in slots.items()})
+    eng_b.set_global_step(TF.global_step_of(prefix))
     eng_b.set_obs(eng_a.obs.clone())
     eng_a.synchronize(); eng_b.synchronize()
     eng_b.rng_state.copy_(eng_a.rng_state)
     torch.cuda.synchronize()
     assert torch.equal(eng_a.flat_params, eng_b.flat_params)
+    for k in eng_a.param_shapes:                                                      # (the 16-byte padding between tensors is not a slot)
+        off, n = eng_a.param_offsets[k], eng_a.param_sizes[k]
+        assert all(torch.equal(fa[off:off + n], fb[off:off + n]) for fa, fb in
+                   ((eng_a.flat_ms, eng_b.flat_ms), (eng_a.flat_mg, eng_b.flat_mg), (eng_a.flat_mom, eng_b.flat_mom))), k
+    assert eng_b.global_step == eng_a.global_step == 1
     eng_a.train_step(); eng_b.train_step()
     eng_a.synchronize(); eng_b.synchronize()
     assert torch.equal(eng_a.flat_params, eng_b.flat_params)

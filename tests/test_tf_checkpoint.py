@@ -146,7 +146,9 @@ def _reference_like_checkpoint(cfg, rng, with_baseline=True):
             i, leaf = rest.split("/")
             tfn = "%s/affine%s/%s" % (scope[g], "" if i == "0" else "_" + i, leaf)
         tensors[tfn] = v; truth[k] = v
-        tensors[tfn + "/RMSProp"] = np.ones(s, np.float32); tensors[tfn + "/RMSProp_1"] = np.zeros(s, np.float32)
+        # centred RMSProp with momentum (model.py:265): slots in creation order rms, mg, momentum
+        for j, suffix in enumerate(("RMSProp", "RMSProp_1", "RMSProp_2")):
+            tensors[tfn + "/" + suffix] = (np.abs(v) + j).astype(np.float32)
     tensors["global_step"] = np.int64(5000)
     tensors["AIRonMNIST/canvas_multiplier"] = np.float32(1.0)
     tensors["AIRonMNIST/learning_rate"] = np.float32(1e-5)
@@ -176,6 +178,19 @@ def test_import_into_engine_names(tmp_path, with_baseline):
     with pytest.raises(KeyError):
         T.import_tf_checkpoint(p, shapes, name_map={"what/w": "missing"})
     assert T.global_step_of(p) == 5000
+    # the optimiser state a Saver writes beside the variables
+    slots = T.import_tf_optimizer_slots(p, shapes)
+    assert set(slots) == {"ms", "mg", "mom"} and all(set(d) == set(truth) for d in slots.values())
+    for j, name in enumerate(("ms", "mg", "mom")):
+        for k in truth:
+            np.testing.assert_array_equal(slots[name][k], (np.abs(truth[k]) + j).astype(np.float32))
+    # an uncentred optimiser leaves two slots: rms and momentum
+    two = {k: v for k, v in tensors.items() if not k.endswith("/RMSProp_2")}
+    p2 = str(tmp_path / "uncentred")
+    T.write_bundle(p2, two)
+    s2 = T.import_tf_optimizer_slots(p2, shapes)
+    assert not s2["mg"] and set(s2["ms"]) == set(s2["mom"]) == set(truth)
+    np.testing.assert_array_equal(s2["mom"]["what/w"], (np.abs(truth["what/w"]) + 1).astype(np.float32))
 
 
 def test_import_at_the_reference_architecture(tmp_path):
