@@ -203,3 +203,32 @@ def test_import_at_the_reference_architecture(tmp_path):
     T.write_bundle(p, tensors)
     got = T.import_tf_checkpoint(p, param_shapes(cfg), verify="index")
     assert set(got) == set(truth) and all(np.array_equal(got[k], truth[k]) for k in truth)
+
+
+def test_round_trip_fuzz(tmp_path):
+    """Random bundles (names with shared prefixes, unicode, any handled dtype, empty and scalar shapes, block sizes from one entry per
+    block to everything in one): reader(writer(x)) == x, names come back in the table's bytewise order."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    dtypes = [np.float32, np.float64, np.int32, np.int64, np.uint8, np.int8, np.int16, np.uint16, np.float16, np.bool_, np.uint32, np.uint64]
+    seg = st.text(alphabet="abcXYZ_09/é-", min_size=1, max_size=12)
+    name = st.builds(lambda a, b: (a + "/" + b).strip("/") or "x", seg, seg)
+    shape = st.lists(st.integers(0, 5), min_size=0, max_size=3).map(tuple)
+    item = st.tuples(name, shape, st.integers(0, len(dtypes) - 1), st.integers(0, 2 ** 31))
+    counter = [0]
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(st.lists(item, min_size=1, max_size=40, unique_by=lambda t: t[0]), st.sampled_from([1, 64, 512, 4096, 1 << 20]))
+    def check(items, block_size):
+        tensors = {}
+        for n, shp, di, seed in items:
+            rng = np.random.default_rng(seed)
+            a = rng.integers(0, 200, shp) if shp else rng.integers(0, 200)
+            tensors[n] = np.asarray(a).astype(dtypes[di])
+        counter[0] += 1
+        p = str(tmp_path / ("f%d" % counter[0]))
+        T.write_bundle(p, tensors, block_size=block_size)
+        back = T.read_bundle(p)
+        assert list(back) == sorted(tensors, key=lambda s: s.encode("utf-8"))
+        for n, v in tensors.items():
+            assert back[n].dtype == v.dtype and back[n].shape == v.shape and np.array_equal(back[n], v), n
+    check()
