@@ -36,6 +36,22 @@ __device__ __forceinline__ int2 floor_span(const float2 *tab, int n, int f_lo, i
     }
     return make_int2(first, last);
 }
+// [first, last] index of a range table with a non-empty entry (lo <= hi); every lane gets the result; none => first > last
+__device__ __forceinline__ int2 nonempty_span(const int2 *rng, int n) {
+    const int lane = threadIdx.x & 63;
+    int first = n, last = -1;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int2 r = rng[k < n ? k : n - 1];
+        const unsigned long long m = __ballot(k < n && r.x <= r.y);
+        if (m) {
+            const int lo = base + (int)__ffsll((long long)m) - 1, hi = base + 63 - (int)__clzll((long long)m);
+            first = lo < first ? lo : first;
+            last = hi > last ? hi : last;
+        }
+    }
+    return make_int2(first, last);
+}
 // The backward's per-pixel arithmetic with its FMAs spelled out (and implicit contraction off): the recompute form, the stored-canvas
 // form and the split / unsplit instantiations are separate compilations of the same expressions, and "the same bits in every form" (the
 // tests compare them with torch.equal) must not depend on which products the compiler chooses to fuse in each.
@@ -626,19 +642,21 @@ static inline size_t carve_img_bytes(int T, int H, int W, int h, int w, int wave
 }
 // the (up to) four contraction weights of source index j from canvas index lo on: weight of canvas index J for source index j is
 // d_J if floor_J == j, 1 - d_J if floor_J + 1 == j (the transpose of the bilinear taps), 0 past the range
-__device__ __forceinline__ float4 touch_weights(const float2 *tab, int2 r, int j) {
+template <typename Acc>
+__device__ __forceinline__ float4 touch_weights_t(const Acc &tab, int2 r, int j) {
     float wv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int J = r.x + u;
         const bool in = J <= r.y;
-        const float2 e = tab[in ? J : (r.x <= r.y ? r.x : 0)];
+        const float2 e = tab(in ? J : (r.x <= r.y ? r.x : 0));
         const int f = __float_as_int(e.x);
         const float wgt = (f == j ? e.y : 0.f) + (f + 1 == j ? 1.f - e.y : 0.f);
         wv[u] = in ? wgt : 0.f;
     }
     return make_float4(wv[0], wv[1], wv[2], wv[3]);
 }
+__device__ __forceinline__ float4 touch_weights(const float2 *tab, int2 r, int j) { return touch_weights_t(TabAcc{tab}, r, j); }
 __global__ __launch_bounds__(512) void st_write_bwd_img_kernel(WriteBwdArgs a, NvilArgs nv) {
     extern __shared__ __align__(16) float smem[];
     const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
@@ -828,6 +846,486 @@ __global__ __launch_bounds__(512) void st_write_bwd_img_kernel(WriteBwdArgs a, N
     }
 }
 
+// ---- glimpse-space backward (round 6) ---------------------------------------------------------------------------------------
+// Both forms above pay a PIXEL PASS for dwhere: every canvas pixel of a unit's footprint evaluates its four taps and the two
+// coordinate derivatives (~40 vector instructions per pixel; 10 000 pixels per unit once a glimpse covers a 100x100 canvas: the
+// 18-39 us, state-dependent position of the configs[3] step and 0.086 of the HBM roofline out of cache, profiles/r05_*).  The
+// bilinear map is separable, so the same five sums can be taken where the column contraction already is:
+//   p  [I,j] = sum_J dc[I,J] wx [J,j]            (T1 of the forms above; wx = the transposed x taps)
+//   px [I,j] = sum_J dc[I,J] dwx[J,j]            dwx[J,j] = +1 if floor_x(J)+1 == j, -1 if floor_x(J) == j   (d wx / d x_g)
+//   pxX[I,j] = sum_J dc[I,J] X_J dwx[J,j]
+//   R  [I,j] = dy_I G[fy_I, j] + (1-dy_I) G[fy_I+1, j]        (the glimpse resampled along y only; zero outside)
+//   D  [I,j] = G[fy_I+1, j] - G[fy_I, j]                       (its derivative along y)
+//   d/d(ax) = cxs sum_{I,j} pxX R,  d/d(bx) = cxs sum px R,  d/d(ay) = cys sum Y_I p D,  d/d(by) = cys sum p D,  d/dpresence = sum p R
+// (sums over the valid canvas rows I and the w glimpse columns j; x_g = cxs (ax X_J + bx + 1), y_g likewise) -- fh*w elements of
+// ~35 instructions instead of fh*fw pixels of ~40, no taps, no `go` image: dcanvas stays as it is and the unit's presence multiplies the
+// finished dglimpse element and the four sums (both are linear in it).  dglimpse = presence Wy^T p as before.
+// One body, three uses: unit-major (one workgroup per (t, b), latency regime; optional NS workgroups per unit), image-major (one per
+// image: dcanvas staged once, the T units' column contractions in one phase, their row contractions in the next: 4 barriers per
+// image) and the recompute form of the fused forward+backward launch (the canvas re-formed on the unit's footprint with the
+// forward's own calls, bit-identical, then the same two phases).  Ranges, weights, tables and the dwhere chain are the ones of the
+// forms above, every reduction has a fixed order; unit-major and recompute form are the same arithmetic on the same bits.
+struct CarveGs {
+    float *g, *t1, *src, *X, *Y, *pres, *scratch;
+    float2 *xe, *ye;
+    int2 *jr, *ir, *rows, *cols;
+    float4 *wx4, *dx4, *xx4, *wy4;
+    int hwp, t1s;
+};
+// TU = units a workgroup runs side by side (1 | T), TS = steps whose glimpse copy and axis tables it holds (1 | T)
+__device__ __forceinline__ CarveGs carve_gs(float *smem, int H, int W, int h, int w, int TU, int TS, int nw) {
+    CarveGs c;
+    float *p = smem;
+    c.hwp = pad_count(h, w);
+    c.t1s = (H * w + 3) & ~3;
+    c.g = p; p += (H * W + 3) & ~3;
+    c.wx4 = reinterpret_cast<float4 *>(p); p += 4 * TU * w;
+    c.dx4 = reinterpret_cast<float4 *>(p); p += 4 * TU * w;
+    c.xx4 = reinterpret_cast<float4 *>(p); p += 4 * TU * w;
+    c.wy4 = reinterpret_cast<float4 *>(p); p += 4 * TU * h;
+    c.t1 = p; p += (size_t)TU * c.t1s;
+    c.src = p; p += (size_t)TS * c.hwp;
+    c.xe = reinterpret_cast<float2 *>(p); p += 2 * TS * W;
+    c.ye = reinterpret_cast<float2 *>(p); p += 2 * TS * H;
+    c.jr = reinterpret_cast<int2 *>(p); p += 2 * TU * w;
+    c.ir = reinterpret_cast<int2 *>(p); p += 2 * TU * h;
+    c.rows = reinterpret_cast<int2 *>(p); p += 2 * ((TU + 1) & ~1);
+    c.cols = reinterpret_cast<int2 *>(p); p += 2 * ((TU + 1) & ~1);
+    c.X = p; p += W;
+    c.Y = p; p += H;
+    c.pres = p; p += (TS + 3) & ~3;
+    c.scratch = p;                                       // [nw][TU][8]
+    (void)nw;
+    return c;
+}
+static inline size_t carve_gs_bytes(int H, int W, int h, int w, int TU, int TS, int nw) {
+    return sizeof(float) * (size_t)(((H * W + 3) & ~3) + 12 * TU * w + 4 * TU * h + (size_t)TU * ((H * w + 3) & ~3) +
+                                    (size_t)TS * pad_count_host(h, w) + 2 * TS * (W + H) + 2 * TU * (w + h) + 4 * ((TU + 1) & ~1) +
+                                    W + H + ((TS + 3) & ~3) + (size_t)nw * TU * 8 + 16);
+}
+// touch_weights for the three column sums: the (up to) four canvas indices from r.x on -> wx, dwx, X dwx
+template <typename Acc>
+__device__ __forceinline__ void touch_weights3(const Acc &tab, int n, double step, int2 r, int j, float4 *w4, float4 *d4, float4 *x4) {
+    float wv[4], dv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int J = r.x + u;
+        const bool in = J <= r.y;
+        const int Jc = in ? J : (r.x <= r.y ? r.x : 0);
+        const float2 e = tab(Jc);
+        const int f = __float_as_int(e.x);
+        const float wgt = (f == j ? e.y : 0.f) + (f + 1 == j ? 1.f - e.y : 0.f);
+        const float dw = (f + 1 == j ? 1.f : 0.f) - (f == j ? 1.f : 0.f);
+        wv[u] = in ? wgt : 0.f;
+        dv[u] = in ? dw : 0.f;
+        xv[u] = in ? lin_m11(Jc, n, step) * dw : 0.f;
+    }
+    *w4 = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    *d4 = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    *x4 = make_float4(xv[0], xv[1], xv[2], xv[3]);
+}
+// Barriers per item: [operands, axis tables, ranges + weights] (1) [RC only: canvas on the footprint (2)] column contraction + sums (3)
+// row contraction.  The ranges and weights are formed from the transform itself (FlyAcc: the table build's own calls) by the LAST
+// threads of the workgroup while the first ones build the tables, so they cost no phase of their own.
+// Spans of one unit from its axis tables: {first valid canvas row, number of valid rows (-1: absent step), first touched glimpse
+// column, number of touched columns}.  An ABSENT step (presence exactly 0) has dglimpse = 0 and zero dwhere sums: both phases are
+// skipped (the dwhere chain still runs on the zero sums, so a degenerate scale gives the same NaN); only a caller that wants
+// dpresence needs them.  The touched glimpse columns are the floors of the first and last valid canvas column and their right
+// neighbours (the map is monotone; a superset is fine, an untouched column in between has an empty range): only they are walked --
+// at scales beyond 1 a third of the columns carries all the work and a lane per column would leave the wave two thirds idle.
+template <bool SPLIT>
+__device__ __forceinline__ int4 gs_unit_spans(const float2 *xe, const float2 *ye, int W, int H, int w, int i0, int i1, bool absent) {
+    const int2 vy = !SPLIT ? valid_span(ye, H) : floor_span(ye, H, i0 - 1, i1 - 1);
+    const int2 vx = valid_span(xe, W);
+    const int fh = absent ? -1 : (vy.y - vy.x + 1 > 0 ? vy.y - vy.x + 1 : 0);
+    int ja = 0, nj = 0;
+    if (vx.x <= vx.y) {
+        const int fa = __float_as_int(xe[vx.x].x), fb = __float_as_int(xe[vx.y].x);
+        const int lo = fa < fb ? fa : fb, hi = (fa < fb ? fb : fa) + 1;
+        ja = lo < 0 ? 0 : lo;
+        nj = (hi > w - 1 ? w - 1 : hi) - ja + 1;
+        if (nj < 0) nj = 0;
+    }
+    return make_int4(vy.x, fh, ja, nj);
+}
+template <bool RC, bool IM, bool SPLIT>
+__device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, const NvilArgs &nv, float *smem, const int vblock, const int vgrid) {
+    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
+    const float *__restrict__ dcanvas = a.dcanvas, *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
+    float *__restrict__ dglimpse = a.dglimpse, *__restrict__ dwhere = a.dwhere, *__restrict__ dpresence = a.dpresence;
+    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w;
+    const int grid_st = nv.imp ? vgrid - 1 : vgrid;
+    const int bid0 = nv.imp ? vblock - 1 : vblock;
+    AIR_TR_INIT();
+    if (bid0 < 0) { nvil_body(nv); AIR_TR_FLUSH(); return; }             // (first workgroup of the role: the long float64 chain starts at once)
+    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+    const int TU = IM ? T : 1, TS = (RC || IM) ? T : 1;
+    CarveGs c = carve_gs(smem, H, W, h, w, TU, TS, nw);
+    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
+    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
+    const float coef = a.loss_scale * a.mult / (a.std * a.std), mult = a.mult;
+    const int pitch = w + 2, nQ = HW >> 2, nq = hw >> 2;
+    const float inv_w = 1.0f / (float)w;
+    const bool v4c = a.vec4_canvas != 0, v4g = a.vec4_glimpse != 0;
+    // once per workgroup: the linspace tables (shapes only) and the zero borders of the glimpse copies (visible after barrier (1))
+    for (int e = tid; e < W + H; e += nt) {
+        if (e < W) c.X[e] = lin_m11(e, W, a.stepX); else c.Y[e - W] = lin_m11(e - W, H, a.stepY);
+    }
+    for (int e = tid; e < TS * pad_border(h, w); e += nt) {
+        const int tt = e / pad_border(h, w);
+        c.src[(size_t)tt * c.hwp + pad_border_index(e - tt * pad_border(h, w), h, w)] = 0.f;
+    }
+    const int NS = SPLIT ? a.NS : 1;
+    const int n_items = IM ? B : T * B * NS;
+    for (int it = bid0; it < n_items; it += grid_st) {
+        // unit-major: item = (unit k = t_own*B + b, split sp); image-major: item = image b, local unit lu = step
+        const int k_um = IM ? 0 : it / NS, sp = IM ? 0 : it - k_um * NS;
+        const int b = IM ? it : k_um % B, t_own = IM ? 0 : k_um / B;
+        const int i0 = (int)(((long)h * sp) / NS), i1 = (int)(((long)h * (sp + 1)) / NS);     // this workgroup's dglimpse rows
+        const int ts_own = (RC && !IM) ? t_own : 0;          // table / copy index of local unit 0 (image-major: lu itself)
+        AIR_TR(0);
+        if (it != bid0) __syncthreads();                     // (0) the previous item's readers are done with the carve
+        // ---- operands -------------------------------------------------------------------------------------------------------
+        // first 16-byte group of the canvas operands requested before anything else waits (latency regime: the tables below only
+        // need `where`); RC: the observation (c.g holds it until the canvas pass replaces the footprint)
+        const float *pa = RC ? obs + (size_t)b * HW : (dcanvas ? dcanvas + (size_t)k_um * HW : final_canvas + (size_t)b * HW);
+        const float *pb = (RC || dcanvas) ? pa : obs + (size_t)b * HW;
+        const bool form = !RC && !dcanvas;                    // g = coef * (mult * final - obs)
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa, qa1 = qa, qb1 = qa, gq0 = qa;
+        if (v4c) {
+            const int q = tid < nQ ? tid : nQ - 1, q1 = tid + nt < nQ ? tid + nt : nQ - 1;
+            qa = reinterpret_cast<const float4 *>(pa)[q];
+            if (form) qb = reinterpret_cast<const float4 *>(pb)[q];
+            if (!IM) {
+                qa1 = reinterpret_cast<const float4 *>(pa)[q1];
+                if (form) qb1 = reinterpret_cast<const float4 *>(pb)[q1];
+            }
+        }
+        if (v4g && !IM) {
+            const int q = tid < TS * nq ? tid : TS * nq - 1, tt = q / nq;
+            gq0 = reinterpret_cast<const float4 *>(glimpse + ((size_t)(RC ? tt : t_own) * B + b) * hw)[q - tt * nq];
+        }
+        // exact contraction ranges + weights of every glimpse column / row of the TU units: EIGHT lanes per column / row, one candidate
+        // canvas index each (src_range leaves at most eight at ordinary scales), entry evaluated from the transform itself (FlyAcc: the
+        // table build's own calls, the same bits), hits gathered with one ballot, the four weights fetched from the lanes that hold
+        // their entries -- ~50 instructions per thread beside the table build instead of a serial phase of its own
+        if (!IM) {
+            const int n_it = TU * (w + h);
+            for (int v0 = 0; v0 < n_it * 8; v0 += nt) {       // (uniform trip count: the ballot / shuffles need every lane)
+                const int v = v0 + tid, e = v >> 3, u = v & 7;
+                const bool live = e < n_it;
+                const int ec = live ? e : 0;
+                const int lu = ec / (w + h), r = ec - lu * (w + h);
+                const bool isx = r < w;
+                const int jj = isx ? r : r - w;
+                const float *wk = where + 4 * ((size_t)(IM ? lu : t_own) * B + b) + (isx ? 0 : 2);
+                const float s_ = wk[0], t_ = wk[1];
+                const int n_c = isx ? W : H;
+                const FlyAcc fa = {1.0f / s_, -t_ / s_, isx ? cxs : cys, isx ? w : h, n_c, isx ? a.stepX : a.stepY};
+                int lo, hi;
+                src_range(s_, fa.b, isx ? inv_cxs : inv_cys, (float)(jj - 1), (float)(jj + 1), n_c, &lo, &hi);
+                const bool narrow = hi - lo < 8;
+                const int J = lo + u;
+                const float2 en = fa(J <= hi ? J : lo);
+                const int f = __float_as_int(en.x);
+                const bool hit = narrow && J <= hi && f != ST_INVALID && (f == jj || f + 1 == jj);
+                const unsigned mask = (unsigned)(__ballot(hit) >> (lane & 56)) & 0xffu;
+                int2 rg = make_int2(1, 0);
+                if (mask) rg = make_int2(lo + __ffs((int)mask) - 1, lo + 31 - __clz((int)mask));
+                // weight slot u (< 4) of this column / row: canvas index rg.x + u, whose entry lane (rg.x - lo + u) of the group holds
+                const int srcl = (lane & 56) + ((rg.x - lo + u) & 7);
+                const float ef = __shfl(en.x, srcl, 64), ed = __shfl(en.y, srcl, 64);
+                if (live && narrow && u < 4) {
+                    const int Jw = rg.x + u;
+                    const bool in = Jw <= rg.y;
+                    const int fw_ = __float_as_int(ef);
+                    const float wgt = in ? (fw_ == jj ? ed : 0.f) + (fw_ + 1 == jj ? 1.f - ed : 0.f) : 0.f;
+                    if (isx) {
+                        const float dw = in ? (fw_ + 1 == jj ? 1.f : 0.f) - (fw_ == jj ? 1.f : 0.f) : 0.f;
+                        const float xw = in ? lin_m11(Jw, W, a.stepX) * dw : 0.f;
+                        reinterpret_cast<float *>(&c.wx4[lu * w + jj])[u] = wgt;
+                        reinterpret_cast<float *>(&c.dx4[lu * w + jj])[u] = dw;
+                        reinterpret_cast<float *>(&c.xx4[lu * w + jj])[u] = xw;
+                        if (u == 0) c.jr[lu * w + jj] = rg;
+                    } else {
+                        reinterpret_cast<float *>(&c.wy4[lu * h + jj])[u] = wgt;
+                        if (u == 0) c.ir[lu * h + jj] = rg;
+                    }
+                }
+                if (live && !narrow && u == 0) {               // degenerate scales: candidate interval of the whole axis, scanned by one lane
+                    const int2 rs = touch_range_t(fa, fa.b, s_, isx ? inv_cxs : inv_cys, jj, n_c);
+                    if (isx) {
+                        c.jr[lu * w + jj] = rs;
+                        touch_weights3(fa, W, a.stepX, rs, jj, &c.wx4[lu * w + jj], &c.dx4[lu * w + jj], &c.xx4[lu * w + jj]);
+                    } else {
+                        c.ir[lu * h + jj] = rs;
+                        c.wy4[lu * h + jj] = touch_weights_t(fa, rs, jj);
+                    }
+                }
+            }
+        }
+        AIR_TR(1);
+        // axis tables of the TS steps, by the first threads
+        for (int a0 = tid; a0 < TS * (W + H); a0 += nt) {
+            const int tt = a0 / (W + H), r = a0 - tt * (W + H);
+            const float *wk = where + 4 * ((size_t)((RC || IM) ? tt : t_own) * B + b);
+            if (r < W) {
+                const float s_ = wk[0], t_ = wk[1];
+                c.xe[tt * W + r] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r, W, a.stepX), -t_ / s_, cxs), w);
+            } else {
+                const float s_ = wk[2], t_ = wk[3];
+                c.ye[tt * H + (r - W)] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r - W, H, a.stepY), -t_ / s_, cys), h);
+            }
+        }
+        if (tid < TS) c.pres[tid] = presence ? presence[(size_t)((RC || IM) ? tid : t_own) * B + b] : 1.0f;
+        // glimpse copies (bordered)
+        if (v4g) {
+            for (int q = tid; q < TS * nq; q += nt) {
+                const int tt = q / nq;
+                const float4 v = (!IM && q == tid) ? gq0
+                                                   : reinterpret_cast<const float4 *>(glimpse + ((size_t)((RC || IM) ? tt : t_own) * B + b) * hw)[q - tt * nq];
+                float *d = c.src + (size_t)tt * c.hwp + pad_index(4 * (q - tt * nq), w, inv_w);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int q = tid; q < TS * hw; q += nt) {
+                const int tt = q / hw;
+                c.src[(size_t)tt * c.hwp + pad_index(q - tt * hw, w, inv_w)] = glimpse[((size_t)((RC || IM) ? tt : t_own) * B + b) * hw + (q - tt * hw)];
+            }
+        }
+        // canvas operand -> c.g
+        if (v4c) {
+            if (tid < nQ) {
+                float4 gv = qa;
+                if (form) { gv.x = dcanvas_of(coef, mult, qa.x, qb.x); gv.y = dcanvas_of(coef, mult, qa.y, qb.y);
+                            gv.z = dcanvas_of(coef, mult, qa.z, qb.z); gv.w = dcanvas_of(coef, mult, qa.w, qb.w); }
+                reinterpret_cast<float4 *>(c.g)[tid] = gv;
+            }
+            if (!IM && tid + nt < nQ) {
+                float4 gv = qa1;
+                if (form) { gv.x = dcanvas_of(coef, mult, qa1.x, qb1.x); gv.y = dcanvas_of(coef, mult, qa1.y, qb1.y);
+                            gv.z = dcanvas_of(coef, mult, qa1.z, qb1.z); gv.w = dcanvas_of(coef, mult, qa1.w, qb1.w); }
+                reinterpret_cast<float4 *>(c.g)[tid + nt] = gv;
+            }
+#pragma unroll 4
+            for (int q = tid + (IM ? 1 : 2) * nt; q < nQ; q += nt) {
+                const float4 a4 = reinterpret_cast<const float4 *>(pa)[q];
+                float4 gv = a4;
+                if (form) {
+                    const float4 b4 = reinterpret_cast<const float4 *>(pb)[q];
+                    gv.x = dcanvas_of(coef, mult, a4.x, b4.x); gv.y = dcanvas_of(coef, mult, a4.y, b4.y);
+                    gv.z = dcanvas_of(coef, mult, a4.z, b4.z); gv.w = dcanvas_of(coef, mult, a4.w, b4.w);
+                }
+                reinterpret_cast<float4 *>(c.g)[q] = gv;
+            }
+        } else {
+            for (int p = tid; p < HW; p += nt) c.g[p] = form ? dcanvas_of(coef, mult, pa[p], pb[p]) : pa[p];
+        }
+        AIR_TR(2);
+        __syncthreads();                                       // (1)
+        AIR_TR(3);
+        if (IM) {
+            // image-major (throughput regime): ranges + weights of the T units from the LDS tables, one thread per column / row -- a
+            // fifth of the instructions of the eight-lane form above, for one more barrier per image
+            for (int e = tid; e < TU * (w + h); e += nt) {
+                const int lu = e / (w + h), r = e - lu * (w + h);
+                const float *wk = where + 4 * ((size_t)lu * B + b);
+                if (r < w) {
+                    const float s_ = wk[0], t_ = wk[1];
+                    const TabAcc ta = {c.xe + lu * W};
+                    const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cxs, r, W);
+                    c.jr[lu * w + r] = rg;
+                    touch_weights3(ta, W, a.stepX, rg, r, &c.wx4[lu * w + r], &c.dx4[lu * w + r], &c.xx4[lu * w + r]);
+                } else {
+                    const float s_ = wk[2], t_ = wk[3];
+                    const int i = r - w;
+                    const TabAcc ta = {c.ye + lu * H};
+                    const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cys, i, H);
+                    c.ir[lu * h + i] = rg;
+                    c.wy4[lu * h + i] = touch_weights_t(ta, rg, i);
+                }
+            }
+            // valid canvas rows and touched glimpse columns of each unit, one wave per unit (see gs_unit_spans)
+            for (int lu = wid; lu < TU; lu += nw) {
+                const int4 sp4 = gs_unit_spans<SPLIT>(c.xe + lu * W, c.ye + lu * H, W, H, w, i0, i1, c.pres[lu] == 0.f && !dpresence);
+                if (lane == 0) { c.rows[lu] = make_int2(sp4.x, sp4.y); c.cols[lu] = make_int2(sp4.z, sp4.w); }
+            }
+            __syncthreads();                                   // (1b)
+        }
+        if (RC) {
+            // the canvas on this unit's footprint, accumulated as the forward does -- ((0 + p0*v0) + p1*v1) + ... over ALL steps with
+            // the forward's table entries and taps: bit-identical values -- then dcanvas from it and the observation c.g holds
+            const float2 *xo = c.xe + ts_own * W, *yo = c.ye + ts_own * H;
+            const int2 vx = valid_span(xo, W), vy = !SPLIT ? valid_span(yo, H) : floor_span(yo, H, i0 - 1, i1 - 1);
+            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
+            const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
+            const float inv_fw = 1.0f / (float)(fw > 0 ? fw : 1);
+            for (int idx = tid; idx < npx; idx += nt) {
+                const int Ir = div_small(idx, fw, inv_fw), I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
+                float cv = 0.f;
+                for (int tt = 0; tt < T; ++tt) {
+                    const float2 ext = c.xe[tt * W + J], eyt = c.ye[tt * H + I];
+                    const int fxt = __float_as_int(ext.x), fyt = __float_as_int(eyt.x);
+                    float vt = 0.f;
+                    if (fxt != ST_INVALID && fyt != ST_INVALID)
+                        vt = bilerp(load_taps_pad(c.src + (size_t)tt * c.hwp, pitch, fyt, fxt), ext.y, eyt.y);
+                    cv = acc_step(cv, c.pres[tt], vt);
+                }
+                c.g[p] = dcanvas_of(coef, mult, cv, c.g[p]);
+            }
+            AIR_TR(4);
+            __syncthreads();                                   // (2)
+        }
+        // ---- phase 1: p, px, pxX on the unit's valid rows; the five sums; T1 = p
+        for (int lu = 0; lu < TU; ++lu) {
+            const int tt = IM ? lu : ts_own;
+            const float2 *xe = c.xe + tt * W, *ye = c.ye + tt * H;
+            // valid canvas rows / touched glimpse columns of the unit: unit-major every wave finds them itself (a few ballots over the
+            // tables), image-major they were left in LDS by one wave per unit (sixteen waves x T units of ballots cost half a phase)
+            int4 sp4;
+            if (IM) { const int2 rw_ = c.rows[lu], cw_ = c.cols[lu]; sp4 = make_int4(rw_.x, rw_.y, cw_.x, cw_.y); }
+            else {
+                sp4 = gs_unit_spans<SPLIT>(xe, ye, W, H, w, i0, i1, c.pres[tt] == 0.f && !dpresence);
+                if (tid == 0) { c.rows[lu] = make_int2(sp4.x, sp4.y); c.cols[lu] = make_int2(sp4.z, sp4.w); }
+            }
+            const int I0 = sp4.x, fh = sp4.y, ja = sp4.z, nj = sp4.w;
+            const float inv_nj = 1.0f / (float)(nj > 0 ? nj : 1);
+            const float *src = c.src + (size_t)tt * c.hwp;
+            float *t1 = c.t1 + (size_t)lu * c.t1s;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int e = tid; e < fh * nj; e += nt) {
+                const int Ir = div_small(e, nj, inv_nj), I = I0 + Ir, j = ja + (e - Ir * nj);
+                const int2 r = c.jr[lu * w + j];
+                const float2 ey = ye[I];
+                const int fy = __float_as_int(ey.x);         // valid by construction of the row span
+                const float *gq = src + (fy + 1) * pitch + (j + 1);
+                const float G0 = gq[0], G1 = gq[pitch];
+                float p = 0.f, px = 0.f, pxX = 0.f;
+                if (r.x <= r.y) {
+                    const float4 wv = c.wx4[lu * w + j], dv = c.dx4[lu * w + j], xv = c.xx4[lu * w + j];
+                    const float *grow = c.g + I * W;
+                    const int Jb = r.x;
+                    const int j1 = Jb + 1 <= r.y ? Jb + 1 : Jb, j2 = Jb + 2 <= r.y ? Jb + 2 : Jb, j3 = Jb + 3 <= r.y ? Jb + 3 : Jb;
+                    const float g0 = grow[Jb], g1 = grow[j1], g2 = grow[j2], g3 = grow[j3];
+                    p = g0 * wv.x; px = g0 * dv.x; pxX = g0 * xv.x;
+                    p = __builtin_fmaf(g1, wv.y, p); px = __builtin_fmaf(g1, dv.y, px); pxX = __builtin_fmaf(g1, xv.y, pxX);
+                    p = __builtin_fmaf(g2, wv.z, p); px = __builtin_fmaf(g2, dv.z, px); pxX = __builtin_fmaf(g2, xv.z, pxX);
+                    p = __builtin_fmaf(g3, wv.w, p); px = __builtin_fmaf(g3, dv.w, px); pxX = __builtin_fmaf(g3, xv.w, pxX);
+                    // wide ranges (scales towards 1 and beyond): the general form, four entries per round trip while four remain
+                    int J = r.x + 4;
+                    for (; J + 3 <= r.y; J += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float2 ex = xe[J + u];
+                            const float gv = grow[J + u], Xv = c.X[J + u];
+                            const int fx = __float_as_int(ex.x);
+                            const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
+                            const float dw = (fx + 1 == j ? 1.f : 0.f) - (fx == j ? 1.f : 0.f);
+                            p = __builtin_fmaf(gv, wgt, p); px = __builtin_fmaf(gv, dw, px); pxX = __builtin_fmaf(gv, Xv * dw, pxX);
+                        }
+                    }
+                    for (; J <= r.y; ++J) {
+                        const float2 ex = xe[J];
+                        const float gv = grow[J], Xv = c.X[J];
+                        const int fx = __float_as_int(ex.x);
+                        const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
+                        const float dw = (fx + 1 == j ? 1.f : 0.f) - (fx == j ? 1.f : 0.f);
+                        p = __builtin_fmaf(gv, wgt, p); px = __builtin_fmaf(gv, dw, px); pxX = __builtin_fmaf(gv, Xv * dw, pxX);
+                    }
+                }
+                t1[Ir * w + j] = p;
+                const float R = __builtin_fmaf(ey.y, G0, (1.f - ey.y) * G1), D = G1 - G0;
+                const int fyc = fy < 0 ? 0 : (fy > h - 1 ? h - 1 : fy);
+                if (!SPLIT || (fyc >= i0 && fyc < i1)) {       // (SPLIT: the row's owner among the unit's NS workgroups)
+                    const float pD = p * D;
+                    acc[0] = __builtin_fmaf(pxX, R, acc[0]); acc[1] = __builtin_fmaf(px, R, acc[1]);
+                    acc[2] = __builtin_fmaf(c.Y[I], pD, acc[2]); acc[3] += pD;
+                    acc[4] = __builtin_fmaf(p, R, acc[4]);
+                }
+            }
+            const float rsum = wave_reduce8(acc);
+            if ((lane & 7) == 0) c.scratch[(wid * TU + lu) * 8 + wave_reduce8_slot()] = rsum;
+        }
+        AIR_TR(5); AIR_TRT(nt - 64, 9);
+        __syncthreads();                                       // (3)
+        AIR_TR(6);
+        // ---- phase 2: dG[lu][i, j] = presence * sum_I wy[I, i] * T1[lu][I, j], this workgroup's rows
+        const int nrow = i1 - i0;
+        const float inv_rw = 1.0f / (float)(nrow * w > 0 ? nrow * w : 1);
+        for (int e0 = tid; e0 < TU * nrow * w; e0 += nt) {
+            const int lu = IM ? div_small(e0, nrow * w, inv_rw) : 0;
+            const int e = i0 * w + (e0 - lu * nrow * w);
+            const int i = div_small(e, w, inv_w), j = e - i * w;
+            const int tt = IM ? lu : ts_own;
+            float *dg = dglimpse + ((size_t)(IM ? lu : t_own) * B + b) * hw;
+            const int2 rw = c.rows[lu], cw = c.cols[lu];
+            float s = 0.f;
+            if (rw.y > 0 && j >= cw.x && j < cw.x + cw.y) {
+                const int2 r = c.ir[lu * h + i];
+                if (r.x <= r.y) {                              // (rows outside the span were never written: weight 0 is not enough)
+                    const float4 wv = c.wy4[lu * h + i];
+                    const float *t1 = c.t1 + (size_t)lu * c.t1s + j - rw.x * w;
+                    const int r1 = r.x + 1 <= r.y ? r.x + 1 : r.x, r2 = r.x + 2 <= r.y ? r.x + 2 : r.x, r3 = r.x + 3 <= r.y ? r.x + 3 : r.x;
+                    s = t1[r.x * w] * wv.x;
+                    s = __builtin_fmaf(t1[r1 * w], wv.y, s);
+                    s = __builtin_fmaf(t1[r2 * w], wv.z, s);
+                    s = __builtin_fmaf(t1[r3 * w], wv.w, s);
+                    const float2 *ye = c.ye + tt * H;
+                    int I = r.x + 4;
+                    for (; I + 3 <= r.y; I += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float2 ey = ye[I + u];
+                            const int fy = __float_as_int(ey.x);
+                            s = __builtin_fmaf(t1[(I + u) * w], (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f), s);
+                        }
+                    }
+                    for (; I <= r.y; ++I) {
+                        const float2 ey = ye[I];
+                        const int fy = __float_as_int(ey.x);
+                        s = __builtin_fmaf(t1[I * w], (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f), s);
+                    }
+                }
+                s *= c.pres[tt];
+            }
+            dg[e] = s;
+        }
+        AIR_TR(7);
+        // ---- dwhere / dpresence: the per-wave partials (visible since barrier 3), fixed order, one wave per unit (from the last
+        //      wave down: it has the least contraction work)
+        for (int lu = nw - 1 - wid; lu < TU; lu += nw) {
+            float part[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[(lane * TU + lu) * 8 + q] : 0.f;
+            const float tot = wave_reduce8(part);
+            const float s0 = __shfl(tot, 0, 64), s1 = __shfl(tot, 8, 64), s2 = __shfl(tot, 16, 64), s3 = __shfl(tot, 24, 64),
+                        r4 = __shfl(tot, 32, 64);
+            if (lane == 0) {
+                const size_t k = (size_t)(IM ? lu : t_own) * B + b;
+                const float pres = c.pres[IM ? lu : ts_own];
+                const float r0 = (pres * s0) * cxs, r1 = (pres * s1) * cxs, r2 = (pres * s2) * cys, r3 = (pres * s3) * cys;
+                const float sx = where[4 * k], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
+                const float ax = 1.0f / sx, bx = -tx / sx, ay = 1.0f / sy, by = -ty / sy;
+                // chain through a = 1/s, b = (-t)/s as automatic differentiation evaluates the two divisions (see st_write_bwd_body):
+                // degenerate scales give NaN / inf / 0 exactly where the reference's gradient does
+                float *d = dwhere + 4 * ((size_t)sp * T * B + k);
+                d[0] = -(r0 * (ax / sx)) - r1 * (bx / sx);
+                d[1] = -(r1 / sx);
+                d[2] = -(r2 * (ay / sy)) - r3 * (by / sy);
+                d[3] = -(r3 / sy);
+                if (dpresence) dpresence[(size_t)sp * T * B + k] = r4;
+            }
+        }
+        AIR_TR(8);
+    }
+    AIR_TR_FLUSH();
+}
+template <bool RC, bool IM>
+__global__ __launch_bounds__(1024) void st_write_bwd_gs_kernel(WriteBwdArgs a, NvilArgs nv) {
+    extern __shared__ __align__(16) float smem[];
+    st_write_bwd_gs_body<RC, IM, false>(a, nv, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // Canvas forward and backward of a train step in ONE launch (latency regime).  The recompute form of the backward reads nothing
 // the forward writes, so the two are independent roles of one grid: workgroups [0, n_fwd) run st_write_fwd_body (image x row
 // band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_body<true> (one per glimpse).  One
@@ -965,6 +1463,60 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
     const int wr_threads = bwd_threads((long)B * T);
     const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, 1};
+    {   // round 6: the glimpse-space form (st_write_bwd_gs_kernel) for the stored-canvas and given-dcanvas backward; AIR_CANVAS_BWD_GS=0
+        // keeps the pixel-pass kernels of rounds 2-5 (A/B runs; read at every call like the switches below)
+        const char *env_gs = getenv("AIR_CANVAS_BWD_GS");
+        const int gs = env_gs ? atoi(env_gs) : 1;
+        const char *env_img = getenv("AIR_CANVAS_BWD_IMG");
+        const int img_major = env_img ? atoi(env_img) : 1;
+        const char *env_thr = getenv("AIR_CANVAS_GS_THREADS");
+        int thr_f = env_thr ? atoi(env_thr) : 0;
+        if (thr_f != 128 && thr_f != 256 && thr_f != 512 && thr_f != 1024) thr_f = 0;
+        const char *env_min = getenv("AIR_CANVAS_IMG_MIN_UNITS");
+        const long img_min_units = env_min ? atol(env_min) : 256 * 8;
+        if (gs && rc && H * W >= 16) {                          // recompute form (the stand-alone launch; the fused one: air_canvas_unroll_fwd_bwd)
+            const int thr_r = thr_f ? thr_f : wr_threads;
+            const size_t lds_r = carve_gs_bytes(H, W, h, w, 1, T, thr_r / 64);
+            if (lds_r <= CV_MAX_LDS) {
+                { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<true, false>, lds_r); if (st_) return st_; }
+                const int grid_r = cv_grid((long)T * B, 256 * 8) + (nvil ? 1 : 0);
+                hipLaunchKernelGGL((st_write_bwd_gs_kernel<true, false>), dim3(grid_r), dim3(thr_r), lds_r, air_stream(stream), a, nv);
+                AIR_LAUNCH_CHECK();
+                return AIR_OK;
+            }
+        }
+        if (gs && !rc && H * W >= 16) {
+            if (img_major && !dcanvas && final_canvas && (long)T * B > img_min_units && T <= 8) {
+                // one workgroup per image; threads from the carve: as many workgroups per CU as the LDS allows, 16 waves per CU
+                int thr_i = thr_f;
+                if (!thr_i) {
+                    const size_t l256 = carve_gs_bytes(H, W, h, w, T, T, 4);
+                    thr_i = l256 <= 40 * 1024 ? 256 : (l256 <= 78 * 1024 ? 512 : 1024);
+                }
+                const size_t lds_i = carve_gs_bytes(H, W, h, w, T, T, thr_i / 64);
+                if (lds_i <= CV_MAX_LDS) {
+                    { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<false, true>, lds_i); if (st_) return st_; }
+                    const int cap_i = cv_resident_cap(st_write_bwd_gs_kernel<false, true>, thr_i, lds_i, 256 * 2);
+                    const int grid_i = cv_grid(B, cap_i) + (nvil ? 1 : 0);
+                    hipLaunchKernelGGL((st_write_bwd_gs_kernel<false, true>), dim3(grid_i), dim3(thr_i), lds_i, air_stream(stream), a, nv);
+                    AIR_LAUNCH_CHECK();
+                    return AIR_OK;
+                }
+            }
+            int thr_u = thr_f ? thr_f : wr_threads;
+            if (!thr_f && carve_gs_bytes(H, W, h, w, 1, 1, 4) > 40 * 1024) thr_u = 512;
+            const size_t lds_u = carve_gs_bytes(H, W, h, w, 1, 1, thr_u / 64);
+            if (lds_u <= CV_MAX_LDS) {
+                { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<false, false>, lds_u); if (st_) return st_; }
+                int cap_u = 256 * 8;
+                if ((long)T * B > cap_u) cap_u = cv_resident_cap(st_write_bwd_gs_kernel<false, false>, thr_u, lds_u, cap_u);
+                const int grid_u = cv_grid((long)T * B, cap_u) + (nvil ? 1 : 0);
+                hipLaunchKernelGGL((st_write_bwd_gs_kernel<false, false>), dim3(grid_u), dim3(thr_u), lds_u, air_stream(stream), a, nv);
+                AIR_LAUNCH_CHECK();
+                return AIR_OK;
+            }
+        }
+    }
     {   // throughput regime, stored-canvas form: one workgroup per IMAGE runs its T units side by side (st_write_bwd_img_kernel)
         // (read at every call, not cached: tests and A/B runs switch forms inside one process; a captured graph keeps what it captured)
         const char *env_img = getenv("AIR_CANVAS_BWD_IMG");
@@ -1045,6 +1597,22 @@ extern "C" int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *whe
                             h, w, mult, std, loss_scale, stream, &nv);
 }
 
+template <bool SPLIT>
+__global__ __launch_bounds__(1024) void canvas_fused_gs_kernel(WriteFwdArgs f, WriteBwdArgs b, int n_fwd) {
+    extern __shared__ __align__(16) float smem[];
+    // the backward role FIRST in the grid: it is the longer chain (operands, tables, canvas pass, two contractions against the
+    // forward's one pass), and workgroups are dispatched in index order
+    const int n_bwd = (int)gridDim.x - n_fwd;
+    if ((int)blockIdx.x >= n_bwd) st_write_fwd_body(f, smem, (int)blockIdx.x - n_bwd, n_fwd);
+    else {
+        const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr};
+        st_write_bwd_gs_body<true, false, SPLIT>(b, none, smem, (int)blockIdx.x, n_bwd);
+    }
+}
+static inline int canvas_gs_enabled() {
+    const char *env_gs = getenv("AIR_CANVAS_BWD_GS");
+    return env_gs ? atoi(env_gs) : 1;
+}
 // The fused launch's shape for a problem: threads per workgroup, and whether it fits (LDS of both roles, both grids small
 // enough to run side by side).  n_split = workgroups per backward unit (1 or 2).
 static int fused_shape(int n_bands, int n_split, int T, int B, int H, int W, int h, int w, int *threads, size_t *lds) {
@@ -1054,7 +1622,8 @@ static int fused_shape(int n_bands, int n_split, int T, int B, int H, int W, int
     if (n_split < 1 || n_split > 4) return AIR_E_SHAPE;
     if ((long)B * NB > 4096 || (long)B * T * n_split > 4096) return AIR_E_UNSUPPORTED;
     const int nt = bwd_threads((long)B * T * n_split);
-    const size_t lds_f = carve_wr_bytes(T, RB, W, h, w), lds_b = carve_bwd_bytes(H, W, h, w, T);
+    const size_t lds_f = carve_wr_bytes(T, RB, W, h, w);
+    const size_t lds_b = canvas_gs_enabled() ? carve_gs_bytes(H, W, h, w, 1, T, nt / 64) : carve_bwd_bytes(H, W, h, w, T);
     *lds = lds_f > lds_b ? lds_f : lds_b;
     *threads = nt;
     return *lds <= CV_MAX_LDS ? AIR_OK : AIR_E_UNSUPPORTED;
@@ -1082,13 +1651,21 @@ extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *wher
     wr_bands(H, n_bands, &NB, &RB);
     const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);
     const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
-    { int st_ = n_split > 1 ? cv_allow_lds(canvas_fused_kernel<true>, lds) : cv_allow_lds(canvas_fused_kernel<false>, lds); if (st_) return st_; }
+    const int gs = canvas_gs_enabled();
+    {
+        int st_ = gs ? (n_split > 1 ? cv_allow_lds(canvas_fused_gs_kernel<true>, lds) : cv_allow_lds(canvas_fused_gs_kernel<false>, lds))
+                     : (n_split > 1 ? cv_allow_lds(canvas_fused_kernel<true>, lds) : cv_allow_lds(canvas_fused_kernel<false>, lds));
+        if (st_) return st_;
+    }
     const WriteFwdArgs f = {glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, vec4g};
     const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, n_split};
     const int n_fwd = B * NB;
-    if (n_split > 1) hipLaunchKernelGGL(canvas_fused_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    if (gs) {
+        if (n_split > 1) hipLaunchKernelGGL(canvas_fused_gs_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+        else hipLaunchKernelGGL(canvas_fused_gs_kernel<false>, dim3(n_fwd + T * B), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    } else if (n_split > 1) hipLaunchKernelGGL(canvas_fused_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
     else hipLaunchKernelGGL(canvas_fused_kernel<false>, dim3(n_fwd + T * B), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
     AIR_LAUNCH_CHECK();
     return AIR_OK;

@@ -144,10 +144,23 @@ __device__ __forceinline__ void src_range(float inv_a, float b, float inv_cs, fl
     *lo = a0 < 0 ? 0 : (a0 > n - 1 ? n - 1 : a0);         // both ends inside the table (a superset of the true set is fine)
     *hi = a1 > n - 1 ? n - 1 : (a1 < 0 ? 0 : a1);
 }
-// exact [lo, hi] of canvas indices whose taps touch source index j (floor == j-1 or j), from the LDS axis table; empty => lo > hi.
-// The candidate interval of src_range is at most a handful of indices: up to eight are tested with independent LDS reads
-// (one round trip); longer intervals (degenerate scales) fall back to a scan from both ends.
-__device__ __forceinline__ int2 touch_range(const float2 *tab, float b, float inv_a, float inv_cs, int j, int n) {
+// exact [lo, hi] of canvas indices whose taps touch source index j (floor == j-1 or j); empty => lo > hi.  `tab(J)` returns the axis
+// entry of canvas index J: from the LDS table (TabAcc) or evaluated on the spot from the transform (FlyAcc: the same calls as the table
+// build, so the same bits -- used where the ranges are wanted before the table is visible).
+// The candidate interval of src_range is at most a handful of indices: up to eight are tested with independent reads (one round
+// trip); longer intervals (degenerate scales) fall back to a scan from both ends.
+struct TabAcc {
+    const float2 *tab;
+    __device__ __forceinline__ float2 operator()(int J) const { return tab[J]; }
+};
+struct FlyAcc {
+    float a, b, cs;          // coord(J) = ((a * X_J + b) + 1) * cs, X_J = linspace(-1, 1, n)[J]
+    int ext, n;
+    double step;
+    __device__ __forceinline__ float2 operator()(int J) const { return axis_entry2(grid_coord(a, lin_m11(J, n, step), b, cs), ext); }
+};
+template <typename Acc>
+__device__ __forceinline__ int2 touch_range_t(const Acc &tab, float b, float inv_a, float inv_cs, int j, int n) {
     int lo, hi;
     src_range(inv_a, b, inv_cs, (float)(j - 1), (float)(j + 1), n, &lo, &hi);
     if (hi - lo < 8) {
@@ -155,15 +168,18 @@ __device__ __forceinline__ int2 touch_range(const float2 *tab, float b, float in
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int J = lo + u;
-            const int f = __float_as_int(tab[J <= hi ? J : lo].x);
+            const int f = __float_as_int(tab(J <= hi ? J : lo).x);
             if (J <= hi && f != ST_INVALID && (f == j || f + 1 == j)) mask |= 1u << u;
         }
         if (!mask) return make_int2(1, 0);
         return make_int2(lo + __ffs((int)mask) - 1, lo + 31 - __clz((int)mask));
     }
-    while (lo <= hi) { const int f = __float_as_int(tab[lo].x); if (f != ST_INVALID && (f == j || f + 1 == j)) break; ++lo; }
-    while (hi >= lo) { const int f = __float_as_int(tab[hi].x); if (f != ST_INVALID && (f == j || f + 1 == j)) break; --hi; }
+    while (lo <= hi) { const int f = __float_as_int(tab(lo).x); if (f != ST_INVALID && (f == j || f + 1 == j)) break; ++lo; }
+    while (hi >= lo) { const int f = __float_as_int(tab(hi).x); if (f != ST_INVALID && (f == j || f + 1 == j)) break; --hi; }
     return make_int2(lo, hi);
+}
+__device__ __forceinline__ int2 touch_range(const float2 *tab, float b, float inv_a, float inv_cs, int j, int n) {
+    return touch_range_t(TabAcc{tab}, b, inv_a, inv_cs, j, n);
 }
 // [first, last] index of an axis table with a valid entry (the valid set of a monotone map is an interval); every lane of the
 // wave gets the result; empty => first > last

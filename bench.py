@@ -479,7 +479,7 @@ def st_read_sweep(cfg, T, batches, device, share_image=True):
     return res
 
 
-def canvas_write_sweep(cfg, T, batches, device):
+def canvas_write_sweep(cfg, T, batches, device, scale=(0.45, 0.2)):
     """The inverse canvas write (north_star names it next to the read) over a batch sweep, forward (T inverse warps + canvas
     accumulation + reconstruction term, per-step canvases kept as the API path keeps them) and backward (dcanvas formed on the
     fly -> dglimpse, dwhere).  Fractions from the bytes each launch must move once; SURVEY 8(d)'s per-(image, step) figures
@@ -497,7 +497,7 @@ def canvas_write_sweep(cfg, T, batches, device):
         g = torch.Generator(device=device).manual_seed(B)
         glm = torch.randn(n, hw, device=device, generator=g)
         where = torch.empty(n, 4, device=device)
-        where[:, 0] = 0.45 + 0.2 * torch.rand(n, device=device, generator=g); where[:, 2] = 0.45 + 0.2 * torch.rand(n, device=device, generator=g)
+        where[:, 0] = scale[0] + scale[1] * torch.rand(n, device=device, generator=g); where[:, 2] = scale[0] + scale[1] * torch.rand(n, device=device, generator=g)
         where[:, 1] = 0.6 * torch.rand(n, device=device, generator=g) - 0.3; where[:, 3] = 0.6 * torch.rand(n, device=device, generator=g) - 0.3
         pres = (torch.rand(n, device=device, generator=g) < 0.7).float()
         obs = torch.rand(B, HW, device=device, generator=g)

@@ -100,18 +100,15 @@ int main(int argc, char **argv) {
     { std::vector<float> ip((size_t)NB * B); for (auto &x : ip) x = (-500.f + 100.f * frand()) / NB; CK(hipMemcpy(d_recp, ip.data(), ip.size() * 4, hipMemcpyHostToDevice)); }
     auto f_cfwd = [&] { air_canvas_unroll_fwd_banded(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, T, B, H, W, h, w, 0.5f, 0.3f, st); };
     auto f_cfwd1 = [&] { air_canvas_unroll_fwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_rec, T, B, H, W, h, w, 0.5f, 0.3f, st); };
-    auto f_cbwd = [&] { air_canvas_unroll_bwd_nvil(d_glm, d_where, d_pres, d_obs, d_final, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, d_recp, NB, d_rec, d_base, d_logp, d_nvil, d_dlogp, d_dbase, st); };
     auto f_cbwd0 = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, d_final, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_cbwd_rc = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, nullptr, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_cfused = [&] { air_canvas_unroll_fwd_bwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, d_dglm, d_dwhere, NS, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
-    auto f_afwd = [&] { air_attend_fwd(d_trh, d_trw, d_trb, Kt, d_sth, d_stw, d_stb, Ks, d_pre, d_logit, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_wh2, d_klrow, d_u, 0.75f, 1e-3f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, d_obs, d_glimpse, T, B, H, W, h, w, 0, st); };
-    auto f_abwd = [&] { air_attend_bwd(d_obs, d_where, d_dgl, d_dwr, d_pre, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_dwhere, NS, d_stepw, 1.0f / B, d_dpre, d_prob, d_pr2, d_prior, 1.0f / B, d_kla, d_klb, 1.0f / B, d_dlogp, d_logit, 0.75f, 1e-3f, d_dlogit, T, B, H, W, h, w, st); };
     auto f_rfwd = [&] { air_st_read_fwd(d_obs, d_where, d_glimpse, M, B, H, W, h, w, st); };
     struct { const char *n; std::function<void()> f; int nb; } K[] = {
-        {"canvas_unroll_fwd_banded", f_cfwd, B * NB}, {"canvas_unroll_fwd(1 band)", f_cfwd1, B}, {"canvas_unroll_bwd_nvil", f_cbwd, M + 1}, {"canvas_unroll_bwd", f_cbwd0, M},
+        {"canvas_unroll_fwd_banded", f_cfwd, B * NB}, {"canvas_unroll_fwd(1 band)", f_cfwd1, B}, {"canvas_unroll_bwd", f_cbwd0, M},
         {"canvas_unroll_bwd(recompute)", f_cbwd_rc, M}, {"canvas_fused(fwd+bwd)", f_cfused, B * NB + M},
-        {"attend_fwd", f_afwd, M + (B + 63) / 64}, {"attend_bwd", f_abwd, M + (B + 63) / 64}, {"st_read_fwd", f_rfwd, B}};
-    f_afwd(); CK(hipStreamSynchronize(st));
+        {"st_read_fwd", f_rfwd, B}};
+    f_cfwd(); CK(hipStreamSynchronize(st));
     printf("B=%d T=%d %dx%d glimpse %dx%d keep_steps=%d bands=%d\n", B, T, H, W, h, w, keep, NB);
     for (auto &k : K) {
         double us = time_us(k.f, 200, st);
