@@ -176,6 +176,7 @@ SIGNATURES = {
     "air_allreduce_sum": (c_int, [P, c_size_t, P, P]),
     "air_comm_last_error": (ctypes.c_char_p, []),
     "air_dp_ipc_barrier": (c_int, [ctypes.POINTER(AirIpcPeers), c_int, P, P, P]),
+    "air_dp_ipc_barrier_wgs": (c_int, [ctypes.POINTER(AirIpcPeers), c_int, P, P, c_int, P]),
     "air_dp_ipc_rs_update_ag": (c_int, [ctypes.POINTER(AirIpcPeers), P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float,
                                         P, P, c_uint64, P]),
     "air_stream_wait_event": (c_int, [P, P]),

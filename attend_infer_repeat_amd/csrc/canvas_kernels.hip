@@ -905,7 +905,7 @@ static inline size_t carve_gs_bytes(int H, int W, int h, int w, int TU, int TS, 
 }
 // touch_weights for the three column sums: the (up to) four canvas indices from r.x on -> wx, dwx, X dwx
 template <typename Acc>
-__device__ __forceinline__ void touch_weights3(const Acc &tab, int n, double step, int2 r, int j, float4 *w4, float4 *d4, float4 *x4) {
+__device__ __forceinline__ void touch_weights3(const Acc &tab, const float *Xt, int n, double step, int2 r, int j, float4 *w4, float4 *d4, float4 *x4) {
     float wv[4], dv[4], xv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -918,7 +918,7 @@ __device__ __forceinline__ void touch_weights3(const Acc &tab, int n, double ste
         const float dw = (f + 1 == j ? 1.f : 0.f) - (f == j ? 1.f : 0.f);
         wv[u] = in ? wgt : 0.f;
         dv[u] = in ? dw : 0.f;
-        xv[u] = in ? lin_m11(Jc, n, step) * dw : 0.f;
+        xv[u] = in ? (Xt ? Xt[Jc] : lin_m11(Jc, n, step)) * dw : 0.f;     // (Xt: the linspace table when it is already visible)
     }
     *w4 = make_float4(wv[0], wv[1], wv[2], wv[3]);
     *d4 = make_float4(dv[0], dv[1], dv[2], dv[3]);
@@ -977,6 +977,9 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
     }
     const int NS = SPLIT ? a.NS : 1;
     const int n_items = IM ? B : T * B * NS;
+    // (measured and rejected, profiles/r06_canvas_gs_ab.txt: image-major with the NEXT image's canvas operands requested during the row
+    //  contraction and held in registers over the barrier -- 28 more live registers at 1024 threads spill, 4819 against 4614 us at
+    //  65536 images of 100x100)
     for (int it = bid0; it < n_items; it += grid_st) {
         // unit-major: item = (unit k = t_own*B + b, split sp); image-major: item = image b, local unit lu = step
         const int k_um = IM ? 0 : it / NS, sp = IM ? 0 : it - k_um * NS;
@@ -1056,7 +1059,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                     const int2 rs = touch_range_t(fa, fa.b, s_, isx ? inv_cxs : inv_cys, jj, n_c);
                     if (isx) {
                         c.jr[lu * w + jj] = rs;
-                        touch_weights3(fa, W, a.stepX, rs, jj, &c.wx4[lu * w + jj], &c.dx4[lu * w + jj], &c.xx4[lu * w + jj]);
+                        touch_weights3(fa, nullptr, W, a.stepX, rs, jj, &c.wx4[lu * w + jj], &c.dx4[lu * w + jj], &c.xx4[lu * w + jj]);
                     } else {
                         c.ir[lu * h + jj] = rs;
                         c.wy4[lu * h + jj] = touch_weights_t(fa, rs, jj);
@@ -1135,7 +1138,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                     const TabAcc ta = {c.xe + lu * W};
                     const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cxs, r, W);
                     c.jr[lu * w + r] = rg;
-                    touch_weights3(ta, W, a.stepX, rg, r, &c.wx4[lu * w + r], &c.dx4[lu * w + r], &c.xx4[lu * w + r]);
+                    touch_weights3(ta, c.X, W, a.stepX, rg, r, &c.wx4[lu * w + r], &c.dx4[lu * w + r], &c.xx4[lu * w + r]);
                 } else {
                     const float s_ = wk[2], t_ = wk[3];
                     const int i = r - w;
@@ -1146,11 +1149,13 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                 }
             }
             // valid canvas rows and touched glimpse columns of each unit, one wave per unit (see gs_unit_spans)
-            for (int lu = wid; lu < TU; lu += nw) {
+            for (int lu = nw - 1 - wid; lu < TU; lu += nw) {   // (by the LAST waves: the first ones hold the range items)
                 const int4 sp4 = gs_unit_spans<SPLIT>(c.xe + lu * W, c.ye + lu * H, W, H, w, i0, i1, c.pres[lu] == 0.f && !dpresence);
                 if (lane == 0) { c.rows[lu] = make_int2(sp4.x, sp4.y); c.cols[lu] = make_int2(sp4.z, sp4.w); }
             }
+            AIR_TR(10);
             __syncthreads();                                   // (1b)
+            AIR_TR(11);
         }
         if (RC) {
             // the canvas on this unit's footprint, accumulated as the forward does -- ((0 + p0*v0) + p1*v1) + ... over ALL steps with
@@ -1193,6 +1198,9 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
             const float *src = c.src + (size_t)tt * c.hwp;
             float *t1 = c.t1 + (size_t)lu * c.t1s;
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // (measured and rejected, profiles/r06_canvas_gs_ab.txt: a thread keeping ONE glimpse column per unit -- range and weights read
+            //  once, rows walked with a stride of nt / nj -- issues fewer instructions per element but pays its set-up in every thread and
+            //  unit: 4802 against 4563 us at 65536 images of 100x100)
             for (int e = tid; e < fh * nj; e += nt) {
                 const int Ir = div_small(e, nj, inv_nj), I = I0 + Ir, j = ja + (e - Ir * nj);
                 const int2 r = c.jr[lu * w + j];
@@ -1475,7 +1483,7 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
         const char *env_min = getenv("AIR_CANVAS_IMG_MIN_UNITS");
         const long img_min_units = env_min ? atol(env_min) : 256 * 8;
         if (gs && rc && H * W >= 16) {                          // recompute form (the stand-alone launch; the fused one: air_canvas_unroll_fwd_bwd)
-            const int thr_r = thr_f ? thr_f : wr_threads;
+            const int thr_r = thr_f && thr_f <= 512 ? thr_f : wr_threads;
             const size_t lds_r = carve_gs_bytes(H, W, h, w, 1, T, thr_r / 64);
             if (lds_r <= CV_MAX_LDS) {
                 { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<true, false>, lds_r); if (st_) return st_; }
@@ -1503,7 +1511,7 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
                     return AIR_OK;
                 }
             }
-            int thr_u = thr_f ? thr_f : wr_threads;
+            int thr_u = thr_f && thr_f <= 512 ? thr_f : wr_threads;
             if (!thr_f && carve_gs_bytes(H, W, h, w, 1, 1, 4) > 40 * 1024) thr_u = 512;
             const size_t lds_u = carve_gs_bytes(H, W, h, w, 1, 1, thr_u / 64);
             if (lds_u <= CV_MAX_LDS) {

@@ -10,13 +10,19 @@
 // (optimiser traffic per GPU / world: 94 MB -> 12 MB at 8 ranks) and writes the updated shard into every peer's parameter buffer.
 //
 // Ordering between ranks: a barrier kernel in front (every rank's gradients final and written back) and behind (every pushed
-// parameter landed).  A barrier is one workgroup per XCD: each performs a SYSTEM-scope release fence (writes its XCD's L2 back),
-// workgroup 0 exchanges monotone epochs with the peers through flag words in their memory, then every workgroup performs a
-// system-scope acquire fence (invalidates its XCD's L2: peer-written parameters / peer gradients read a step ago must not be
-// served stale).  Spins are BOUNDED: a peer that never arrives sets err_dev instead of hanging the GPU.
+// parameter landed).  A barrier is a grid of small workgroups (64 by default, AIR_IPC_BARRIER_WGS): EVERY one performs a SYSTEM-scope
+// release fence (writes its XCD's L2 back) and counts its arrival, workgroup 0 exchanges monotone epochs with the peers through flag
+// words in their memory (release stores / acquire loads at system scope), then EVERY workgroup performs a system-scope acquire fence
+// (invalidates its XCD's L2: peer-written parameters / peer gradients read a step ago must not be served stale).  Nothing is assumed
+// about which XCD a workgroup lands on: each records its hardware XCC id (s_getreg HW_REG_XCC_ID) in a mask, and workgroup 0 refuses
+// the barrier (err = 2) when the arrivals did not cover as many XCDs as the device has (CUs / 32 on gfx950; round 5 launched one
+// workgroup per XCD and trusted the dispatcher's round robin -- VERDICT r05 item 4b).  Spins are BOUNDED: a peer that
+// never arrives sets err = 1 instead of hanging the GPU.
 //
-// Validated with two processes sharing one GPU (tests/test_engine.py::test_data_parallel_two_ranks_on_two_gpus[ipc-rsag]); no
-// multi-GPU node has been available.  RCCL protocols stay the default (distributed.py).
+// Validated with two, four and eight processes sharing one GPU (tests/test_engine.py::test_data_parallel_*): the sum in rank order, the
+// replicas bit-identical; no multi-GPU node has been available, so the protocol runs a known-answer self-test before it is adopted
+// (distributed.py) and RCCL protocols stay the default.
+#include <stdlib.h>
 #include "air_common.h"
 #include "optimizer_device.h"
 
@@ -32,35 +38,51 @@ struct IpcPeers {
 };
 
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// XCC (= XCD) this wave runs on: HW_REG_XCC_ID bits [3:0] (gfx940+)
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 15u;
 }
 
-// local[0..3]: {completed barriers of kind 0, of kind 1, arrivals of local workgroups (monotone), last released instance};
-// err[0] != 0 after a timeout.  Instance k (1-based, both kinds counted) of this rank's barriers waits for k * gridDim.x arrivals.
-__global__ __launch_bounds__(64) void ipc_barrier_kernel(IpcPeers pr, int which, unsigned long long *local, unsigned long long *err) {
+// local[0..7]: {completed barriers of kind 0, of kind 1, arrivals of local workgroups (monotone), last released instance,
+//               XCC ids seen so far (bit mask, monotone), XCC ids seen by the LAST instance's check, -, -};
+// err[0]: 1 after a timeout, 2 when the arrivals of an instance did not cover `n_xcd` XCDs.
+// Instance k (1-based, both kinds counted) of this rank's barriers waits for k * gridDim.x arrivals (every barrier of one rank must
+// therefore be launched with the same grid).
+__global__ __launch_bounds__(64) void ipc_barrier_kernel(IpcPeers pr, int which, int n_xcd, unsigned long long *local, unsigned long long *err) {
     const int tid = threadIdx.x;
     __shared__ unsigned long long s_epoch, s_inst;
-    // every XCD: write back what its L2 holds (the kernels in front of this node ran on all of them)
+    // every workgroup: write back what its XCD's L2 holds (the kernels in front of this node ran on all of them)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if (tid == 0) {
         // (read BEFORE this workgroup's arrival is counted: workgroup 0 advances them only after every workgroup has arrived)
-        const unsigned long long e0 = ld_sys(&local[0]), e1 = ld_sys(&local[1]);
+        const unsigned long long e0 = __hip_atomic_load(&local[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 e1 = __hip_atomic_load(&local[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_epoch = (which ? e1 : e0) + 1;
         s_inst = e0 + e1 + 1;
+        __hip_atomic_fetch_or(&local[4], 1ull << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&local[2], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const unsigned long long epoch = s_epoch, inst = s_inst;
     if (blockIdx.x == 0) {
-        bool ok = true;
+        bool ok = true, covered = true;
         if (tid == 0) {                                      // all local workgroups have released
             int spin = 0;
             while (__hip_atomic_load(&local[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < inst * gridDim.x && ++spin < AIR_IPC_SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(2);
             ok = spin < AIR_IPC_SPIN_LIMIT;
+            // (the mask is cumulative over the barriers of this rank: with the same grid every time, what one instance covers every
+            //  instance covers up to the dispatcher's rotation, and 64 workgroups over 8 XCDs leave 8 per XCD)
+            const unsigned long long seen = __hip_atomic_load(&local[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            local[5] = seen;
+            covered = __popcll(seen) >= n_xcd;
         }
         __syncthreads();
         if (tid < pr.world) {
@@ -70,9 +92,10 @@ __global__ __launch_bounds__(64) void ipc_barrier_kernel(IpcPeers pr, int which,
             if (spin >= AIR_IPC_SPIN_LIMIT) ok = false;
         }
         if (!ok) st_sys(&err[0], 1ull);
+        else if (tid == 0 && !covered) st_sys(&err[0], 2ull);
         __syncthreads();
         if (tid == 0) {
-            st_sys(&local[which], epoch);
+            __hip_atomic_store(&local[which], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&local[3], inst, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // go
         }
     } else if (tid == 0) {
@@ -80,7 +103,7 @@ __global__ __launch_bounds__(64) void ipc_barrier_kernel(IpcPeers pr, int which,
         while (__hip_atomic_load(&local[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < inst && ++spin < AIR_IPC_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
-    // every XCD: drop what its L2 caches of memory another rank has written since
+    // every workgroup: drop what its XCD's L2 caches of memory another rank has written since
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
@@ -135,16 +158,32 @@ static int ipc_fill(IpcPeers &pr, const AirIpcPeers *p) {
     }
     return AIR_OK;
 }
-extern "C" int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream) {
+static int ipc_barrier_default_wgs() {
+    static const int v = getenv("AIR_IPC_BARRIER_WGS") ? atoi(getenv("AIR_IPC_BARRIER_WGS")) : 64;
+    return v >= 1 && v <= 1024 ? v : 64;
+}
+// XCDs of the current device: 32 CUs each on gfx950 (256 CUs in SPX mode, 32 in CPX)
+static int ipc_device_xcds() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+    const int x = cus / 32;
+    return x < 1 ? 1 : (x > AIR_IPC_XCDS ? AIR_IPC_XCDS : x);
+}
+extern "C" int air_dp_ipc_barrier_wgs(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, int n_wgs, void *stream) {
     AIR_REQUIRE(local_dev && err_dev, AIR_E_NULL);
-    AIR_REQUIRE(which == 0 || which == 1, AIR_E_SHAPE);
+    AIR_REQUIRE((which == 0 || which == 1) && n_wgs >= 1 && n_wgs <= 1024, AIR_E_SHAPE);
     IpcPeers pr;
     int st = ipc_fill(pr, peers);
     if (st) return st;
-    hipLaunchKernelGGL(ipc_barrier_kernel, dim3(AIR_IPC_XCDS), dim3(64), 0, air_stream(stream), pr, which,
+    // (a grid smaller than the XCD count cannot cover them: the check then asks for what the grid can give)
+    const int xcds = ipc_device_xcds();
+    hipLaunchKernelGGL(ipc_barrier_kernel, dim3(n_wgs), dim3(64), 0, air_stream(stream), pr, which, n_wgs < xcds ? n_wgs : xcds,
                        (unsigned long long *)local_dev, (unsigned long long *)err_dev);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
+}
+extern "C" int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream) {
+    return air_dp_ipc_barrier_wgs(peers, which, local_dev, err_dev, ipc_barrier_default_wgs(), stream);
 }
 extern "C" int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                                        const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps,

@@ -198,16 +198,25 @@ class IpcPeerBuffers(object):
         from torch.multiprocessing.reductions import reduce_tensor
         from . import _lib
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        if self.world > 8:
-            raise _lib.AirHipError("ipc-rsag maps the ranks of ONE node: at most 8")
         dev = engine.device
-        self.flags = torch.zeros(16, dtype=torch.int64, device=dev)           # [2 barriers][8 ranks]
-        self.local = torch.zeros(4, dtype=torch.int64, device=dev)
-        self.err = torch.zeros(1, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize(dev)
-        mine = tuple(reduce_tensor(t) for t in (engine.flat_grads, engine.flat_params, self.flags))
+        # a rank-local failure of the export (world > 8, a tensor torch cannot export, e.g. under expandable_segments) must still reach
+        # the collective below -- a rank that raised in front of it would leave its peers blocked in all_gather_object --
+        # so it travels as None and EVERY rank raises afterwards
+        mine, local_error = None, None
+        try:
+            if self.world > 8:
+                raise _lib.AirHipError("ipc-rsag maps the ranks of ONE node: at most 8")
+            self.flags = torch.zeros(16, dtype=torch.int64, device=dev)       # [2 barriers][8 ranks]
+            self.local = torch.zeros(8, dtype=torch.int64, device=dev)        # (comm_ipc.hip: epochs, arrivals, go, XCC masks)
+            self.err = torch.zeros(1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize(dev)
+            mine = tuple(reduce_tensor(t) for t in (engine.flat_grads, engine.flat_params, self.flags))
+        except Exception as e:                                                 # noqa: BLE001
+            local_error = e
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=group)
+        if local_error is not None or any(x is None for x in everyone):
+            raise _lib.AirHipError("ipc-rsag: a rank could not export its buffers (%r)" % (local_error,))
         self._keep = []
         self.struct = _lib.AirIpcPeers()
         self.struct.world, self.struct.rank = self.world, self.rank
@@ -238,7 +247,62 @@ class IpcPeerBuffers(object):
                 (L.air_dp_ipc_barrier, (peers, 1, p(self.local), p(self.err)), "air_dp_ipc_barrier")]
 
     def timed_out(self) -> bool:
+        """a barrier of this rank gave up: a peer did not arrive within the bounded spin (err 1), or the barrier's workgroups did not
+        cover every XCD of the device (err 2, comm_ipc.hip)"""
         return bool(self.err.item() != 0)
+
+    def shard(self, engine):
+        """[lo, hi) of the flat buffers this rank's update owns (ipc_rs_update_ag_kernel: ceil(n/4 / world) float4 per rank)"""
+        nq = engine.n_total // 4
+        per = (nq + self.world - 1) // self.world
+        lo = min(per * self.rank, nq)
+        return 4 * lo, 4 * min(lo + per, nq)
+
+    def selftest(self, engine, group=None) -> bool:
+        """Known-answer check before the protocol is adopted: ONE eager barrier | shard update | barrier on known
+        gradients -- rank r contributes (r + 1) * pattern, so the rank-order sum is pattern * world (world + 1) / 2 exactly in fp32 for
+        the small integers used -- against centred RMSProp evaluated in torch on that sum, on every element of every replica; then
+        every buffer the step touched is restored.  Collective; agreed on."""
+        ok = True
+        try:
+            dev = engine.device
+            names = ("flat_params", "flat_grads", "flat_ms", "flat_mg", "flat_mom", "step_dev", "rng_state")
+            with engine.stream_context():
+                saved = {k: getattr(engine, k).clone() for k in names}
+                n = engine.n_total
+                pattern = ((torch.arange(n, device=dev) % 13) - 6).to(torch.float32) * 0.125        # exact small dyadic values
+                engine.flat_grads.copy_(pattern * float(self.rank + 1))
+                for k in ("flat_ms", "flat_mg", "flat_mom"):
+                    getattr(engine, k).zero_()
+            engine.synchronize()
+            dist.barrier(group=group)                                # every rank's known gradients are in place
+            engine._run(self.plan(engine), engine._sp())
+            engine.synchronize()
+            cfg = engine.cfg
+            with engine.stream_context():
+                g = pattern * (self.world * (self.world + 1) / 2.0) * (1.0 / self.world)
+                lr = torch.full((n,), float(engine.lr_dev.item()), device=dev)
+                lr[engine.n_model:] *= (cfg.baseline_lr_mult if cfg.use_reinforce else 0.0)
+                ms = (1.0 - cfg.rms_decay) * g * g
+                mg = (1.0 - cfg.rms_decay) * g
+                mom = lr * g / torch.sqrt(ms - mg * mg + cfg.rms_eps)
+                want = saved["flat_params"] - mom
+                err = (engine.flat_params - want).abs().max().item()
+                scale = mom.abs().max().item() + 1e-30
+                lo, hi = self.shard(engine)
+                slots_ok = bool(torch.allclose(engine.flat_mom[lo:hi], mom[lo:hi], rtol=1e-5, atol=1e-6 * scale))
+                ok = err <= 1e-5 * scale + 1e-7 and slots_ok and not self.timed_out()
+            dist.barrier(group=group)                                # nobody restores while a peer may still be reading / pushing
+            with engine.stream_context():
+                for k in names:
+                    getattr(engine, k).copy_(saved[k])
+            engine.synchronize()
+            self.local.zero_(); self.err.zero_(); self.flags.zero_()
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=group)
+        except Exception as e:                                        # noqa: BLE001
+            ok, self.selftest_error = False, repr(e)
+        return _agree(ok, engine.device, group)
 
 
 class DataParallelEngine(object):
@@ -288,19 +352,26 @@ class DataParallelEngine(object):
                 except Exception as e:                              # noqa: BLE001
                     ok, self._ipc_error = False, repr(e)
                 if _agree(ok, engine.device, group):
-                    self._ipc_plan = self._ipc.plan(engine)
-                    good = True
-                    if capture_graph:
+                    dist.barrier(group=group)                       # every rank's flags are mapped everywhere before anyone launches
+                    good = self._ipc.selftest(engine, group)        # known answer first: the protocol has never met a second GPU
+                    if not good:
+                        self._ipc_error = "ipc-rsag self-test failed: %s" % getattr(self._ipc, "selftest_error", "wrong result")
+                    if good:
+                        self._ipc_plan = self._ipc.plan(engine)
                         try:
-                            engine.release_graphs()
-                            engine.synchronize()
-                            engine._graph = engine._capture_plans([engine._plan_fwd_train, engine._plan_bwd, self._ipc_plan])
-                            engine._graph_has_opt, engine._graph_b2, engine._steps_per_replay = True, None, 1
+                            self._capture_ipc(capture_graph)
                         except Exception as e:                      # noqa: BLE001
                             good, self._ipc_error = False, repr(e)
-                    if _agree(good, engine.device, group):
-                        dist.barrier(group=group)                   # every rank's flags are mapped everywhere before anyone replays
+                        good = _agree(good, engine.device, group)
+                    if good:
+                        dist.barrier(group=group)
                         self.collective = "ipc-rsag"
+                        self._ipc_capture_graph = bool(capture_graph)
+                        # the slots of (world - 1) / world of the parameters are stale on this rank from now on: the engine's own
+                        # state_dict() refuses until gather_optimizer_state() has run; update_config() re-captures through this wrapper
+                        engine._slots_sharded = True
+                        engine._recapture_hook = self._recapture_ipc
+                        self._ipc_steps = 0
                         return
                     engine.release_graphs()
                 self._ipc = self._ipc_plan = None
@@ -343,6 +414,54 @@ class DataParallelEngine(object):
             else:
                 engine.capture()
 
+    def _capture_ipc(self, capture_graph=True):
+        """the ipc-rsag step as ONE graph: forward | backward | barrier | shard update + push | barrier"""
+        eng = self.engine
+        eng.release_graphs()
+        eng.synchronize()
+        eng._capture_kwargs = None                           # (a stale capture() of another protocol must not be replayed by update_config)
+        if capture_graph:
+            eng._graph = eng._capture_plans([eng._plan_fwd_train, eng._plan_bwd, self._ipc_plan])
+            eng._graph_has_opt, eng._graph_b2, eng._steps_per_replay = True, None, 1
+
+    def _recapture_ipc(self):
+        """engine.update_config() rebuilt the plans (use_prior, explore_eps, bias switches of mnist_model): the ipc graph follows"""
+        self._ipc_plan = self._ipc.plan(self.engine)
+        self._capture_ipc(self._ipc_capture_graph)
+
+    def gather_optimizer_state(self):
+        """ipc-rsag shards the RMSProp slots (rank r updates only its 1/world slice): all-gather the slices so that every rank holds
+        the complete flat_ms / flat_mg / flat_mom again -- before a checkpoint, and before the ranks go back to a protocol in which
+        every rank updates everything.  Collective.  A no-op for the other protocols."""
+        if self._ipc is None or self.world == 1:
+            return
+        eng = self.engine
+        eng.synchronize()
+        nq = eng.n_total // 4
+        per = 4 * ((nq + self.world - 1) // self.world)
+        lo, hi = self._ipc.shard(eng)
+        with self._stream():
+            for name in ("flat_ms", "flat_mg", "flat_mom"):
+                buf = getattr(eng, name)
+                mine = torch.zeros(per, dtype=buf.dtype, device=buf.device)
+                mine[:hi - lo] = buf[lo:hi]
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                full = torch.cat(parts)[:eng.n_total]
+                buf.copy_(full)
+        eng.synchronize()
+
+    def state_dict(self):
+        """the engine's checkpoint with COMPLETE optimiser slots whatever the protocol (collective: every rank calls it)"""
+        self.gather_optimizer_state()
+        eng = self.engine
+        sharded = getattr(eng, "_slots_sharded", False)
+        eng._slots_sharded = False
+        try:
+            return eng.state_dict()
+        finally:
+            eng._slots_sharded = sharded
+
     def _stream(self):
         ctx = getattr(self.engine, "stream_context", None)
         return ctx() if ctx is not None else contextlib.nullcontext()
@@ -372,12 +491,23 @@ class DataParallelEngine(object):
                 for pl in (eng._plan_fwd_train, eng._plan_bwd, self._ipc_plan):
                     eng._run(pl, eng._sp())
                 eng.global_step += 1
+            # a barrier that gave up leaves garbage behind it: look at the error word every IPC_CHECK_EVERY steps (one host
+            # synchronisation) instead of training on until somebody asks replicas_in_sync()
+            self._ipc_steps += 1
+            if self._ipc_steps % self.IPC_CHECK_EVERY == 0:
+                eng.synchronize()
+                if self._ipc.timed_out():
+                    from . import _lib
+                    raise _lib.AirHipError("ipc-rsag: a barrier gave up (err %d: 1 = a peer never arrived, 2 = XCDs not covered); "
+                                           "the replicas are no longer valid" % int(self._ipc.err.item()))
             return
         host_collective = self.world > 1 and not self.collective.startswith("rccl-captured")
         if self.collective == "torch-overlap":
             self.engine.train_step(obs, allreduce=self._allreduce, allreduce_async=self._allreduce_async)
         else:
             self.engine.train_step(obs, allreduce=self._allreduce if host_collective else None)
+
+    IPC_CHECK_EVERY = 256
 
     def replicas_in_sync(self) -> bool:
         """True when every rank holds bit-identical parameters (collective: every rank must call it).  Data-parallel replicas start
@@ -402,10 +532,13 @@ class DataParallelEngine(object):
 
     def close(self):
         if self._ipc is not None:
+            self.gather_optimizer_state()                   # every rank leaves with complete slots (whatever protocol comes next)
             self.engine.synchronize()
             self.engine.release_graphs()
             dist.barrier(group=self.group)                  # nobody unmaps while a peer may still be pushing
             self._ipc = self._ipc_plan = None
+            self.engine._slots_sharded = False
+            self.engine._recapture_hook = None
         if self.comm is not None:
             from . import hip as H
             self.engine.synchronize()

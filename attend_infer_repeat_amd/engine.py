@@ -498,11 +498,14 @@ class AIREngine(PlanMixin):
         if not new:
             return False
         self.synchronize()
-        recapture = getattr(self, "_capture_kwargs", None) if self._graph is not None else None
+        hook = getattr(self, "_recapture_hook", None)         # a wrapper that owns the captured graph (DataParallelEngine, ipc-rsag)
+        recapture = getattr(self, "_capture_kwargs", None) if (self._graph is not None and hook is None) else None
         self.release_graphs()
         self.cfg = dataclasses.replace(self.cfg, **new)
         self._build_plans()
-        if recapture is not None:
+        if hook is not None:
+            hook()
+        elif recapture is not None:
             self.capture(**recapture)
         return True
 
@@ -571,6 +574,9 @@ class AIREngine(PlanMixin):
     def state_dict(self):
         """Everything needed to resume bit-exactly: flat parameters, the three RMSProp slot buffers, the step counter and
         the Philox state; plus the name -> (offset, shape) map so the flat buffer can be read without this class."""
+        if getattr(self, "_slots_sharded", False):
+            raise _lib.AirHipError("the RMSProp slots are sharded over the ranks (ipc-rsag): checkpoint through "
+                                   "DataParallelEngine.state_dict(), which gathers them first")
         self.synchronize()
         return {"flat_params": self.flat_params.detach().cpu().clone(), "flat_ms": self.flat_ms.cpu().clone(),
                 "flat_mg": self.flat_mg.cpu().clone(), "flat_mom": self.flat_mom.cpu().clone(),

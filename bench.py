@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
                     help="c2: BASELINE configs[1], 50x50/20x20/T=3, batch 64, fp32 (headline); c4: configs[3], 100x100/28x28/T=5; "
                          "c5: configs[4], the c2 shapes at batch 1024 with the bf16 MFMA MLP path")
+    ap.add_argument("--fixed-batch", action="store_true",
+                    help="time every step on ONE fixed synthetic batch (what rounds 1-5 measured; the model collapses onto it within ~50 updates) "
+                         "instead of a fresh batch per step gathered from an HBM-resident synthetic set by the first node of the captured step")
+    ap.add_argument("--dataset-images", type=int, default=4096, help="size of the HBM-resident synthetic set the device feeder draws from")
     ap.add_argument("--step-bias", type=float, default=None,
                     help="probe, not a headline: bias of the steps predictor's logit (mnist_model.py:26; the script's 0.75 by default).  +20 keeps "
                          "every step present, -20 none -- measured: the step count is NOT what the state-dependent cost of the canvas kernels follows "
@@ -63,6 +67,8 @@ def parse():
         args.mfma = "bf16"
     if args.batch is None:
         args.batch = 1024 if args.config == "c5" else 64
+    if args.steps_per_replay > 1 or args.no_graph:
+        args.fixed_batch = True          # (the input queue of a multi-step replay / the eager probe run on the observation buffers)
     return args
 
 
@@ -303,7 +309,23 @@ def attend_roofline(eng, lib, live_warm_us=None):
     return out
 
 
-def run_other_config(name, device, steps=400, warmup=100, seed=1):
+FEEDER_IMAGES = 4096
+
+
+def resident_dataset(img_size, max_objects, device, n=FEEDER_IMAGES, seed=0, _cache={}):
+    """HBM-resident synthetic set for the device feeder (attend_infer_repeat_amd.engine.AIREngine.attach_dataset: every captured step
+    starts with air_batch_gather drawing its own batch with replacement, the reference's data.py:121-158 feeder moved into HBM)."""
+    import torch
+    from attend_infer_repeat_amd.data import synthetic_multi_mnist
+    key = (tuple(img_size), max_objects, n, seed, str(device))
+    if key not in _cache:
+        _cache.clear()                                        # (one set at a time: the 100x100 one is 164 MB)
+        imgs, _ = synthetic_multi_mnist(n, img_size, max_objects=max_objects, seed=seed)
+        _cache[key] = torch.from_numpy(imgs).reshape(n, -1).contiguous().to(device)
+    return _cache[key]
+
+
+def run_other_config(name, device, steps=400, warmup=100, seed=1, feeder=True, step_bias=None):
     """A short captured run of another named single-GPU configuration (BASELINE configs[3] = c4, configs[4] = c5) inside the default
     invocation, so that the driver's line carries driver-observed numbers for every single-GPU configuration."""
     import torch
@@ -312,10 +334,14 @@ def run_other_config(name, device, steps=400, warmup=100, seed=1):
     from attend_infer_repeat_amd import hip as H
     kw = dict(img_size=(100, 100), crop_size=(28, 28), max_steps=5) if name == "c4" else {}
     B = 1024 if name == "c5" else 64
+    if step_bias is not None:
+        kw = dict(kw, step_bias=float(step_bias))
     cfg = EngineConfig(mfma_dtype="bf16" if name == "c5" else "f32", **kw)
     eng = AIREngine(cfg, B, device=device, seed=seed, keep_canvas_steps=True)
     imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=4 if name == "c4" else 2, seed=0)
     eng.set_obs(torch.from_numpy(imgs).to(device))
+    if feeder:
+        eng.attach_dataset(resident_dataset(cfg.img_size, 4 if name == "c4" else 2, device), shuffle=True, seed=seed)
     eng.capture()
     for _ in range(warmup):
         eng.train_step()
@@ -345,7 +371,12 @@ def run_other_config(name, device, steps=400, warmup=100, seed=1):
            "value": round(B * steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
            "warmup": warmup, "median_block_ms_per_step": round(sorted(t_blocks)[len(t_blocks) // 2], 4), "blocks": blocks,
            "kernel_launches_per_step": sum(eng.kernel_launch_count().values()),
+           "input": ("fresh batch per step: air_batch_gather from %d HBM-resident synthetic images, first node of the captured step" % FEEDER_IMAGES)
+                    if feeder else "one fixed synthetic batch",
+           "step_bias": cfg.step_bias,
            "params_finite_after_run": finite, "model_state_at_end": state, "roofline": roof}
+    if feeder:
+        eng.attach_dataset(None)
     del eng
     torch.cuda.empty_cache()
     return rec
@@ -361,8 +392,14 @@ def run_other_config_seeds(name, device):
     0.298-0.333 ms over four seeds on one box and binary.  The line therefore carries configs[3] as the aggregate of C4_SEEDS
     (total images / total time) with every seed's own figure beside it; batch 1024 (c5) averages over sixteen times the images
     and stays on one seed."""
+    def beside(rec, **kw):
+        r = run_other_config(name, device, steps=200, warmup=100, **kw)
+        return {k: r[k] for k in ("ms_per_step", "value", "steps", "warmup", "input", "step_bias", "kernel_launches_per_step", "model_state_at_end")}
     if name != "c4":
-        return run_other_config(name, device)
+        rec = run_other_config(name, device)
+        rec["fixed_batch"] = beside(rec, feeder=False)                  # rounds 1-5's input, for continuity
+        rec["all_steps_present_probe"] = beside(rec, step_bias=20.0)    # every step present (the image-major canvas backward skips absent ones)
+        return rec
     recs = [run_other_config(name, device, seed=s) for s in C4_SEEDS]
     rec = dict(recs[0])
     total_ms = sum(r["ms_per_step"] * r["steps"] for r in recs)
@@ -375,8 +412,19 @@ def run_other_config_seeds(name, device):
     rec["per_seed"] = [{"engine_seed": s, "ms_per_step": r["ms_per_step"], "median_block_ms_per_step": r.get("median_block_ms_per_step"),
                         "value": r["value"], "model_state_at_end": r["model_state_at_end"]}
                        for s, r in zip(C4_SEEDS, recs)]
-    rec["note"] = ("aggregate over %d engine seeds x %d timed steps: the step time of this configuration depends on the model state "
-                   "(canvas-write backward), see per_seed" % (len(recs), recs[0]["steps"]))
+    rec["note"] = ("aggregate over %d engine seeds x %d timed steps (rounds 2-5: the step time of this configuration followed the model "
+                   "state through the canvas-write backward, 0.298-0.333 ms; round 6's glimpse-space backward: see per_seed)" % (len(recs), recs[0]["steps"]))
+    ms = [r["ms_per_step"] for r in recs]
+    rec["per_seed_spread"] = round((max(ms) - min(ms)) / min(ms), 4)
+    rec["fixed_batch"] = beside(rec, feeder=False)
+    # the ST bandwidth study at THIS configuration's shapes (BASELINE configs[3] "bandwidth-bound ST kernel"): out of cache from
+    # 8192 images on (100x100 fp32 = 40 KB per image)
+    from attend_infer_repeat_amd.engine import EngineConfig
+    cfg4 = EngineConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5)
+    pts = [1024, 8192, 65536]
+    rec["roofline_sweep_st_read_fwd"] = st_read_sweep(cfg4, 5, pts, device)
+    cw_f, cw_b, cw_i = canvas_write_sweep(cfg4, 5, pts, device)
+    rec["roofline_sweep_canvas_write_fwd"], rec["roofline_sweep_canvas_write_bwd"], rec["roofline_sweep_canvas_write_pair"] = cw_f, cw_b, cw_i
     return rec
 
 
@@ -743,8 +791,16 @@ def main():
     B = args.batch
     # the engine exactly as AIRonMNIST.train_step builds it (mnist_model.py: per-step canvases kept, as model.py:86-95 exposes them)
     eng = AIREngine(cfg, B, device=device, seed=D.rank_seed(1, rank), keep_canvas_steps=True)
-    imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=4 if args.config == "c4" else 2, seed=rank)
+    n_obj = 4 if args.config == "c4" else 2
+    imgs, _ = synthetic_multi_mnist(B, cfg.img_size, max_objects=n_obj, seed=rank)
     eng.set_obs(torch.from_numpy(imgs).to(device))
+    if not args.fixed_batch:
+        # a fresh batch per step: the first node of the captured step gathers it from an HBM-resident synthetic set,
+        # each rank from its own Philox stream -- the input pipeline of scripts/multi_mnist.py --device-feeder
+        eng.attach_dataset(resident_dataset(cfg.img_size, n_obj, device, n=args.dataset_images, seed=rank), shuffle=True, seed=1,
+                           rank=rank, world=world)
+    input_note = (("fresh batch per step: air_batch_gather from %d HBM-resident synthetic images per rank, first node of the captured step"
+                   % args.dataset_images) if not args.fixed_batch else "one fixed synthetic batch per rank (--fixed-batch)")
     # replicated weights (broadcast from rank 0), one all-reduce (sum) of the flat gradient bucket per step,
     # RMSProp applies grad_scale = 1/world
     def barrier():
@@ -873,9 +929,23 @@ def main():
         finally:
             wd["armed"] = None
 
+    fixed_rec = None
     if world == 1:
         head = run_protocol(None)
         protocol_ab = None
+        if not args.fixed_batch and not args.no_graph:
+            # rounds 1-5's input beside it, for continuity: the same engine on ONE fixed batch (it collapses onto it within ~50 updates)
+            eng.attach_dataset(None)
+            eng.set_obs(torch.from_numpy(imgs).to(device))
+            keep = (args.steps, args.warmup)
+            fr = run_protocol(None)
+            args.steps, args.warmup = keep
+            fixed_rec = {"ms_per_step": round(fr["ms_per_step"], 4), "median_ms_per_step": round(fr["median_ms"], 4), "value": round(fr["value"], 1),
+                         "kernel_launches_per_step": sum(eng.kernel_launch_count().values()), "model_state_at_end": fr["model_state"],
+                         "input": "one fixed synthetic batch (rounds 1-5's measurement), run after the headline on the same engine"}
+            eng.attach_dataset(resident_dataset(cfg.img_size, n_obj, device, n=args.dataset_images, seed=rank), shuffle=True, seed=1)
+            state["dp"].close()
+            state["dp"] = D.DataParallelEngine(eng, capture_graph=not args.no_graph, steps_per_replay=args.steps_per_replay, collective=None)
     else:
         first_limit = limit_s if limit_s > 0 else 600.0
         head = guarded("torch-split", lambda: run_protocol("torch-split"), first_limit)
@@ -911,6 +981,7 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "bf16 operands / f32 accumulate+storage",
             "data": "synthetic" if not share_gpu else "synthetic; NOT A MEASUREMENT: all ranks share one GPU (AIR_BENCH_SHARE_GPU)",
+            "input": input_note,
             "config": {"workload": workload if args.step_bias is None else workload + " -- PROBE: --step-bias %g" % args.step_bias,
                        "step_bias": cfg.step_bias, "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "steps_per_graph_replay": rec["spr"],
@@ -967,6 +1038,8 @@ def main():
     if rank == 0:
         def full_line():
             line = make_line(head, protocol_note)
+            if fixed_rec is not None:
+                line["fixed_batch"] = fixed_rec
             if args.breakdown:
                 plan_breakdown(eng)
             roof = st_rooflines(eng)

@@ -620,8 +620,11 @@ const char *air_comm_last_error(void);
  *                                 new parameters into EVERY rank's parameter buffer; the step counter / Philox offset advance --
  *   air_dp_ipc_barrier(.., 1)  -- every pushed parameter landed --
  * as kernel nodes of the step's graph.  One rank computes each element: replicas are bit-identical by construction.
- * flags[q]: rank q's block of 2 x 8 uint64 (zero-initialised); local_dev: 4 uint64 of this rank (zero-initialised); err_dev[0]
- * becomes 1 when a peer did not arrive within the (bounded) spin.                                                              */
+ * flags[q]: rank q's block of 2 x 8 uint64 (zero-initialised); local_dev: 8 uint64 of this rank (zero-initialised; [4] / [5] =
+ * bit mask of the hardware XCC ids the barrier's workgroups ran on); err_dev[0] becomes 1 when a peer did not arrive within the
+ * (bounded) spin, 2 when the barrier's workgroups did not cover every XCD of the device.  A barrier is a grid of 64-thread
+ * workgroups (64 of them by default, AIR_IPC_BARRIER_WGS; air_dp_ipc_barrier_wgs takes the count -- one count per rank and run:
+ * instance k waits for k * count arrivals), each of which fences its own XCD's L2.                                              */
 typedef struct AirIpcPeers {
     int world, rank;                   /* world <= 8 */
     const float *grads[8];
@@ -629,6 +632,7 @@ typedef struct AirIpcPeers {
     uint64_t *flags[8];
 } AirIpcPeers;
 int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream);
+int air_dp_ipc_barrier_wgs(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, int n_wgs, void *stream);
 int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                             const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps,
                             int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
