@@ -414,18 +414,22 @@ def run_other_config_seeds(name, device):
                        for s, r in zip(C4_SEEDS, recs)]
     rec["note"] = ("aggregate over %d engine seeds x %d timed steps (rounds 2-5: the step time of this configuration followed the model "
                    "state through the canvas-write backward, 0.298-0.333 ms; round 6's glimpse-space backward: see per_seed)" % (len(recs), recs[0]["steps"]))
-    ms = [r["ms_per_step"] for r in recs]
+    ms = [r.get("median_block_ms_per_step") or r["ms_per_step"] for r in recs]    # (median block: a one-off stall is not state dependence)
     rec["per_seed_spread"] = round((max(ms) - min(ms)) / min(ms), 4)
     rec["fixed_batch"] = beside(rec, feeder=False)
-    # the ST bandwidth study at THIS configuration's shapes (BASELINE configs[3] "bandwidth-bound ST kernel"): out of cache from
-    # 8192 images on (100x100 fp32 = 40 KB per image)
+    rec.update(c4_shape_sweeps(device))
+    return rec
+
+
+def c4_shape_sweeps(device, pts=(1024, 8192, 65536)):
+    """The ST bandwidth study at configs[3]'s shapes (BASELINE configs[3] "bandwidth-bound ST kernel") on the default line
+    (VERDICT r05 item 2a): out of cache from 8192 images on (100x100 fp32 = 40 KB per image)."""
     from attend_infer_repeat_amd.engine import EngineConfig
     cfg4 = EngineConfig(img_size=(100, 100), crop_size=(28, 28), max_steps=5)
-    pts = [1024, 8192, 65536]
-    rec["roofline_sweep_st_read_fwd"] = st_read_sweep(cfg4, 5, pts, device)
-    cw_f, cw_b, cw_i = canvas_write_sweep(cfg4, 5, pts, device)
-    rec["roofline_sweep_canvas_write_fwd"], rec["roofline_sweep_canvas_write_bwd"], rec["roofline_sweep_canvas_write_pair"] = cw_f, cw_b, cw_i
-    return rec
+    out = {"roofline_sweep_st_read_fwd": st_read_sweep(cfg4, 5, list(pts), device)}
+    cw_f, cw_b, cw_i = canvas_write_sweep(cfg4, 5, list(pts), device)
+    out["roofline_sweep_canvas_write_fwd"], out["roofline_sweep_canvas_write_bwd"], out["roofline_sweep_canvas_write_pair"] = cw_f, cw_b, cw_i
+    return out
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)

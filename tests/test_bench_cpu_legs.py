@@ -22,23 +22,29 @@ def test_all_cores_replica_leg_never_blocks_the_line():
 
 
 def test_configs3_line_is_the_aggregate_over_engine_seeds(monkeypatch):
-    """other_configs.c4 = total images / total time over bench.C4_SEEDS with each seed's own figure beside it (its step time follows the
-    model state, profiles/r05_c4_seed_dependence.txt); configs[4] stays on one seed."""
+    """other_configs.c4 = total images / total time over bench.C4_SEEDS (fresh batch per step from the HBM feeder) with each seed's own
+    figure and the spread beside it, the fixed-batch figure of rounds 1-5 for continuity and the configs[3]-shape ST sweeps; configs[4]
+    stays on one seed and carries the fixed-batch figure and the all-steps-present probe."""
     import bench
-    ms = {1: 0.3225, 1000004: 0.3026, 7: 0.3075}
+    ms = {1: 0.3025, 1000004: 0.3026, 7: 0.3075}
     calls = []
 
-    def fake(name, device, steps=400, warmup=100, seed=1):
-        calls.append((name, seed))
+    def fake(name, device, steps=400, warmup=100, seed=1, feeder=True, step_bias=None):
+        calls.append((name, seed, feeder, step_bias))
         return {"workload": name, "value": round(64 / (ms.get(seed, 0.4) * 1e-3), 1), "unit": "images/sec", "ms_per_step": ms.get(seed, 0.4),
-                "steps": steps, "warmup": warmup, "kernel_launches_per_step": 35, "params_finite_after_run": seed != 7,
+                "steps": steps, "warmup": warmup, "kernel_launches_per_step": 36, "params_finite_after_run": seed != 7,
+                "input": "feeder" if feeder else "fixed", "step_bias": 0.75 if step_bias is None else step_bias,
                 "model_state_at_end": {"steps_present_per_image": float(seed % 3), "mean_abs_where": [1.0] * 4}, "roofline": {"frac": 0.1}}
     monkeypatch.setattr(bench, "run_other_config", fake)
+    monkeypatch.setattr(bench, "c4_shape_sweeps", lambda device: {"roofline_sweep_canvas_write_bwd": [{"batch": 65536, "frac": 0.2}]})
     rec = bench.run_other_config_seeds("c4", None)
-    assert calls == [("c4", s) for s in bench.C4_SEEDS] and 1000004 in bench.C4_SEEDS     # the seed of `bench.py --config c4` is one of them
+    assert calls[:3] == [("c4", s, True, None) for s in bench.C4_SEEDS] and 1000004 in bench.C4_SEEDS    # the seed of `bench.py --config c4` is one of them
+    assert calls[3] == ("c4", 1, False, None) and rec["fixed_batch"]["input"] == "fixed"
     assert rec["steps"] == 1200 and abs(rec["ms_per_step"] - sum(ms.values()) / 3) < 1e-4
     assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 / 64 - 1.0) < 1e-3 and rec["params_finite_after_run"] is False
     assert [p["engine_seed"] for p in rec["per_seed"]] == list(bench.C4_SEEDS) and all("model_state_at_end" in p for p in rec["per_seed"])
+    assert abs(rec["per_seed_spread"] - (0.3075 - 0.3025) / 0.3025) < 1e-3 and rec["roofline_sweep_canvas_write_bwd"][0]["frac"] == 0.2
     calls.clear()
     one = bench.run_other_config_seeds("c5", None)
-    assert calls == [("c5", 1)] and "per_seed" not in one
+    assert calls == [("c5", 1, True, None), ("c5", 1, False, None), ("c5", 1, True, 20.0)] and "per_seed" not in one
+    assert one["fixed_batch"]["input"] == "fixed" and one["all_steps_present_probe"]["step_bias"] == 20.0

@@ -992,14 +992,17 @@ def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
     dp = D.DataParallelEngine(eng, collective=collective)
     start = eng.flat_params.cpu().clone()
     # one step with the gradient read back before the update: split protocols expose it between the two graphs
-    for _ in range(20 if collective in ("ipc-rsag",) or os.environ.get("AIR_TEST_DP_STEPS") else 3):
+    n_steps = int(os.environ.get("AIR_TEST_DP_STEPS") or (20 if collective == "ipc-rsag" else 3))
+    for _ in range(n_steps):
         dp.train_step()
     eng.synchronize()
     in_sync = dp.replicas_in_sync()
     assert in_sync, "replicas diverged under %s" % dp.collective
     torch.save(dict(start=start, params=eng.flat_params.cpu(), grads=eng.flat_grads.cpu(), collective=dp.collective,
                     nranks=dp.rccl_nranks, noise=eng.eps_what.cpu(), steps=int(eng.step_dev.item()),
-                    timed_out=bool(dp._ipc.timed_out()) if dp._ipc is not None else False),
+                    timed_out=bool(dp._ipc.timed_out()) if dp._ipc is not None else False,
+                    ipc_local=dp._ipc.local.cpu() if dp._ipc is not None else None,
+                    state=dp.state_dict() if os.environ.get("AIR_TEST_DP_STATE") else None),
                os.path.join(out_dir, f"{collective}_{rank}.pt"))
     dp.close()
     import torch.distributed as dist
@@ -1056,6 +1059,77 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     assert torch.equal(r[0]["grads"], r[1]["grads"]) and r[0]["grads"].abs().max() > 0
     assert torch.equal(r[0]["params"], r[1]["params"]) and not torch.equal(r[0]["params"], r[0]["start"])
     assert not torch.equal(r[0]["noise"], r[1]["noise"])
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("collective", ["ipc-rsag", "torch-split", "torch-overlap"])
+def test_data_parallel_many_ranks_sharing_one_gpu(gpu_device, tmp_path, monkeypatch, collective, world):
+    """FOUR and EIGHT ranks (processes sharing GPU 0, gradients over gloo or the hipIpc mapping) -- the first
+    configurations in which the order of a float sum can differ.  After ONE update from identical parameters: every replica holds
+    the same bits; ipc-rsag's parameters are EXACTLY the engine's update of the host-side sum of the ranks' local gradients taken
+    in rank order ((g0 + g1) + g2) + ... -- what comm_ipc.hip promises -- with every rank's slots complete after the gather
+    (DataParallelEngine.state_dict); the library protocols' replicas all carry the same summed gradient and the engine's update
+    of it, which agrees with the rank-order sum to rounding.  ipc-rsag's barriers (64 workgroups each) covered all eight XCDs."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("AIR_TEST_DP_STEPS", "1")
+    monkeypatch.setenv("AIR_TEST_DP_STATE", "1")
+    mp.spawn(_dp_rank_main, args=(world, D_free_port(), str(tmp_path), collective, True), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(world)]
+    assert all(x["collective"] == collective for x in r)
+    assert all(torch.equal(x["start"], r[0]["start"]) for x in r) and all(x["steps"] == 1 for x in r)
+    assert all(torch.equal(x["params"], r[0]["params"]) for x in r), "replicas differ"
+    assert not torch.equal(r[0]["params"], r[0]["start"])
+    # the reference update: one engine, the start parameters, a given summed gradient, grad_scale = 1 / world
+    ocfg, B = CONFIGS["mnist_b8"]
+    from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
+    fields = {f.name for f in dataclasses.fields(EngineConfig)}
+
+    def update_of(gsum):
+        eng = AIREngine(EngineConfig(**{k: v for k, v in dataclasses.asdict(ocfg).items() if k in fields}), B, device=torch.device("cuda", 0), seed=3)
+        eng._copy_in(eng.flat_params, r[0]["start"]); eng._copy_in(eng.flat_grads, gsum)
+        eng.optimizer_step(grad_scale=1.0 / world); eng.synchronize()
+        return eng.flat_params.cpu(), eng.flat_mom.cpu()
+
+    rank_order = r[0]["grads"].clone()
+    if collective == "ipc-rsag":
+        for k in range(1, world):
+            rank_order = rank_order + r[k]["grads"]               # fp32, rank order: ((g0 + g1) + g2) + ...
+        assert not any(x["timed_out"] for x in r)
+        assert len({x["grads"].double().abs().sum().item() for x in r}) == world       # flat_grads keeps each rank's LOCAL gradient
+        want, want_mom = update_of(rank_order)
+        assert torch.equal(r[0]["params"], want)
+        for x in r:                                               # complete slots on every rank after the gather
+            assert torch.equal(x["state"]["flat_mom"], want_mom) and torch.equal(x["state"]["flat_params"], want)
+            assert bin(int(x["ipc_local"][4])).count("1") == 8, "the barrier's workgroups did not cover the eight XCDs"
+    else:
+        assert all(torch.equal(x["grads"], r[0]["grads"]) for x in r)          # the all-reduced buffer, on every rank
+        want, _ = update_of(r[0]["grads"])
+        assert torch.equal(r[0]["params"], want)
+
+
+def test_ipc_barrier_grids_cover_every_xcd(gpu_device):
+    """the barrier of the ipc-rsag protocol as a grid of 16 and of 64 workgroups (one rank, its own flag block):
+    every instance completes, the epochs advance, and the hardware XCC ids the workgroups recorded cover all eight XCDs -- nothing is
+    assumed about which XCD workgroup i lands on; with ONE workgroup the coverage check is what it can be (no error), with the
+    device's XCD count demanded of a grid that cannot give it the barrier reports err = 2."""
+    import ctypes
+    from attend_infer_repeat_amd import _lib, hip as H
+    L, P = H.lib(), H._p
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n_wgs in (16, 64, 1):
+        flags = torch.zeros(16, dtype=torch.int64, device="cuda"); local = torch.zeros(8, dtype=torch.int64, device="cuda")
+        err = torch.zeros(1, dtype=torch.int64, device="cuda")
+        g = torch.zeros(16, device="cuda"); pr = torch.zeros(16, device="cuda")
+        peers = _lib.AirIpcPeers(); peers.world, peers.rank = 1, 0
+        peers.grads[0], peers.params[0], peers.flags[0] = g.data_ptr(), pr.data_ptr(), flags.data_ptr()
+        for k in range(6):
+            assert L.air_dp_ipc_barrier_wgs(ctypes.byref(peers), k % 2, P(local), P(err), n_wgs, sp) == 0
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0, (n_wgs, int(err.item()))
+        assert local[0].item() == 3 and local[1].item() == 3 and local[2].item() == 6 * n_wgs and local[3].item() == 6
+        xcds = bin(int(local[4].item())).count("1")
+        assert xcds == (8 if n_wgs >= 16 else 1), (n_wgs, xcds)
+        assert flags[0].item() == 3 and flags[8].item() == 3
 
 
 def test_data_parallel_semantics_two_virtual_ranks(gpu_device):
