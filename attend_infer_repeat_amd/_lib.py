@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_PKG, "lib", "libair_hip.so")
 c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p,
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
-ABI_VERSION = 9  # == AIR_ABI_VERSION in include/air_hip.h
+ABI_VERSION = 10        # == AIR_ABI_VERSION in include/air_hip.h (the stable contract, AIR_API)
+ENGINE_ABI_VERSION = 1  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -55,6 +56,7 @@ class AirGaussBwdEpi(ctypes.Structure):
 # name -> (restype, argtypes); order and meaning exactly as in include/air_hip.h
 SIGNATURES = {
     "air_abi_version": (c_int, []),
+    "air_engine_abi_version": (c_int, []),
     "air_status_string": (ctypes.c_char_p, [c_int]),
     "air_build_digest": (ctypes.c_char_p, []),
     "air_st_read_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -214,9 +216,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.air_abi_version() != ABI_VERSION:
-        raise AirHipError(f"libair_hip.so ABI version {lib.air_abi_version()} != binding {ABI_VERSION}: rebuild "
-                          "(python -m attend_infer_repeat_amd.build)")
+    if lib.air_abi_version() != ABI_VERSION or lib.air_engine_abi_version() != ENGINE_ABI_VERSION:
+        raise AirHipError(f"libair_hip.so ABI version {lib.air_abi_version()} / engine {lib.air_engine_abi_version()} != binding "
+                          f"{ABI_VERSION} / {ENGINE_ABI_VERSION}: rebuild (python -m attend_infer_repeat_amd.build)")
     # a binary compiled from other sources than the ones next to it (a checkout that changed csrc/ without a rebuild) would
     # be called with possibly changed argument lists -- ctypes cannot notice -- so it is refused
     from . import build as _build

@@ -332,6 +332,7 @@ extern "C" int air_event_destroy(void *event) {
 }
 
 extern "C" int air_abi_version(void) { return AIR_ABI_VERSION; }
+extern "C" int air_engine_abi_version(void) { return AIR_ENGINE_ABI_VERSION; }
 #ifndef AIR_BUILD_DIGEST
 #define AIR_BUILD_DIGEST "unstamped"
 #endif

@@ -457,6 +457,19 @@ def import_tf_checkpoint(prefix: str, shapes: "Dict[str, Tuple[int, ...]]",
     return {k: raw[tfn].astype(np.float32) for k, tfn in m.items()}
 
 
+def mapping_report(prefix: str, shapes: "Dict[str, Tuple[int, ...]]", name_map: "Optional[Dict[str, str]]" = None) -> "Dict[str, list]":
+    """What an import leaves behind: engine parameters the name map does not cover (they keep their random initial values)
+    and trainable-looking checkpoint variables nobody uses (rank >= 1, not an optimiser slot, not global_step) -- the two silent ways a
+    wrong guess about Sonnet's variable names can go unnoticed.  scripts/multi_mnist.py prints both lists."""
+    _, entries = read_index(prefix, False)
+    tf_shapes = {n: e["shape"] for n, e in entries.items()}
+    m = dict(name_map) if name_map is not None else default_name_map(shapes, tf_shapes)
+    used = set(m.values())
+    is_slot = lambda n: "/RMSProp" in n or n.rsplit("/", 1)[-1].startswith("RMSProp")
+    unused = sorted(n for n, sh in tf_shapes.items() if n not in used and len(sh) >= 1 and not is_slot(n) and "global_step" not in n)
+    return {"unmapped_engine_parameters": sorted(k for k in shapes if k not in m), "unused_checkpoint_variables": unused}
+
+
 def import_tf_optimizer_slots(prefix: str, shapes: "Dict[str, Tuple[int, ...]]", name_map: "Optional[Dict[str, str]]" = None,
                               verify: str = "all") -> "Dict[str, Dict[str, np.ndarray]]":
     """The RMSProp slots a Saver wrote beside the variables (model.py:265: `tf.train.RMSPropOptimizer(momentum=.9, centered=True)` for the

@@ -465,9 +465,23 @@ def gemm_roofline(eng, reps=50):
     # bf16 mode: v_mfma_f32_16x16x16_bf16, half the K per instruction of the gfx950 16x16x32 form -> price against the
     # dense bf16 peak of MI355X_MICROARCH.md (2.5 PF) all the same; the operands are still fetched as fp32
     peak = F32_MFMA_PEAK_TFLOPS if eng.cfg.mfma_dtype == "f32" else 2516.6
-    return {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(tf / peak, 5), "traffic": None, "gemm_launches": launches,
-            "gemm_flops_per_step": int(flops), "gemm_us_per_step_isolated": round(us, 1)}
+    out = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
+           "frac": round(tf / peak, 5), "traffic": None, "gemm_launches": launches,
+           "gemm_flops_per_step": int(flops), "gemm_us_per_step_isolated": round(us, 1)}
+    # MFMA utilisation from the counters (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES and against the dispatches' wall time) of the
+    # committed PMC pass of THIS binary and shape (tools/profile_round.sh -> tools/rocpd_pmc.py --mfma-json), next to FLOP/s / peak
+    import glob
+    (Hh, Ww), (h, w) = eng.cfg.img_size, eng.cfg.crop_size
+    digest = lib.air_build_digest().decode()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_util.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("build_digest") == digest and d.get("shape") == [Hh, Ww, h, w, eng.T, eng.B] and d.get("mfma_dtype", "f32") == eng.cfg.mfma_dtype:
+            out["mfma_busy_utilisation"] = dict(d["dense_kernels_total"], source="profiles/" + os.path.basename(path))
+            break
+    return out
 
 
 def plan_breakdown(eng, reps=100):

@@ -23,8 +23,21 @@
 extern "C" {
 #endif
 
-/* bumped whenever a signature below changes (ctypes cannot check argument lists) */
-#define AIR_ABI_VERSION 9
+/* TWO classes of entry points, marked on every declaration:
+ *   AIR_API         -- the STABLE CONTRACT: the operator boundary of SURVEY 8(b) (spatial transformer read / write, linear + GEMM,
+ *                      LSTM cell, Gaussian sample + KL, presence, reconstruction term, num-steps posterior, NVIL, centred RMSProp,
+ *                      each with its `_bwd`), the whole-step canvas forms, the RNG / utility launches, hipGraph / event / stream
+ *                      plumbing and the RCCL communicator.  What a maintainer of the reference binds.  Its
+ *                      prototypes are pinned in tests/golden/abi_stable.txt; AIR_ABI_VERSION changes when one of them does.
+ *   AIR_ENGINE_API  -- ENGINE PLAN ENTRIES: the fused / folded launches attend_infer_repeat_amd/engine_plan.py strings together
+ *                      (riders, struct-argument epilogues, bf16 mirrors, the hipIpc data-parallel nodes).  They change whenever a
+ *                      fold changes -- AIR_ENGINE_ABI_VERSION counts those changes -- and nobody outside this repository should
+ *                      bind them.
+ * ctypes cannot check argument lists: the loader compares both numbers and the build digest. */
+#define AIR_ABI_VERSION 10
+#define AIR_ENGINE_ABI_VERSION 1
+#define AIR_API
+#define AIR_ENGINE_API
 
 enum {
     AIR_OK = 0,
@@ -47,30 +60,31 @@ enum {
     AIR_EPI_ADD_AUX_ELU = 5  /* elu(acc + aux[m,n] (+ bias[n] if given))     layer whose input is a concat: parts summed */
 };
 
-int air_abi_version(void);
+AIR_API int air_abi_version(void);
+AIR_ENGINE_API int air_engine_abi_version(void);
 /* sha256 of the sources + headers this binary was compiled from (attend_infer_repeat_amd/build.py passes it at compile
  * time); the loader compares it with the sources it finds next to the library, so a stale binary is refused instead of
  * being called with a changed argument list. */
-const char *air_build_digest(void);
-const char *air_status_string(int status);
+AIR_API const char *air_build_digest(void);
+AIR_API const char *air_status_string(int status);
 
 /* ---- spatial transformer ------------------------------------------------------------------------------------
  * Replaces snt.AffineGridWarper + snt.resampler (+ registered gradient) at modules.py:100-109.                     */
 
 /* Glimpse read, cell.py:135.  glimpse[k] = bilinear(img[k % n_img], grid(where[k])), k < n.
  * n_img == n for one image per glimpse; n = T*n_img when T glimpses are read from each image (batched unroll).   */
-int air_st_read_fwd(const float *img, const float *where, float *glimpse,
+AIR_API int air_st_read_fwd(const float *img, const float *where, float *glimpse,
                     int n, int n_img, int H, int W, int h, int w, void *stream);
 /* dwhere[n,4] always; dimg[n_img,H,W] optional (NULL to skip; requires n_img == n).                               */
-int air_st_read_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere, float *dimg,
+AIR_API int air_st_read_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere, float *dimg,
                     int n, int n_img, int H, int W, int h, int w, void *stream);
 
 /* Canvas write, cell.py:159-165: canvas_out[k] = canvas_in[k] + presence[k] * inverse_warp(glimpse[k], where[k]).
  * canvas_in may be NULL (zeros) or alias canvas_out; presence may be NULL (ones).                                  */
-int air_st_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
+AIR_API int air_st_write_fwd(const float *glimpse, const float *where, const float *presence, const float *canvas_in,
                      float *canvas_out, int n, int H, int W, int h, int w, void *stream);
 /* Gradients of the above wrt glimpse, where and (optionally, NULL to skip) presence given dcanvas[n,H,W].         */
-int air_st_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
+AIR_API int air_st_write_bwd(const float *glimpse, const float *where, const float *presence, const float *dcanvas,
                      float *dglimpse, float *dwhere, float *dpresence,
                      int n, int H, int W, int h, int w, void *stream);
 
@@ -79,33 +93,33 @@ int air_st_write_bwd(const float *glimpse, const float *where, const float *pres
  *   canvas_steps[T,B,H,W] (optional): running canvas after each step, UNscaled.
  *   final_canvas[B,H,W]: canvas after T steps, UNscaled.
  *   rec_per_sample[B] (optional, needs obs): sum_pix -log N(obs | mult*canvas, std).                              */
-int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+AIR_API int air_canvas_unroll_fwd(const float *glimpse, const float *where, const float *presence, const float *obs,
                           float *canvas_steps, float *final_canvas, float *rec_per_sample,
                           int T, int B, int H, int W, int h, int w, float mult, float std, void *stream);
 /* The same unroll with each image cut into `n_bands` horizontal row bands, one workgroup per (image, band): a small batch
  * then fills the chip (64 images x 4 bands = 256 workgroups).  rec_parts[n_bands, B] receives each band's share of the
  * reconstruction term; consumers add the shares in band order (air_nvil_parts, air_canvas_unroll_bwd_nvil, or
  * air_sum_leading for the plain sum).  n_bands must be what air_canvas_unroll_bands(B, H) returns (or 1).            */
-int air_canvas_unroll_bands(int B, int H);
-int air_canvas_unroll_fwd_banded(const float *glimpse, const float *where, const float *presence, const float *obs,
+AIR_ENGINE_API int air_canvas_unroll_bands(int B, int H);
+AIR_ENGINE_API int air_canvas_unroll_fwd_banded(const float *glimpse, const float *where, const float *presence, const float *obs,
                                  float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands,
                                  int T, int B, int H, int W, int h, int w, float mult, float std, void *stream);
 
 /* Backward of mean_b(rec_per_sample) * loss_scale through the fused op: dcanvas is formed on the fly from
  * (final_canvas, obs).  Outputs dglimpse[T,B,h,w], dwhere[T,B,4].                                                  */
-int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+AIR_API int air_canvas_unroll_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
                           const float *final_canvas, float *dglimpse, float *dwhere,
                           int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                           void *stream);
 /* air_canvas_unroll_bwd that also returns dpresence[T,B] = sum_pix dL/dcanvas * (the step's write) -- what a continuous presence
  * (discrete_steps=False: cell.py:150-151, 163) receives from the canvas write.                                           */
-int air_canvas_unroll_bwd_dpresence(const float *glimpse, const float *where, const float *presence, const float *obs,
+AIR_ENGINE_API int air_canvas_unroll_bwd_dpresence(const float *glimpse, const float *where, const float *presence, const float *obs,
                                     const float *final_canvas, float *dglimpse, float *dwhere, float *dpresence,
                                     int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                                     void *stream);
 /* The same launch with one extra workgroup that evaluates air_nvil(imp, baseline, logp, nvil_out, dlogp, dbaseline, B)
  * (the two are independent; the step is bound by the number of dependent launches).                                  */
-int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence, const float *obs,
+AIR_ENGINE_API int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const float *presence, const float *obs,
                                const float *final_canvas, float *dglimpse, float *dwhere,
                                int T, int B, int H, int W, int h, int w, float mult, float std, float loss_scale,
                                const float *imp_parts, int n_parts, float *imp_sum, const float *baseline,
@@ -118,8 +132,8 @@ int air_canvas_unroll_bwd_nvil(const float *glimpse, const float *where, const f
  * n_split slabs, dwhere[n_split][T*B][4], whose SUM (slab 0 + slab 1 + ..., in that order) is the gradient -- the consumer adds
  * them (air_attend_bwd's `dwhere_w_slabs`).  B * n_bands and B * T * n_split at most 4096, and the launch's LDS must fit:
  * air_canvas_unroll_fwd_bwd_fits(...) == 1 says so without launching (plan builders ask it and keep the two launches otherwise). */
-int air_canvas_unroll_fwd_bwd_fits(int n_bands, int n_split, int T, int B, int H, int W, int h, int w);
-int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
+AIR_ENGINE_API int air_canvas_unroll_fwd_bwd_fits(int n_bands, int n_split, int T, int B, int H, int W, int h, int w);
+AIR_ENGINE_API int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const float *presence, const float *obs,
                               float *canvas_steps, float *final_canvas, float *rec_parts, int n_bands, float *dglimpse,
                               float *dwhere, int n_split, int T, int B, int H, int W, int h, int w, float mult, float std,
                               float loss_scale, void *stream);
@@ -130,13 +144,13 @@ int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *where, const fl
  * tb==0: B is [K,N] (ldb); tb!=0: B is stored [N,K].  fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32 accumulate.
  * bias[N] / aux[M,N](ldaux) as required by `epilogue`.  If colsum != NULL (only with ta!=0): colsum[n] = sum_k
  * op(B)[k,n] (bias gradient fused into the dW GEMM).  ws / ws_bytes: optional split-K workspace (may be NULL).    */
-int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+AIR_API int air_gemm(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
              float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
              float *colsum, void *ws, size_t ws_bytes, void *stream);
 /* Same contract with the operands rounded to bf16 (round-to-nearest-even) in registers and multiplied on
  * v_mfma_f32_16x16x16_bf16 (fp32 accumulate, fp32 storage everywhere): BASELINE.json configs[4], "bf16 MFMA MLP path".
  * colsum (the bias gradient) is summed from the un-rounded fp32 values.                                             */
-int air_gemm_bf16(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+AIR_ENGINE_API int air_gemm_bf16(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
              float *C, int ldc, const float *bias, int epilogue, const float *aux, int ldaux, float beta,
              float *colsum, void *ws, size_t ws_bytes, void *stream);
 size_t air_gemm_workspace_bytes(int M, int N, int K);
@@ -177,22 +191,22 @@ typedef struct AirGemmDesc {
 /* count <= 8; up to 24 for the deferred weight gradients of a whole step in one launch: problems the wide-tile kernel takes
  * (ta = 1, tb = 0, M, N, K and ldb multiples of 4, B 16-byte aligned) on 64x64 tiles -- at least one --, any other problem
  * (no A2) on 16x16 tiles in the same grid.                                                                                 */
-int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
+AIR_ENGINE_API int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
 
 /* y = act(x.w + b), neural.py:56-60.  x[M,K], w[K,N] (Sonnet layout), b[N] (may be NULL), y[M,N].                 */
-int air_linear_fwd(const float *x, const float *w, const float *b, float *y, int M, int K, int N, int act,
+AIR_API int air_linear_fwd(const float *x, const float *w, const float *b, float *y, int M, int K, int N, int act,
                    void *ws, size_t ws_bytes, void *stream);
 /* Backward: g = dy * act'(y); dx = g.w^T (NULL to skip); dw = x^T.g; db = colsum(g) (NULL to skip).
  * gbuf[M,N] is required when act != AIR_ACT_NONE (holds g).                                                        */
-int air_linear_bwd(const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db,
+AIR_API int air_linear_bwd(const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db,
                    float *gbuf, int M, int K, int N, int act, void *ws, size_t ws_bytes, void *stream);
 
 /* LSTM pointwise, Sonnet v1 gate order i,j,f,o (cell.py:126-127): c' = sig(f+fb)*c + sig(i)*tanh(j);
  * h' = tanh(c')*sig(o).  gates[M,4H] pre-activation; gate_act[M,4H] receives the activated gates (saved for bwd). */
-int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, float *c, float *gate_act,
+AIR_API int air_lstm_pointwise_fwd(const float *gates, const float *c_prev, float *h, float *c, float *gate_act,
                            int M, int Hd, float forget_bias, void *stream);
 /* dgates[M,4H], dc_prev[M,H] from dh[M,H] (+ dh2) and (optional) dc[M,H] flowing in from step t+1.              */
-int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
+AIR_API int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const float *c, const float *dh,
                            const float *dh2 /* optional second dh term, summed */, const float *dc, float *dgates,
                            float *dc_prev, int M, int Hd, void *stream);
 
@@ -200,13 +214,13 @@ int air_lstm_pointwise_bwd(const float *gate_act, const float *c_prev, const flo
  *   gates = h_prev[M,Hd] . w_h[Hd,4Hd](ldw) + gx[M,4Hd](ldgx)      (gx = x.W_x + b, hoisted out of the time loop)
  *   then air_lstm_pointwise_fwd on `gates`; h, c [M,Hd] and gate_act [M,4Hd] are written, `gates` never exists.
  * precision: AIR_PREC_F32 / AIR_PREC_BF16 for the product.                                                          */
-int air_lstm_step_fwd(const float *h_prev, const float *c_prev, const float *w_h, int ldw, const float *gx, int ldgx,
+AIR_ENGINE_API int air_lstm_step_fwd(const float *h_prev, const float *c_prev, const float *w_h, int ldw, const float *gx, int ldgx,
                       float *h, float *c, float *gate_act, int M, int Hd, float forget_bias, int precision,
                       void *stream);
 /* The first LSTM step of a train step with air_step_prologue riding along as extra workgroups: h0 / c0 [1,Hd] are read
  * with a broadcast row stride; the noise, the annealed prior and the tiled initial state (h_tiled, c_tiled [M,Hd]) are
  * written for the launches that follow.  Argument meaning as in air_lstm_step_fwd and air_step_prologue (B = M).        */
-int air_lstm_step_fwd_prologue(const float *h0, const float *c0, const float *w_h, int ldw, const float *gx, int ldgx,
+AIR_ENGINE_API int air_lstm_step_fwd_prologue(const float *h0, const float *c0, const float *w_h, int ldw, const float *gx, int ldgx,
                                float *h, float *c, float *gate_act, int M, int Hd, float forget_bias, int precision,
                                float *normal, size_t n_normal, float *uniform, size_t n_uniform,
                                const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
@@ -217,7 +231,7 @@ int air_lstm_step_fwd_prologue(const float *h0, const float *c0, const float *w_
  * accumulates x[M,E](ldx) . w_x[E,4Hd](ldw) and h0[1,Hd] . w_h[Hd,4Hd](ldw) side by side, writes gx_out[M,4Hd](ldgx) = x . w_x +
  * b_gates for the later steps and finishes step 0 on gx + h0 . w_h: the results of the gx launch + air_lstm_step_fwd_prologue it
  * replaces, bit for bit.  Latency regime only: AIR_E_UNSUPPORTED beyond 512 tiles of 16 x 16 over (M, Hd).                    */
-int air_lstm_first_step_fwd(const float *x, int ldx, int E, const float *w_x, const float *b_gates, const float *h0,
+AIR_ENGINE_API int air_lstm_first_step_fwd(const float *x, int ldx, int E, const float *w_x, const float *b_gates, const float *h0,
                             const float *c0, const float *w_h, int ldw, float *gx_out, int ldgx, float *h, float *c,
                             float *gate_act, int M, int Hd, float forget_bias, int precision, float *normal, size_t n_normal,
                             float *uniform, size_t n_uniform, const uint64_t *rng_state_dev, const int64_t *global_step_dev,
@@ -227,7 +241,7 @@ int air_lstm_first_step_fwd(const float *x, int ldx, int E, const float *w_x, co
  * air_lstm_pointwise_bwd of the step that gate_act / c_prev / c belong to -> dgates[M,4Hd], dc_prev[M,Hd]; and, if
  * dgx_out != NULL, dgx_out = dgx_in + dgates (the running sum over time that the hoisted x.W_x product receives;
  * dgx_in may alias dgates_next or dgx_out, NULL = 0).                                                                */
-int air_lstm_step_bwd(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
+AIR_ENGINE_API int air_lstm_step_bwd(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
                       const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                       const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
                       void *stream);
@@ -258,7 +272,7 @@ typedef struct AirGaussBwdEpi {
     int D;
     float guard_eps;
 } AirGaussBwdEpi;
-int air_gemm_grouped_gauss_bwd(const AirGemmDesc *descs, int count, const AirGaussBwdEpi *epi, const float *imp_parts, int n_parts,
+AIR_ENGINE_API int air_gemm_grouped_gauss_bwd(const AirGemmDesc *descs, int count, const AirGaussBwdEpi *epi, const float *imp_parts, int n_parts,
                                float *imp_sum, const float *baseline, const float *logp, float *nvil_out, float *dlogp,
                                float *dbaseline, int B, float *ema_dev, const float *kl_parts, int n_kl_parts, float *kl_row_out,
                                int kl_rows, void *stream);
@@ -280,9 +294,9 @@ typedef struct AirOptFold {
     size_t range_lo[4], range_hi[4];
     int64_t *global_step_dev; uint64_t *rng_state_dev; uint64_t rng_increment;
 } AirOptFold;
-int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const AirOptFold *opt, void *stream);
+AIR_ENGINE_API int air_gemm_grouped_opt(const AirGemmDesc *descs, int count, const AirOptFold *opt, void *stream);
 /* air_lstm_step_bwd / air_lstm_pointwise_bwd with an optimiser slice riding along (opt == NULL or lo == hi: none).          */
-int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
+AIR_ENGINE_API int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const float *dh_a, const float *dh_b,
                           const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                           const float *dgx_in, float *dgates, float *dc_prev, float *dgx_out, int M, int Hd, int precision,
                           const AirRmspropSlice *opt, void *stream);
@@ -293,8 +307,8 @@ int air_lstm_step_bwd_opt(const float *dgates_next, const float *w_h, const floa
  * gate_act, c_prev, c -> dgates, dc_prev); dgates1 / dc_prev1 [M,4Hd] / [M,Hd] receive the entry's own results (the weight
  * gradient reads dgates1), dgx_out (optional) = dgates1 + dgates, the running sum over time.  All operands 16-byte aligned.
  * air_lstm_step_bwd_entry_fits(M, Hd) == 1 says whether the launch takes the shape.  opt: as air_lstm_step_bwd_opt.            */
-int air_lstm_step_bwd_entry_fits(int M, int Hd);
-int air_lstm_step_bwd_entry(const float *gate_act1, const float *c_prev1, const float *c1, const float *dh_a1,
+AIR_ENGINE_API int air_lstm_step_bwd_entry_fits(int M, int Hd);
+AIR_ENGINE_API int air_lstm_step_bwd_entry(const float *gate_act1, const float *c_prev1, const float *c1, const float *dh_a1,
                             const float *dh_b1, float *dgates1, float *dc_prev1, const float *w_h, const float *dh_a,
                             const float *dh_b, const float *gate_act, const float *c_prev, const float *c, float *dgates,
                             float *dc_prev, float *dgx_out, int M, int Hd, const AirRmspropSlice *opt, void *stream);
@@ -302,16 +316,16 @@ int air_lstm_step_bwd_entry(const float *gate_act1, const float *c_prev1, const 
  * read from the bf16 shadow of the parameters (w_h_bf16: same layout as w_h), h_prev / dgates_next from their bf16 mirrors when
  * given (NULL: the fp32 buffer, rounded in registers), products on v_mfma_f32_16x16x32_bf16; h_bf16 / dgates_bf16 / dgx_bf16
  * (optional) receive the mirrors of the outputs.  Otherwise exactly air_lstm_step_fwd / air_lstm_step_bwd / air_lstm_pointwise_bwd. */
-int air_lstm_step_fwd_bf16(const float *h_prev, const void *h_prev_bf16, const float *c_prev, const void *w_h_bf16, int ldw,
+AIR_ENGINE_API int air_lstm_step_fwd_bf16(const float *h_prev, const void *h_prev_bf16, const float *c_prev, const void *w_h_bf16, int ldw,
                            const float *gx, int ldgx, float *h, void *h_bf16, float *c, float *gate_act, int M, int Hd,
                            float forget_bias, void *stream);
-int air_lstm_step_bwd_bf16(const float *dgates_next, const void *dgates_next_bf16, const void *w_h_bf16, const float *dh_a,
+AIR_ENGINE_API int air_lstm_step_bwd_bf16(const float *dgates_next, const void *dgates_next_bf16, const void *w_h_bf16, const float *dh_a,
                            const float *dh_b, const float *dc_in, const float *gate_act, const float *c_prev, const float *c,
                            const float *dgx_in, float *dgates, void *dgates_bf16, float *dc_prev, float *dgx_out,
                            void *dgx_bf16, int M, int Hd, void *stream);
-int air_lstm_pointwise_bwd_bf16(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
+AIR_ENGINE_API int air_lstm_pointwise_bwd_bf16(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
                                 const float *dc, float *dgates, void *dgates_bf16, float *dc_prev, int M, int Hd, void *stream);
-int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
+AIR_ENGINE_API int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
                                const float *dc, float *dgates, float *dc_prev, int M, int Hd, const AirRmspropSlice *opt,
                                void *stream);
 
@@ -331,19 +345,19 @@ int air_lstm_pointwise_bwd_opt(const float *gate_act, const float *c_prev, const
  *   loc_odd, scale_odd} passed by value (where: even dims = scale prior, odd = shift prior; what: both equal).
  *   A prior location of NaN means "centred on the posterior's own mean" -- the where-shift prior given without `loc`,
  *   model.py:203-207: the (mu - p_loc)^2 term of the KL and its gradient vanish (every KL entry point honours it).  */
-int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+AIR_API int air_gauss_sample_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          float *loc, float *scale, float *sample, float *kl_row, int M, int D, float guard_eps, void *stream);
 /* dpre[M,ld_dpre] (both halves) from dsample[M,D] (+ dsample2[M,D]; either may be NULL) and dkl_row[M]*dkl_scale
  * (dkl_row may be NULL).                                                                                            */
-int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+AIR_API int air_gauss_sample_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                          float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                          const float *loc, const float *scale, const float *dsample, const float *dsample2,
                          const float *dkl_row, float dkl_scale, float *dpre, int ld_dpre, int M, int D, float guard_eps,
                          const float *kl_parts, int n_kl_parts, float *kl_row_out /* air_what_head_fwd's shares -> rows; 0: off */,
                          void *stream);
 /* air_gauss_sample_bwd with air_nvil_parts riding as one extra workgroup (arguments of both, in that order; B = batch).  */
-int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
+AIR_ENGINE_API int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode,
                               float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc,
                               const float *scale, const float *dsample, const float *dsample2, const float *dkl_row,
                               float dkl_scale, float *dpre, int ld_dpre, int M, int D, const float *imp_parts, int n_parts,
@@ -353,40 +367,40 @@ int air_gauss_sample_bwd_nvil(const float *pre, int ld_pre, const float *eps, fl
 
 /* KL(N(loc,scale) || N(p_loc[d&1], p_scale[d&1])) summed over D per row, for given loc/scale tensors (model.py:
  * 174-209 evaluated on the cell's outputs).  kl_row[M].  Backward: dloc, dscale [M,D] from dkl_row[M].              */
-int air_normal_kl_fwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even, float p_loc_odd,
+AIR_API int air_normal_kl_fwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even, float p_loc_odd,
                       float p_scale_odd, float *kl_row, int M, int D, void *stream);
-int air_normal_kl_bwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even, float p_loc_odd,
+AIR_API int air_normal_kl_bwd(const float *loc, const float *scale, float p_loc_even, float p_scale_even, float p_loc_odd,
                       float p_scale_odd, const float *dkl_row, float *dloc, float *dscale, int M, int D,
                       void *stream);
 
 /* Presence, cell.py:137-151: p = sigmoid(logit + step_bias); if explore_eps >= 0: p = eps/2 + (1-eps)*p;
  * discrete: z = (u < p), presence[t] = presence[t-1]*z (presence[-1] = presence_in or 1); else presence = p.
  * logit/u/presence_prob/presence are [T,B] time-major (T = 1 for a single cell step).                              */
-int air_presence_fwd(const float *logit, const float *u, const float *presence_in, float step_bias,
+AIR_API int air_presence_fwd(const float *logit, const float *u, const float *presence_in, float step_bias,
                      float explore_eps, int discrete, float *presence_prob, float *presence, int T, int B,
                      void *stream);
 /* dlogit[T,B] from dpresence_prob[T,B] (and dpresence[T,B] when !discrete; NULL otherwise).                        */
-int air_presence_bwd(const float *logit, float step_bias, float explore_eps, int discrete,
+AIR_API int air_presence_bwd(const float *logit, float step_bias, float explore_eps, int discrete,
                      const float *dpresence_prob, const float *dpresence, float *dlogit, int T, int B, void *stream);
 
 /* ---- objective ----------------------------------------------------------------------------------------------*/
 
 /* Reconstruction term, model.py:319-324: per_sample[b] = sum_p 0.5*((obs-mult*canvas)/std)^2 + 0.5*log(2pi)+log(std) */
-int air_rec_loglik_fwd(const float *obs, const float *canvas, float mult, float std, float *per_sample,
+AIR_API int air_rec_loglik_fwd(const float *obs, const float *canvas, float mult, float std, float *per_sample,
                        int B, int P, void *stream);
 /* dcanvas[b,p] = dper_sample[b] * mult*(mult*canvas-obs)/std^2  (dper_sample NULL => uniform `scale`)             */
-int air_rec_loglik_bwd(const float *obs, const float *canvas, float mult, float std, const float *dper_sample,
+AIR_API int air_rec_loglik_bwd(const float *obs, const float *canvas, float mult, float std, const float *dper_sample,
                        float scale, float *dcanvas, int B, int P, void *stream);
 
 /* Number-of-steps posterior and its KL (prior.py:62-151, model.py:139-163), evaluated in float64 like the reference.
  *   presence_prob[T,B], presence[T,B] (sampled, cumulative); prior_f64[T+1] DEVICE doubles = geometric_prior(...).
  *   q[B,T+1]; kl_per_sample[B] = sum_n tabular_kl; logp[B] = log max(q[b, sum_t presence], 1e-32);
  *   step_weight[T,B] = sum_{n>t} q(n).                                                                             */
-int air_numsteps_fwd(const float *presence_prob, const float *presence, const double *prior_f64, float *q,
+AIR_API int air_numsteps_fwd(const float *presence_prob, const float *presence, const double *prior_f64, float *q,
                      float *kl_per_sample, float *logp, float *step_weight, int T, int B, void *stream);
 /* dpresence_prob[T,B] of  kl_scale*sum_b kl_per_sample[b] + sum_{t,b} dstep_weight[t,b]*step_weight[t,b]
  *                         + sum_b dlogp[b]*logp[b]   (dstep_weight / dlogp may be NULL).                           */
-int air_numsteps_bwd(const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
+AIR_API int air_numsteps_bwd(const float *presence_prob, const float *presence, const double *prior_f64, float kl_scale,
                      const float *dstep_weight, const float *dlogp, float *dpresence_prob, int T, int B,
                      void *stream);
 
@@ -397,10 +411,10 @@ int air_numsteps_bwd(const float *presence_prob, const float *presence, const do
  * Continuous steps (AIRCell(discrete_steps=False), cell.py:150-151): every *_fwd entry that draws the presence takes u == NULL and
  * then writes presence = presence_prob (no Bernoulli chain); every *_bwd entry that forms dlogit takes `dpresence[T,B]` -- what the
  * canvas write's backward (air_canvas_unroll_bwd_dpresence) holds for the presence -- and adds it to d/d presence_prob (NULL: discrete). */
-int air_presence_numsteps_fwd(const float *logit, const float *u, float step_bias, float explore_eps,
+AIR_ENGINE_API int air_presence_numsteps_fwd(const float *logit, const float *u, float step_bias, float explore_eps,
                               const double *prior_f64, float *presence_prob, float *presence, float *q,
                               float *kl_per_sample, float *logp, float *step_weight, int T, int B, void *stream);
-int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
+AIR_ENGINE_API int air_numsteps_presence_bwd(const float *presence_prob, const float *presence, const double *prior_f64,
                               float kl_scale, const float *kl_row_a, const float *kl_row_b, float w_scale,
                               const float *dlogp, const float *dpresence, const float *logit, float step_bias,
                               float explore_eps, float *dlogit, int T, int B, void *stream);
@@ -409,12 +423,12 @@ int air_numsteps_presence_bwd(const float *presence_prob, const float *presence,
  *   air_heads_fwd = air_gauss_sample_fwd (the where sample)  ||  air_presence_numsteps_fwd
  *   air_heads_bwd = air_gauss_sample_bwd (the where sample)  ||  air_numsteps_presence_bwd
  * Argument meaning exactly as in the four constituent entry points.                                                  */
-int air_heads_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
+AIR_ENGINE_API int air_heads_fwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
                   float p_scale_even, float p_loc_odd, float p_scale_odd, float *loc, float *scale, float *sample,
                   float *kl_row, int M, int D, const float *logit, const float *u, float step_bias, float explore_eps,
                   const double *prior_f64, float *presence_prob, float *presence, float *q, float *kl_per_sample,
                   float *logp, float *step_weight, int T, int B, float guard_eps, void *stream);
-int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
+AIR_ENGINE_API int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offset, int loc_mode, float p_loc_even,
                   float p_scale_even, float p_loc_odd, float p_scale_odd, const float *loc, const float *scale,
                   const float *dsample, const float *dsample2, const float *dkl_row, float dkl_scale, float *dpre,
                   int ld_dpre, int M, int D, const float *presence_prob, const float *presence,
@@ -428,10 +442,10 @@ int air_heads_bwd(const float *pre, int ld_pre, const float *eps, float raw_offs
  *   (1 - step'/anneal_steps)).  s is clipped to [1e-7, 1-1e-15]; prior_out_f64[n] = (1-s) s^n, n = 0..T (float64,
  *   NOT renormalised, exactly like the reference).  Reading the step counter on device keeps a captured hipGraph
  *   valid across replays; air_counter_add advances it.                                                             */
-int air_steps_prior(const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+AIR_API int air_steps_prior(const int64_t *global_step_dev, int anneal_type, double init, double final_value,
                     double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
                     void *stream);
-int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
+AIR_API int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
 
 /* NVIL / REINFORCE with the reference's [B]-[B,1]->[B,B] broadcast (model.py:218-259).
  *   imp[B] (= rec_loss_per_sample), baseline[B], logp[B].
@@ -442,19 +456,19 @@ int air_counter_add(int64_t *counter_dev, int64_t increment, void *stream);
  *   weight is shifted by the moving mean and divided by max(sqrt(moving_var), 1) as the variables stand BEFORE this step, then --
  *   when update != 0 (train steps; evaluation passes read only) -- both move towards this batch's mean / variance (zero_debias
  *   off).  Kept on the device so that a captured graph carries the state from replay to replay.                        */
-int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
+AIR_API int air_nvil(const float *imp, const float *baseline, const float *logp, float *out, float *dlogp,
              float *dbaseline, int B, float *ema_dev, void *stream);
 /* The importance weight of a NON-analytic num-steps prior (model.py:157-163, 339-340: the step weights are the sampled presences
  * and reinforce_imp_weight += prior_loss.per_sample): rec_out[B] (optional) = sum of rec_parts[n_parts, B] in share order;
  * imp_out[b] = rec[b] + nsp_weight * kl_n[b] + sum_t step_weight[t,b] * (kl_row_a[t,b] + kl_row_b[t,b])   (kl_n / kl_row_* may be NULL).
  * dpresence_inout[T,B] (optional; continuous steps, where the step weight is the presence probability itself and carries a gradient):
  * += dkl_scale * (kl_row_a + kl_row_b).  One of imp_out / dpresence_inout may be NULL.                                       */
-int air_imp_weight(const float *rec_parts, int n_parts, float *rec_out, const float *kl_n, float nsp_weight, const float *kl_row_a,
+AIR_ENGINE_API int air_imp_weight(const float *rec_parts, int n_parts, float *rec_out, const float *kl_n, float nsp_weight, const float *kl_row_a,
                    const float *kl_row_b, const float *step_weight, int T, int B, float *imp_out, float *dpresence_inout,
                    float dkl_scale, void *stream);
 /* air_nvil with the importance weight given as n_parts shares per sample (imp_parts[n_parts, B], added in share order in
  * fp32); the sum is also written to imp_sum[B] when given (the complete rec_loss_per_sample).                          */
-int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline, const float *logp,
+AIR_ENGINE_API int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const float *baseline, const float *logp,
                    float *out, float *dlogp, float *dbaseline, int B, float *ema_dev, void *stream);
 
 
@@ -462,13 +476,13 @@ int air_nvil_parts(const float *imp_parts, int n_parts, float *imp_sum, const fl
  * [img | what (batch-major) | where | presence | state] from time-major what[T,B,A], where[T,B,4], presence[T,B],
  * state[B,S] = concat of up to two state parts (h, c).  HW may be 0 (img NULL): only the latent columns are packed
  * (the engine multiplies the image part of the first baseline layer straight from obs).                             */
-int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
+AIR_API int air_baseline_pack(const float *img, const float *what, const float *where, const float *presence,
                       const float *state0, const float *state1, float *out, int T, int B, int P, int A, int S0,
                       int S1, void *stream);
 /* air_gauss_sample_fwd for `what` (loc_mode 0, one prior) and the latent part of air_baseline_pack (HW = 0) in ONE launch:
  * pre[T*B, ld_pre] -> loc, scale, sample [T*B, D] time-major, kl_row[T*B]; pack_out[B, T*D + T*4 + T + S0 + S1] =
  * [what | where | presence | state0 | state1] batch-major (the sample is written to both places as it is drawn).      */
-int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float raw_offset, float p_loc, float p_scale,
+AIR_ENGINE_API int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float raw_offset, float p_loc, float p_scale,
                          float *loc, float *scale, float *sample, float *kl_row, int D, const float *where,
                          const float *presence, const float *state0, const float *state1, float *pack_out,
                          int T, int B, int S0, int S1, float guard_eps, void *stream);
@@ -479,8 +493,8 @@ int air_what_sample_pack(const float *pre, int ld_pre, const float *eps, float r
  * air_what_sample_pack), while extra workgroups copy the where / presence / state columns of pack_out.  The KL row of a sample spans
  * air_what_head_parts(A) = ceil(A / 8) tiles: each writes its share to kl_parts[parts][T*B]; air_gauss_sample_bwd[_nvil] of the same
  * head adds them in tile order (kl_parts / n_kl_parts / kl_row_out).  Replaces a GEMM launch + air_what_sample_pack.            */
-int air_what_head_parts(int A);
-int air_what_head_fwd(const float *x, int ldx, int K, const float *w, const float *b, const float *eps, float raw_offset,
+AIR_ENGINE_API int air_what_head_parts(int A);
+AIR_ENGINE_API int air_what_head_fwd(const float *x, int ldx, int K, const float *w, const float *b, const float *eps, float raw_offset,
                       float p_loc, float p_scale, float *q, float *loc, float *scale, float *sample, float *kl_parts, int A,
                       const float *where, const float *presence, const float *state0, const float *state1, float *pack_out,
                       int T, int B, int S0, int S1, float guard_eps, int precision, void *stream);
@@ -491,7 +505,7 @@ int air_what_head_fwd(const float *x, int ldx, int K, const float *w, const floa
  * (where ~ N(loc, softplus(raw + raw_offset)), its KL rows, presence, q(n), KL, log q(n), step weights) and
  * air_st_read_fwd(img[B,H,W], where) -> glimpse[T*B,h,w] with `where` handed over inside the workgroup.
  * Needs H*W % 4 == 0, H*W <= 12288, 16-byte aligned img / tr_w (AIR_E_UNSUPPORTED otherwise: use the separate entries). */
-int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int tr_k, const float *st_h,
+AIR_ENGINE_API int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int tr_k, const float *st_h,
                    const float *st_w, const float *st_b, int st_k, float *pre, float *logit, const float *eps,
                    float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd, float p_scale_odd,
                    float *loc, float *scale, float *where, float *kl_row, const float *u, float step_bias,
@@ -503,7 +517,7 @@ int air_attend_fwd(const float *tr_h, const float *tr_w, const float *tr_b, int 
  * workgroup by the where-sampling backward of that row (dsample = dwhere_w + dwhere_r, KL term dkl_row*dkl_scale;
  * dwhere_w[dwhere_w_slabs][T*B][4]: the canvas backward's gradient as 1..4 partial slabs, added here in slab order) ->
  * dpre[T*B,8]; and, in separate workgroups, the steps-logit backward of air_heads_bwd -> dlogit[T*B].                */
-int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
+AIR_ENGINE_API int air_attend_bwd(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
                    const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
                    float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w, int dwhere_w_slabs,
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
@@ -515,7 +529,7 @@ int air_attend_bwd(const float *img, const float *where, const float *dglimpse, 
  *   tr_dx[k, n] = (sum_o dpre[k, o] * tr_w[n, o]) * elu'(tr_y[k, n]),  n < tr_k;   st_dx[k, n] = dlogit[k] * st_w[n] * elu'(st_y[k, n]).
  * tr_y / st_y: the layer's input activation (an ELU output) or NULL when the input is not an ELU output (no factor).
  * Their dW (and bias gradients) remain ordinary air_gemm problems over dpre / dlogit.                                        */
-int air_attend_bwd_dx(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
+AIR_ENGINE_API int air_attend_bwd_dx(const float *img, const float *where, const float *dglimpse, float *dwhere_r, const float *pre,
                    const float *eps, float raw_offset, float p_loc_even, float p_scale_even, float p_loc_odd,
                    float p_scale_odd, const float *loc, const float *scale, const float *dwhere_w, int dwhere_w_slabs,
                    const float *dkl_row, float dkl_scale, float *dpre, const float *presence_prob,
@@ -529,72 +543,72 @@ int air_attend_bwd_dx(const float *img, const float *where, const float *dglimps
  * to AIR_L2_MAX_RANGES slices [range_lo[k], range_hi[k]) of the flat buffers (host arrays; biases and baseline variables are not
  * in any slice).  Runs between the backward and the update.                                                            */
 #define AIR_L2_MAX_RANGES 32
-int air_l2_grad_add(float *g, const float *p, const size_t *range_lo, const size_t *range_hi, int n_ranges, float l2_weight,
+AIR_ENGINE_API int air_l2_grad_add(float *g, const float *p, const size_t *range_lo, const size_t *range_hi, int n_ranges, float l2_weight,
                     void *stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------------
  * TF centred RMSProp with momentum (model.py:265, 355-367): ms<-d*ms+(1-d)g^2; mg<-d*mg+(1-d)g;
  * mom<-m*mom + lr*g/sqrt(ms-mg^2+eps); p<-p-mom.  lr = *lr_dev * lr_mult (lr_dev: device float, graph-safe).
  * grad_scale multiplies g first (1/world_size after an all-reduce sum).                                            */
-int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev,
+AIR_API int air_rmsprop_centered(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev,
                          float lr_mult, float decay, float momentum, float eps, float grad_scale, void *stream);
 /* The reference instantiates its optimiser as optimizer(learning_rate, **opt_kwargs) (model.py:265,355-363), so the keyword
  * set of tf.train.RMSPropOptimizer is part of the surface: decay, momentum, epsilon, centered.  centered = 0 drops the
  * squared mean-gradient term from the denominator (the mg slot is still maintained, as scratch).                       */
-int air_rmsprop(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev, float lr_mult,
+AIR_API int air_rmsprop(float *p, const float *g, float *ms, float *mg, float *mom, size_t n, const float *lr_dev, float lr_mult,
                 float decay, float momentum, float eps, int centered, float grad_scale, void *stream);
 
 /* Fused step prologue / epilogue for the launch-bound train step.
  *   prologue: air_rng_fill + air_steps_prior + tiling of the trainable LSTM initial state (h0,c0 [1,Hd] -> [B,Hd]).
  *   epilogue: centred RMSProp over the whole flat buffer (elements >= n_model use lr * lr_mult_tail: the baseline
  *             optimiser, model.py:363), then *global_step_dev += 1 and rng_state_dev[1] += rng_increment.            */
-int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
+AIR_ENGINE_API int air_step_prologue(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
                       const int64_t *global_step_dev, int anneal_type, double init, double final_value,
                       double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
                       const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, void *stream);
 /* air_step_prologue with air_f32_to_bf16(x -> x_bf16, n_x elements, n_x % 4 == 0) riding as extra workgroups (bf16 data path: the
  * observation batch's mirror is refreshed at the start of every step).                                                        */
-int air_step_prologue_cvt(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
+AIR_ENGINE_API int air_step_prologue_cvt(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
                           const int64_t *global_step_dev, int anneal_type, double init, double final_value,
                           double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
                           const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, const float *x,
                           void *x_bf16, size_t n_x, void *stream);
-int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+AIR_ENGINE_API int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                       const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
                       int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
 /* air_step_epilogue + the bf16 shadow of the parameters (bf16 data path): p_bf16[i] = bf16(p[i]) for every updated element, so
  * the next step's dense products read half the weight bytes; NULL = no shadow.  air_f32_to_bf16: the same rounding as a launch of
  * its own, for buffers no kernel of this library produces (the observation batch, parameters after a load).               */
-int air_step_epilogue_shadow(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+AIR_ENGINE_API int air_step_epilogue_shadow(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                              const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
                              int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *p_bf16,
                              void *stream);
-int air_f32_to_bf16(const float *x, void *out_bf16, size_t n, void *stream);
+AIR_API int air_f32_to_bf16(const float *x, void *out_bf16, size_t n, void *stream);
 
 /* HBM-resident batch feeder (replaces tensors_from_data's per-step tf.py_func round trip, data.py:121-158): out[b, :] =
  * dataset[idx_b, :] with idx_b drawn with replacement (shuffle != 0: Philox(seed_dev[0], stream 1, counter step*B + b), like
  * np.random.choice(n, batch_size)) or idx_b = (step*B + b) mod n_items; step = *step_dev, the DEVICE step counter that
  * air_step_epilogue advances, so the launch can be part of a captured step.  idx_out[B] (optional) receives the indices.     */
-int air_batch_gather(const float *dataset, long long n_items, int item_floats, const uint64_t *seed_dev,
+AIR_API int air_batch_gather(const float *dataset, long long n_items, int item_floats, const uint64_t *seed_dev,
                      const int64_t *step_dev, int shuffle, float *out, int B, int64_t *idx_out, void *stream);
 
 /* ---- noise --------------------------------------------------------------------------------------------------
  * Philox4x32-10 counter RNG (replaces TF's sampler ops behind .sample(), cell.py:133,147,156).
  * normal[n_normal] ~ N(0,1), uniform[n_uniform] ~ U[0,1).  state_dev[2] = {seed, offset} DEVICE uint64; the
  * offset is advanced by air_rng_advance (separate launch, so a captured graph draws fresh noise per replay).      */
-int air_rng_fill(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *state_dev,
+AIR_API int air_rng_fill(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *state_dev,
                  void *stream);
-int air_rng_advance(uint64_t *state_dev, uint64_t increment, void *stream);
+AIR_API int air_rng_advance(uint64_t *state_dev, uint64_t increment, void *stream);
 
 /* ---- small utilities ---------------------------------------------------------------------------------------*/
-int air_fill(float *p, size_t n, float v, void *stream);
+AIR_API int air_fill(float *p, size_t n, float v, void *stream);
 /* out[m, n] = a[m, n] * row_scale[m]  (+ b[m,n] if b) : used for weighting per-row KL gradients etc.              */
-int air_axpby(const float *a, float alpha, const float *b, float beta, float *out, size_t n, void *stream);
+AIR_API int air_axpby(const float *a, float alpha, const float *b, float beta, float *out, size_t n, void *stream);
 /* broadcast rows: out[r, :] = src[0, :] for r < rows (tiling the trainable LSTM initial state, cell.py:103)       */
-int air_tile_rows(const float *src, float *out, int rows, int cols, void *stream);
-int air_colsum(const float *x, int ld, float *out, int M, int N, void *stream);   /* out[n] = sum_m x[m,n] */
+AIR_API int air_tile_rows(const float *src, float *out, int rows, int cols, void *stream);
+AIR_API int air_colsum(const float *x, int ld, float *out, int M, int N, void *stream);   /* out[n] = sum_m x[m,n] */
 /* out[i] = sum_t x[t*n + i], t < T: sums a time-major [T, n] stack over time (dGX = sum_t dgates_t in the LSTM BPTT) */
-int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream);
+AIR_API int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream);
 
 /* ---- hipGraph capture + timing helpers (plumbing for bench / the fused train step) --------------------------*/
 /* ---- data parallel: RCCL all-reduce of the flat gradient bucket, capturable into the step's hipGraph ----------------
@@ -604,13 +618,13 @@ int air_sum_leading(const float *x, float *out, int T, size_t n, void *stream);
  * call; the thread's current device is the rank's GPU).  air_allreduce_sum: in place on `stream`, no allocation / host
  * sync, legal inside a capture.  air_stream_wait_event = hipStreamWaitEvent (fork / join of a side stream in a capture).
  * Failures return AIR_E_UNSUPPORTED; air_comm_last_error() has the RCCL message.                                      */
-int air_comm_unique_id(void *id_out_128_bytes);
-int air_comm_init(void **comm_out, int world_size, int rank, const void *id_128_bytes);
-int air_comm_available(void);                     /* 0 if RCCL can be bound here; not collective (agree on it BEFORE air_comm_init) */
-int air_comm_count(void *comm, int *count_out);   /* ncclCommCount: the number of ranks RCCL itself sees */
-int air_comm_destroy(void *comm);
-int air_allreduce_sum(float *buf, size_t n, void *comm, void *stream);
-const char *air_comm_last_error(void);
+AIR_API int air_comm_unique_id(void *id_out_128_bytes);
+AIR_API int air_comm_init(void **comm_out, int world_size, int rank, const void *id_128_bytes);
+AIR_API int air_comm_available(void);                     /* 0 if RCCL can be bound here; not collective (agree on it BEFORE air_comm_init) */
+AIR_API int air_comm_count(void *comm, int *count_out);   /* ncclCommCount: the number of ranks RCCL itself sees */
+AIR_API int air_comm_destroy(void *comm);
+AIR_API int air_allreduce_sum(float *buf, size_t n, void *comm, void *stream);
+AIR_API const char *air_comm_last_error(void);
 
 /* Data-parallel update WITHOUT a library collective (csrc/comm_ipc.hip): the ranks of one node map each other's
  * flat gradient / parameter buffers and a block of flag words (hipIpc; the caller exchanges the handles) and every step runs
@@ -631,21 +645,21 @@ typedef struct AirIpcPeers {
     float *params[8];
     uint64_t *flags[8];
 } AirIpcPeers;
-int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream);
-int air_dp_ipc_barrier_wgs(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, int n_wgs, void *stream);
-int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
+AIR_ENGINE_API int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream);
+AIR_ENGINE_API int air_dp_ipc_barrier_wgs(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, int n_wgs, void *stream);
+AIR_ENGINE_API int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                             const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps,
                             int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);
-int air_stream_wait_event(void *stream, void *event);
+AIR_API int air_stream_wait_event(void *stream, void *event);
 
-int air_graph_begin_capture(void *stream);
-int air_graph_end_capture(void *stream, void **graph_exec_out);
-int air_graph_launch(void *graph_exec, void *stream);
-int air_graph_destroy(void *graph_exec);
-int air_event_create(void **event_out);
-int air_event_record(void *event, void *stream);
-int air_event_elapsed_ms(void *start, void *stop, float *ms_host_out);   /* synchronises on `stop` */
-int air_event_destroy(void *event);
+AIR_API int air_graph_begin_capture(void *stream);
+AIR_API int air_graph_end_capture(void *stream, void **graph_exec_out);
+AIR_API int air_graph_launch(void *graph_exec, void *stream);
+AIR_API int air_graph_destroy(void *graph_exec);
+AIR_API int air_event_create(void **event_out);
+AIR_API int air_event_record(void *event, void *stream);
+AIR_API int air_event_elapsed_ms(void *start, void *stop, float *ms_host_out);   /* synchronises on `stop` */
+AIR_API int air_event_destroy(void *event);
 
 #ifdef __cplusplus
 }

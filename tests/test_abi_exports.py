@@ -27,6 +27,26 @@ def test_header_and_ctypes_table_agree():
     assert _declared() == sorted(_lib.SIGNATURES)
 
 
+def test_stable_contract_did_not_change():
+    """include/air_hip.h marks every declaration AIR_API (the stable contract: SURVEY 8(b)'s operator boundary + plumbing) or AIR_ENGINE_API
+    (engine plan entries that change with every fold).  The stable prototypes are pinned: a change here needs a new AIR_ABI_VERSION,
+    a new tests/golden/abi_stable.txt and a line in INTEGRATION.md's change log."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = re.findall(r"AIR_API\s+((?:int|const char \*)\s*air_[a-z0-9_]+\s*\([^;]*\));", src, flags=re.S)
+    have = sorted(re.sub(r"\s+", " ", x).strip() for x in protos)
+    want = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "abi_stable.txt")) if l.strip() and not l.startswith("#")]
+    assert have == want
+    # every declaration carries exactly one of the two marks, and SURVEY 8(b)'s nine exports are on the stable side
+    unmarked = re.findall(r"^(?:int|const char \*) ?air_[a-z0-9_]+\(", src, flags=re.M)
+    assert not unmarked, unmarked
+    names = {re.search(r"(air_[a-z0-9_]+)\s*\(", x).group(1) for x in have}
+    for n in ("air_st_read_fwd", "air_st_read_bwd", "air_st_write_fwd", "air_st_write_bwd", "air_linear_fwd", "air_linear_bwd",
+              "air_lstm_pointwise_fwd", "air_lstm_pointwise_bwd", "air_gauss_sample_fwd", "air_gauss_sample_bwd", "air_rec_loglik_fwd",
+              "air_rec_loglik_bwd", "air_numsteps_fwd", "air_numsteps_bwd", "air_nvil", "air_rmsprop_centered", "air_canvas_unroll_fwd",
+              "air_canvas_unroll_bwd", "air_graph_launch", "air_allreduce_sum"):
+        assert n in names, n
+
+
 def test_library_exports_every_declared_symbol(libpath):
     out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
     exported = set(re.findall(r"\bT (air_[a-z0-9_]+)\b", out))
@@ -37,7 +57,7 @@ def test_library_exports_every_declared_symbol(libpath):
 def test_library_loads_and_reports_abi(libpath):
     from attend_infer_repeat_amd import _lib
     lib = _lib.load()
-    assert lib.air_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.air_abi_version() == _lib.ABI_VERSION == 10 and lib.air_engine_abi_version() == _lib.ENGINE_ABI_VERSION == 1
     from attend_infer_repeat_amd import build
     assert lib.air_build_digest().decode() == build.source_digest()
     assert lib.air_status_string(-2).decode().startswith("AIR_E_SHAPE")

@@ -178,6 +178,14 @@ def test_import_into_engine_names(tmp_path, with_baseline):
     with pytest.raises(KeyError):
         T.import_tf_checkpoint(p, shapes, name_map={"what/w": "missing"})
     assert T.global_step_of(p) == 5000
+    # what an import leaves behind is reported, not silent: engine parameters without a checkpoint variable (the baseline
+    # before its first REINFORCE call), and trainable-looking checkpoint variables nobody used
+    rep = T.mapping_report(p, shapes)
+    assert rep["unmapped_engine_parameters"] == sorted(k for k in shapes if k not in truth)
+    assert (not with_baseline) == any(k.startswith("baseline/") for k in rep["unmapped_engine_parameters"])
+    assert rep["unused_checkpoint_variables"] == []                          # scalars, slots and global_step are not candidates
+    rep1 = T.mapping_report(p, shapes, {"what/w": "AIRonMNIST/air_cell/parametrised_gaussian/affine/w"})
+    assert "what/b" in rep1["unmapped_engine_parameters"] and "AIRonMNIST/air_cell/parametrised_gaussian/affine/b" in rep1["unused_checkpoint_variables"]
     # the optimiser state a Saver writes beside the variables
     slots = T.import_tf_optimizer_slots(p, shapes)
     assert set(slots) == {"ms", "mg", "mom"} and all(set(d) == set(truth) for d in slots.values())

@@ -18,7 +18,7 @@ KERNELS = {                      # bench.py key -> kernel-name prefix in the tra
     "st_read_fwd": "st_read_fwd_", "st_read_bwd": "st_read_bwd_kernel",
     "canvas_unroll_fwd": "st_write_fwd_kernel", "canvas_unroll_bwd": "st_write_bwd_",     # (unit-major and image-major forms)
     "attend_fwd": "attend_fwd_kernel", "attend_bwd": "attend_bwd_kernel",
-    "canvas_fused": "canvas_fused_kernel",     # forward + recompute-form backward as one launch (latency-regime train step)
+    "canvas_fused": "canvas_fused_",     # forward + recompute-form backward as one launch (latency-regime train step)
 }
 
 

@@ -45,9 +45,11 @@ if [ "$MODE" = pmc ] || [ "$MODE" = all ]; then
     rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_c2_b64_$N" -o r -- $PY --no-cpu-baseline --no-sweep --no-other-configs --steps 20 --warmup 5 > /dev/null 2> "$OUT/pmc_$N.log"
   done
   python $ROOT/tools/rocpd_pmc.py $(find "$OUT" -path "*pmc_c2_b64_*" -name "*.db" | sort) > "$OUT/${TAG}_bench_c2_b64_pmc.txt"
+  python $ROOT/tools/rocpd_pmc.py --mfma-json $(find "$OUT/pmc_c2_b64_SQ_VALU_MFMA_BUSY_CYCLES_SQ_BUSY_CYCLES" -name "*.db" | head -1) $DIGEST f32 50 50 20 20 3 64 > "$OUT/${TAG}_c2_b64_mfma_util.json"
   for N in c5_b1024; do :; done
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d "$OUT/pmc_c5_mfma" -o r -- $PY --config c5 --no-cpu-baseline --no-sweep --no-other-configs --steps 20 --warmup 5 > /dev/null 2> "$OUT/pmc_c5_mfma.log"
   python $ROOT/tools/rocpd_pmc.py $(find "$OUT/pmc_c5_mfma" -name "*.db" | sort) > "$OUT/${TAG}_bench_c5_b1024_pmc.txt"
+  python $ROOT/tools/rocpd_pmc.py --mfma-json $(find "$OUT/pmc_c5_mfma" -name "*.db" | head -1) $DIGEST bf16 50 50 20 20 3 1024 > "$OUT/${TAG}_c5_b1024_mfma_util.json"
   # kernel trace + per-position picture of the replayed step at every named shape
   rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $PY --no-cpu-baseline --no-sweep --no-other-configs > "$OUT/${TAG}_bench_c2_b64_profiled.json" 2> "$OUT/trace.log"
   python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --steps 2600 > "$OUT/${TAG}_bench_c2_b64_kernel_stats.txt"
