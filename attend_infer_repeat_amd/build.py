@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libair_hip.so")
 SOURCES = ["st_kernels.hip", "canvas_kernels.hip", "gemm_kernels.hip", "pointwise_kernels.hip", "loss_kernels.hip", "engine_kernels.hip",
-           "comm_rccl.hip", "comm_ipc.hip"]
+           "comm_rccl.hip", "comm_ipc.hip", "mlp_chain_kernels.hip"]
 ARCH = "gfx950"
 
 

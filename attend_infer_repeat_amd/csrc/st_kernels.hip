@@ -360,6 +360,11 @@ extern "C" int air_st_read_fwd(const float *img, const float *where, float *glim
                 const int res_ = air_resident_grid(st_read_fwd_lean_kernel<NT_, VEC_>, nthr, lds_l, 256 * 8);                 \
                 int want_ = big ? (VEC_ ? n_img / 4 : 16384) : res_;    /* (one glimpse per image: 46 against 50 us at 24576 images with 16384) */ \
                 want_ = want_ > 16384 ? 16384 : want_;                                                                        \
+                /* images above 3 x 256 groups (100x100: 1024-thread workgroups, two per CU): exactly the resident workgroups, each    \
+                   walking its images with the next one in flight -- 0.74 / 0.75 / 0.70 of 8 TB/s at 8192 / 32768 / 65536 images of    \
+                   100x100 / 28x28 / T=5 against 0.71 / 0.73 / 0.66 with the rule above; beyond 48 k images two images per workgroup   \
+                   (0.70 against 0.70: a tie, kept for the short workgroups' tail) -- profiles/r06_read_c4_grid.txt */                 \
+                if (big && nthr == 1024) want_ = n_img >= 49152 ? n_img / 2 : res_;                                              \
                 if (grid_forced > 0) want_ = grid_forced;                                                                     \
                 cap_ = want_ <= res_ ? res_ : (want_ / res_) * res_;                                                          \
             }                                                                                                                 \

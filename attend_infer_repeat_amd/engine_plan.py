@@ -732,6 +732,11 @@ class PlanMixin:
         pre_fwd = []
         if use16:
             pre_fwd = self._apply_bf16_mirrors([fwd, bwd])
+            self._dx_chain_launches = 0
+            # (round 6, measured and not adopted: 0.47-0.50 against 0.415-0.425 ms per step at configs[4], profiles/r06_dx_chain_rejected.txt;
+            #  AIR_DX_CHAIN=1 switches the pass on)
+            if throughput and os.environ.get("AIR_DX_CHAIN", "0") == "1":
+                bwd[:] = self._fuse_dx_chains(bwd)
             shadow = p(self.flat_params16)
             self._opt_calls_factory = lambda gscale: [
                 (L.air_step_epilogue_shadow, (p(self.flat_params), p(self.flat_grads), p(self.flat_ms), p(self.flat_mg),
@@ -1065,6 +1070,71 @@ class PlanMixin:
         self._sync_param_shadow()
         return [(L.air_f32_to_bf16, (p(self.obs), ctypes.c_void_p(self.obs16.data_ptr()), ctypes.c_size_t(self.obs.numel())),
                  "air_f32_to_bf16")]
+
+    def _fuse_dx_chains(self, plan):
+        """bf16 data path, throughput regime (round 6): runs of consecutive grouped-GEMM launches whose dX problems feed each other
+        -- layer after layer of an MLP's backward, dA_{l-1} = (dA_l . W_l^T) * elu'(out_{l-1}) -- become ONE row-slab launch
+        (air_mlp_dx_chain_bf16: a workgroup walks the whole chain for its 16 rows; nothing crosses rows).  A chain starts at a dX
+        problem whose input no earlier problem of the run produces and is placed where its first layer was (every later layer only
+        needs the layer before it and saved activations, so running it earlier is safe); problems that are not part of a chain of at
+        least two layers stay in their grouped launch.  Same values as the per-layer launches up to the order of the fp32
+        accumulation (each layer reads bf16 of the previous fp32 result either way)."""
+        L = H.lib()
+        MDELU, NONE = H.EPI_MUL_DELU, H.EPI_NONE
+
+        def dx_ok(d):
+            return (not d.ta and d.tb and d.epilogue in (MDELU, NONE) and d.beta == 0.0 and not d.A2 and not d.colsum and not d.bias
+                    and d.B16 and d.ldb == d.K and (d.epilogue == NONE or d.aux) and L.air_mlp_dx_chain_fits(d.K, d.N) == 1)
+
+        out, i = [], 0
+        while i < len(plan):
+            e = plan[i]
+            if e is None or e[2] != "air_gemm_grouped":
+                out.append(e); i += 1
+                continue
+            j = i
+            while j < len(plan) and plan[j] is not None and plan[j][2] == "air_gemm_grouped":
+                j += 1
+            launches = [[x[1][0][q] for q in range(x[1][1])] for x in plan[i:j]]
+            chains = []                                      # [first launch index, last launch index, [descs]]
+            for a_idx, ds in enumerate(launches):
+                for d in ds:
+                    if not dx_ok(d):
+                        continue
+                    host = None
+                    for c in chains:
+                        t = c[2][-1]
+                        if (c[1] < a_idx and len(c[2]) < 4 and int(d.A) == int(t.C) and d.lda == t.ldc and d.K == t.N and d.M == t.M):
+                            host = c
+                            break
+                    if host is not None:
+                        host[2].append(d); host[1] = a_idx
+                    else:
+                        chains.append([a_idx, a_idx, [d]])
+            chains = [c for c in chains if len(c[2]) >= 2]
+            fused = {id(d) for c in chains for d in c[2]}
+            for a_idx, ds in enumerate(launches):
+                starts = [c for c in chains if c[0] == a_idx]
+                for k0 in range(0, len(starts), 4):
+                    grp = starts[k0:k0 + 4]
+                    arr = (_lib.AirDxChain * len(grp))()
+                    for ci, c in enumerate(grp):
+                        d0 = c[2][0]
+                        arr[ci].g_in, arr[ci].ld_in, arr[ci].rows, arr[ci].n_layers = d0.A, d0.lda, d0.M, len(c[2])
+                        for li, d in enumerate(c[2]):
+                            y = arr[ci].layer[li]
+                            y.w_bf16, y.aux, y.out, y.out_bf16 = d.B16, (d.aux if d.epilogue == MDELU else None), d.C, d.C16
+                            y.n_in, y.n_out, y.ldaux, y.ldout = d.K, d.N, d.ldaux, d.ldc
+                    self._keep.append(arr)
+                    out.append((L.air_mlp_dx_chain_bf16, (arr, len(grp)), "air_mlp_dx_chain_bf16"))
+                    self._dx_chain_launches += 1
+                rest = [d for d in ds if id(d) not in fused]
+                if rest:
+                    arr = (_lib.AirGemmDesc * len(rest))(*rest)
+                    self._keep.append(arr)
+                    out.append((L.air_gemm_grouped, (arr, len(rest)), "air_gemm_grouped"))
+            i = j
+        return out
 
     def _sync_param_shadow(self):
         """bf16 shadow of the parameters after anything but the optimiser launch wrote them"""

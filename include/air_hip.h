@@ -35,7 +35,7 @@ extern "C" {
  *                      bind them.
  * ctypes cannot check argument lists: the loader compares both numbers and the build digest. */
 #define AIR_ABI_VERSION 10
-#define AIR_ENGINE_ABI_VERSION 1
+#define AIR_ENGINE_ABI_VERSION 2
 #define AIR_API
 #define AIR_ENGINE_API
 
@@ -192,6 +192,31 @@ typedef struct AirGemmDesc {
  * (ta = 1, tb = 0, M, N, K and ldb multiples of 4, B 16-byte aligned) on 64x64 tiles -- at least one --, any other problem
  * (no A2) on 16x16 tiles in the same grid.                                                                                 */
 AIR_ENGINE_API int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
+
+/* Row-slab dX chains of MLPs on the bf16 data path (csrc/mlp_chain_kernels.hip; neural.py:93-102 backward): through Linear + ELU layers
+ * row r of dA_{l-1} = (dA_l . W_l^T) * elu'(out_{l-1}) needs only row r of dA_l, so ONE launch walks a whole chain of layers per slab of
+ * 16 rows instead of one dependent launch per layer.  Chain c: g_in[rows, layer[0].n_in] (fp32, row pitch ld_in) is the gradient wrt
+ * the last layer's pre-activation; layer l (listed from the output side): w_bf16 = the bf16 shadow of W_l[n_out, n_in] (row-major: the
+ * Sonnet layout w[in, out] of the FORWARD layer, whose `in` is this n_out), aux = the saved ELU output the result is differentiated
+ * through (NULL: none), out[rows, n_out] fp32 (pitch ldout) and optionally its bf16 mirror with the same pitch.  n_in % 4 == 0 or
+ * n_in < 32; widths up to 1024; up to 4 chains of up to 4 layers share the launch.  fp32 accumulate; a layer consumes bf16 of the
+ * previous fp32 result -- what the per-layer launches read from the mirrors.                                                        */
+#define AIR_DXC_MAX_LAYERS 4
+#define AIR_DXC_MAX_CHAINS 4
+typedef struct AirDxLayer {
+    const void *w_bf16;
+    const float *aux;
+    float *out;
+    void *out_bf16;
+    int n_in, n_out, ldaux, ldout;
+} AirDxLayer;
+typedef struct AirDxChain {
+    const float *g_in;
+    int ld_in, rows, n_layers;
+    AirDxLayer layer[AIR_DXC_MAX_LAYERS];
+} AirDxChain;
+AIR_ENGINE_API int air_mlp_dx_chain_fits(int n_in, int n_out);
+AIR_ENGINE_API int air_mlp_dx_chain_bf16(const AirDxChain *chains, int n_chains, void *stream);
 
 /* y = act(x.w + b), neural.py:56-60.  x[M,K], w[K,N] (Sonnet layout), b[N] (may be NULL), y[M,N].                 */
 AIR_API int air_linear_fwd(const float *x, const float *w, const float *b, float *y, int M, int K, int N, int act,

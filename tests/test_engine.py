@@ -208,6 +208,34 @@ def _separate_borderline_draws(noise, res, margin=0.05):
     return dict(noise, u_pres=u), int(near.sum().item())
 
 
+def test_dx_chain_plan_pass_matches_the_per_layer_plan(gpu_device, monkeypatch):
+    """Round 6 (measured, not adopted: profiles/r06_dx_chain_rejected.txt): with AIR_DX_CHAIN=1 the throughput plan of the bf16 data path
+    replaces runs of per-layer dX launches by row-slab chain launches (air_mlp_dx_chain_bf16).  Same forward (untouched: bit-equal
+    outputs), fewer launches, and every gradient agrees with the per-layer plan to the bf16 path's own noise -- the two differ in the
+    order of the fp32 accumulation, and each layer consumes bf16 of the previous result."""
+    ocfg, B = O.AIRConfig(), 1024
+    monkeypatch.setenv("AIR_DX_CHAIN", "0")
+    eng0, params, obs, noise = make_pair(ocfg, B, mfma_dtype="bf16")
+    monkeypatch.setenv("AIR_DX_CHAIN", "1")
+    eng1, *_ = make_pair(ocfg, B, mfma_dtype="bf16")
+    n0, n1 = sum(eng0.kernel_launch_count().values()), sum(eng1.kernel_launch_count().values())
+    names1 = [n for plan in eng1._single_gpu_step_plans() for _, _, n in plan]
+    assert n1 < n0 and names1.count("air_mlp_dx_chain_bf16") >= 3 and eng1._dx_chain_launches == names1.count("air_mlp_dx_chain_bf16")
+    for e in (eng0, eng1):
+        e.set_noise(noise["eps_where"].cuda(), noise["eps_what"].cuda(), noise["u_pres"].cuda())
+        e.forward(sample_noise=False); e.backward(); e.synchronize()
+    assert torch.equal(eng0.final_canvas, eng1.final_canvas) and torch.equal(eng0.what, eng1.what)
+    g0, g1 = eng0.named_grads(), eng1.named_grads()
+    for k in g0:
+        a, b = g1[k].double().cpu().reshape(-1), g0[k].double().cpu().reshape(-1)
+        assert torch.isfinite(a).all()
+        # (bulk: relative L2; tensors that are heavily cancelling batch sums move by more under any change of rounding: bounded loosely)
+        assert l2_err(a, b) < 0.2, (k, l2_err(a, b))
+    heavy = ["glimpse_decoder/0/w", "glimpse_decoder/1/w", "glimpse_decoder/2/w", "what/w"]
+    for k in heavy:
+        assert l2_err(g1[k].double().cpu().reshape(-1), g0[k].double().cpu().reshape(-1)) < 2e-2, k
+
+
 def test_bf16_path_at_batch_1024_matches_bf16_emulating_oracle(gpu_device):
     """BASELINE configs[4] at its own size (batch 1024, 3072 glimpse rows: the throughput-regime plan) against the oracle that
     emulates the bf16-operand arithmetic, evaluated in fp32 (0.6 s on the host).  Outputs AND gradients are compared on every

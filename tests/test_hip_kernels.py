@@ -1078,6 +1078,59 @@ def test_lstm_steps_on_the_bf16_data_path(hip, mirror_in):
     assert torch.equal(pw, pw_ref) and torch.equal(pw_dc, pw_dc2) and torch.equal(pw16, pw.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("widths,rows", [((400, 256, 256, 50), 3072), ((1, 128, 256), 1024), ((100, 256, 256, 400), 100), ((64, 128, 256), 37),
+                                         ((8, 24, 40), 16), ((36, 44, 100, 52), 33)])
+def test_mlp_dx_chain_matches_per_layer_products(hip, widths, rows):
+    """Round 6: air_mlp_dx_chain_bf16 -- a whole dX chain dA_{l-1} = (dA_l . W_l^T) * elu'(out_{l-1}) per slab of 16 rows in ONE launch --
+    against the same chain evaluated layer by layer in float64 on the bf16-rounded operands (what the per-layer launches of the bf16 data
+    path compute: every layer reads bf16 of the previous fp32 result): the configs[4] decoder chain, the baseline's (1-wide output layer:
+    the scalar path), the glimpse encoder's, ragged row counts and widths that are not multiples of 32; two chains in one launch."""
+    import ctypes
+    from attend_infer_repeat_amd import _lib
+    lib = hip.lib()
+    rng = np.random.default_rng(len(widths) * 1000 + rows)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+
+    def make(widths, rows):
+        g_in = torch.tensor(rng.standard_normal((rows, widths[0])).astype(np.float32), device="cuda")
+        layers, keep = [], [g_in]
+        cur = bf(g_in).double()
+        for l in range(len(widths) - 1):
+            n_in, n_out = widths[l], widths[l + 1]
+            w = torch.tensor((rng.standard_normal((n_out, n_in)) / np.sqrt(n_in)).astype(np.float32), device="cuda")
+            w16 = w.to(torch.bfloat16).contiguous()
+            aux = torch.tensor(rng.standard_normal((rows, n_out)).astype(np.float32), device="cuda") if l < len(widths) - 2 else None
+            out = torch.full((rows, n_out), float("nan"), device="cuda"); out16 = torch.zeros(rows, n_out, dtype=torch.bfloat16, device="cuda")
+            ref = cur @ w16.float().double().t()
+            if aux is not None:
+                ref = ref * torch.where(aux > 0, torch.ones_like(aux), aux + 1.0).double()
+            cur = bf(ref.float()).double()
+            layers.append((w16, aux, out, out16, n_in, n_out, ref))
+            keep += [w, w16, aux, out, out16]
+        return g_in, layers, keep
+
+    sets = [make(widths, rows), make((64, 256, 96), 50)]                      # a second, short chain in the same launch
+    arr = (_lib.AirDxChain * len(sets))()
+    for ci, (g_in, layers, _) in enumerate(sets):
+        arr[ci].g_in, arr[ci].ld_in, arr[ci].rows, arr[ci].n_layers = g_in.data_ptr(), g_in.shape[1], g_in.shape[0], len(layers)
+        for li, (w16, aux, out, out16, n_in, n_out, _) in enumerate(layers):
+            y = arr[ci].layer[li]
+            y.w_bf16, y.aux, y.out, y.out_bf16 = w16.data_ptr(), (aux.data_ptr() if aux is not None else None), out.data_ptr(), out16.data_ptr()
+            y.n_in, y.n_out, y.ldaux, y.ldout = n_in, n_out, n_out, n_out
+            assert lib.air_mlp_dx_chain_fits(n_in, n_out) == 1
+    _lib.check(lib.air_mlp_dx_chain_bf16(arr, len(sets), hip._stream()), "air_mlp_dx_chain_bf16")
+    torch.cuda.synchronize()
+    for g_in, layers, _ in sets:
+        for w16, aux, out, out16, n_in, n_out, ref in layers:
+            scale = ref.abs().max().item() + 1e-30
+            assert torch.isfinite(out).all()
+            # (a value that sits on a bf16 rounding boundary may round the other way in the next layer's input: bf16 ulp = 2^-8 relative)
+            err = ((out.double() - ref).abs().max() / scale).item()
+            assert err < 2e-2 if (layers[0][0] is not w16) else err < 1e-5, (n_in, n_out, err)
+            assert torch.equal(out16, out.to(torch.bfloat16))
+    assert lib.air_mlp_dx_chain_fits(38, 64) == 0 and lib.air_mlp_dx_chain_fits(2048, 64) == 0
+
+
 @pytest.mark.parametrize("case", range(24))
 def test_canvas_kernels_random_shapes_and_transforms(hip, case):
     """Seeded sweep over canvas / glimpse shapes (odd sizes, w % 4 in {0..3}, glimpses larger than the canvas), step counts, batch sizes
