@@ -36,40 +36,12 @@ __device__ __forceinline__ int2 floor_span(const float2 *tab, int n, int f_lo, i
     }
     return make_int2(first, last);
 }
-// [first, last] index of a range table with a non-empty entry (lo <= hi); every lane gets the result; none => first > last
-__device__ __forceinline__ int2 nonempty_span(const int2 *rng, int n) {
-    const int lane = threadIdx.x & 63;
-    int first = n, last = -1;
-    for (int base = 0; base < n; base += 64) {
-        const int k = base + lane;
-        const int2 r = rng[k < n ? k : n - 1];
-        const unsigned long long m = __ballot(k < n && r.x <= r.y);
-        if (m) {
-            const int lo = base + (int)__ffsll((long long)m) - 1, hi = base + 63 - (int)__clzll((long long)m);
-            first = lo < first ? lo : first;
-            last = hi > last ? hi : last;
-        }
-    }
-    return make_int2(first, last);
-}
 // The backward's per-pixel arithmetic with its FMAs spelled out (and implicit contraction off): the recompute form, the stored-canvas
 // form and the split / unsplit instantiations are separate compilations of the same expressions, and "the same bits in every form" (the
 // tests compare them with torch.equal) must not depend on which products the compiler chooses to fuse in each.
 __device__ __forceinline__ float dcanvas_of(float coef, float mult, float canvas, float obs) {
 #pragma clang fp contract(off)
     return coef * __builtin_fmaf(mult, canvas, -obs);
-}
-__device__ __forceinline__ void where_grad_accum(float (&acc)[8], const Taps &t, float dx, float dy, float go, float dc, float v,
-                                                 float cxs, float cys, float X, float Y, bool own) {
-#pragma clang fp contract(off)
-    const float gx = __builtin_fmaf(dy, t.fc - t.ff, (1.f - dy) * (t.cc - t.cf));
-    const float gy = __builtin_fmaf(dx, t.cf - t.ff, (1.f - dx) * (t.cc - t.fc));
-    const float gax = (go * gx) * cxs, gay = (go * gy) * cys;
-    if (own) {
-        acc[0] = __builtin_fmaf(gax, X, acc[0]); acc[1] = acc[1] + gax;
-        acc[2] = __builtin_fmaf(gay, Y, acc[2]); acc[3] = acc[3] + gay;
-        acc[4] = __builtin_fmaf(dc, v, acc[4]);
-    }
 }
 // canvas accumulation step, rounded as the oracle's `canvas + presence * inversed` (cell.py:164)
 __device__ __forceinline__ float acc_step(float acc, float p, float v) {
@@ -122,7 +94,7 @@ struct WriteFwdArgs {
     int vec4_glimpse;
 };
 // (vblock of vgrid: the workgroup's index among the workgroups that run this role -- the whole grid of st_write_fwd_kernel, the
-//  first part of the grid of canvas_fused_kernel)
+//  second part of the grid of canvas_fused_gs_kernel)
 __device__ __forceinline__ void st_write_fwd_body(const WriteFwdArgs &a, float *smem, const int vblock, const int vgrid) {
 #pragma clang fp contract(off)
     const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
@@ -245,49 +217,9 @@ __global__ __launch_bounds__(1024) void st_write_fwd_kernel(WriteFwdArgs a) {
 // evaluated as two small LDS passes in a fixed order (no float atomics => bitwise reproducible):
 //   T1[I,j] = sum_J g[I,J] * wx[J,j]   over the contiguous J-range that touches glimpse column j
 //   dG[i,j] = sum_I wy[I,i] * T1[I,j]  over the contiguous I-range that touches glimpse row i
-struct CarveBwd {
-    float *src, *g, *t1, *X, *Y, *scratch, *pres;
-    float2 *xe, *ye;
-    int2 *jr, *ir;               // exact [lo, hi] canvas column / row range that touches glimpse column j / row i
-    int hwp;
-};
-// n_src = 1: the unit's own glimpse and axis tables; n_src = T (recompute form): those of all T steps of the unit's image,
-// step-major (src + t*hwp, xe + t*W, ye + t*H)
-__device__ __forceinline__ CarveBwd carve_bwd(float *smem, int H, int W, int h, int w, int n_src) {
-    CarveBwd c;
-    float *p = smem;
-    c.hwp = pad_count(h, w);             // bordered LDS copies (load_taps_pad)
-    c.src = p; p += n_src * c.hwp;
-    c.g = p; p += (H * W + 3) & ~3;
-    c.t1 = p; p += (H * w + 3) & ~3;
-    c.xe = reinterpret_cast<float2 *>(p); p += 2 * W * n_src;
-    c.ye = reinterpret_cast<float2 *>(p); p += 2 * H * n_src;
-    c.jr = reinterpret_cast<int2 *>(p); p += 2 * w;
-    c.ir = reinterpret_cast<int2 *>(p); p += 2 * h;
-    c.X = p; p += W;
-    c.Y = p; p += H;
-    c.pres = p; p += (n_src + 3) & ~3;
-    c.scratch = p;
-    return c;
-}
-static inline size_t carve_bwd_bytes(int H, int W, int h, int w, int n_src) {
-    return sizeof(float) * (size_t)(n_src * pad_count_host(h, w) + ((H * W + 3) & ~3) + ((H * w + 3) & ~3) + W + H +
-                                    2 * n_src * (W + H) + 2 * w + 2 * h + ((n_src + 3) & ~3) + 128 + 16);
-}
-
-// Workgroup barriers per unit: [operands staged + axis tables] | footprint pixel pass (+ exact contraction ranges) | column
-// contraction | row contraction.  What the r01 kernel spent its 10 us on (traced with tools/kbench/st_trace.cpp: 2.7 us in
-// three serialised load round trips, 2.3 us walking all H*W canvas pixels on one CU, 1.3 + 2.1 us in the two contractions
-// with data-dependent loop bounds behind LDS min/max atomics) is cut by: requesting every global operand first and building
-// the axis tables -- which only need `where`, the oldest request -- while the rest is in flight; walking only the glimpse's
-// FOOTPRINT on the canvas (the ~(W*sx)*(H*sy) pixels with a valid source coordinate; all others contribute exactly zero;
-// found with two ballots over the tables); exact per-column / per-row source ranges from the inverse affine map, re-checked
-// against the tables, computed by the idlest wave during the pixel pass; 4-wide predicated contraction loops (one LDS round
-// trip); and multi-value wave reductions.
-// RC ("recompute") form: no final canvas is read.  The unit stages ALL T glimpses, `where` rows and presences of its image,
-// re-forms the canvas on its own footprint exactly as st_write_fwd_kernel does (same table entries, same taps, t in order:
-// bit-identical values) and derives dcanvas from it and the observation.  The backward then no longer depends on the canvas
-// forward launch: in the two-lane step the forward (needed for the outputs and the NVIL loss value) leaves the dX chain.
+// Rounds 2-5 ran this with a PIXEL PASS for dwhere (st_write_bwd_kernel: one workgroup per unit; round 5's st_write_bwd_img_kernel:
+// one per image; both in the history of round 6's first commits, same-box A/Bs in profiles/r06_canvas_gs_ab.txt); round 6's
+// glimpse-space form below replaced them in every regime.
 struct WriteBwdArgs {
     const float *glimpse, *where, *presence, *dcanvas, *final_canvas, *obs;
     float *dglimpse, *dwhere, *dpresence;
@@ -297,349 +229,6 @@ struct WriteBwdArgs {
     int vec4_glimpse, vec4_canvas;
     int NS;                           // workgroups per unit: dglimpse rows are disjoint, dwhere is written as NS slabs [NS][T*B][4]
 };
-template <bool RC, bool SPLIT = false>      // SPLIT: a.NS > 1 workgroups per unit (otherwise NS is the constant 1: no ownership tests)
-__device__ __forceinline__ void st_write_bwd_body(const WriteBwdArgs &a, const NvilArgs &nv, float *smem, const int vblock, const int vgrid) {
-    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
-    const float *__restrict__ dcanvas = a.dcanvas, *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
-    float *__restrict__ dglimpse = a.dglimpse, *__restrict__ dwhere = a.dwhere, *__restrict__ dpresence = a.dpresence;
-    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w, vec4_glimpse = a.vec4_glimpse, vec4_canvas = a.vec4_canvas;
-    const double stepX = a.stepX, stepY = a.stepY;
-    const float mult = a.mult, std = a.std, loss_scale = a.loss_scale;
-    // optional second role: one workgroup evaluates the NVIL objective (independent of the canvas gradient; it only
-    // has to precede the baseline / logit backward that follow this launch)
-    AIR_TR_INIT();
-    // the NVIL workgroup is the FIRST of the role's workgroups (a long float64 chain: at the end of a grid that fills the chip it
-    // would only start when the first glimpse workgroups retire)
-    const int grid_st = nv.imp ? vgrid - 1 : vgrid;
-    const int bid0 = nv.imp ? vblock - 1 : vblock;
-    if (bid0 < 0) {
-        AIR_TR(5);
-        nvil_body(nv);
-        AIR_TR(6);
-        AIR_TR_FLUSH();
-        return;
-    }
-    AIR_TR(0);
-    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    CarveBwd c = carve_bwd(smem, H, W, h, w, RC ? T : 1);
-    float *const src_all = c.src;
-    float2 *const xe_all = c.xe, *const ye_all = c.ye;
-    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
-    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
-    const float coef = loss_scale * mult / (std * std);
-    const int n = T * B;
-    const int pitch = w + 2;
-    const float inv_w = 1.0f / (float)w;
-    // the zero borders of the bordered glimpse copies: written once, never overwritten (visible after barrier (1) of the first unit)
-    for (int e = tid; e < (RC ? T : 1) * pad_border(h, w); e += nt) {
-        const int tt = e / pad_border(h, w);
-        src_all[(size_t)tt * c.hwp + pad_border_index(e - tt * pad_border(h, w), h, w)] = 0.f;
-    }
-    const int NS = SPLIT ? a.NS : 1;
-    for (int u = bid0; u < n * NS; u += grid_st) {
-        // NS workgroups per unit: workgroup `sp` of unit k owns rows [i0, i1) of the unit's dglimpse.  It walks the canvas rows
-        // whose taps touch those rows (neighbouring workgroups overlap by the rows between two glimpse rows), contracts them
-        // into ITS dglimpse rows only, and adds to dwhere / dpresence only the canvas rows it owns -- a row belongs to the
-        // workgroup that holds dglimpse row clamp(floor(y), 0, h-1) -- so the NS dwhere slabs sum to the gradient.
-        const int k = u / NS, sp = u - k * NS;
-        const int i0 = (int)(((long)h * sp) / NS), i1 = (int)(((long)h * (sp + 1)) / NS);
-        const int b = k % B;
-        const int t_own = k / B;
-        if (RC) { c.src = src_all + (size_t)t_own * c.hwp; c.xe = xe_all + t_own * W; c.ye = ye_all + t_own * H; }
-        if (u != bid0) __syncthreads();                      // grid-stride reuse of the LDS carve
-        // ---- every global load of the unit is requested first; the axis tables (which only need `where`, the oldest
-        //      request) are built while the rest is still in flight, then the staged operands are written to LDS
-        const int z0 = opaque_zero();                          // vector-path loads of the wave-uniform operands (see opaque_zero)
-        const float sx = where[4 * (size_t)k + z0], tx = where[4 * (size_t)k + 1 + z0];
-        const float sy = where[4 * (size_t)k + 2 + z0], ty = where[4 * (size_t)k + 3 + z0];
-        const float pres = presence ? presence[k + z0] : 1.0f;
-        const float *dcp = dcanvas ? dcanvas + (size_t)k * HW : nullptr;
-        const float *fcp = final_canvas ? final_canvas + (size_t)b * HW : nullptr;
-        const float *obp = obs ? obs + (size_t)b * HW : nullptr;
-        const float *gsrc = glimpse + (size_t)k * hw;
-        // 16-byte requests from clamped addresses, all issued before anything waits (a per-element `if (p < HW) load` makes
-        // hipcc branch around every load and wait for each one separately -- eight serialised round trips, measured 4 us;
-        // dword requests cost four times the load and LDS-store instructions)
-        const bool v4 = vec4_canvas != 0;
-        const int nQ = HW >> 2;
-        const float *pa = RC ? obp : (dcp ? dcp : fcp), *pb = RC ? obp : (dcp ? dcp : obp);
-        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
-        if (v4) {
-            const int q = tid < nQ ? tid : nQ - 1;
-            if (!RC) qa = reinterpret_cast<const float4 *>(pa)[q];
-            qb = reinterpret_cast<const float4 *>(pb)[q];
-            if (RC) qa = qb;
-        }
-        const int nq = hw >> 2;
-        const int n_gq = RC ? T * nq : nq;                     // recompute form: the T glimpses of image b, step-major in LDS
-        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec4_glimpse && tid < n_gq) {
-            if (RC) { const int tt = tid / nq; gq = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[tid - tt * nq]; }
-            else gq = reinterpret_cast<const float4 *>(gsrc)[tid];
-        }
-        const float ax = 1.0f / sx, bx = -tx / sx;
-        const float ay = 1.0f / sy, by = -ty / sy;
-        {   // axis tables: columns by the first ceil(W/64) waves, rows by the next ceil(H/64) (no divergence inside a wave);
-            // recompute form: one such block per step, each from that step's `where` row
-            const int Wp = (W + 63) & ~63, Hp = (H + 63) & ~63;
-            const int n_tab = RC ? T : 1;
-            for (int a0 = tid; a0 < n_tab * (Wp + Hp); a0 += nt) {
-                const int tt = RC ? a0 / (Wp + Hp) : 0, a = a0 - tt * (Wp + Hp);
-                float axt = ax, bxt = bx, ayt = ay, byt = by;
-                if (RC) {
-                    const float *wk = where + 4 * ((size_t)tt * B + b);
-                    if (a < Wp) { const float s_ = wk[0], t_ = wk[1]; axt = 1.0f / s_; bxt = -t_ / s_; }
-                    else { const float s_ = wk[2], t_ = wk[3]; ayt = 1.0f / s_; byt = -t_ / s_; }
-                }
-                float2 *xe_t = RC ? xe_all + tt * W : c.xe, *ye_t = RC ? ye_all + tt * H : c.ye;
-                if (a < Wp) {
-                    if (a < W) {
-                        const float X = lin_m11(a, W, stepX);
-                        if (!RC || tt == 0) c.X[a] = X;
-                        xe_t[a] = axis_entry2(grid_coord(axt, X, bxt, cxs), w);
-                    }
-                } else {
-                    const int i = a - Wp;
-                    if (i < H) {
-                        const float Y = lin_m11(i, H, stepY);
-                        if (!RC || tt == 0) c.Y[i] = Y;
-                        ye_t[i] = axis_entry2(grid_coord(ayt, Y, byt, cys), h);
-                    }
-                }
-            }
-            if (RC && tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
-        }
-        AIR_TR(7);
-        if (RC) {
-            if (vec4_glimpse) {
-                if (tid < n_gq) {
-                    const int tt = tid / nq;
-                    float *d = src_all + (size_t)tt * c.hwp + pad_index(4 * (tid - tt * nq), w, inv_w);
-                    d[0] = gq.x; d[1] = gq.y; d[2] = gq.z; d[3] = gq.w;
-                }
-                for (int q = tid + nt; q < n_gq; q += nt) {
-                    const int tt = q / nq;
-                    const float4 v = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[q - tt * nq];
-                    float *d = src_all + (size_t)tt * c.hwp + pad_index(4 * (q - tt * nq), w, inv_w);
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                }
-            } else {
-                for (int q = tid; q < T * hw; q += nt) {
-                    const int tt = q / hw;
-                    src_all[(size_t)tt * c.hwp + pad_index(q - tt * hw, w, inv_w)] = glimpse[((size_t)tt * B + b) * hw + (q - tt * hw)];
-                }
-            }
-        } else if (vec4_glimpse) {
-            if (tid < nq) { float *d = c.src + pad_index(4 * tid, w, inv_w); d[0] = gq.x; d[1] = gq.y; d[2] = gq.z; d[3] = gq.w; }
-            for (int q = tid + nt; q < nq; q += nt) {
-                const float4 v = reinterpret_cast<const float4 *>(gsrc)[q];
-                float *d = c.src + pad_index(4 * q, w, inv_w);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int q = tid; q < hw; q += nt) c.src[pad_index(q, w, inv_w)] = gsrc[q];
-        }
-        if (RC) {                                              // c.g holds the OBSERVATION until the pixel pass replaces it
-            if (v4) {
-                if (tid < nQ) reinterpret_cast<float4 *>(c.g)[tid] = qb;
-                for (int q = tid + nt; q < nQ; q += nt) reinterpret_cast<float4 *>(c.g)[q] = reinterpret_cast<const float4 *>(obp)[q];
-            } else {
-                for (int p = tid; p < HW; p += nt) c.g[p] = obp[p];
-            }
-        } else if (v4) {
-            if (tid < nQ) {
-                float4 gv = qa;
-                if (!dcp) { gv.x = dcanvas_of(coef, mult, qa.x, qb.x); gv.y = dcanvas_of(coef, mult, qa.y, qb.y);
-                            gv.z = dcanvas_of(coef, mult, qa.z, qb.z); gv.w = dcanvas_of(coef, mult, qa.w, qb.w); }
-                reinterpret_cast<float4 *>(c.g)[tid] = gv;
-            }
-            for (int q = tid + nt; q < nQ; q += nt) {            // images above 4096 pixels
-                const float4 a4 = reinterpret_cast<const float4 *>(pa)[q], b4 = reinterpret_cast<const float4 *>(pb)[q];
-                float4 gv = a4;
-                if (!dcp) { gv.x = dcanvas_of(coef, mult, a4.x, b4.x); gv.y = dcanvas_of(coef, mult, a4.y, b4.y);
-                            gv.z = dcanvas_of(coef, mult, a4.z, b4.z); gv.w = dcanvas_of(coef, mult, a4.w, b4.w); }
-                reinterpret_cast<float4 *>(c.g)[q] = gv;
-            }
-        } else {
-            for (int p = tid; p < HW; p += nt) c.g[p] = dcp ? dcp[p] : dcanvas_of(coef, mult, fcp[p], obp[p]);
-        }
-        AIR_TRT(128, 6);
-        __syncthreads();                                       // (1)
-        AIR_TR(1);
-        // footprint of the glimpse on the canvas (valid columns x valid rows): two ballots per wave over the tables
-        const int2 vx = valid_span(c.xe, W), vy = !SPLIT ? valid_span(c.ye, H) : floor_span(c.ye, H, i0 - 1, i1 - 1);
-        const int J0 = vx.x, J1 = vx.y, I0 = vy.x, I1 = vy.y;
-        const int fw = J1 - J0 + 1, fh = I1 - I0 + 1;
-        const int npx = (fw > 0 && fh > 0) ? fw * fh : 0;
-        AIR_TR(8);
-        const float inv_fw = 1.0f / (float)(fw > 0 ? fw : 1);
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d/d(ax), d/d(bx), d/d(ay), d/d(by), dpresence, -, -, -
-        for (int idx = tid; idx < npx; idx += nt) {
-            const int Ir = div_small(idx, fw, inv_fw), I = I0 + Ir, J = J0 + (idx - Ir * fw), p = I * W + J;
-            const float2 ex = c.xe[J], ey = c.ye[I];
-            const int fx = __float_as_int(ex.x), fy = __float_as_int(ey.x);       // valid by construction of the footprint
-            const float dx = ex.y, dy = ey.y;
-            const Taps t = load_taps_pad(c.src, pitch, fy, fx);
-            const float v = bilerp(t, dx, dy);
-            float dc = c.g[p];
-            if (RC) {
-                // the canvas at this pixel, accumulated as the forward does: ((0 + p0*v0) + p1*v1) + ... over ALL steps
-                float cv = 0.f;
-                for (int tt = 0; tt < T; ++tt) {
-                    float vt = v;
-                    if (tt != t_own) {
-                        const float2 ext = xe_all[tt * W + J], eyt = ye_all[tt * H + I];
-                        const int fxt = __float_as_int(ext.x), fyt = __float_as_int(eyt.x);
-                        vt = 0.f;
-                        if (fxt != ST_INVALID && fyt != ST_INVALID)
-                            vt = bilerp(load_taps_pad(src_all + (size_t)tt * c.hwp, pitch, fyt, fxt), ext.y, eyt.y);
-                    }
-                    cv = acc_step(cv, c.pres[tt], vt);
-                }
-                dc = dcanvas_of(coef, mult, cv, dc);           // (dc held the observation)
-            }
-            const float go = pres * dc;
-            const int fyc = fy < 0 ? 0 : (fy > h - 1 ? h - 1 : fy);
-            // (SPLIT: this canvas row's owner among the unit's NS workgroups adds it to dwhere / dpresence)
-            where_grad_accum(acc, t, dx, dy, go, dc, v, cxs, cys, c.X[J], c.Y[I], !SPLIT || (fyc >= i0 && fyc < i1));
-            c.g[p] = go;
-        }
-        AIR_TR(9); AIR_TRT(nt - 64, 10);
-        {
-            const float r = wave_reduce8(acc);
-            if ((lane & 7) == 0) c.scratch[wid * 8 + wave_reduce8_slot()] = r;
-        }
-        // exact source ranges of the two contractions, by the two waves with the fewest footprint pixels
-        if (wid == nw - 1) for (int j = lane; j < w; j += 64) c.jr[j] = touch_range(c.xe, bx, sx, inv_cxs, j, W);   // 1/ax = sx
-        if (wid == (nw > 1 ? nw - 2 : 0)) for (int i = lane; i < h; i += 64) c.ir[i] = touch_range(c.ye, by, sy, inv_cys, i, H);
-        AIR_TRT(nt - 64, 11);
-        __syncthreads();                                       // (2)
-        AIR_TR(2);
-        // pass 1: T1[I, j] = sum_J go[I, J] * wx[J, j] over the exact column range of j, valid rows only
-        for (int e = tid; e < (fh > 0 ? fh : 0) * w; e += nt) {
-            const int Ir = div_small(e, w, inv_w), I = I0 + Ir, j = e - Ir * w;
-            const int2 r = c.jr[j];
-            const float *grow = c.g + I * W;
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                  // the first four candidates: loads issued together
-                const int J = r.x + u;
-                const bool in = J <= r.y;
-                const int Jc = in ? J : r.x <= r.y ? r.x : 0;
-                const float2 ex = c.xe[Jc];
-                const float gv = grow[Jc];
-                const int fx = __float_as_int(ex.x);
-                const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                if (in) s += gv * wgt;
-            }
-            for (int J = r.x + 4; J <= r.y; ++J) {
-                const float2 ex = c.xe[J];
-                const int fx = __float_as_int(ex.x);
-                const float wgt = (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f);
-                s += grow[J] * wgt;
-            }
-            c.t1[I * w + j] = s;
-        }
-        __syncthreads();                                       // (3)
-        AIR_TR(3);
-        float *dg = dglimpse + (size_t)k * hw;
-        for (int e0 = tid; e0 < (i1 - i0) * w; e0 += nt) {  // pass 2: dG[i, j] = sum_I wy[I, i] * T1[I, j], this workgroup's rows
-            const int e = i0 * w + e0;
-            const int i = div_small(e, w, inv_w), j = e - i * w;
-            const int2 r = c.ir[i];
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int I = r.x + u;
-                const bool in = I <= r.y;
-                const int Ic = in ? I : r.x <= r.y ? r.x : 0;
-                const float2 ey = c.ye[Ic];
-                const float tv = in ? c.t1[Ic * w + j] : 0.f;
-                const int fy = __float_as_int(ey.x);
-                const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
-                if (in) s += tv * wgt;
-            }
-            for (int I = r.x + 4; I <= r.y; ++I) {
-                const float2 ey = c.ye[I];
-                const int fy = __float_as_int(ey.x);
-                const float wgt = (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f);
-                s += c.t1[I * w + j] * wgt;
-            }
-            dg[e] = s;
-        }
-        if (wid == nw - 1) {                               // the per-wave dwhere partials (visible since barrier 2), fixed order;
-            float part[8];                                 // by the LAST wave: it has the least contraction work
-#pragma unroll
-            for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[lane * 8 + q] : 0.f;
-            const float tot = wave_reduce8(part);
-            const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64),
-                        r4 = __shfl(tot, 32, 64);
-            if (lane == 0) {
-                // chain through a = 1/s, b = (-t)/s (linear in the partial sums: each of the NS slabs carries its share), written as
-                // automatic differentiation evaluates the two divisions -- d(x/y) = g/y for x, -g * ((x/y)/y) for y -- so that a
-                // degenerate scale (0, denormal: 1/s = inf; 1e-20: 1/s^2 = inf) gives NaN / inf / 0 exactly where the reference's
-                // gradient does (tests/test_extreme_scales.py): e.g. a zero partial sum over s = 1e-40 is 0/s = 0, not 0 * (1/s) = NaN
-                float *d = dwhere + 4 * ((size_t)sp * n + k);
-                d[0] = -(r0 * (ax / sx)) - r1 * (bx / sx);
-                d[1] = -(r1 / sx);
-                d[2] = -(r2 * (ay / sy)) - r3 * (by / sy);
-                d[3] = -(r3 / sy);
-                if (dpresence) dpresence[(size_t)sp * n + k] = r4;
-            }
-        }
-        AIR_TR(4);
-    }
-    AIR_TR_FLUSH();
-}
-template <bool RC>
-__global__ __launch_bounds__(1024) void st_write_bwd_kernel(WriteBwdArgs a, NvilArgs nv) {
-    extern __shared__ __align__(16) float smem[];
-    st_write_bwd_body<RC>(a, nv, smem, (int)blockIdx.x, (int)gridDim.x);
-}
-// ---- image-major backward for the throughput regime (round 5) ------------------------------------------------------------
-// The unit-major kernel above is bound by vector-instruction issue once the chip is full (879 vector instructions per wave and
-// unit at 65536 images; 5 waves per SIMD waiting for the pipe, profiles/r04_canvas_pmc.txt), and two thirds of a unit are fixed
-// work that the T units of one image repeat: staging and forming dcanvas (it does not depend on t), the linspace tables, three
-// barriers.  Here one workgroup owns an IMAGE and runs its T units side by side:
-//   * dcanvas = coef * (mult * final - obs) is formed ONCE into LDS and never copied: the column contraction reads it directly and
-//     the unit's presence multiplies the finished dglimpse element (dG is linear in it) -- no per-unit `go` image;
-//   * the contraction weights of a glimpse column / row (<= 4 canvas columns / rows touch it at the scales AIR trains at; longer
-//     ranges take the general loop) are formed once per (t, j) / (t, i) next to the exact ranges, so a contraction element is
-//     4 LDS reads + 4 FMAs instead of 4 x (table read, two compares, two selects, FMA);
-//   * 4 barriers per IMAGE (operands | footprint pass + ranges | column contraction | row contraction) instead of 4 per unit.
-// Same tables, taps, ranges and dwhere chain as the unit-major kernel (degenerate scales give the same NaN / inf placement); the
-// summation orders differ, so results agree to rounding, not bit for bit.  Stored-canvas form only (final_canvas given).
-struct CarveImg {
-    float *gimg, *src, *t1, *X, *Y, *scratch, *pres;
-    float2 *xe, *ye;
-    int2 *jr, *ir, *rows;
-    float4 *wx4, *wy4;
-    int hwp;
-};
-__device__ __forceinline__ CarveImg carve_img(float *smem, int T, int H, int W, int h, int w) {
-    CarveImg c;
-    float *p = smem;
-    c.hwp = pad_count(h, w);
-    c.gimg = p; p += (H * W + 3) & ~3;
-    c.wx4 = reinterpret_cast<float4 *>(p); p += 4 * T * w;
-    c.wy4 = reinterpret_cast<float4 *>(p); p += 4 * T * h;
-    c.src = p; p += T * c.hwp;
-    c.t1 = p; p += T * ((H * w + 3) & ~3);
-    c.xe = reinterpret_cast<float2 *>(p); p += 2 * T * W;
-    c.ye = reinterpret_cast<float2 *>(p); p += 2 * T * H;
-    c.jr = reinterpret_cast<int2 *>(p); p += 2 * T * w;
-    c.ir = reinterpret_cast<int2 *>(p); p += 2 * T * h;
-    c.X = p; p += W;
-    c.Y = p; p += H;
-    c.pres = p; p += (T + 3) & ~3;
-    c.rows = reinterpret_cast<int2 *>(p); p += 2 * ((T + 1) & ~1);       // per unit: first valid canvas row, number of valid rows
-    c.scratch = p;                                       // [waves][T][8]
-    return c;
-}
-static inline size_t carve_img_bytes(int T, int H, int W, int h, int w, int waves) {
-    return sizeof(float) * (size_t)(((H * W + 3) & ~3) + 4 * T * (w + h) + T * pad_count_host(h, w) + T * ((H * w + 3) & ~3) +
-                                    2 * T * (W + H) + 2 * T * (w + h) + W + H + ((T + 3) & ~3) + 2 * ((T + 1) & ~1) + waves * T * 8 + 16);
-}
 // the (up to) four contraction weights of source index j from canvas index lo on: weight of canvas index J for source index j is
 // d_J if floor_J == j, 1 - d_J if floor_J + 1 == j (the transpose of the bilinear taps), 0 past the range
 template <typename Acc>
@@ -657,195 +246,6 @@ __device__ __forceinline__ float4 touch_weights_t(const Acc &tab, int2 r, int j)
     return make_float4(wv[0], wv[1], wv[2], wv[3]);
 }
 __device__ __forceinline__ float4 touch_weights(const float2 *tab, int2 r, int j) { return touch_weights_t(TabAcc{tab}, r, j); }
-__global__ __launch_bounds__(512) void st_write_bwd_img_kernel(WriteBwdArgs a, NvilArgs nv) {
-    extern __shared__ __align__(16) float smem[];
-    const float *__restrict__ glimpse = a.glimpse, *__restrict__ where = a.where, *__restrict__ presence = a.presence;
-    const float *__restrict__ final_canvas = a.final_canvas, *__restrict__ obs = a.obs;
-    float *__restrict__ dglimpse = a.dglimpse, *__restrict__ dwhere = a.dwhere, *__restrict__ dpresence = a.dpresence;
-    const int T = a.T, B = a.B, H = a.H, W = a.W, h = a.h, w = a.w;
-    const int grid_st = nv.imp ? (int)gridDim.x - 1 : (int)gridDim.x;
-    const int bid0 = nv.imp ? (int)blockIdx.x - 1 : (int)blockIdx.x;
-    if (bid0 < 0) { nvil_body(nv); return; }
-    const int HW = H * W, hw = h * w, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
-    CarveImg c = carve_img(smem, T, H, W, h, w);
-    const float cxs = (float)((w - 1) / 2.0), cys = (float)((h - 1) / 2.0);
-    const float inv_cxs = 1.0f / cxs, inv_cys = 1.0f / cys;
-    const float coef = a.loss_scale * a.mult / (a.std * a.std), mult = a.mult;
-    const int pitch = w + 2, nQ = HW >> 2, nq = hw >> 2, t1s = (H * w + 3) & ~3;
-    const float inv_w = 1.0f / (float)w;
-    // once per workgroup: the linspace tables (they depend on the shapes only) and the zero borders of the T glimpse copies
-    for (int e = tid; e < W + H; e += nt) {
-        if (e < W) c.X[e] = lin_m11(e, W, a.stepX); else c.Y[e - W] = lin_m11(e - W, H, a.stepY);
-    }
-    for (int e = tid; e < T * pad_border(h, w); e += nt) {
-        const int tt = e / pad_border(h, w);
-        c.src[(size_t)tt * c.hwp + pad_border_index(e - tt * pad_border(h, w), h, w)] = 0.f;
-    }
-    __syncthreads();
-    for (int b = bid0; b < B; b += grid_st) {
-        if (b != bid0) __syncthreads();                       // the previous image's readers are done with the carve
-        // ---- operands: dcanvas of the image (once), the T glimpses, the T pairs of axis tables
-        {
-            const float4 *fc4 = reinterpret_cast<const float4 *>(final_canvas + (size_t)b * HW);
-            const float4 *ob4 = reinterpret_cast<const float4 *>(obs + (size_t)b * HW);
-            for (int q = tid; q < nQ; q += nt) {
-                const float4 f = fc4[q], o = ob4[q];
-                float4 gv;
-                gv.x = dcanvas_of(coef, mult, f.x, o.x); gv.y = dcanvas_of(coef, mult, f.y, o.y);
-                gv.z = dcanvas_of(coef, mult, f.z, o.z); gv.w = dcanvas_of(coef, mult, f.w, o.w);
-                reinterpret_cast<float4 *>(c.gimg)[q] = gv;
-            }
-        }
-        if (a.vec4_glimpse) {
-            for (int q = tid; q < T * nq; q += nt) {
-                const int tt = q / nq;
-                const float4 v = reinterpret_cast<const float4 *>(glimpse + ((size_t)tt * B + b) * hw)[q - tt * nq];
-                float *d = c.src + (size_t)tt * c.hwp + pad_index(4 * (q - tt * nq), w, inv_w);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int q = tid; q < T * hw; q += nt) {
-                const int tt = q / hw;
-                c.src[(size_t)tt * c.hwp + pad_index(q - tt * hw, w, inv_w)] = glimpse[((size_t)tt * B + b) * hw + (q - tt * hw)];
-            }
-        }
-        for (int a0 = tid; a0 < T * (W + H); a0 += nt) {
-            const int tt = a0 / (W + H), r = a0 - tt * (W + H);
-            const float *wk = where + 4 * ((size_t)tt * B + b);
-            if (r < W) {
-                const float s_ = wk[0], t_ = wk[1];
-                c.xe[tt * W + r] = axis_entry2(grid_coord(1.0f / s_, c.X[r], -t_ / s_, cxs), w);
-            } else {
-                const float s_ = wk[2], t_ = wk[3];
-                c.ye[tt * H + (r - W)] = axis_entry2(grid_coord(1.0f / s_, c.Y[r - W], -t_ / s_, cys), h);
-            }
-        }
-        if (tid < T) c.pres[tid] = presence ? presence[(size_t)tid * B + b] : 1.0f;
-        __syncthreads();                                       // (1)
-        // ---- exact contraction ranges + weights of every glimpse column / row (they only need the tables)
-        for (int e = tid; e < T * (w + h); e += nt) {
-            const int tt = e / (w + h), r = e - tt * (w + h);
-            const float *wk = where + 4 * ((size_t)tt * B + b);
-            if (r < w) {
-                const float s_ = wk[0], t_ = wk[1];
-                const int2 rg = touch_range(c.xe + tt * W, -t_ / s_, s_, inv_cxs, r, W);
-                c.jr[tt * w + r] = rg;
-                c.wx4[tt * w + r] = touch_weights(c.xe + tt * W, rg, r);
-            } else {
-                const float s_ = wk[2], t_ = wk[3];
-                const int i = r - w;
-                const int2 rg = touch_range(c.ye + tt * H, -t_ / s_, s_, inv_cys, i, H);
-                c.ir[tt * h + i] = rg;
-                c.wy4[tt * h + i] = touch_weights(c.ye + tt * H, rg, i);
-            }
-        }
-        // ---- footprint pass per unit: the dwhere / dpresence sums (dglimpse needs no pixel pass here)
-        for (int tt = 0; tt < T; ++tt) {
-            const float2 *xe = c.xe + tt * W, *ye = c.ye + tt * H;
-            const int2 vx = valid_span(xe, W), vy = valid_span(ye, H);
-            const int J0 = vx.x, I0 = vy.x, fw = vx.y - vx.x + 1, fh = vy.y - vy.x + 1;
-            const float pres = c.pres[tt];
-            // an ABSENT step (presence exactly 0 -- the sampled z_pres of cell.py:147-148) has dglimpse = 0 and zero dwhere sums: its
-            // pixel pass and both contractions are skipped (the dwhere chain below still runs on the zero sums, so a degenerate
-            // scale gives the same NaN as before); only a caller that wants dpresence needs the pass
-            const bool absent = pres == 0.f && !dpresence;
-            const int npx = (fw > 0 && fh > 0 && !absent) ? fw * fh : 0;
-            if (tid == 0) c.rows[tt] = make_int2(I0, absent ? -1 : (fh > 0 ? fh : 0));   // (every valid row gets its T1 row, even under an empty column span)
-            const float inv_fw = 1.0f / (float)(fw > 0 ? fw : 1);
-            const float *src = c.src + (size_t)tt * c.hwp;
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int idx = tid; idx < npx; idx += nt) {
-                const int Ir = div_small(idx, fw, inv_fw), I = I0 + Ir, J = J0 + (idx - Ir * fw);
-                const float2 ex = xe[J], ey = ye[I];
-                const Taps tp = load_taps_pad(src, pitch, __float_as_int(ey.x), __float_as_int(ex.x));
-                const float v = bilerp(tp, ex.y, ey.y);
-                const float dc = c.gimg[I * W + J];
-                where_grad_accum(acc, tp, ex.y, ey.y, pres * dc, dc, v, cxs, cys, c.X[J], c.Y[I], true);
-            }
-            const float r = wave_reduce8(acc);
-            if ((lane & 7) == 0) c.scratch[(wid * T + tt) * 8 + wave_reduce8_slot()] = r;
-        }
-        __syncthreads();                                       // (2)
-        // ---- pass 1: T1[t][I, j] = sum_J dcanvas[I, J] * wx[J, j] on the unit's valid rows
-        for (int tt = 0; tt < T; ++tt) {
-            const int2 rw = c.rows[tt];
-            const int I0 = rw.x, fh = rw.y;
-            float *t1 = c.t1 + (size_t)tt * t1s;
-            for (int e = tid; e < fh * w; e += nt) {
-                const int Ir = div_small(e, w, inv_w), I = I0 + Ir, j = e - Ir * w;
-                const int2 r = c.jr[tt * w + j];
-                const float4 wv = c.wx4[tt * w + j];
-                const float *grow = c.gimg + I * W;
-                float s = 0.f;
-                if (r.x <= r.y) {                              // (an empty range contributes exactly zero, whatever dcanvas holds)
-                    const int Jb = r.x;
-                    const int j1 = Jb + 1 <= r.y ? Jb + 1 : Jb, j2 = Jb + 2 <= r.y ? Jb + 2 : Jb, j3 = Jb + 3 <= r.y ? Jb + 3 : Jb;
-                    s = grow[Jb] * wv.x;
-                    s = __builtin_fmaf(grow[j1], wv.y, s);
-                    s = __builtin_fmaf(grow[j2], wv.z, s);
-                    s = __builtin_fmaf(grow[j3], wv.w, s);
-                    for (int J = r.x + 4; J <= r.y; ++J) {     // wide ranges (scales towards 1 and beyond): the general form
-                        const float2 ex = c.xe[tt * W + J];
-                        const int fx = __float_as_int(ex.x);
-                        s = __builtin_fmaf(grow[J], (fx == j ? ex.y : 0.f) + (fx + 1 == j ? 1.f - ex.y : 0.f), s);
-                    }
-                }
-                t1[I * w + j] = s;
-            }
-        }
-        __syncthreads();                                       // (3)
-        // ---- pass 2: dG[t][i, j] = presence_t * sum_I wy[I, i] * T1[t][I, j]
-        for (int tt = 0; tt < T; ++tt) {
-            const float *t1 = c.t1 + (size_t)tt * t1s;
-            const float pres = c.pres[tt];
-            float *dg = dglimpse + ((size_t)tt * B + b) * hw;
-            if (c.rows[tt].y < 0) {                            // absent step
-                for (int e = tid; e < hw; e += nt) dg[e] = 0.f;
-                continue;
-            }
-            for (int e = tid; e < hw; e += nt) {
-                const int i = div_small(e, w, inv_w), j = e - i * w;
-                const int2 r = c.ir[tt * h + i];
-                const float4 wv = c.wy4[tt * h + i];
-                float s = 0.f;
-                if (r.x <= r.y) {                              // (rows outside the footprint were never written: weight 0 is not enough)
-                    const int i1 = r.x + 1 <= r.y ? r.x + 1 : r.x, i2 = r.x + 2 <= r.y ? r.x + 2 : r.x, i3 = r.x + 3 <= r.y ? r.x + 3 : r.x;
-                    s = t1[r.x * w + j] * wv.x;
-                    s = __builtin_fmaf(t1[i1 * w + j], wv.y, s);
-                    s = __builtin_fmaf(t1[i2 * w + j], wv.z, s);
-                    s = __builtin_fmaf(t1[i3 * w + j], wv.w, s);
-                    for (int I = r.x + 4; I <= r.y; ++I) {
-                        const float2 ey = c.ye[tt * H + I];
-                        const int fy = __float_as_int(ey.x);
-                        s = __builtin_fmaf(t1[I * w + j], (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f), s);
-                    }
-                }
-                dg[e] = pres * s;
-            }
-        }
-        // ---- dwhere / dpresence of the T units: the per-wave partials (visible since barrier 2), fixed order, one wave per unit
-        for (int tt = wid; tt < T; tt += nw) {
-            float part[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) part[q] = (lane < nw && q < 5) ? c.scratch[(lane * T + tt) * 8 + q] : 0.f;
-            const float tot = wave_reduce8(part);
-            const float r0 = __shfl(tot, 0, 64), r1 = __shfl(tot, 8, 64), r2 = __shfl(tot, 16, 64), r3 = __shfl(tot, 24, 64),
-                        r4 = __shfl(tot, 32, 64);
-            if (lane == 0) {
-                const size_t k = (size_t)tt * B + b;
-                const float sx = where[4 * k], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
-                const float ax = 1.0f / sx, bx = -tx / sx, ay = 1.0f / sy, by = -ty / sy;
-                float *d = dwhere + 4 * k;                     // (the chain through 1/s, (-t)/s as the unit-major kernel writes it)
-                d[0] = -(r0 * (ax / sx)) - r1 * (bx / sx);
-                d[1] = -(r1 / sx);
-                d[2] = -(r2 * (ay / sy)) - r3 * (by / sy);
-                d[3] = -(r3 / sy);
-                if (dpresence) dpresence[k] = r4;
-            }
-        }
-    }
-}
-
 // ---- glimpse-space backward (round 6) ---------------------------------------------------------------------------------------
 // Both forms above pay a PIXEL PASS for dwhere: every canvas pixel of a unit's footprint evaluates its four taps and the two
 // coordinate derivatives (~40 vector instructions per pixel; 10 000 pixels per unit once a glimpse covers a 100x100 canvas: the
@@ -1314,7 +714,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                 const float r0 = (pres * s0) * cxs, r1 = (pres * s1) * cxs, r2 = (pres * s2) * cys, r3 = (pres * s3) * cys;
                 const float sx = where[4 * k], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
                 const float ax = 1.0f / sx, bx = -tx / sx, ay = 1.0f / sy, by = -ty / sy;
-                // chain through a = 1/s, b = (-t)/s as automatic differentiation evaluates the two divisions (see st_write_bwd_body):
+                // chain through a = 1/s, b = (-t)/s as automatic differentiation evaluates the two divisions:
                 // degenerate scales give NaN / inf / 0 exactly where the reference's gradient does
                 float *d = dwhere + 4 * ((size_t)sp * T * B + k);
                 d[0] = -(r0 * (ax / sx)) - r1 * (bx / sx);
@@ -1336,19 +736,9 @@ __global__ __launch_bounds__(1024) void st_write_bwd_gs_kernel(WriteBwdArgs a, N
 
 // Canvas forward and backward of a train step in ONE launch (latency regime).  The recompute form of the backward reads nothing
 // the forward writes, so the two are independent roles of one grid: workgroups [0, n_fwd) run st_write_fwd_body (image x row
-// band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_body<true> (one per glimpse).  One
+// band: per-step canvases, final canvas, reconstruction shares), the rest st_write_bwd_gs_body<true, ...> (one per glimpse).  One
 // dependent launch less on the step's chain; NVIL -- which needs the forward's reconstruction shares -- rides on a later launch
 // (air_gauss_sample_bwd_nvil).
-template <bool SPLIT>
-__global__ __launch_bounds__(1024) void canvas_fused_kernel(WriteFwdArgs f, WriteBwdArgs b, int n_fwd) {
-    extern __shared__ __align__(16) float smem[];
-    if ((int)blockIdx.x < n_fwd) st_write_fwd_body(f, smem, (int)blockIdx.x, n_fwd);
-    else {
-        const NvilArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr};
-        st_write_bwd_body<true, SPLIT>(b, none, smem, (int)blockIdx.x - n_fwd, (int)gridDim.x - n_fwd);
-    }
-}
-
 // ============================================================================================================
 // host side
 // ============================================================================================================
@@ -1459,96 +849,60 @@ static int launch_write_bwd(const float *glimpse, const float *where, const floa
                             float *dpresence, int T, int B, int H, int W, int h, int w, float mult, float std,
                             float loss_scale, void *stream, const NvilArgs *nvil = nullptr) {
     const bool rc = !dcanvas && !final_canvas;                // recompute form: the canvas is re-formed on the unit's footprint
-    const size_t lds = carve_bwd_bytes(H, W, h, w, rc ? T : 1);
     NvilArgs nv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr};
     if (nvil) nv = *nvil;
-    AIR_REQUIRE(lds <= CV_MAX_LDS, AIR_E_UNSUPPORTED);
     const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);   // 16-byte groups that never straddle a glimpse row
     const int vec4c = ((H * W) % 4 == 0) && (dcanvas ? air_aligned16(dcanvas) : ((rc || air_aligned16(final_canvas)) && air_aligned16(obs)));
-    { int st_ = rc ? cv_allow_lds(st_write_bwd_kernel<true>, lds) : cv_allow_lds(st_write_bwd_kernel<false>, lds); if (st_) return st_; }
-    // 512 threads (about one per footprint pixel) while the launch does not fill the chip: 7.5 us at 192 units against 8.2 with
-    // 1024; beyond that 256-thread workgroups, 8 per CU, hide each other's barriers (29 vs 74 us at 3072 units, 11 vs 21 at 768)
+    // 512 threads while the launch does not fill the chip; beyond that 256-thread workgroups hide each other's barriers
     const int wr_threads = bwd_threads((long)B * T);
     const WriteBwdArgs a = {glimpse, where, presence, dcanvas, final_canvas, obs, dglimpse, dwhere, dpresence, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, 1};
-    {   // round 6: the glimpse-space form (st_write_bwd_gs_kernel) for the stored-canvas and given-dcanvas backward; AIR_CANVAS_BWD_GS=0
-        // keeps the pixel-pass kernels of rounds 2-5 (A/B runs; read at every call like the switches below)
-        const char *env_gs = getenv("AIR_CANVAS_BWD_GS");
-        const int gs = env_gs ? atoi(env_gs) : 1;
-        const char *env_img = getenv("AIR_CANVAS_BWD_IMG");
-        const int img_major = env_img ? atoi(env_img) : 1;
-        const char *env_thr = getenv("AIR_CANVAS_GS_THREADS");
-        int thr_f = env_thr ? atoi(env_thr) : 0;
-        if (thr_f != 128 && thr_f != 256 && thr_f != 512 && thr_f != 1024) thr_f = 0;
-        const char *env_min = getenv("AIR_CANVAS_IMG_MIN_UNITS");
-        const long img_min_units = env_min ? atol(env_min) : 256 * 8;
-        if (gs && rc && H * W >= 16) {                          // recompute form (the stand-alone launch; the fused one: air_canvas_unroll_fwd_bwd)
-            const int thr_r = thr_f && thr_f <= 512 ? thr_f : wr_threads;
-            const size_t lds_r = carve_gs_bytes(H, W, h, w, 1, T, thr_r / 64);
-            if (lds_r <= CV_MAX_LDS) {
-                { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<true, false>, lds_r); if (st_) return st_; }
-                const int grid_r = cv_grid((long)T * B, 256 * 8) + (nvil ? 1 : 0);
-                hipLaunchKernelGGL((st_write_bwd_gs_kernel<true, false>), dim3(grid_r), dim3(thr_r), lds_r, air_stream(stream), a, nv);
-                AIR_LAUNCH_CHECK();
-                return AIR_OK;
-            }
-        }
-        if (gs && !rc && H * W >= 16) {
-            if (img_major && !dcanvas && final_canvas && (long)T * B > img_min_units && T <= 8) {
-                // one workgroup per image; threads from the carve: as many workgroups per CU as the LDS allows, 16 waves per CU
-                int thr_i = thr_f;
-                if (!thr_i) {
-                    const size_t l256 = carve_gs_bytes(H, W, h, w, T, T, 4);
-                    thr_i = l256 <= 40 * 1024 ? 256 : (l256 <= 78 * 1024 ? 512 : 1024);
-                }
-                const size_t lds_i = carve_gs_bytes(H, W, h, w, T, T, thr_i / 64);
-                if (lds_i <= CV_MAX_LDS) {
-                    { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<false, true>, lds_i); if (st_) return st_; }
-                    const int cap_i = cv_resident_cap(st_write_bwd_gs_kernel<false, true>, thr_i, lds_i, 256 * 2);
-                    const int grid_i = cv_grid(B, cap_i) + (nvil ? 1 : 0);
-                    hipLaunchKernelGGL((st_write_bwd_gs_kernel<false, true>), dim3(grid_i), dim3(thr_i), lds_i, air_stream(stream), a, nv);
-                    AIR_LAUNCH_CHECK();
-                    return AIR_OK;
-                }
-            }
-            int thr_u = thr_f && thr_f <= 512 ? thr_f : wr_threads;
-            if (!thr_f && carve_gs_bytes(H, W, h, w, 1, 1, 4) > 40 * 1024) thr_u = 512;
-            const size_t lds_u = carve_gs_bytes(H, W, h, w, 1, 1, thr_u / 64);
-            if (lds_u <= CV_MAX_LDS) {
-                { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<false, false>, lds_u); if (st_) return st_; }
-                int cap_u = 256 * 8;
-                if ((long)T * B > cap_u) cap_u = cv_resident_cap(st_write_bwd_gs_kernel<false, false>, thr_u, lds_u, cap_u);
-                const int grid_u = cv_grid((long)T * B, cap_u) + (nvil ? 1 : 0);
-                hipLaunchKernelGGL((st_write_bwd_gs_kernel<false, false>), dim3(grid_u), dim3(thr_u), lds_u, air_stream(stream), a, nv);
-                AIR_LAUNCH_CHECK();
-                return AIR_OK;
-            }
-        }
+    // developer switches, read at every call (tests and A/B runs switch forms inside one process; a captured graph keeps what it
+    // captured): AIR_CANVAS_BWD_IMG=0 keeps the unit-major form beyond 2048 units, AIR_CANVAS_GS_THREADS forces the workgroup size,
+    // AIR_CANVAS_IMG_MIN_UNITS moves the switch to the image-major form
+    const char *env_img = getenv("AIR_CANVAS_BWD_IMG");
+    const int img_major = env_img ? atoi(env_img) : 1;
+    const char *env_thr = getenv("AIR_CANVAS_GS_THREADS");
+    int thr_f = env_thr ? atoi(env_thr) : 0;
+    if (thr_f != 128 && thr_f != 256 && thr_f != 512 && thr_f != 1024) thr_f = 0;
+    const char *env_min = getenv("AIR_CANVAS_IMG_MIN_UNITS");
+    const long img_min_units = env_min ? atol(env_min) : 256 * 8;
+    if (rc) {                                                   // recompute form (the stand-alone launch; the fused one: air_canvas_unroll_fwd_bwd)
+        const int thr_r = thr_f && thr_f <= 512 ? thr_f : wr_threads;
+        const size_t lds_r = carve_gs_bytes(H, W, h, w, 1, T, thr_r / 64);
+        AIR_REQUIRE(lds_r <= CV_MAX_LDS, AIR_E_UNSUPPORTED);
+        { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<true, false>, lds_r); if (st_) return st_; }
+        const int grid_r = cv_grid((long)T * B, 256 * 8) + (nvil ? 1 : 0);
+        hipLaunchKernelGGL((st_write_bwd_gs_kernel<true, false>), dim3(grid_r), dim3(thr_r), lds_r, air_stream(stream), a, nv);
+        AIR_LAUNCH_CHECK();
+        return AIR_OK;
     }
-    {   // throughput regime, stored-canvas form: one workgroup per IMAGE runs its T units side by side (st_write_bwd_img_kernel)
-        // (read at every call, not cached: tests and A/B runs switch forms inside one process; a captured graph keeps what it captured)
-        const char *env_img = getenv("AIR_CANVAS_BWD_IMG");
-        const int img_major = env_img ? atoi(env_img) : 1;
-        const char *env_thr = getenv("AIR_CANVAS_IMG_THREADS");
-        const int thr_i = env_thr ? atoi(env_thr) : 256;
-        const size_t lds_i = carve_img_bytes(T, H, W, h, w, thr_i / 64);
-        if (img_major && !dcanvas && final_canvas && (long)T * B > 256 * 8 && T <= 8 && vec4c && lds_i <= 64 * 1024 && H * W >= 16 &&
-            (thr_i == 256 || thr_i == 512 || thr_i == 128)) {
-            const int cap_i = cv_resident_cap(st_write_bwd_img_kernel, thr_i, lds_i, 256 * 4);
+    if (img_major && !dcanvas && final_canvas && (long)T * B > img_min_units && T <= 8) {
+        // throughput regime: one workgroup per image; threads from the carve: as many workgroups per CU as the LDS allows, 16 waves per CU
+        int thr_i = thr_f;
+        if (!thr_i) {
+            const size_t l256 = carve_gs_bytes(H, W, h, w, T, T, 4);
+            thr_i = l256 <= 40 * 1024 ? 256 : (l256 <= 78 * 1024 ? 512 : 1024);
+        }
+        const size_t lds_i = carve_gs_bytes(H, W, h, w, T, T, thr_i / 64);
+        if (lds_i <= CV_MAX_LDS) {
+            { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<false, true>, lds_i); if (st_) return st_; }
+            const int cap_i = cv_resident_cap(st_write_bwd_gs_kernel<false, true>, thr_i, lds_i, 256 * 2);
             const int grid_i = cv_grid(B, cap_i) + (nvil ? 1 : 0);
-            hipLaunchKernelGGL(st_write_bwd_img_kernel, dim3(grid_i), dim3(thr_i), lds_i, air_stream(stream), a, nv);
+            hipLaunchKernelGGL((st_write_bwd_gs_kernel<false, true>), dim3(grid_i), dim3(thr_i), lds_i, air_stream(stream), a, nv);
             AIR_LAUNCH_CHECK();
             return AIR_OK;
         }
     }
-    int cap = 256 * 8;
-    // (the recompute form -- 118 VGPRs, four workgroups per CU -- measured 1-2 % SLOWER with the resident cap: it keeps 2048)
-    if ((long)T * B > cap && !rc) cap = cv_resident_cap(st_write_bwd_kernel<false>, wr_threads, lds, cap);
-    const int grid = cv_grid((long)T * B, cap) + (nvil ? 1 : 0);
-    if (rc)
-        hipLaunchKernelGGL(st_write_bwd_kernel<true>, dim3(grid), dim3(wr_threads), lds, air_stream(stream), a, nv);
-    else
-        hipLaunchKernelGGL(st_write_bwd_kernel<false>, dim3(grid), dim3(wr_threads), lds, air_stream(stream), a, nv);
+    int thr_u = thr_f && thr_f <= 512 ? thr_f : wr_threads;
+    if (!thr_f && carve_gs_bytes(H, W, h, w, 1, 1, 4) > 40 * 1024) thr_u = 512;
+    const size_t lds_u = carve_gs_bytes(H, W, h, w, 1, 1, thr_u / 64);
+    AIR_REQUIRE(lds_u <= CV_MAX_LDS, AIR_E_UNSUPPORTED);
+    { int st_ = cv_allow_lds(st_write_bwd_gs_kernel<false, false>, lds_u); if (st_) return st_; }
+    int cap_u = 256 * 8;
+    if ((long)T * B > cap_u) cap_u = cv_resident_cap(st_write_bwd_gs_kernel<false, false>, thr_u, lds_u, cap_u);
+    const int grid_u = cv_grid((long)T * B, cap_u) + (nvil ? 1 : 0);
+    hipLaunchKernelGGL((st_write_bwd_gs_kernel<false, false>), dim3(grid_u), dim3(thr_u), lds_u, air_stream(stream), a, nv);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
@@ -1617,10 +971,6 @@ __global__ __launch_bounds__(1024) void canvas_fused_gs_kernel(WriteFwdArgs f, W
         st_write_bwd_gs_body<true, false, SPLIT>(b, none, smem, (int)blockIdx.x, n_bwd);
     }
 }
-static inline int canvas_gs_enabled() {
-    const char *env_gs = getenv("AIR_CANVAS_BWD_GS");
-    return env_gs ? atoi(env_gs) : 1;
-}
 // The fused launch's shape for a problem: threads per workgroup, and whether it fits (LDS of both roles, both grids small
 // enough to run side by side).  n_split = workgroups per backward unit (1 or 2).
 static int fused_shape(int n_bands, int n_split, int T, int B, int H, int W, int h, int w, int *threads, size_t *lds) {
@@ -1630,8 +980,7 @@ static int fused_shape(int n_bands, int n_split, int T, int B, int H, int W, int
     if (n_split < 1 || n_split > 4) return AIR_E_SHAPE;
     if ((long)B * NB > 4096 || (long)B * T * n_split > 4096) return AIR_E_UNSUPPORTED;
     const int nt = bwd_threads((long)B * T * n_split);
-    const size_t lds_f = carve_wr_bytes(T, RB, W, h, w);
-    const size_t lds_b = canvas_gs_enabled() ? carve_gs_bytes(H, W, h, w, 1, T, nt / 64) : carve_bwd_bytes(H, W, h, w, T);
+    const size_t lds_f = carve_wr_bytes(T, RB, W, h, w), lds_b = carve_gs_bytes(H, W, h, w, 1, T, nt / 64);
     *lds = lds_f > lds_b ? lds_f : lds_b;
     *threads = nt;
     return *lds <= CV_MAX_LDS ? AIR_OK : AIR_E_UNSUPPORTED;
@@ -1659,22 +1008,14 @@ extern "C" int air_canvas_unroll_fwd_bwd(const float *glimpse, const float *wher
     wr_bands(H, n_bands, &NB, &RB);
     const int vec4g = (w % 4 == 0) && air_aligned16(glimpse);
     const int vec4c = ((H * W) % 4 == 0) && air_aligned16(obs);
-    const int gs = canvas_gs_enabled();
-    {
-        int st_ = gs ? (n_split > 1 ? cv_allow_lds(canvas_fused_gs_kernel<true>, lds) : cv_allow_lds(canvas_fused_gs_kernel<false>, lds))
-                     : (n_split > 1 ? cv_allow_lds(canvas_fused_kernel<true>, lds) : cv_allow_lds(canvas_fused_kernel<false>, lds));
-        if (st_) return st_;
-    }
+    { int st_ = n_split > 1 ? cv_allow_lds(canvas_fused_gs_kernel<true>, lds) : cv_allow_lds(canvas_fused_gs_kernel<false>, lds); if (st_) return st_; }
     const WriteFwdArgs f = {glimpse, where, presence, nullptr, obs, canvas_steps, final_canvas, rec_parts, T, B, NB, RB, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, vec4g};
     const WriteBwdArgs b = {glimpse, where, presence, nullptr, nullptr, obs, dglimpse, dwhere, nullptr, T, B, H, W, h, w,
                             lin_step(W), lin_step(H), mult, std, loss_scale, vec4g, vec4c, n_split};
     const int n_fwd = B * NB;
-    if (gs) {
-        if (n_split > 1) hipLaunchKernelGGL(canvas_fused_gs_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
-        else hipLaunchKernelGGL(canvas_fused_gs_kernel<false>, dim3(n_fwd + T * B), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
-    } else if (n_split > 1) hipLaunchKernelGGL(canvas_fused_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
-    else hipLaunchKernelGGL(canvas_fused_kernel<false>, dim3(n_fwd + T * B), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    if (n_split > 1) hipLaunchKernelGGL(canvas_fused_gs_kernel<true>, dim3(n_fwd + T * B * n_split), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
+    else hipLaunchKernelGGL(canvas_fused_gs_kernel<false>, dim3(n_fwd + T * B), dim3(threads), lds, air_stream(stream), f, b, n_fwd);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

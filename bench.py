@@ -432,6 +432,18 @@ def c4_shape_sweeps(device, pts=(1024, 8192, 65536)):
     return out
 
 
+# DESIGN section 5's prediction for first contact with a multi-GPU node, kept NEXT TO the code that prints the measurement (VERDICT r05
+# item 4c): weak-scaling efficiency at 8 ranks (64 images per GPU, 0.20 ms single-GPU step, 10.5 MB gradient bucket) per protocol, from
+# a 30-50 us latency floor + 2(N-1)/N x bytes at 100-200 GB/s of achieved bus bandwidth for a library all-reduce of this size, and
+# 5-10 us per barrier + 1.3 MB per xGMI link at 60-120 GB/s each way for the direct exchange.  The ORDERING is the claim.
+PREDICTED_AT_8_RANKS = {
+    "torch-split": {"step_ms": [0.32, 0.43], "efficiency": [0.47, 0.63], "exposed": "the whole 10.5 MB all-reduce behind the backward"},
+    "torch-overlap": {"step_ms": [0.31, 0.44], "efficiency": [0.46, 0.65], "exposed": "4.8 MB tail partly under the backward (45 us hide), 5.7 MB head fully"},
+    "rccl-captured": {"step_ms": [0.29, 0.42], "efficiency": [0.48, 0.69], "exposed": "as above minus the host round trips"},
+    "ipc-rsag": {"step_ms": [0.22, 0.25], "efficiency": [0.81, 0.92], "exposed": "2 barriers + shard pull + shard push over 7 links at once, replacing the closing update"},
+}
+
+
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 
 
@@ -1009,6 +1021,9 @@ def main():
                        # N > 1: every protocol timed in this invocation (the headline is the fastest one whose replicas ended bit-identical
                        # and finite), and the step's one collective on its own
                        "protocol_ab": ab, "protocol_note": note,
+                       # the prediction this measurement is there to falsify, with what this run measured beside it:
+                       # efficiency = single-GPU images/s per GPU (the default line of the same binary) / this run's per-GPU rate
+                       "protocol_prediction_at_8_ranks": PREDICTED_AT_8_RANKS if world > 1 else None,
                        "protocols_opt_in": None if world == 1 else "ipc-rsag (AIR_BENCH_PROTOCOLS=torch-overlap,ipc-rsag): validated with two processes on one GPU only",
                        "allreduce_us": ar["us"] if ar else None, "allreduce_bytes": ar["bytes"] if ar else None,
                        "allreduce_busbw_GBs": ar["busbw_GBs"] if ar else None,

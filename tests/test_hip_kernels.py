@@ -238,7 +238,7 @@ def test_canvas_kernels_in_every_workgroup_shape_match_the_oracle(hip, T, B, H, 
     st2, final2, rec2 = hip.canvas_unroll_fwd(sl(glm), sl(where), sl(pres), (H, W), obs=g(obs[:nb2]), mult=mult, std=std)
     assert torch.equal(st2, st[:, :nb2]) and torch.equal(final2, final[:nb2])
     assert_close(rec2, rec[:nb2], 1e-5, 1e-3, "rec")
-    # (beyond 2048 units the stored-canvas backward runs image-major -- st_write_bwd_img_kernel, round 5: one workgroup per image,
+    # (beyond 2048 units the stored-canvas backward runs image-major -- st_write_bwd_gs_kernel<false, true>: one workgroup per image,
     #  dcanvas formed once, presence applied to the finished element -- which agrees with the unit-major form to rounding)
     img_major = T * B > 2048 and T <= 8
     for fc in (final2, None):
@@ -252,9 +252,9 @@ def test_canvas_kernels_in_every_workgroup_shape_match_the_oracle(hip, T, B, H, 
 
 @pytest.mark.parametrize("T,B,H,W,h,w", [(3, 704, 50, 50, 20, 20), (5, 420, 40, 60, 12, 16), (1, 2100, 17, 13, 5, 7), (2, 1100, 50, 50, 21, 19)])
 def test_canvas_backward_image_major_equals_unit_major(hip, monkeypatch, T, B, H, W, h, w):
-    """Round 5: beyond 2048 units the stored-canvas backward runs one workgroup per IMAGE (st_write_bwd_img_kernel: dcanvas formed
-    once per image, contraction weights once per glimpse column / row, 4 barriers per image) instead of one per (t, b) unit.  Same
-    tables, taps, exact ranges and dwhere chain: dglimpse / dwhere agree with the unit-major kernel to rounding on ordinary,
+    """Rounds 5-6: beyond 2048 units the stored-canvas backward runs one workgroup per IMAGE (image-major form of st_write_bwd_gs_kernel:
+    dcanvas formed once per image, contraction weights once per glimpse column / row, 4 barriers per image) instead of one per (t, b)
+    unit.  Same tables, exact ranges and dwhere chain: dglimpse / dwhere agree with the unit-major form to rounding on ordinary,
     mirrored, tiny, oversized (ranges wider than four canvas columns: the general loop) and off-canvas transforms, and are NaN /
     inf exactly where it is on degenerate scales (the reference's inverse warp has no guard: tests/test_extreme_scales.py)."""
     rng = np.random.default_rng(T * 1000 + B)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Round 6: same-box A/B of the stored-canvas backward -- the pixel-pass kernels of rounds 2-5 (AIR_CANVAS_BWD_GS=0) against the
 glimpse-space form (=1) -- on bench.py's own sweep at configs[1] and configs[3] shapes, at the sweep's scales (0.45-0.65) and at the
-scales the slow configs[3] states sit at (1.4-2.8)."""
+scales the slow configs[3] states sit at (1.4-2.8).  The pixel-pass kernels and the AIR_CANVAS_BWD_GS switch left the tree once the
+A/Bs were recorded (profiles/r06_canvas_gs_ab.txt): on the current tree the "old" leg times the same kernel as "gs"; check out the
+commit "Data-parallel tests with four and eight ranks sharing one GPU" (or any earlier round-6 commit) to repeat the comparison."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -54,7 +54,7 @@ if [ "$MODE" = pmc ] || [ "$MODE" = all ]; then
   rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $PY --no-cpu-baseline --no-sweep --no-other-configs > "$OUT/${TAG}_bench_c2_b64_profiled.json" 2> "$OUT/trace.log"
   python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --steps 2600 > "$OUT/${TAG}_bench_c2_b64_kernel_stats.txt"
   # (round 5: the latency-regime step ends with the weight-gradient launch that carries the folded update)
-  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --by-position gemm_grouped_opt_kernel --every ${EVERY:-1} --json "$OUT/${TAG}_c2_b64_instep_durations.json" --digest $DIGEST --shape 50 50 20 20 3 64 > "$OUT/${TAG}_positions_c2_b64.txt"
+  python $ROOT/tools/rocpd_summary.py $(find "$OUT/trace" -name "*.db" | head -1) --by-position gemm_grouped_opt_kernel --every ${EVERY_C2:-2} --json "$OUT/${TAG}_c2_b64_instep_durations.json" --digest $DIGEST --shape 50 50 20 20 3 64 > "$OUT/${TAG}_positions_c2_b64.txt"
   ANCHOR=gemm_grouped_opt_kernel EVERY_C4=${EVERY:-1} positions c4_b64 "100 100 28 28 5 64" --config c4
   DTYPE=bf16 positions c5_b1024 "50 50 20 20 3 1024" --config c5
   positions c2_b1024_f32 "50 50 20 20 3 1024" --batch 1024
