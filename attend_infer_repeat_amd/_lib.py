@@ -13,7 +13,7 @@ c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ct
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
 ABI_VERSION = 10        # == AIR_ABI_VERSION in include/air_hip.h (the stable contract, AIR_API)
-ENGINE_ABI_VERSION = 2  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
+ENGINE_ABI_VERSION = 3  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -39,6 +39,13 @@ class AirOptFold(ctypes.Structure):
                 ("lr_mult_tail", c_float), ("decay", c_float), ("momentum", c_float), ("eps", c_float), ("grad_scale", c_float),
                 ("fold_mask", ctypes.c_uint), ("n_ranges", c_int), ("range_lo", c_size_t * 4), ("range_hi", c_size_t * 4),
                 ("global_step_dev", c_void_p), ("rng_state_dev", c_void_p), ("rng_increment", c_uint64)]
+
+
+class AirBatchGather(ctypes.Structure):
+    """mirror of `struct AirBatchGather` (include/air_hip.h)"""
+    _fields_ = [("dataset", ctypes.c_void_p), ("n_items", ctypes.c_longlong), ("item_floats", ctypes.c_int), ("shuffle", ctypes.c_int),
+                ("B", ctypes.c_int), ("seed_dev", ctypes.c_void_p), ("step_dev", ctypes.c_void_p), ("obs", ctypes.c_void_p),
+                ("idx_out", ctypes.c_void_p), ("copy_mask", ctypes.c_uint)]
 
 
 class AirDxLayer(ctypes.Structure):
@@ -189,6 +196,8 @@ SIGNATURES = {
     "air_comm_destroy": (c_int, [P]),
     "air_allreduce_sum": (c_int, [P, c_size_t, P, P]),
     "air_comm_last_error": (ctypes.c_char_p, []),
+    "air_gemm_grouped_gather_fits": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, ctypes.POINTER(AirBatchGather)]),
+    "air_gemm_grouped_gather": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, ctypes.POINTER(AirBatchGather), P]),
     "air_mlp_dx_chain_fits": (c_int, [c_int, c_int]),
     "air_mlp_dx_chain_bf16": (c_int, [ctypes.POINTER(AirDxChain), c_int, P]),
     "air_dp_ipc_barrier": (c_int, [ctypes.POINTER(AirIpcPeers), c_int, P, P, P]),

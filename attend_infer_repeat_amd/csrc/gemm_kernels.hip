@@ -109,6 +109,31 @@ struct GaussEpi {
     float raw_offset, pl, ps, dkl_scale, guard;
     unsigned mask;                                          // bit i: problem i carries the epilogue
 };
+// The HBM feeder's gather folded into the step's FIRST product (round 6): the problems of that launch contract over the pixels of the
+// observation batch, so row m of their A operand is read straight from item idx_m of the resident dataset -- idx_m drawn exactly as
+// air_batch_gather draws it (Philox(seed, stream 1, counter step*B + m), or the sequential walk) -- and the first column of tiles of the
+// problems in copy_mask writes the fragments it loaded into the observation buffer, which every later launch of the step reads as before.
+// One dependent launch less at the head of the step.  A separate kernel argument of the one kernel that uses it, like AproArgs.
+struct GatherArgs {
+    const float *data, *obs;
+    float *obs_out;
+    long long n_items;
+    int item_floats, shuffle, B;
+    const uint64_t *seed;
+    const int64_t *step;
+    int64_t *idx_out;
+    unsigned copy_mask;
+};
+__device__ __forceinline__ long long gather_item(const GatherArgs &gt, int m) {
+    const unsigned long long ctr = (unsigned long long)gt.step[0] * (unsigned long long)gt.B + (unsigned long long)m;
+    if (gt.shuffle) {
+        uint32_t r[4];
+        philox4x32(ctr, 1, gt.seed[0], r);
+        const unsigned long long wide = ((unsigned long long)r[0] << 32) | r[1];
+        return (long long)(((unsigned __int128)wide * (unsigned __int128)gt.n_items) >> 64);        // uniform in [0, n)
+    }
+    return (long long)(ctr % (unsigned long long)gt.n_items);
+}
 struct GemmArgs {
     const float *A, *B, *bias, *aux;
     float *C, *colsum, *ws;
@@ -188,10 +213,10 @@ __device__ __forceinline__ float apply_epilogue(float v, int m, int n, const Gem
 // MT x NT 16x16 MFMA tiles per wave.  KW = 4 / 16: the workgroup's KW waves split K for ONE tile (LDS reduce; 16
 // waves = 1024 threads for long-K problems with few tiles, so no second split-K launch is needed);
 // KW = 1: the 4 waves own 4 neighbouring N-tiles.
-template <int MT, int NT, int KW, bool BF, bool APRO = false, bool OPT = false, bool GBW = false>
+template <int MT, int NT, int KW, bool BF, bool APRO = false, bool OPT = false, bool GBW = false, bool GATH = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_tile, const int split, const AproArgs pro = AproArgs(),
                                           void *c16 = nullptr, const OptFold *opt = nullptr, const bool fold = false,
-                                          const GaussEpi *gb = nullptr) {
+                                          const GaussEpi *gb = nullptr, const GatherArgs *gt = nullptr, const bool gcopy = false) {
     const gh_t hC = (gh_t)c16;             // bf16 mirror of C (bf16 data path: the next product reads it instead of the fp32 value)
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWN = (KW == 1) ? 4 : 1;               // waves across N
@@ -297,6 +322,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
     for (int a = 0; a < MT; ++a) rowAc[a] = okA[a] ? rowA[a] : g.M - 1;
 #pragma unroll
     for (int b = 0; b < NT; ++b) colBc[b] = okB[b] ? colB[b] : g.N - 1;
+    // GATH: row m of A = item idx_m of the dataset, at the problem's column offset inside an observation row (A points into row 0 of obs)
+    const int gcol = GATH ? (int)(gA - (gcf)gt->obs) : 0;
+    const gcf gAs = GATH ? (gcf)gt->data + gcol : gA;
+    const int ldAs = GATH ? gt->item_floats : g.lda;
+    int rowAs[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) rowAs[a] = GATH ? (int)gather_item(*gt, rowAc[a]) : rowAc[a];
+    if (GATH && gcopy && tn == 0 && split == 0 && wave == 0 && lg == 0 && gt->idx_out && gcol == 0) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) if (okA[a]) gt->idx_out[rowA[a]] = rowAs[a];
+    }
 #pragma nounroll
     for (; c < full_end; c += U * c_step) {   // (unrolling this loop doubles the live operand registers: 94 -> 194 VGPRs)
         f32x4 fa[U][MT], fb[U][NT];
@@ -309,7 +345,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
                     fa[u][a] = g.ta ? ld_kstrided_full(gA, g.lda, rowAc[a], k)
-                                    : ld_kcontig_full(gA, g.lda, rowAc[a], k, g.vecA != 0);
+                                    : ld_kcontig_full(gAs, ldAs, rowAs[a], k, g.vecA != 0);
                     if (APRO) {       // second K-split slab + bias of the producing layer: requested with the operand itself
                         fa2[u][a] = ld_kcontig_full((gcf)pro.A2, g.lda, rowAc[a], k, g.vecA != 0);
                         fab[u] = ld_kcontig_full((gcf)pro.a_bias, 0, 0, k, g.vecA != 0);
@@ -339,6 +375,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
                         *(f32x4 *)(pro.a_out + (size_t)rowA[a] * g.lda + (((c + u * c_step) << 4) + 4 * lg)) = v;
                 }
             }
+            if (GATH && gcopy && tn == 0) {                // the gathered rows, for every later reader of the observation batch
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+                    if (okA[a]) *(f32x4 *)(gt->obs_out + (size_t)rowA[a] * g.lda + gcol + (((c + u * c_step) << 4) + 4 * lg)) = fa[u][a];
+            }
             mfma_chunk<MT, NT, BF>(acc, fa[u], fb[u]);
             if (want_colsum) {
 #pragma unroll
@@ -355,7 +396,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int block_til
 #pragma unroll
         for (int a = 0; a < MT; ++a)
             fa[a] = g.ta ? ld_kstrided(gA, g.lda, rowA[a], okA[a], k, g.K)
-                         : ld_kcontig(gA, g.lda, rowA[a], okA[a], k, g.K, g.vecA != 0);
+                         : ld_kcontig(gAs, ldAs, GATH ? rowAs[a] : rowA[a], okA[a], k, g.K, g.vecA != 0);
+        if (GATH && gcopy && tn == 0) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                if (!okA[a]) continue;
+                float *d = gt->obs_out + (size_t)rowA[a] * g.lda + gcol + k;
+                if (k < g.K) d[0] = fa[a].x;
+                if (k + 1 < g.K) d[1] = fa[a].y;
+                if (k + 2 < g.K) d[2] = fa[a].z;
+                if (k + 3 < g.K) d[3] = fa[a].w;
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NT; ++b)
             fb[b] = g.tb ? ld_kcontig(gB, g.ldb, colB[b], okB[b], k, g.K, g.vecB != 0)
@@ -1001,6 +1053,29 @@ __global__ __launch_bounds__(KW == 1 ? 256 : 64 * KW) void gemm_grouped_kernel(G
     }
 }
 
+// gemm_grouped_kernel<1, 1, 16> whose problems read their A rows through the feeder's index (GatherArgs): the first launch of a
+// latency-regime train step with an HBM-resident dataset attached (air_gemm_grouped_gather)
+__global__ __launch_bounds__(1024) void gemm_grouped_gather_kernel(GroupArgs ga, GatherArgs gt) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < AIR_GEMM_GROUP_MAX; ++i)
+        if (i < ga.count && (int)blockIdx.x >= ga.tile_start[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const bool cp = (gt.copy_mask >> p) & 1u;
+#define AIR_GG_CASE(I_) gemm_body<1, 1, 16, false, false, false, false, true>(ga.g[I_], (int)blockIdx.x - ga.tile_start[I_], blockIdx.y, AproArgs(), nullptr, nullptr, false, nullptr, &gt, cp)
+    switch (p) {       // constant descriptor index per copy, as in gemm_grouped_kernel
+        case 0: AIR_GG_CASE(0); break;
+        case 1: AIR_GG_CASE(1); break;
+        case 2: AIR_GG_CASE(2); break;
+        case 3: AIR_GG_CASE(3); break;
+        case 4: AIR_GG_CASE(4); break;
+        case 5: AIR_GG_CASE(5); break;
+        case 6: AIR_GG_CASE(6); break;
+        default: AIR_GG_CASE(7); break;
+    }
+#undef AIR_GG_CASE
+}
+
 // gemm_grouped_kernel whose weight-gradient problems (fold_mask) apply the centred-RMSProp update to the elements they finish, with
 // rider workgroups (blockIdx >= tiles) updating the slices earlier launches left final and advancing the step counters
 template <int MT, int NT, int KW, bool BF>
@@ -1621,6 +1696,48 @@ static int launch_grouped_sk(const AirGemmDesc *descs, int count, unsigned sk_ma
     hipStream_t st = air_stream(stream);
     if (T_ == 16) hipLaunchKernelGGL((gemm_grouped_sk_kernel<1, 1>), dim3(tiles), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gemm_grouped_sk_kernel<2, 2>), dim3(tiles), dim3(256), 0, st, ga);
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
+// air_gemm_grouped for the first product(s) of a train step whose input batch is drawn from an HBM-resident dataset: every problem's A
+// operand lies inside the observation buffer g->obs [B, item_floats] (row 0 + a column offset, lda = item_floats) and is read from the
+// dataset through the feeder's index instead; the problems of g->copy_mask write what they read into g->obs (together they must
+// cover every column once); g->idx_out receives the indices.  16x16 tiles, 16 waves splitting K (the latency-regime form of these
+// long-K products).  Returns AIR_E_UNSUPPORTED for anything else: the caller then plans air_batch_gather + air_gemm_grouped.
+extern "C" int air_gemm_grouped_gather_fits(const AirGemmDesc *descs, int count, const AirBatchGather *g) {
+    if (!descs || !g || count < 1 || count > AIR_GEMM_GROUP_MAX) return 0;
+    if (!g->dataset || !g->obs || !g->seed_dev || !g->step_dev || g->n_items <= 0 || g->item_floats <= 0 || g->B <= 0) return 0;
+    if (g->item_floats % 4 || !air_aligned16(g->dataset) || !air_aligned16(g->obs)) return 0;
+    long tiles16 = 0;
+    for (int i = 0; i < count; ++i) {
+        const AirGemmDesc &d = descs[i];
+        if (d.ta || d.A2 || d.C16 || d.precision != AIR_PREC_F32 || d.M != g->B || d.lda != g->item_floats) return 0;
+        const long off = (const float *)d.A - (const float *)g->obs;
+        if (off < 0 || off + d.K > g->item_floats || off % 4) return 0;
+        if (d.K < 512) return 0;
+        tiles16 += (long)air_cdiv(d.M, 16) * air_cdiv(d.N, 16);
+    }
+    return tiles16 <= 1024 ? 1 : 0;
+}
+extern "C" int air_gemm_grouped_gather(const AirGemmDesc *descs, int count, const AirBatchGather *g, void *stream) {
+    AIR_REQUIRE(descs && g, AIR_E_NULL);
+    AIR_REQUIRE(air_gemm_grouped_gather_fits(descs, count, g) == 1, AIR_E_UNSUPPORTED);
+    GroupArgs ga;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        int st = fill_gemm_args(ga.g[i], descs[i]);
+        if (st) return st;
+        ga.g[i].vecA = 1;                                  // (dataset rows and column offsets are 16-byte aligned: checked above)
+        ga.tile_start[i] = tiles;
+        tiles += air_cdiv(descs[i].M, 16) * air_cdiv(descs[i].N, 16);
+    }
+    for (int i = count; i <= AIR_GEMM_GROUP_MAX; ++i) ga.tile_start[i] = tiles;
+    for (int i = count; i < AIR_GEMM_GROUP_MAX; ++i) ga.g[i] = ga.g[0];
+    ga.count = count; ga.xcd_map = 0; ga.sk_mask = 0;
+    const GatherArgs gt = {g->dataset, g->obs, g->obs, g->n_items, g->item_floats, g->shuffle ? 1 : 0, g->B, g->seed_dev, g->step_dev,
+                           g->idx_out, g->copy_mask};
+    hipLaunchKernelGGL(gemm_grouped_gather_kernel, dim3(tiles), dim3(1024), 0, air_stream(stream), ga, gt);
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }

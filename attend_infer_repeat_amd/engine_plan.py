@@ -814,9 +814,36 @@ class PlanMixin:
         if feeder is not None:
             # the batch itself is drawn by the first launch of the train step (attach_dataset): no host work between updates
             data, shuffle = feeder
-            self._plan_fwd_train = [(L.air_batch_gather, (p(data), ctypes.c_longlong(data.shape[0]), int(data.shape[1]),
-                                                          p(self.feeder_seed), p(self.step_dev), int(shuffle), p(self.obs), B,
-                                                          p(self.batch_idx)), "air_batch_gather")] + self._plan_fwd_train
+            gather = (L.air_batch_gather, (p(data), ctypes.c_longlong(data.shape[0]), int(data.shape[1]),
+                                           p(self.feeder_seed), p(self.step_dev), int(shuffle), p(self.obs), B,
+                                           p(self.batch_idx)), "air_batch_gather")
+            # Round 6: when the step opens with the products over the pixels of obs (latency regime: the K-split halves of the input
+            # encoder's and the baseline's first layers), the gather is folded into their A-operand load -- row m is read from item
+            # idx_m of the dataset and the first column of tiles writes it to `obs` for every later reader -- instead of being a
+            # dependent launch of its own (air_gemm_grouped_gather; AIR_FOLD_GATHER=0: the two launches).  Bit-identical either way.
+            self._fold_gather = False
+            first = self._plan_fwd_train[0] if self._plan_fwd_train else None
+            if (first is not None and first[2] == "air_gemm_grouped" and os.environ.get("AIR_FOLD_GATHER", "1") == "1"):
+                arr, n_d = first[1]
+                obs_lo = self.obs.data_ptr()
+                offs = [(int(arr[i].A) - obs_lo) // 4 for i in range(n_d)]
+                # the problems that write obs: one per distinct (column offset, K) -- together they must tile [0, P)
+                seen, mask = {}, 0
+                for i in range(n_d):
+                    key = (offs[i], arr[i].K)
+                    if key not in seen:
+                        seen[key] = i; mask |= 1 << i
+                cover = sorted(seen)
+                tiled = bool(cover) and cover[0][0] == 0 and all(cover[j][0] + cover[j][1] == cover[j + 1][0] for j in range(len(cover) - 1)) \
+                    and cover[-1][0] + cover[-1][1] == P
+                bg = _lib.AirBatchGather(data.data_ptr(), int(data.shape[0]), int(data.shape[1]), int(shuffle), B,
+                                         self.feeder_seed.data_ptr(), self.step_dev.data_ptr(), obs_lo, self.batch_idx.data_ptr(), mask)
+                if tiled and int(data.shape[1]) == P and L.air_gemm_grouped_gather_fits(arr, n_d, ctypes.byref(bg)) == 1:
+                    self._keep.append(bg)
+                    self._plan_fwd_train = [(L.air_gemm_grouped_gather, (arr, n_d, ctypes.byref(bg)), "air_gemm_grouped_gather")] + self._plan_fwd_train[1:]
+                    self._fold_gather = True
+            if not self._fold_gather:
+                self._plan_fwd_train = [gather] + self._plan_fwd_train
         self._plan_bwd = bwd
         # data-parallel gradient buckets: (end index in the backward plan, [lo, hi) slice of the flat gradient buffer that
         # is final once the plan has run up to that index); contiguous, from the tail of the buffer to its head

@@ -458,8 +458,8 @@ def gemm_roofline(eng, reps=50):
         for fn, a, name in plan:
             if name in ("air_gemm", "air_gemm_bf16"):
                 f = 2.0 * a[2] * a[3] * a[4]
-            elif name == "air_gemm_grouped":
-                f = sum(2.0 * d.M * d.N * d.K for d in a[0])
+            elif name in ("air_gemm_grouped", "air_gemm_grouped_gather"):
+                f = sum(2.0 * a[0][q].M * a[0][q].N * a[0][q].K for q in range(a[1]))
             elif name in ("air_lstm_step_fwd", "air_lstm_step_fwd_prologue"):   # h[M,Hd] . W_h[Hd,4Hd], gate math fused
                 f = 2.0 * a[9] * a[10] * 4 * a[10]
             elif name == "air_what_head_fwd":                      # ge_out[T*B,K] . W[K,2A], sampling fused
@@ -508,7 +508,7 @@ def plan_breakdown(eng, reps=100):
             desc = ""
             if name in ("air_gemm", "air_gemm_bf16"):
                 desc = f"ta={a[0]} tb={a[1]} M={a[2]} N={a[3]} K={a[4]} epi={a[12]}"
-            elif name == "air_gemm_grouped":
+            elif name in ("air_gemm_grouped", "air_gemm_grouped_gather"):
                 desc = " | ".join(f"{'T' if d.ta else 'N'}{'T' if d.tb else 'N'} {d.M}x{d.N}x{d.K}" for d in a[0])
             rows.append((phase, i, name, desc, ms * 1e3))
     tot = sum(r[4] for r in rows)

@@ -35,7 +35,7 @@ extern "C" {
  *                      bind them.
  * ctypes cannot check argument lists: the loader compares both numbers and the build digest. */
 #define AIR_ABI_VERSION 10
-#define AIR_ENGINE_ABI_VERSION 2
+#define AIR_ENGINE_ABI_VERSION 3
 #define AIR_API
 #define AIR_ENGINE_API
 
@@ -192,6 +192,24 @@ typedef struct AirGemmDesc {
  * (ta = 1, tb = 0, M, N, K and ldb multiples of 4, B 16-byte aligned) on 64x64 tiles -- at least one --, any other problem
  * (no A2) on 16x16 tiles in the same grid.                                                                                 */
 AIR_ENGINE_API int air_gemm_grouped(const AirGemmDesc *descs, int count, void *stream);
+
+/* air_gemm_grouped for the FIRST product(s) of a train step whose batch is drawn from an HBM-resident dataset (data.py:121-158's feeder
+ * in HBM): the gather of air_batch_gather folded into the A-operand load.  Every problem's A lies inside obs[B, item_floats] (row 0 + a
+ * column offset, lda = item_floats, not transposed, fp32) and is read from item idx_m of `dataset` instead -- idx_m drawn exactly as
+ * air_batch_gather draws it --; the problems of copy_mask write the rows they read into obs (together they must cover every column),
+ * idx_out (optional) receives the indices.  air_gemm_grouped_gather_fits answers, without launching, whether a launch qualifies.       */
+typedef struct AirBatchGather {
+    const float *dataset;
+    long long n_items;
+    int item_floats, shuffle, B;
+    const uint64_t *seed_dev;
+    const int64_t *step_dev;
+    float *obs;
+    int64_t *idx_out;
+    unsigned copy_mask;
+} AirBatchGather;
+AIR_ENGINE_API int air_gemm_grouped_gather_fits(const AirGemmDesc *descs, int count, const AirBatchGather *g);
+AIR_ENGINE_API int air_gemm_grouped_gather(const AirGemmDesc *descs, int count, const AirBatchGather *g, void *stream);
 
 /* Row-slab dX chains of MLPs on the bf16 data path (csrc/mlp_chain_kernels.hip; neural.py:93-102 backward): through Linear + ELU layers
  * row r of dA_{l-1} = (dA_l . W_l^T) * elu'(out_{l-1}) needs only row r of dA_l, so ONE launch walks a whole chain of layers per slab of

@@ -872,7 +872,7 @@ def test_device_feeder_draws_the_batch_inside_the_step(gpu_device):
     eng_a, *_ = make_pair(ocfg, B, seed=3, gstep=0)
     eng_b, *_ = make_pair(ocfg, B, seed=3, gstep=0)
     eng_a.attach_dataset(data, shuffle=True, seed=11)
-    assert eng_a._plan_fwd_train[0][2] == "air_batch_gather"
+    assert eng_a._plan_fwd_train[0][2] in ("air_batch_gather", "air_gemm_grouped_gather")     # (folded into the first product where it fits)
     eng_a.capture(); eng_b.capture()
     seen = []
     for step in range(4):
@@ -895,6 +895,39 @@ def test_device_feeder_draws_the_batch_inside_the_step(gpu_device):
     eng_d.attach_dataset(data, shuffle=True, seed=11); eng_d.capture(steps_per_replay=2)
     eng_d.train_step(); eng_d.train_step(); eng_d.synchronize()
     assert torch.equal(eng_d.flat_params, eng_a.flat_params)
+
+
+@pytest.mark.parametrize("name", ["mnist_b64", "c4_b64", "mnist_b8"])
+def test_feeder_gather_folded_into_the_first_product_equals_the_gather_launch(gpu_device, monkeypatch, name):
+    """Round 6: with a dataset attached the latency-regime step opens with the products over the pixels of obs; the feeder's gather is
+    folded into their A-operand load (air_gemm_grouped_gather: rows read from the dataset through the Philox index, written to `obs` by
+    the first column of tiles) instead of being a launch of its own.  Same indices, same observation buffer, and BIT-identical
+    parameters / optimiser state over graph-replayed updates (the product's arithmetic is untouched); one launch fewer."""
+    ocfg, B = CONFIGS[name]
+    P = ocfg.img_size[0] * ocfg.img_size[1]
+    N = 53
+    data = torch.stack([O.synthetic_batch(ocfg, 1, seed=500 + i)[0][0] for i in range(N)]).reshape(N, P).cuda()
+    engs = []
+    for fold in ("0", "1"):
+        monkeypatch.setenv("AIR_FOLD_GATHER", fold)
+        e, *_ = make_pair(ocfg, B, seed=3, gstep=0)
+        e.attach_dataset(data, shuffle=True, seed=5)
+        engs.append(e)
+    e0, e1 = engs
+    assert e0._plan_fwd_train[0][2] == "air_batch_gather" and not e0._fold_gather
+    assert e1._plan_fwd_train[0][2] == "air_gemm_grouped_gather" and e1._fold_gather
+    assert sum(e1.kernel_launch_count().values()) == sum(e0.kernel_launch_count().values()) - 1
+    for e in engs:
+        e.capture()
+    for step in range(4):
+        for e in engs:
+            e.train_step(); e.synchronize()
+        assert torch.equal(e0.batch_idx, e1.batch_idx) and torch.equal(e1.obs, data[e1.batch_idx]), step
+        assert torch.equal(e0.flat_params, e1.flat_params) and torch.equal(e0.flat_mom, e1.flat_mom), step
+    # the sequential walk as well
+    for e in engs:
+        e.attach_dataset(data, shuffle=False); e.train_step(); e.synchronize()
+    assert torch.equal(e0.batch_idx, e1.batch_idx) and torch.equal(e0.flat_params, e1.flat_params)
 
 
 def test_noise_changes_every_step_and_prior_anneals(gpu_device):
