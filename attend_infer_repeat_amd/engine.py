@@ -28,6 +28,26 @@ from .engine_config import (EngineConfig, _Mlp, _mlp_shapes, anneal_weight, geom
 from .engine_plan import PlanMixin
 
 
+_ROCTX = [False, None]
+
+
+def _roctx():
+    """libroctx64 when AIR_ROCTX=1 (and the library is there), else None; resolved once per process"""
+    if not _ROCTX[0]:
+        _ROCTX[0] = True
+        if os.environ.get("AIR_ROCTX", "0") == "1":
+            for name in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so"):
+                try:
+                    lib = ctypes.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]; lib.roctxRangePushA.restype = ctypes.c_int
+                    lib.roctxRangePop.restype = ctypes.c_int
+                    _ROCTX[1] = lib
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _ROCTX[1]
+
+
 class AIREngine(PlanMixin):
     def __init__(self, cfg: EngineConfig, batch_size: int, device=None, seed: int = 0, keep_canvas_steps: bool = True):
         H.lib()
@@ -233,9 +253,16 @@ class AIREngine(PlanMixin):
     # ------------------------------------------------------------------------------------------------------------
 
     def _run(self, plan, stream_ptr):
-        """Issue a plan: entries (fn, args, name[, ...]) on the engine stream, in order."""
-        for e in plan:
+        """Issue a plan: entries (fn, args, name[, ...]) on the engine stream, in order.  AIR_ROCTX=1: every entry inside a roctx range
+        named "<position> <C-ABI entry>" (rocprofv3 --marker-trace shows the plan next to the kernel trace of an EAGER
+        step -- `bench.py --no-graph`; a captured graph replays kernel nodes only, its positions are tools/probes/plan_dump.py's)."""
+        rx = _roctx()
+        for i, e in enumerate(plan):
+            if rx is not None:
+                rx.roctxRangePushA(("%02d %s" % (i, e[2])).encode())
             st = e[0](*e[1], stream_ptr)
+            if rx is not None:
+                rx.roctxRangePop()
             if st != 0:
                 _lib.check(st, e[2])
 

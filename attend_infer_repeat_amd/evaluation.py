@@ -67,22 +67,35 @@ def make_fig(air, checkpoint_dir=None, global_step=None, n_samples=10):
     return fig
 
 
-def gradient_summaries(named_grads, named_vars, norm=True, ratio=True):
-    """The scalar part of evaluation.py:221-248: the global norm of the gradient and, per variable, mean(|g| / (|v| + 1e-8))
-    (log_ratio, evaluation.py:169-180).  `named_grads` / `named_vars`: name -> tensor (AIREngine.named_grads() / .params; on the
-    engine the gradients are those of the last update and the variables the ones it produced).  Histograms are TensorBoard
-    artefacts and are not produced.  Returns {'grad_norm': ..., 'grad_ratio/<name>': ...} of Python floats."""
+def gradient_summaries(named_grads, named_vars, norm=True, ratio=True, histogram=False, bins=30):
+    """evaluation.py:221-248: the global norm of the gradient, per variable mean(|g| / (|v| + 1e-8)) (log_ratio,
+    evaluation.py:169-180) and -- histogram=True, the reference's default -- a histogram of every gradient tensor, the content of its
+    `tf.summary.histogram('grad_hist/<name>', g)` as plain data: {'counts': [...], 'edges': [...]} over `bins` equal-width bins between
+    the tensor's min and max (TensorBoard's own compression of the same values is a display artefact).  `named_grads` / `named_vars`:
+    name -> tensor (AIREngine.named_grads() / .params; on the engine the gradients are those of the last update and the variables the
+    ones it produced).  Returns {'grad_norm': float, 'grad_ratio/<name>': float, 'grad_hist/<name>': dict}.  Off by default here
+    because the script logs JSON lines, not event files: scripts/multi_mnist.py --grad-histograms switches it on."""
     import torch
     out = {}
     if norm:
         out['grad_norm'] = float(torch.sqrt(sum((g.double() ** 2).sum() for g in named_grads.values())))
-    if ratio:
-        for k, g in named_grads.items():
+    for k, g in named_grads.items():
+        if ratio:
             out['grad_ratio/' + k] = float((g.abs() / (named_vars[k].abs() + 1e-8)).mean())
+        if histogram:
+            gf = g.detach().float().reshape(-1)
+            fin = gf[torch.isfinite(gf)]
+            lo, hi = (float(fin.min()), float(fin.max())) if fin.numel() else (0.0, 0.0)
+            if hi <= lo:
+                hi = lo + 1e-12
+            counts = torch.histc(fin, bins=bins, min=lo, max=hi) if fin.numel() else torch.zeros(bins)
+            out['grad_hist/' + k] = {'counts': [int(c) for c in counts.tolist()],
+                                     'edges': [lo + (hi - lo) * i / bins for i in range(bins + 1)],
+                                     'non_finite': int(gf.numel() - fin.numel())}
     return out
 
 
-def step_summaries(air):
+def step_summaries(air, histogram=False):
     """The scalars the reference registers with tf.summary.scalar and writes every 1000 iterations (multi_mnist.py:138-140;
     model.py:152,185,213,244-257,323-371), read from the engine after a train step: the objective's terms on the batch just
     trained on + the gradient summaries of that update."""
@@ -93,7 +106,7 @@ def step_summaries(air):
         pick += ["imp_weight_mean", "imp_weight_var", "reinforce_loss", "baseline_loss"]
     out = {('rec' if k == 'rec_loss' else 'prior' if k == 'prior_loss' else k): _scalar(o[k]) for k in pick}
     out['num_step'] = _scalar(o["num_step_per_sample"].mean())
-    out.update(gradient_summaries(eng.named_grads(), eng.params))
+    out.update(gradient_summaries(eng.named_grads(), eng.params, histogram=histogram))
     return out
 
 

@@ -59,6 +59,9 @@ def main(argv=None):
                     help="prefix of a checkpoint the reference's tf.train.Saver wrote (e.g. ../results/multi_mnist/model.ckpt-175000): "
                          "the model / baseline variables become the initial parameters, its RMSProp slots (where the file holds them) the "
                          "optimiser state and its global_step the step counter (tf_checkpoint.py: format and names unvalidated without TensorFlow)")
+    ap.add_argument("--grad-histograms", action="store_true",
+                    help="add the per-variable gradient histograms of evaluation.gradient_summaries(histogram=True) (the reference's default, "
+                         "evaluation.py:221-248) to the 1000-iteration summaries in log.jsonl")
     ap.add_argument("--tf-name-map", default=None, metavar="JSON",
                     help="with --init-from-tf-ckpt: a JSON file {engine parameter name: checkpoint variable name} that replaces the shape-based "
                          "matcher (tf_checkpoint.default_name_map) when it stops or guesses wrong")
@@ -175,7 +178,7 @@ def main(argv=None):
             writer.write(json.dumps(diag) + "\n"); writer.flush()
         if args.summary_every and train_itr % args.summary_every == 0:
             # the reference's `all_summaries` (model.py's tf.summary scalars + evaluation.gradient_summaries), every 1000 iterations
-            writer.write(json.dumps(dict(step=train_itr, data="summary", **step_summaries(air))) + "\n")
+            writer.write(json.dumps(dict(step=train_itr, data="summary", **step_summaries(air, histogram=args.grad_histograms))) + "\n")
         if train_itr % args.log_every == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0
