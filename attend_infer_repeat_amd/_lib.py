@@ -13,7 +13,7 @@ c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ct
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
 ABI_VERSION = 10        # == AIR_ABI_VERSION in include/air_hip.h (the stable contract, AIR_API)
-ENGINE_ABI_VERSION = 3  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
+ENGINE_ABI_VERSION = 4  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -200,6 +200,12 @@ SIGNATURES = {
     "air_gemm_grouped_gather": (c_int, [ctypes.POINTER(AirGemmDesc), c_int, ctypes.POINTER(AirBatchGather), P]),
     "air_mlp_dx_chain_fits": (c_int, [c_int, c_int]),
     "air_mlp_dx_chain_bf16": (c_int, [ctypes.POINTER(AirDxChain), c_int, P]),
+    "air_ipc_flags_alloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
+    "air_ipc_flags_free": (c_int, [P]),
+    "air_ipc_flags_zero": (c_int, [P, c_size_t, P]),
+    "air_ipc_handle_get": (c_int, [P, P]),
+    "air_ipc_handle_open": (c_int, [P, ctypes.POINTER(c_void_p)]),
+    "air_ipc_handle_close": (c_int, [P]),
     "air_dp_ipc_barrier": (c_int, [ctypes.POINTER(AirIpcPeers), c_int, P, P, P]),
     "air_dp_ipc_barrier_wgs": (c_int, [ctypes.POINTER(AirIpcPeers), c_int, P, P, c_int, P]),
     "air_dp_ipc_rs_update_ag": (c_int, [ctypes.POINTER(AirIpcPeers), P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float,

@@ -17,12 +17,14 @@
 // about which XCD a workgroup lands on: each records its hardware XCC id (s_getreg HW_REG_XCC_ID) in a mask, and workgroup 0 refuses
 // the barrier (err = 2) when the arrivals did not cover as many XCDs as the device has (CUs / 32 on gfx950; round 5 launched one
 // workgroup per XCD and trusted the dispatcher's round robin -- VERDICT r05 item 4b).  Spins are BOUNDED: a peer that
-// never arrives sets err = 1 instead of hanging the GPU.
+// never arrives sets err = 1 instead of hanging the GPU.  The flag words sit in fine-grained memory (air_ipc_flags_alloc, bottom of this
+// file) where the runtime provides it.
 //
 // Validated with two, four and eight processes sharing one GPU (tests/test_engine.py::test_data_parallel_*): the sum in rank order, the
 // replicas bit-identical; no multi-GPU node has been available, so the protocol runs a known-answer self-test before it is adopted
 // (distributed.py) and RCCL protocols stay the default.
 #include <stdlib.h>
+#include <string.h>
 #include "air_common.h"
 #include "optimizer_device.h"
 
@@ -203,3 +205,55 @@ extern "C" int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, floa
     AIR_LAUNCH_CHECK();
     return AIR_OK;
 }
+
+// ---- flag words in FINE-GRAINED device memory ---------------------------------------------------------------------------
+// In-kernel visibility of a peer's flag store is only defined for fine-grained (or uncached) memory; torch's caching allocator hands
+// out ordinary coarse-grained allocations.  These entry points allocate the flag block with hipExtMallocWithFlags(
+// hipDeviceMallocFinegrained), export / open it with the HIP IPC calls themselves (the handle travels through torch.distributed as 64
+// bytes) and zero it on a stream.  distributed.IpcPeerBuffers uses them when every rank succeeds and falls back to torch tensors
+// otherwise (agreed on inside the same exchange).
+extern "C" int air_ipc_flags_alloc(void **ptr_out, size_t bytes) {
+    AIR_REQUIRE(ptr_out && bytes > 0, AIR_E_NULL);
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+    *ptr_out = p;
+    return AIR_OK;
+}
+extern "C" int air_ipc_flags_free(void *ptr) {
+    if (!ptr) return AIR_OK;
+    const hipError_t e = hipFree(ptr);
+    return e == hipSuccess ? AIR_OK : (int)e;
+}
+extern "C" int air_ipc_flags_zero(void *ptr, size_t bytes, void *stream) {
+    AIR_REQUIRE(ptr && bytes > 0, AIR_E_NULL);
+    const hipError_t e = hipMemsetAsync(ptr, 0, bytes, air_stream(stream));
+    return e == hipSuccess ? AIR_OK : (int)e;
+}
+extern "C" int air_ipc_handle_get(void *ptr, void *handle_64_bytes) {
+    AIR_REQUIRE(ptr && handle_64_bytes, AIR_E_NULL);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    memcpy(handle_64_bytes, &h, sizeof(h));
+    return AIR_OK;
+}
+extern "C" int air_ipc_handle_open(const void *handle_64_bytes, void **ptr_out) {
+    AIR_REQUIRE(handle_64_bytes && ptr_out, AIR_E_NULL);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle_64_bytes, sizeof(h));
+    void *p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    *ptr_out = p;
+    return AIR_OK;
+}
+extern "C" int air_ipc_handle_close(void *ptr) {
+    if (!ptr) return AIR_OK;
+    const hipError_t e = hipIpcCloseMemHandle(ptr);
+    return e == hipSuccess ? AIR_OK : (int)e;
+}
+

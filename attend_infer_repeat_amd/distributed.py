@@ -202,7 +202,10 @@ class IpcPeerBuffers(object):
         # a rank-local failure of the export (world > 8, a tensor torch cannot export, e.g. under expandable_segments) must still reach
         # the collective below -- a rank that raised in front of it would leave its peers blocked in all_gather_object --
         # so it travels as None and EVERY rank raises afterwards
+        from . import hip as H
+        L = H.lib()
         mine, local_error = None, None
+        self._fg_ptr, self._fg_open, self.flags_kind = None, [], "torch (coarse-grained)"
         try:
             if self.world > 8:
                 raise _lib.AirHipError("ipc-rsag maps the ranks of ONE node: at most 8")
@@ -210,13 +213,46 @@ class IpcPeerBuffers(object):
             self.local = torch.zeros(8, dtype=torch.int64, device=dev)        # (comm_ipc.hip: epochs, arrivals, go, XCC masks)
             self.err = torch.zeros(1, dtype=torch.int64, device=dev)
             torch.cuda.synchronize(dev)
-            mine = tuple(reduce_tensor(t) for t in (engine.flat_grads, engine.flat_params, self.flags))
+            # the flag block in FINE-GRAINED memory where the runtime gives it (in-kernel visibility of a peer's store is
+            # only defined there), exported with the HIP IPC call itself; AIR_IPC_FINEGRAINED=0 keeps the torch allocation.  Both
+            # forms travel: every rank uses the fine-grained blocks only if EVERY rank has one and can open all the others'.
+            fg = None
+            if os.environ.get("AIR_IPC_FINEGRAINED", "1") == "1":
+                with torch.cuda.device(dev):
+                    ptr = ctypes.c_void_p()
+                    if L.air_ipc_flags_alloc(ctypes.byref(ptr), 16 * 8) == 0:
+                        buf = ctypes.create_string_buffer(64)
+                        if L.air_ipc_handle_get(ptr, buf) == 0:
+                            self._fg_ptr, fg = ptr, bytes(buf.raw)
+                        else:
+                            L.air_ipc_flags_free(ptr)
+            mine = tuple(reduce_tensor(t) for t in (engine.flat_grads, engine.flat_params, self.flags)) + (fg,)
         except Exception as e:                                                 # noqa: BLE001
             local_error = e
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=group)
         if local_error is not None or any(x is None for x in everyone):
             raise _lib.AirHipError("ipc-rsag: a rank could not export its buffers (%r)" % (local_error,))
+        # fine-grained flags: open every peer's block; agreed on (one more exchange of a boolean per rank)
+        fg_ptrs, fg_ok = [None] * self.world, all(x[3] is not None for x in everyone)
+        if fg_ok:
+            with torch.cuda.device(dev):
+                for q in range(self.world):
+                    if q == self.rank:
+                        fg_ptrs[q] = self._fg_ptr.value
+                        continue
+                    pp = ctypes.c_void_p()
+                    if L.air_ipc_handle_open(ctypes.create_string_buffer(everyone[q][3], 64), ctypes.byref(pp)) != 0:
+                        fg_ok = False
+                        break
+                    self._fg_open.append(pp); fg_ptrs[q] = pp.value
+        oks = [None] * self.world
+        dist.all_gather_object(oks, bool(fg_ok), group=group)
+        fg_ok = all(oks)
+        if not fg_ok:
+            self._release_finegrained()
+        else:
+            self.flags_kind = "fine-grained (hipExtMallocWithFlags), HIP IPC handles"
         self._keep = []
         self.struct = _lib.AirIpcPeers()
         self.struct.world, self.struct.rank = self.world, self.rank
@@ -224,14 +260,38 @@ class IpcPeerBuffers(object):
             if q == self.rank:
                 g, p_, f = engine.flat_grads, engine.flat_params, self.flags
             else:
-                g, p_, f = (fn(*args) for fn, args in everyone[q])
+                g, p_, f = (fn(*args) for fn, args in everyone[q][:3])
                 if g.device != dev:                                             # another GPU of the node: peer access both ways
                     if not torch.cuda.can_device_access_peer(dev.index, g.device.index):
                         raise _lib.AirHipError("GPU %d cannot map GPU %d's memory" % (dev.index, g.device.index))
                     _ = f[:1].to(dev)                                           # (torch enables peer access on the first P2P copy)
                 self._keep += [g, p_, f]
-            self.struct.grads[q], self.struct.params[q], self.struct.flags[q] = g.data_ptr(), p_.data_ptr(), f.data_ptr()
+            self.struct.grads[q], self.struct.params[q] = g.data_ptr(), p_.data_ptr()
+            self.struct.flags[q] = fg_ptrs[q] if fg_ok else f.data_ptr()
         torch.cuda.synchronize(dev)
+
+    def _release_finegrained(self):
+        from . import hip as H
+        L = H.lib()
+        for pp in self._fg_open:
+            L.air_ipc_handle_close(pp)
+        self._fg_open = []
+        if self._fg_ptr is not None:
+            L.air_ipc_flags_free(self._fg_ptr)
+            self._fg_ptr = None
+
+    def zero_flags(self, engine):
+        """this rank's flag block back to zero (self-test; collective callers synchronise around it)"""
+        if self._fg_ptr is not None:
+            from . import hip as H
+            _ = H.lib().air_ipc_flags_zero(self._fg_ptr, 16 * 8, engine._sp())
+            engine.synchronize()
+        else:
+            self.flags.zero_()
+
+    def release(self):
+        """unmap the peers' fine-grained blocks and free this rank's (after a barrier: nobody may still be spinning on them)"""
+        self._release_finegrained()
 
     def plan(self, engine):
         """the three launches that follow the backward in the step's graph"""
@@ -297,7 +357,7 @@ class IpcPeerBuffers(object):
                 for k in names:
                     getattr(engine, k).copy_(saved[k])
             engine.synchronize()
-            self.local.zero_(); self.err.zero_(); self.flags.zero_()
+            self.local.zero_(); self.err.zero_(); self.zero_flags(engine)
             torch.cuda.synchronize(dev)
             dist.barrier(group=group)
         except Exception as e:                                        # noqa: BLE001
@@ -374,6 +434,9 @@ class DataParallelEngine(object):
                         self._ipc_steps = 0
                         return
                     engine.release_graphs()
+                if self._ipc is not None:
+                    dist.barrier(group=group)                       # (nobody frees a flag block a peer's self-test may still touch)
+                    self._ipc.release()
                 self._ipc = self._ipc_plan = None
                 want = "torch-split"
             if on_gpu and want in ("rccl-split", "rccl-captured"):
@@ -536,6 +599,7 @@ class DataParallelEngine(object):
             self.engine.synchronize()
             self.engine.release_graphs()
             dist.barrier(group=self.group)                  # nobody unmaps while a peer may still be pushing
+            self._ipc.release()
             self._ipc = self._ipc_plan = None
             self.engine._slots_sharded = False
             self.engine._recapture_hook = None

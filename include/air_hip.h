@@ -35,7 +35,7 @@ extern "C" {
  *                      bind them.
  * ctypes cannot check argument lists: the loader compares both numbers and the build digest. */
 #define AIR_ABI_VERSION 10
-#define AIR_ENGINE_ABI_VERSION 3
+#define AIR_ENGINE_ABI_VERSION 4
 #define AIR_API
 #define AIR_ENGINE_API
 
@@ -690,6 +690,15 @@ typedef struct AirIpcPeers {
 } AirIpcPeers;
 AIR_ENGINE_API int air_dp_ipc_barrier(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, void *stream);
 AIR_ENGINE_API int air_dp_ipc_barrier_wgs(const AirIpcPeers *peers, int which, uint64_t *local_dev, uint64_t *err_dev, int n_wgs, void *stream);
+/* The barrier's flag words in FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained): in-kernel visibility of a
+ * peer's store is only defined there), exported / opened with the HIP IPC calls; the handle is 64 bytes.  Not stream-ordered except
+ * air_ipc_flags_zero.  distributed.IpcPeerBuffers falls back to ordinary allocations when any rank cannot use these.               */
+AIR_ENGINE_API int air_ipc_flags_alloc(void **ptr_out, size_t bytes);
+AIR_ENGINE_API int air_ipc_flags_free(void *ptr);
+AIR_ENGINE_API int air_ipc_flags_zero(void *ptr, size_t bytes, void *stream);
+AIR_ENGINE_API int air_ipc_handle_get(void *ptr, void *handle_64_bytes);
+AIR_ENGINE_API int air_ipc_handle_open(const void *handle_64_bytes, void **ptr_out);
+AIR_ENGINE_API int air_ipc_handle_close(void *ptr);
 AIR_ENGINE_API int air_dp_ipc_rs_update_ag(const AirIpcPeers *peers, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                             const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps,
                             int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);

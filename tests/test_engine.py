@@ -1063,6 +1063,7 @@ def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
                     nranks=dp.rccl_nranks, noise=eng.eps_what.cpu(), steps=int(eng.step_dev.item()),
                     timed_out=bool(dp._ipc.timed_out()) if dp._ipc is not None else False,
                     ipc_local=dp._ipc.local.cpu() if dp._ipc is not None else None,
+                    flags_kind=dp._ipc.flags_kind if dp._ipc is not None else None,
                     state=dp.state_dict() if os.environ.get("AIR_TEST_DP_STATE") else None),
                os.path.join(out_dir, f"{collective}_{rank}.pt"))
     dp.close()
@@ -1162,6 +1163,9 @@ def test_data_parallel_many_ranks_sharing_one_gpu(gpu_device, tmp_path, monkeypa
         for x in r:                                               # complete slots on every rank after the gather
             assert torch.equal(x["state"]["flat_mom"], want_mom) and torch.equal(x["state"]["flat_params"], want)
             assert bin(int(x["ipc_local"][4])).count("1") == 8, "the barrier's workgroups did not cover the eight XCDs"
+        # the flag words sit in fine-grained memory exported with the HIP IPC calls where the runtime provides it (every rank the same)
+        assert len({x["flags_kind"] for x in r}) == 1
+        print("ipc-rsag flag block:", r[0]["flags_kind"])
     else:
         assert all(torch.equal(x["grads"], r[0]["grads"]) for x in r)          # the all-reduced buffer, on every rank
         want, _ = update_of(r[0]["grads"])
