@@ -530,18 +530,21 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
         if (IM) {
             // image-major (throughput regime): ranges + weights of the T units from the LDS tables, one thread per column / row -- a
             // fifth of the instructions of the eight-lane form above, for one more barrier per image
-            for (int e = tid; e < TU * (w + h); e += nt) {
-                const int lu = e / (w + h), r = e - lu * (w + h);
-                const float *wk = where + 4 * ((size_t)lu * B + b);
-                if (r < w) {
+            // (column items first, row items from the next wave on: a wave that held both kinds ran the two paths one after the other)
+            const int n_x = TU * w, n_x_pad = (n_x + 63) & ~63;
+            for (int e = tid; e < n_x_pad + TU * h; e += nt) {
+                if (e < n_x) {
+                    const int lu = e / w, r = e - lu * w;
+                    const float *wk = where + 4 * ((size_t)lu * B + b);
                     const float s_ = wk[0], t_ = wk[1];
                     const TabAcc ta = {c.xe + lu * W};
                     const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cxs, r, W);
                     c.jr[lu * w + r] = rg;
                     touch_weights3(ta, c.X, W, a.stepX, rg, r, &c.wx4[lu * w + r], &c.dx4[lu * w + r], &c.xx4[lu * w + r]);
-                } else {
+                } else if (e >= n_x_pad) {
+                    const int e2 = e - n_x_pad, lu = e2 / h, i = e2 - lu * h;
+                    const float *wk = where + 4 * ((size_t)lu * B + b);
                     const float s_ = wk[2], t_ = wk[3];
-                    const int i = r - w;
                     const TabAcc ta = {c.ye + lu * H};
                     const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cys, i, H);
                     c.ir[lu * h + i] = rg;
