@@ -468,16 +468,19 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
             }
         }
         AIR_TR(1);
-        // axis tables of the TS steps, by the first threads
-        for (int a0 = tid; a0 < TS * (W + H); a0 += nt) {
-            const int tt = a0 / (W + H), r = a0 - tt * (W + H);
-            const float *wk = where + 4 * ((size_t)((RC || IM) ? tt : t_own) * B + b);
-            if (r < W) {
+        // axis tables of the TS steps, by the first threads (column entries, then row entries from the next wave on: no wave holds both)
+        const int n_xe = TS * W, n_xe_pad = (n_xe + 63) & ~63;
+        for (int a0 = tid; a0 < n_xe_pad + TS * H; a0 += nt) {
+            if (a0 < n_xe) {
+                const int tt = a0 / W, r = a0 - tt * W;
+                const float *wk = where + 4 * ((size_t)((RC || IM) ? tt : t_own) * B + b);
                 const float s_ = wk[0], t_ = wk[1];
                 c.xe[tt * W + r] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r, W, a.stepX), -t_ / s_, cxs), w);
-            } else {
+            } else if (a0 >= n_xe_pad) {
+                const int a1 = a0 - n_xe_pad, tt = a1 / H, r = a1 - tt * H;
+                const float *wk = where + 4 * ((size_t)((RC || IM) ? tt : t_own) * B + b);
                 const float s_ = wk[2], t_ = wk[3];
-                c.ye[tt * H + (r - W)] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r - W, H, a.stepY), -t_ / s_, cys), h);
+                c.ye[tt * H + r] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r, H, a.stepY), -t_ / s_, cys), h);
             }
         }
         if (tid < TS) c.pres[tid] = presence ? presence[(size_t)((RC || IM) ? tid : t_own) * B + b] : 1.0f;

@@ -12,3 +12,5 @@ for name, kw, T in (("c4", dict(img_size=(100, 100), crop_size=(28, 28), max_ste
         f, b, pair = bench.canvas_write_sweep(cfg, T, [1024, 8192, 65536], dev)
         print(name, "bwd", [(x["batch"], x["us_per_launch"], x["frac"]) for x in b], "pair", [x["frac"] for x in pair])
 PY
+for i in 1 2; do python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-sweep --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("c2", d['ms_per_step'], d['value'])"; done
+for i in 1 2; do python bench.py --config c4 --steps 2000 --warmup 200 --no-cpu-baseline --no-sweep --no-other-configs 2>/dev/null | tail -1 | cut -c1-200; done
