@@ -430,6 +430,7 @@ struct AttendFwdArgs {
     const float *img; float *glimpse;
     int T, B, H, W, h, w, bf16;
     int img_major;      // role A: one workgroup per IMAGE runs its T glimpses (the image is staged once) instead of one per glimpse
+    int lean;           // ... and (image-major only) resamples them as st_read_fwd_lean_kernel does: bordered image, axis tables, 4 outputs per thread
     double stepx, stepy;
 };
 // operand of a dense product: as is, or rounded to bf16 (EngineConfig.mfma_dtype = "bf16": same arithmetic as the MFMA path)
@@ -518,16 +519,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
     const int t0 = g.img_major ? 0 : bid / B, t1 = g.img_major ? T : t0 + 1;
     const int H = g.H, W = g.W, h = g.h, w = g.w, HW = H * W, hw = h * w, nq = HW >> 2;
     Carve c = carve_lds(smem, HW, 0, w, h);
-    float *s_where = c.scratch;                                // [t1 - t0][4]
+    // lean layout (g.lean, see below): bordered image | xe[T][w] | ye[T][h] | sX[w] | sY[h] | where rows
+    const int pitch = W + 2, padn = ((H + 2) * pitch + 3) & ~3;
+    float2 *lxe = reinterpret_cast<float2 *>(smem + padn), *lye = lxe + T * w;
+    float *lsX = reinterpret_cast<float *>(lye + T * h), *lsY = lsX + w;
+    float *s_where = g.lean ? lsY + h : c.scratch;             // [t1 - t0][4]
     const float cxs = (float)((W - 1) / 2.0), cys = (float)((H - 1) / 2.0);
-    const int q0 = tid < nq ? tid : nq - 1, q1 = tid + nt < nq ? tid + nt : nq - 1;
-    const int q2 = tid + 2 * nt < nq ? tid + 2 * nt : nq - 1;
+    // (512 threads: five 16-byte groups per thread -- a 100x100 image with two workgroups per CU, see air_attend_fwd)
+    constexpr int NP = NT == 512 ? 5 : 3;
+    const int nwv = nt >> 6;
+    const bool wr = wave < t1 - t0;
     const float4 *s4 = reinterpret_cast<const float4 *>(g.img + (size_t)b * HW);
-    const float4 p0 = s4[q0], p1 = s4[q1], p2 = s4[q2];       // in flight while wave 0 forms `where`
+    float4 pf[NP];                                             // in flight while the first waves form `where`
+    // (requesting the row's operands BEFORE the image -- loads return in issue order -- changed nothing, traced: the `where` phase waits
+    //  for its own cold operands and, at batch 1024, behind the chip-wide queue of every workgroup's image, not behind this wave's share)
+#pragma unroll
+    for (int u = 0; u < NP; ++u) pf[u] = s4[tid + u * NT < nq ? tid + u * NT : nq - 1];
     // one wave per `where` row: wave 0 for a single glimpse; image-major, the T rows of the image go to different waves
     // (serially on wave 0 they were the longest phase of the workgroup: 4.9 of 8.3 us at T = 3)
-    const int nwv = nt >> 6;
-    if (wave < t1 - t0) {
+    if (wr) {
         const int o = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1), d = o & 3;
         const float bias_o = g.tr_b[o];
         for (int t = t0 + wave; t < t1; t += nwv) {
@@ -569,10 +579,67 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 
         }
         AIR_TR(1);
     }
+    if (g.lean) {
+        // Image-major in the throughput regime (round 6): the chip holds four or five of these workgroups per CU and the launch is bound by
+        // VALU issue, as the stand-alone read was before its instruction diet -- ~90 instructions per output pixel in the loop below
+        // (per-pixel axis entries, an integer division, four bounds-checked taps).  Same diet here: the image goes to LDS with a zero
+        // border (an out-of-range tap reads the +0.0f the bounds check selects), the axis entries of the T glimpses are formed once
+        // (T (w + h) instead of 2 T h w), a thread forms four consecutive outputs of a glimpse row and stores 16 bytes.  Arithmetic
+        // untouched (grid_coord / axis_entry2 / bilerp): bit-identical outputs.  The waves that form no `where` row zero the border and
+        // fill the linspace tables meanwhile; LDS-only barriers (nobody waits for the stores of the `where` phase).
+        float *s_img = smem;
+        const int n_aux = 2 * pitch + 2 * H + w + h;
+        const int wf0 = (t1 - t0) < nwv ? (t1 - t0) : 0;      // first wave without a `where` row (all of them when there is none)
+        for (int e = tid - wf0 * 64; e >= 0 && e < n_aux; e += NT - wf0 * 64) {
+            if (e < pitch) s_img[e] = 0.f;
+            else if (e < 2 * pitch) s_img[(H + 1) * pitch + (e - pitch)] = 0.f;
+            else if (e < 2 * pitch + 2 * H) { const int k2 = e - 2 * pitch; s_img[(1 + (k2 >> 1)) * pitch + ((k2 & 1) ? W + 1 : 0)] = 0.f; }
+            else { const int a = e - 2 * pitch - 2 * H; if (a < w) lsX[a] = lin_m11(a, w, g.stepx); else lsY[a - w] = lin_m11(a - w, h, g.stepy); }
+        }
+        const float inv_W = 1.0f / (float)W;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int q = tid + u * NT;
+            if (q < nq) {
+                const int r = div_small(4 * q, W, inv_W), cc = 4 * q - r * W, bb = 4 * q + 2 * r + pitch + 1;
+                s_img[bb] = pf[u].x; s_img[bb + 1 + (cc + 1 >= W ? 2 : 0)] = pf[u].y;
+                s_img[bb + 2 + (cc + 2 >= W ? 2 : 0)] = pf[u].z; s_img[bb + 3 + (cc + 3 >= W ? 2 : 0)] = pf[u].w;
+            }
+        }
+        lds_barrier();                                         // image, border, linspace tables, `where` rows
+        AIR_TR(2);
+        for (int a = tid; a < T * (w + h); a += NT) {
+            const int r = a / (w + h), e = a - r * (w + h);
+            const float *sw = s_where + 4 * r;
+            if (e < w) lxe[r * w + e] = axis_entry2(grid_coord(sw[0], lsX[e], sw[1], cxs), W);
+            else lye[r * h + (e - w)] = axis_entry2(grid_coord(sw[2], lsY[e - w], sw[3], cys), H);
+        }
+        lds_barrier();
+        const int wq = w >> 2, hwq = hw >> 2;
+        const float inv_wq = 1.0f / (float)wq;
+        for (int gi = tid; gi < T * hwq; gi += NT) {
+            const int r = gi / hwq, q = gi - r * hwq;
+            const int i = div_small(q, wq, inv_wq), j = 4 * (q - i * wq);
+            const float2 ey = lye[r * h + i];
+            const int fy = __float_as_int(ey.x);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (fy != ST_INVALID) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 ex = lxe[r * w + j + u];
+                    const int fx = __float_as_int(ex.x);
+                    if (fx != ST_INVALID) v[u] = bilerp(load_taps_pad(s_img, pitch, fy, fx), ex.y, ey.y);
+                }
+            }
+            st_stream4<false>(g.glimpse + ((size_t)r * B + b) * hw + 4 * q, v[0], v[1], v[2], v[3]);
+        }
+        AIR_TR(3);
+        AIR_TR_FLUSH();
+        return;
+    }
     float4 *d4 = reinterpret_cast<float4 *>(c.src);
-    if (tid < nq) d4[tid] = p0;
-    if (tid + nt < nq) d4[tid + nt] = p1;
-    if (tid + 2 * nt < nq) d4[tid + 2 * nt] = p2;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) if (tid + u * NT < nq) d4[tid + u * NT] = pf[u];
     __syncthreads();                                           // image + every `where` row of this workgroup visible
     AIR_TR(2);
     for (int t = t0; t < t1; ++t) {
@@ -611,7 +678,7 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
     const int nq = (H * W) / 4;
     // the register-prefetch staging needs a 16-byte addressable image of at most 3 float4 per thread
     AIR_REQUIRE((H * W) % 4 == 0 && air_aligned16(img) && nq <= 3 * 1024 && air_aligned16(tr_w), AIR_E_UNSUPPORTED);
-    const size_t lds = carve_bytes(H * W, 0, w, h);
+    size_t lds = carve_bytes(H * W, 0, w, h);
     AIR_REQUIRE(lds <= ST_MAX_LDS, AIR_E_UNSUPPORTED);
     AttendFwdArgs g;
     g.tr_h = tr_h; g.tr_w = tr_w; g.tr_b = tr_b; g.tr_k = tr_k; g.st_h = st_h; g.st_w = st_w; g.st_b = st_b; g.st_k = st_k;
@@ -625,6 +692,11 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
     // one workgroup per glimpse while that is what fills the chip; beyond ~4 workgroups per CU one per image, which stages its
     // image once for the T reads (measured at batch 1024: 20 -> see DESIGN.md)
     g.img_major = ((long)T * B > 2048 && T > 1) ? 1 : 0;
+    // image-major: the read role in the lean kernel's form when its outputs come in 16-byte groups (AIR_ATTEND_LEAN=0: the per-pixel form, A/B)
+    const size_t lds_lean = read_lean_bytes(H, W, h, w, T) + 16 * (size_t)T;
+    const char *env_lean = getenv("AIR_ATTEND_LEAN");
+    g.lean = (g.img_major && w % 4 == 0 && air_aligned16(glimpse) && lds_lean <= ST_MAX_LDS && !(env_lean && atoi(env_lean) == 0)) ? 1 : 0;
+    if (g.lean && lds_lean > lds) lds = lds_lean;
     const int grid = (g.img_major ? B : T * B) + air_cdiv(B, 64);
 #define AIR_ATTEND_FWD_LAUNCH(MT_, NT_, EX_)                                                                         \
     do {                                                                                                                \
@@ -639,7 +711,11 @@ extern "C" int air_attend_fwd(const float *tr_h, const float *tr_w, const float 
         else if (T <= 8) AIR_ATTEND_FWD_LAUNCH(8, NT_, false);                                                          \
         else AIR_ATTEND_FWD_LAUNCH(32, NT_, false);                                                                     \
     } while (0)
-    if (nq <= 3 * 256) AIR_ATTEND_FWD_BY_T(256); else AIR_ATTEND_FWD_BY_T(1024);
+    // 1024-thread workgroups sit one per CU (16 waves): a grid of more of them than CUs runs in two rounds (configs[3]: 320 glimpses,
+    // the last 64 started when the first retired -- 3.6 us into an 8.3 us launch, traced); 512 threads with five groups each: two per CU
+    if (nq <= 3 * 256) AIR_ATTEND_FWD_BY_T(256);
+    else if (nq <= 5 * 512 && !g.img_major && (long)T * B > 256 && getenv("AIR_ATTEND_FWD_1024") == nullptr) AIR_ATTEND_FWD_BY_T(512);
+    else AIR_ATTEND_FWD_BY_T(1024);
 #undef AIR_ATTEND_FWD_BY_T
 #undef AIR_ATTEND_FWD_LAUNCH
     AIR_LAUNCH_CHECK();
@@ -961,6 +1037,8 @@ static int attend_bwd_launch(AttendBwdArgs &g, int T, int B, int H, int W, int h
     } while (0)
     // about one glimpse pixel per thread
     // (image-major: 256 threads, so that one workgroup per image -- B of them -- is resident at once: 5 per CU)
+    // (512 threads at 28x28 with 320 units -- two workgroups per CU instead of two rounds, as air_attend_fwd does -- measured slower
+    //  in the configs[3] step: 13.9 against 12.0 us, two pixels per thread on the long per-pixel path)
     if (hw_ <= 256 || (g.img_major && hw_ <= 1024)) AIR_ATTEND_BWD_BY_T(256);
     else if (hw_ <= 512) AIR_ATTEND_BWD_BY_T(512); else AIR_ATTEND_BWD_BY_T(1024);
 #undef AIR_ATTEND_BWD_BY_T

@@ -1334,3 +1334,44 @@ def test_grid_stride_launches_equal_small_launches_bit_for_bit(hip, T, B, H, W, 
         for name, (dg, dw), fc in (("stored", (dg_s, dw_s), fi_c), ("recompute", (dg_r, dw_r), None)):
             dg_c, dw_c = hip.canvas_unroll_bwd(gl_c, wh_c, pr_c, img[b0:b1].contiguous(), fc, 1.0, 0.3, 1.0 / B)
             assert torch.equal(dg[:, b0:b1], dg_c) and torch.equal(dw[:, b0:b1], dw_c), f"canvas backward ({name}), images {b0}..{b1}"
+
+
+@pytest.mark.parametrize("B,T,H,W,h,w", [(704, 3, 50, 50, 20, 20), (416, 5, 100, 100, 28, 28), (688, 3, 12, 10, 3, 4)])
+def test_attend_fwd_image_major_lean_read_is_bit_identical(hip, monkeypatch, B, T, H, W, h, w):
+    """air_attend_fwd beyond 2048 glimpses runs one workgroup per image; round 6 resamples the T glimpses there as the lean read kernel does
+    (bordered image in LDS, axis tables, four outputs per thread).  Every output equals the per-pixel form's bit for bit, and the glimpses
+    equal the CPU oracle's read of the same images with the `where` rows the launch sampled (modules.py:94-109, cell.py:129-135)."""
+    import ctypes
+    from attend_infer_repeat_amd import _lib
+    lib = hip.lib()
+    rng = np.random.default_rng(B + T)
+    M, Kt, Ks = T * B, 64, 32
+    f = lambda *shape, s=1.0: g((s * rng.standard_normal(shape)).astype(np.float32))
+    img = g((rng.random((B, H, W)) * (rng.random((B, H, W)) < 0.3)).astype(np.float32))
+    tr_h, tr_w, tr_b = f(M, Kt), f(Kt, 8, s=0.2), f(8, s=0.5)
+    st_h, st_w, st_b = f(M, Ks), f(Ks, 1, s=0.2), f(1)
+    eps, u = f(M, 4), g(rng.random(M).astype(np.float32))
+    prior = g(np.array([0.5 ** (n + 1) for n in range(T + 1)]), torch.float64)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run(lean):
+        if lean:
+            monkeypatch.delenv("AIR_ATTEND_LEAN", raising=False)
+        else:
+            monkeypatch.setenv("AIR_ATTEND_LEAN", "0")
+        z = lambda *shape: torch.full(shape, float("nan"), device="cuda")
+        out = dict(pre=z(M, 8), logit=z(M), loc=z(M, 4), scale=z(M, 4), where=z(M, 4), kl=z(M), prob=z(M), pres=z(M), q=z(B, T + 1),
+                   klps=z(B), logp=z(B), stepw=z(M), glimpse=z(M, h * w))
+        _lib.check(lib.air_attend_fwd(p(tr_h), p(tr_w), p(tr_b), Kt, p(st_h), p(st_w), p(st_b), Ks, p(out["pre"]), p(out["logit"]), p(eps),
+                                      0.5, 0.0, 1.0, 0.0, 1.0, p(out["loc"]), p(out["scale"]), p(out["where"]), p(out["kl"]), p(u), 0.0, 0.0,
+                                      p(prior), p(out["prob"]), p(out["pres"]), p(out["q"]), p(out["klps"]), p(out["logp"]), p(out["stepw"]),
+                                      p(img), p(out["glimpse"]), T, B, H, W, h, w, 0, 1e-3, hip._stream()), "air_attend_fwd")
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in out.items()}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert not np.isnan(a[k]).any(), k
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    ref = C.st_read_fwd(np.tile(img.cpu().numpy(), (T, 1, 1)), a["where"], (h, w))
+    np.testing.assert_array_equal(a["glimpse"].reshape(M, h, w), ref)

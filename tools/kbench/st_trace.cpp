@@ -4,6 +4,7 @@
 // every workgroup stamps s_memrealtime (100 MHz, chip-wide) at the phase boundaries marked AIR_TR(i) in the kernels.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <vector>
 #include <algorithm>
@@ -104,13 +105,19 @@ int main(int argc, char **argv) {
     auto f_cbwd_rc = [&] { air_canvas_unroll_bwd(d_glm, d_where, d_pres, d_obs, nullptr, d_dglm, d_dwhere, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_cfused = [&] { air_canvas_unroll_fwd_bwd(d_glm, d_where, d_pres, d_obs, keep ? d_steps : nullptr, d_final, d_recp, NB, d_dglm, d_dwhere, NS, T, B, H, W, h, w, 0.5f, 0.3f, 1.0f / B, st); };
     auto f_rfwd = [&] { air_st_read_fwd(d_obs, d_where, d_glimpse, M, B, H, W, h, w, st); };
+    const int prec = getenv("PREC") ? atoi(getenv("PREC")) : 0;   // 1: operands rounded to bf16 (the configs[4] plan)
+    auto f_attend = [&] { air_attend_fwd(d_trh, d_trw, d_trb, Kt, d_sth, d_stw, d_stb, Ks, d_pre, d_logit, d_eps, 0.5f, 0.f, 1.f, 0.f, 1.f, d_loc, d_scale, d_wh2, d_klrow,
+                                         d_u, 0.f, 0.f, d_prior, d_prob, d_pr2, d_q, d_klps, d_lp2, d_stepw, d_obs, d_glimpse, T, B, H, W, h, w, prec, 1e-3f, st); };
+    const int n_attend = ((long)T * B > 2048 && T > 1 ? B : M) + (B + 63) / 64;
     struct { const char *n; std::function<void()> f; int nb; } K[] = {
         {"canvas_unroll_fwd_banded", f_cfwd, B * NB}, {"canvas_unroll_fwd(1 band)", f_cfwd1, B}, {"canvas_unroll_bwd", f_cbwd0, M},
         {"canvas_unroll_bwd(recompute)", f_cbwd_rc, M}, {"canvas_fused(fwd+bwd)", f_cfused, B * NB + M},
-        {"st_read_fwd", f_rfwd, B}};
+        {"st_read_fwd", f_rfwd, B}, {"attend_fwd", f_attend, n_attend}};
     f_cfwd(); CK(hipStreamSynchronize(st));
     printf("B=%d T=%d %dx%d glimpse %dx%d keep_steps=%d bands=%d\n", B, T, H, W, h, w, keep, NB);
+    const char *only = getenv("ONLY");
     for (auto &k : K) {
+        if (only && !strstr(k.n, only)) continue;
         double us = time_us(k.f, 200, st);
         printf("%-26s %7.2f us/launch (median of 7 x 200 back-to-back)\n", k.n, us);
 #ifdef AIR_TRACE
