@@ -73,6 +73,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # one process per GPU: the ranks of a node share its host cores (torchrun exports OMP_NUM_THREADS = 1 itself; a plain spawn
+        # does not, and eight ranks x every core made the host side of an engine build take tens of seconds -- measured in the tests)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), (os.cpu_count() or 1) // max(1, local_world))))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -1039,9 +1039,28 @@ def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dev_index = 0 if share_gpu else rank
+    torch.set_num_threads(2)                        # (world processes x every host core otherwise)
     torch.cuda.set_device(dev_index)
     from attend_infer_repeat_amd import distributed as D
     D.init_from_env(backend="gloo" if share_gpu else "nccl")
+    import gc
+    import torch.distributed as dist
+    keep = []
+    try:
+        for c in collective.split("+"):             # several protocols, one after the other, on one process group (as bench.py's A/B)
+            keep.append(_dp_rank_protocol(rank, dev_index, out_dir, c))     # (engines stay alive to the end, as in a one-protocol process)
+            dist.barrier()
+    except BaseException:
+        import traceback
+        with open(os.path.join(out_dir, "rank%d_error.txt" % rank), "w") as f:      # (a process that dies in its exit handlers loses spawn's report)
+            traceback.print_exc(file=f)
+        traceback.print_exc()
+        raise
+    dist.destroy_process_group()
+
+
+def _dp_rank_protocol(rank, dev_index, out_dir, collective):
+    from attend_infer_repeat_amd import distributed as D
     ocfg, B = CONFIGS["mnist_b8"]
     from attend_infer_repeat_amd.engine import AIREngine, EngineConfig
     fields = {f.name for f in dataclasses.fields(EngineConfig)}
@@ -1067,8 +1086,7 @@ def _dp_rank_main(rank, world, port, out_dir, collective, share_gpu=False):
                     state=dp.state_dict() if os.environ.get("AIR_TEST_DP_STATE") else None),
                os.path.join(out_dir, f"{collective}_{rank}.pt"))
     dp.close()
-    import torch.distributed as dist
-    dist.barrier(); dist.destroy_process_group()
+    return eng, dp
 
 
 @pytest.mark.parametrize("collective", ["torch-overlap", "torch-split", "rccl-split", "rccl-captured", "ipc-rsag"])
@@ -1123,19 +1141,41 @@ def test_data_parallel_two_ranks_on_two_gpus(gpu_device, tmp_path, collective):
     assert not torch.equal(r[0]["noise"], r[1]["noise"])
 
 
+@pytest.fixture(scope="module")
+def many_ranks_runs(tmp_path_factory):
+    """world -> directory with every rank's record of the three shared-GPU protocols, from ONE spawn per world size (the processes
+    run the protocols one after the other on one process group: a spawn of eight torch processes costs more than the updates)"""
+    import torch.multiprocessing as mp
+    done = {}
+
+    def get(world):
+        if world not in done:
+            out = tmp_path_factory.mktemp("dp_world%d" % world)
+            saved = {k: os.environ.get(k) for k in ("AIR_TEST_DP_STEPS", "AIR_TEST_DP_STATE")}
+            os.environ.update(AIR_TEST_DP_STEPS="1", AIR_TEST_DP_STATE="1")
+            try:
+                mp.spawn(_dp_rank_main, args=(world, D_free_port(), str(out), "torch-split+torch-overlap+ipc-rsag", True), nprocs=world, join=True)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            done[world] = out
+        return done[world]
+    return get
+
+
 @pytest.mark.parametrize("world", [4, 8])
 @pytest.mark.parametrize("collective", ["ipc-rsag", "torch-split", "torch-overlap"])
-def test_data_parallel_many_ranks_sharing_one_gpu(gpu_device, tmp_path, monkeypatch, collective, world):
+def test_data_parallel_many_ranks_sharing_one_gpu(gpu_device, many_ranks_runs, collective, world):
     """FOUR and EIGHT ranks (processes sharing GPU 0, gradients over gloo or the hipIpc mapping) -- the first
     configurations in which the order of a float sum can differ.  After ONE update from identical parameters: every replica holds
     the same bits; ipc-rsag's parameters are EXACTLY the engine's update of the host-side sum of the ranks' local gradients taken
     in rank order ((g0 + g1) + g2) + ... -- what comm_ipc.hip promises -- with every rank's slots complete after the gather
     (DataParallelEngine.state_dict); the library protocols' replicas all carry the same summed gradient and the engine's update
     of it, which agrees with the rank-order sum to rounding.  ipc-rsag's barriers (64 workgroups each) covered all eight XCDs."""
-    import torch.multiprocessing as mp
-    monkeypatch.setenv("AIR_TEST_DP_STEPS", "1")
-    monkeypatch.setenv("AIR_TEST_DP_STATE", "1")
-    mp.spawn(_dp_rank_main, args=(world, D_free_port(), str(tmp_path), collective, True), nprocs=world, join=True)
+    tmp_path = many_ranks_runs(world)
     r = [torch.load(os.path.join(tmp_path, f"{collective}_{k}.pt")) for k in range(world)]
     assert all(x["collective"] == collective for x in r)
     assert all(torch.equal(x["start"], r[0]["start"]) for x in r) and all(x["steps"] == 1 for x in r)
