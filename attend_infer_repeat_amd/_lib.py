@@ -13,7 +13,7 @@ c_int, c_float, c_size_t, c_void_p, c_uint64 = (ctypes.c_int, ctypes.c_float, ct
                                                  ctypes.c_uint64)
 P = c_void_p   # device pointers travel as void*
 ABI_VERSION = 10        # == AIR_ABI_VERSION in include/air_hip.h (the stable contract, AIR_API)
-ENGINE_ABI_VERSION = 4  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
+ENGINE_ABI_VERSION = 5  # == AIR_ENGINE_ABI_VERSION (the engine plan entries, AIR_ENGINE_API)
 
 class AirGemmDesc(ctypes.Structure):
     """mirror of `struct AirGemmDesc` (include/air_hip.h)"""
@@ -165,6 +165,9 @@ SIGNATURES = {
     "air_step_prologue_cvt": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
                                       c_int, P, P, c_size_t, P]),
+    "air_step_prologue_gather_cvt": (c_int, [P, c_size_t, P, c_size_t, P, P, c_int, ctypes.c_double, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, P, c_int, P, P, P, P, c_int,
+                                             c_int, P, P, P]),
     "air_batch_gather": (c_int, [P, ctypes.c_longlong, c_int, P, P, c_int, P, c_int, P, P]),
     "air_step_epilogue": (c_int, [P, P, P, P, P, c_size_t, c_size_t, P, c_float, c_float, c_float, c_float, c_float,
                                   P, P, c_uint64, P]),

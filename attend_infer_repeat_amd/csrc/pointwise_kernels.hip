@@ -581,6 +581,65 @@ extern "C" int air_step_prologue_cvt(float *normal, size_t n_normal, float *unif
     return AIR_OK;
 }
 
+// ... and with the HBM feeder attached (round 6): the rows the conversion reads come straight from the resident dataset -- row b = item
+// idx_b, idx_b drawn exactly as air_batch_gather draws it -- and the workgroup writes BOTH the fp32 batch every later launch reads and its
+// bf16 mirror: the gather launch that opened the throughput-regime step (7 us at batch 1024) is gone.  One workgroup per row at a time.
+struct GatherRows {
+    const float *data; long long n_items; int item_floats, shuffle, B;
+    const uint64_t *seed; const int64_t *step; float *obs; int64_t *idx_out;
+};
+__global__ __launch_bounds__(PW_THREADS) void step_prologue_gather_cvt_kernel(PrologueArgs a, int pro_blocks, GatherRows gr, uint2 *__restrict__ out16) {
+    if ((int)blockIdx.x < pro_blocks) { step_prologue_body(a, blockIdx.x, pro_blocks); return; }
+    const int vb = (int)blockIdx.x - pro_blocks, vg = (int)gridDim.x - pro_blocks;
+    const long long step = gr.step[0];
+    const int nq = gr.item_floats >> 2;
+    for (int b = vb; b < gr.B; b += vg) {
+        const unsigned long long ctr = (unsigned long long)step * (unsigned long long)gr.B + (unsigned long long)b;
+        long long idx;
+        if (gr.shuffle) {
+            uint32_t r[4];
+            philox4x32(ctr, 1, gr.seed[0], r);
+            const unsigned long long wide = ((unsigned long long)r[0] << 32) | r[1];
+            idx = (long long)(((unsigned __int128)wide * (unsigned __int128)gr.n_items) >> 64);     // uniform in [0, n): as batch_gather_kernel
+        } else {
+            idx = (long long)(ctr % (unsigned long long)gr.n_items);
+        }
+        if (threadIdx.x == 0 && gr.idx_out) gr.idx_out[b] = idx;
+        const float4 *src = reinterpret_cast<const float4 *>(gr.data + (size_t)idx * gr.item_floats);
+        float4 *dst = reinterpret_cast<float4 *>(gr.obs + (size_t)b * gr.item_floats);
+        uint2 *d16 = out16 + (size_t)b * nq;
+        for (int q = threadIdx.x; q < nq; q += PW_THREADS) {
+            const float4 v = src[q];
+            dst[q] = v;
+            const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.y) << 16);
+            const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.z) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v.w) << 16);
+            d16[q] = make_uint2(lo, hi);
+        }
+    }
+}
+extern "C" int air_step_prologue_gather_cvt(float *normal, size_t n_normal, float *uniform, size_t n_uniform,
+                                            const uint64_t *rng_state_dev, const int64_t *global_step_dev, int anneal_type,
+                                            double init, double final_value, double anneal_steps, double hold_for,
+                                            double steps_div, double *prior_out_f64, int T, const float *h0, const float *c0,
+                                            float *h_tiled, float *c_tiled, int B, int Hd, const AirBatchGather *bg, void *x_bf16,
+                                            void *stream) {
+    AIR_REQUIRE(rng_state_dev && global_step_dev && prior_out_f64 && h0 && c0 && h_tiled && c_tiled && bg && x_bf16, AIR_E_NULL);
+    AIR_REQUIRE(bg->dataset && bg->seed_dev && bg->step_dev && bg->obs, AIR_E_NULL);
+    AIR_REQUIRE((n_normal == 0 || normal) && (n_uniform == 0 || uniform), AIR_E_NULL);
+    AIR_REQUIRE(T > 0 && B > 0 && Hd > 0 && anneal_type >= 0 && anneal_type <= 2, AIR_E_SHAPE);
+    AIR_REQUIRE(bg->n_items > 0 && bg->item_floats > 0 && bg->item_floats % 4 == 0 && bg->B > 0, AIR_E_SHAPE);
+    AIR_REQUIRE(air_aligned16(bg->dataset) && air_aligned16(bg->obs) && ((uintptr_t)x_bf16 % 8 == 0), AIR_E_ALIGN);
+    const PrologueArgs a = make_prologue_args(normal, n_normal, uniform, n_uniform, rng_state_dev, global_step_dev,
+                                              anneal_type, init, final_value, anneal_steps, hold_for, steps_div,
+                                              prior_out_f64, T, h0, c0, h_tiled, c_tiled, B, Hd);
+    const int pb = prologue_blocks(a);
+    const GatherRows gr = {bg->dataset, bg->n_items, bg->item_floats, bg->shuffle ? 1 : 0, bg->B, bg->seed_dev, bg->step_dev, bg->obs, bg->idx_out};
+    hipLaunchKernelGGL(step_prologue_gather_cvt_kernel, dim3(pb + (bg->B < 4096 ? bg->B : 4096)), dim3(PW_THREADS), 0, air_stream(stream), a, pb, gr,
+                       reinterpret_cast<uint2 *>(x_bf16));
+    AIR_LAUNCH_CHECK();
+    return AIR_OK;
+}
+
 // epilogue: both centred-RMSProp updates (model segment [0, n_model) at lr, baseline segment at lr * lr_mult_tail) in
 //           one pass over the flat buffers, then the device counters (global step, Philox offset) advance.
 // 16-byte accesses: the pass moves 9 x 4 B per parameter (94 MB at the 50x50 configuration) and is bound by memory-pipe

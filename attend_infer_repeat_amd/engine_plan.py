@@ -842,6 +842,18 @@ class PlanMixin:
                     self._keep.append(bg)
                     self._plan_fwd_train = [(L.air_gemm_grouped_gather, (arr, n_d, ctypes.byref(bg)), "air_gemm_grouped_gather")] + self._plan_fwd_train[1:]
                     self._fold_gather = True
+            if (not self._fold_gather and first is not None and first[2] == "air_step_prologue_cvt" and os.environ.get("AIR_FOLD_GATHER", "1") == "1"
+                    and int(data.shape[1]) == P and P % 4 == 0):
+                # bf16 data path (throughput regime): the step opens with the prologue whose extra workgroups convert obs to its bf16
+                # mirror -- they read the rows from the dataset instead and write both (air_step_prologue_gather_cvt): no gather launch
+                bg = _lib.AirBatchGather(data.data_ptr(), int(data.shape[0]), int(data.shape[1]), int(shuffle), B,
+                                         self.feeder_seed.data_ptr(), self.step_dev.data_ptr(), self.obs.data_ptr(), self.batch_idx.data_ptr(), 0)
+                self._keep.append(bg)
+                pro = first[1]                       # (..., x, x_bf16, n_x): the prologue's own arguments, then the conversion's
+                assert int(pro[-1].value) == B * P
+                self._plan_fwd_train = [(L.air_step_prologue_gather_cvt, pro[:-3] + (ctypes.byref(bg), pro[-2]), "air_step_prologue_gather_cvt")] \
+                    + self._plan_fwd_train[1:]
+                self._fold_gather = True
             if not self._fold_gather:
                 self._plan_fwd_train = [gather] + self._plan_fwd_train
         self._plan_bwd = bwd

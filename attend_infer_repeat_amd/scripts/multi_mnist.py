@@ -106,7 +106,6 @@ def main(argv=None):
         from attend_infer_repeat_amd.tf_checkpoint import global_step_of, import_tf_checkpoint, import_tf_optimizer_slots, mapping_report
         name_map = None
         if args.tf_name_map:
-            import json
             name_map = json.load(open(args.tf_name_map))
         named = import_tf_checkpoint(args.init_from_tf_ckpt, air._engine.param_shapes, name_map=name_map)
         air._engine.load_parameters({k: torch.from_numpy(v) for k, v in named.items()})

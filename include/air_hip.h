@@ -35,7 +35,7 @@ extern "C" {
  *                      bind them.
  * ctypes cannot check argument lists: the loader compares both numbers and the build digest. */
 #define AIR_ABI_VERSION 10
-#define AIR_ENGINE_ABI_VERSION 4
+#define AIR_ENGINE_ABI_VERSION 5
 #define AIR_API
 #define AIR_ENGINE_API
 
@@ -616,6 +616,13 @@ AIR_ENGINE_API int air_step_prologue_cvt(float *normal, size_t n_normal, float *
                           double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
                           const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, const float *x,
                           void *x_bf16, size_t n_x, void *stream);
+/* ... and with the HBM feeder attached: row b of the batch is read from item idx_b of g->dataset (drawn as air_batch_gather draws it) and
+ * written to g->obs (fp32) AND to x_bf16 -- air_batch_gather + air_step_prologue_cvt in one launch (g->copy_mask unused).          */
+AIR_ENGINE_API int air_step_prologue_gather_cvt(float *normal, size_t n_normal, float *uniform, size_t n_uniform, const uint64_t *rng_state_dev,
+                          const int64_t *global_step_dev, int anneal_type, double init, double final_value,
+                          double anneal_steps, double hold_for, double steps_div, double *prior_out_f64, int T,
+                          const float *h0, const float *c0, float *h_tiled, float *c_tiled, int B, int Hd, const AirBatchGather *g,
+                          void *x_bf16, void *stream);
 AIR_ENGINE_API int air_step_epilogue(float *p, const float *g, float *ms, float *mg, float *mom, size_t n_model, size_t n_total,
                       const float *lr_dev, float lr_mult_tail, float decay, float momentum, float eps, float grad_scale,
                       int64_t *global_step_dev, uint64_t *rng_state_dev, uint64_t rng_increment, void *stream);

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol(libpath):
 def test_library_loads_and_reports_abi(libpath):
     from attend_infer_repeat_amd import _lib
     lib = _lib.load()
-    assert lib.air_abi_version() == _lib.ABI_VERSION == 10 and lib.air_engine_abi_version() == _lib.ENGINE_ABI_VERSION == 4
+    assert lib.air_abi_version() == _lib.ABI_VERSION == 10 and lib.air_engine_abi_version() == _lib.ENGINE_ABI_VERSION == 5
     from attend_infer_repeat_amd import build
     assert lib.air_build_digest().decode() == build.source_digest()
     assert lib.air_status_string(-2).decode().startswith("AIR_E_SHAPE")

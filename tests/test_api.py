@@ -280,9 +280,14 @@ def test_training_script_counterpart_runs(amd, tmp_path):
     """scripts/multi_mnist.py counterpart: a short run trains, logs the reference's scalar set and checkpoints."""
     from attend_infer_repeat_amd.scripts import multi_mnist
     air = multi_mnist.main(["--iters", "40", "--log-every", "20", "--save-every", "40", "--synthetic-samples", "512",
-                            "--eval-batches", "2", "--results-dir", str(tmp_path)])
+                            "--eval-batches", "2", "--summary-every", "20", "--results-dir", str(tmp_path)])
     import json, os
     lines = [json.loads(l) for l in open(os.path.join(tmp_path, "multi_mnist", "log.jsonl"))]
+    # (the 1000-iteration summaries of the reference's all_summaries: written here every 20 -- round 6's 300 k-update runs died at
+    #  their first one, which no test had ever reached)
+    summaries = [l for l in lines if l["data"] == "summary"]
+    assert summaries and all(l["step"] % 20 == 0 for l in summaries)
+    lines = [l for l in lines if l["data"] != "summary"]
     assert {l["data"] for l in lines} == {"train", "test"} and {l["step"] for l in lines} == {0, 20, 40}
     for k in ("loss", "rec_loss", "num_step_acc", "num_step", "prior_loss", "kl_num_steps", "kl_what", "kl_where",
               "baseline_loss", "reinforce_loss", "imp_weight"):

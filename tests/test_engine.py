@@ -930,6 +930,37 @@ def test_feeder_gather_folded_into_the_first_product_equals_the_gather_launch(gp
     assert torch.equal(e0.batch_idx, e1.batch_idx) and torch.equal(e0.flat_params, e1.flat_params)
 
 
+def test_feeder_gather_in_the_bf16_prologue_equals_the_gather_launch(gpu_device, monkeypatch):
+    """Round 6, bf16 data path (BASELINE configs[4], batch 1024): the step opens with the prologue whose extra workgroups write the bf16
+    mirror of obs; with a dataset attached they read the rows from the dataset through the Philox index and write obs AND the mirror
+    (air_step_prologue_gather_cvt) -- no gather launch.  Same indices, same batch, same mirror, bit-identical updates; one launch fewer."""
+    ocfg, B = O.AIRConfig(), 1024
+    P = ocfg.img_size[0] * ocfg.img_size[1]
+    N = 97
+    data = torch.stack([O.synthetic_batch(ocfg, 1, seed=700 + i)[0][0] for i in range(N)]).reshape(N, P).cuda()
+    engs = []
+    for fold in ("0", "1"):
+        monkeypatch.setenv("AIR_FOLD_GATHER", fold)
+        e, *_ = make_pair(ocfg, B, seed=3, gstep=0, mfma_dtype="bf16")
+        e.attach_dataset(data, shuffle=True, seed=5)
+        engs.append(e)
+    e0, e1 = engs
+    assert [n for _, _, n in e0._plan_fwd_train[:2]] == ["air_batch_gather", "air_step_prologue_cvt"] and not e0._fold_gather
+    assert e1._plan_fwd_train[0][2] == "air_step_prologue_gather_cvt" and e1._fold_gather
+    assert sum(e1.kernel_launch_count().values()) == sum(e0.kernel_launch_count().values()) - 1
+    for e in engs:
+        e.capture()
+    for step in range(3):
+        for e in engs:
+            e.train_step(); e.synchronize()
+        assert torch.equal(e0.batch_idx, e1.batch_idx) and torch.equal(e1.obs.reshape(B, P), data[e1.batch_idx]), step
+        assert torch.equal(e0.obs16, e1.obs16) and torch.equal(e1.obs16.reshape(B, P), data[e1.batch_idx].to(torch.bfloat16)), step
+        assert torch.equal(e0.flat_params, e1.flat_params) and torch.equal(e0.flat_mom, e1.flat_mom), step
+    for e in engs:                                   # the sequential walk as well
+        e.attach_dataset(data, shuffle=False); e.train_step(); e.synchronize()
+    assert torch.equal(e0.batch_idx, e1.batch_idx) and torch.equal(e0.flat_params, e1.flat_params)
+
+
 def test_noise_changes_every_step_and_prior_anneals(gpu_device):
     ocfg, B = CONFIGS["tiny"]
     eng, *_ = make_pair(ocfg, B, gstep=0)
