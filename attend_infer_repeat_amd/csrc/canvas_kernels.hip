@@ -266,7 +266,7 @@ __device__ __forceinline__ float4 touch_weights(const float2 *tab, int2 r, int j
 // forward's own calls, bit-identical, then the same two phases).  Ranges, weights, tables and the dwhere chain are the ones of the
 // forms above, every reduction has a fixed order; unit-major and recompute form are the same arithmetic on the same bits.
 struct CarveGs {
-    float *g, *t1, *src, *X, *Y, *pres, *scratch;
+    float *g, *t1, *src, *X, *Y, *pres, *wh, *scratch;
     float2 *xe, *ye;
     int2 *jr, *ir, *rows, *cols;
     float4 *wx4, *dx4, *xx4, *wy4;
@@ -293,7 +293,8 @@ __device__ __forceinline__ CarveGs carve_gs(float *smem, int H, int W, int h, in
     c.cols = reinterpret_cast<int2 *>(p); p += 2 * ((TU + 1) & ~1);
     c.X = p; p += W;
     c.Y = p; p += H;
-    c.pres = p; p += (TS + 3) & ~3;
+    c.pres = p; p += 2 * ((TS + 3) & ~3);                // (two buffers: image-major keeps the NEXT image's presences / `where` rows
+    c.wh = p; p += 8 * TS;                               //  beside the current one's, see the image loop)
     c.scratch = p;                                       // [nw][TU][8]
     (void)nw;
     return c;
@@ -301,7 +302,7 @@ __device__ __forceinline__ CarveGs carve_gs(float *smem, int H, int W, int h, in
 static inline size_t carve_gs_bytes(int H, int W, int h, int w, int TU, int TS, int nw) {
     return sizeof(float) * (size_t)(((H * W + 3) & ~3) + 12 * TU * w + 4 * TU * h + (size_t)TU * ((H * w + 3) & ~3) +
                                     (size_t)TS * pad_count_host(h, w) + 2 * TS * (W + H) + 2 * TU * (w + h) + 4 * ((TU + 1) & ~1) +
-                                    W + H + ((TS + 3) & ~3) + (size_t)nw * TU * 8 + 16);
+                                    W + H + 2 * ((TS + 3) & ~3) + 8 * TS + (size_t)nw * TU * 8 + 16);
 }
 // touch_weights for the three column sums: the (up to) four canvas indices from r.x on -> wx, dwx, X dwx
 template <typename Acc>
@@ -380,14 +381,30 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
     // (measured and rejected, profiles/r06_canvas_gs_ab.txt: image-major with the NEXT image's canvas operands requested during the row
     //  contraction and held in registers over the barrier -- 28 more live registers at 1024 threads spill, 4819 against 4614 us at
     //  65536 images of 100x100)
-    for (int it = bid0; it < n_items; it += grid_st) {
+    // Image-major: the `where` rows and presences of an image (5 T floats) are requested one image AHEAD and parked in LDS (two buffers), so
+    // that the table build at the top of an image does not start with a global round trip (3.0 us from image start to the tables, traced)
+    const int prs = (TS + 3) & ~3;
+    if (IM && bid0 < n_items) {
+        if (tid < TS * 4) c.wh[tid] = where[4 * ((size_t)(tid >> 2) * B + bid0) + (tid & 3)];
+        else if (tid < TS * 5) c.pres[tid - TS * 4] = presence ? presence[(size_t)(tid - TS * 4) * B + bid0] : 1.0f;
+    }
+    int par = 0;
+    for (int it = bid0; it < n_items; it += grid_st, par ^= (IM ? 1 : 0)) {
         // unit-major: item = (unit k = t_own*B + b, split sp); image-major: item = image b, local unit lu = step
         const int k_um = IM ? 0 : it / NS, sp = IM ? 0 : it - k_um * NS;
         const int b = IM ? it : k_um % B, t_own = IM ? 0 : k_um / B;
         const int i0 = (int)(((long)h * sp) / NS), i1 = (int)(((long)h * (sp + 1)) / NS);     // this workgroup's dglimpse rows
         const int ts_own = (RC && !IM) ? t_own : 0;          // table / copy index of local unit 0 (image-major: lu itself)
         AIR_TR(0);
-        if (it != bid0) __syncthreads();                     // (0) the previous item's readers are done with the carve
+        if (it != bid0 || IM) __syncthreads();               // (0) the previous item's readers are done with the carve
+        float *presb = c.pres + par * prs;
+        const float *whb = c.wh + par * 4 * TS;
+        float wnx = 0.f;
+        if (IM && it + grid_st < n_items) {
+            const int nb = it + grid_st;
+            if (tid < TS * 4) wnx = where[4 * ((size_t)(tid >> 2) * B + nb) + (tid & 3)];
+            else if (tid < TS * 5) wnx = presence ? presence[(size_t)(tid - TS * 4) * B + nb] : 1.0f;
+        }
         // ---- operands -------------------------------------------------------------------------------------------------------
         // first 16-byte group of the canvas operands requested before anything else waits (latency regime: the tables below only
         // need `where`); RC: the observation (c.g holds it until the canvas pass replaces the footprint)
@@ -473,17 +490,17 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
         for (int a0 = tid; a0 < n_xe_pad + TS * H; a0 += nt) {
             if (a0 < n_xe) {
                 const int tt = a0 / W, r = a0 - tt * W;
-                const float *wk = where + 4 * ((size_t)((RC || IM) ? tt : t_own) * B + b);
+                const float *wk = IM ? whb + 4 * tt : where + 4 * ((size_t)(RC ? tt : t_own) * B + b);
                 const float s_ = wk[0], t_ = wk[1];
                 c.xe[tt * W + r] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r, W, a.stepX), -t_ / s_, cxs), w);
             } else if (a0 >= n_xe_pad) {
                 const int a1 = a0 - n_xe_pad, tt = a1 / H, r = a1 - tt * H;
-                const float *wk = where + 4 * ((size_t)((RC || IM) ? tt : t_own) * B + b);
+                const float *wk = IM ? whb + 4 * tt : where + 4 * ((size_t)(RC ? tt : t_own) * B + b);
                 const float s_ = wk[2], t_ = wk[3];
                 c.ye[tt * H + r] = axis_entry2(grid_coord(1.0f / s_, lin_m11(r, H, a.stepY), -t_ / s_, cys), h);
             }
         }
-        if (tid < TS) c.pres[tid] = presence ? presence[(size_t)((RC || IM) ? tid : t_own) * B + b] : 1.0f;
+        if (!IM && tid < TS) c.pres[tid] = presence ? presence[(size_t)(RC ? tid : t_own) * B + b] : 1.0f;
         // glimpse copies (bordered)
         if (v4g) {
             for (int q = tid; q < TS * nq; q += nt) {
@@ -538,7 +555,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
             for (int e = tid; e < n_x_pad + TU * h; e += nt) {
                 if (e < n_x) {
                     const int lu = e / w, r = e - lu * w;
-                    const float *wk = where + 4 * ((size_t)lu * B + b);
+                    const float *wk = whb + 4 * lu;
                     const float s_ = wk[0], t_ = wk[1];
                     const TabAcc ta = {c.xe + lu * W};
                     const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cxs, r, W);
@@ -546,7 +563,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                     touch_weights3(ta, c.X, W, a.stepX, rg, r, &c.wx4[lu * w + r], &c.dx4[lu * w + r], &c.xx4[lu * w + r]);
                 } else if (e >= n_x_pad) {
                     const int e2 = e - n_x_pad, lu = e2 / h, i = e2 - lu * h;
-                    const float *wk = where + 4 * ((size_t)lu * B + b);
+                    const float *wk = whb + 4 * lu;
                     const float s_ = wk[2], t_ = wk[3];
                     const TabAcc ta = {c.ye + lu * H};
                     const int2 rg = touch_range_t(ta, -t_ / s_, s_, inv_cys, i, H);
@@ -556,7 +573,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
             }
             // valid canvas rows and touched glimpse columns of each unit, one wave per unit (see gs_unit_spans)
             for (int lu = nw - 1 - wid; lu < TU; lu += nw) {   // (by the LAST waves: the first ones hold the range items)
-                const int4 sp4 = gs_unit_spans<SPLIT>(c.xe + lu * W, c.ye + lu * H, W, H, w, i0, i1, c.pres[lu] == 0.f && !dpresence);
+                const int4 sp4 = gs_unit_spans<SPLIT>(c.xe + lu * W, c.ye + lu * H, W, H, w, i0, i1, presb[lu] == 0.f && !dpresence);
                 if (lane == 0) { c.rows[lu] = make_int2(sp4.x, sp4.y); c.cols[lu] = make_int2(sp4.z, sp4.w); }
             }
             AIR_TR(10);
@@ -580,7 +597,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                     float vt = 0.f;
                     if (fxt != ST_INVALID && fyt != ST_INVALID)
                         vt = bilerp(load_taps_pad(c.src + (size_t)tt * c.hwp, pitch, fyt, fxt), ext.y, eyt.y);
-                    cv = acc_step(cv, c.pres[tt], vt);
+                    cv = acc_step(cv, presb[tt], vt);
                 }
                 c.g[p] = dcanvas_of(coef, mult, cv, c.g[p]);
             }
@@ -596,7 +613,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
             int4 sp4;
             if (IM) { const int2 rw_ = c.rows[lu], cw_ = c.cols[lu]; sp4 = make_int4(rw_.x, rw_.y, cw_.x, cw_.y); }
             else {
-                sp4 = gs_unit_spans<SPLIT>(xe, ye, W, H, w, i0, i1, c.pres[tt] == 0.f && !dpresence);
+                sp4 = gs_unit_spans<SPLIT>(xe, ye, W, H, w, i0, i1, presb[tt] == 0.f && !dpresence);
                 if (tid == 0) { c.rows[lu] = make_int2(sp4.x, sp4.y); c.cols[lu] = make_int2(sp4.z, sp4.w); }
             }
             const int I0 = sp4.x, fh = sp4.y, ja = sp4.z, nj = sp4.w;
@@ -700,7 +717,7 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                         s = __builtin_fmaf(t1[I * w], (fy == i ? ey.y : 0.f) + (fy + 1 == i ? 1.f - ey.y : 0.f), s);
                     }
                 }
-                s *= c.pres[tt];
+                s *= presb[tt];
             }
             dg[e] = s;
         }
@@ -716,9 +733,10 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
                         r4 = __shfl(tot, 32, 64);
             if (lane == 0) {
                 const size_t k = (size_t)(IM ? lu : t_own) * B + b;
-                const float pres = c.pres[IM ? lu : ts_own];
+                const float pres = presb[IM ? lu : ts_own];
                 const float r0 = (pres * s0) * cxs, r1 = (pres * s1) * cxs, r2 = (pres * s2) * cys, r3 = (pres * s3) * cys;
-                const float sx = where[4 * k], tx = where[4 * k + 1], sy = where[4 * k + 2], ty = where[4 * k + 3];
+                const float *wr = IM ? whb + 4 * lu : where + 4 * k;
+                const float sx = wr[0], tx = wr[1], sy = wr[2], ty = wr[3];
                 const float ax = 1.0f / sx, bx = -tx / sx, ay = 1.0f / sy, by = -ty / sy;
                 // chain through a = 1/s, b = (-t)/s as automatic differentiation evaluates the two divisions:
                 // degenerate scales give NaN / inf / 0 exactly where the reference's gradient does
@@ -731,6 +749,10 @@ __device__ __forceinline__ void st_write_bwd_gs_body(const WriteBwdArgs &a, cons
             }
         }
         AIR_TR(8);
+        if (IM) {                                            // the next image's rows into the OTHER buffer (nobody reads it during this image)
+            if (tid < TS * 4) c.wh[(par ^ 1) * 4 * TS + tid] = wnx;
+            else if (tid < TS * 5) c.pres[(par ^ 1) * prs + tid - TS * 4] = wnx;
+        }
     }
     AIR_TR_FLUSH();
 }

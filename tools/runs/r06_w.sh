@@ -14,3 +14,4 @@ for name, kw, T in (("c4", dict(img_size=(100, 100), crop_size=(28, 28), max_ste
 PY
 for i in 1 2; do python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-sweep --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("c2", d['ms_per_step'], d['value'])"; done
 for i in 1 2; do python bench.py --config c4 --steps 2000 --warmup 200 --no-cpu-baseline --no-sweep --no-other-configs 2>/dev/null | tail -1 | cut -c1-200; done
+ONLY="canvas_unroll_bwd" timeout 120 tools/kbench/bin/st_trace_tr 2048 5 100 28 | grep -v amdgpu.ids | head -16
